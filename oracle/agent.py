@@ -1,0 +1,212 @@
+"""Read/write loops. Oracle (test infrastructure).
+
+Restates the control flow of agents/default_agent.py (wait-k / MMA) and
+agents/cif_agent.py (CIF): chunk schedule, policy(), predict(),
+update_model_encoder(), and the offline greedy loop whose stopwatch placement
+eval/generate.py:187-209 defines.
+
+The SimulEval client/server that drives the agent is third-party and absent;
+``FrameSource`` below is a frame-granular stand-in for it (documented in
+DESIGN.md "Synthetic harness"): a READ delivers the next ``expected_frames``
+fbank frames (fewer at the end) and raises ``finish_read`` together with the
+last frames; every committed token is stamped with the source milliseconds
+released so far (15 ms window tail + 10 ms per frame).
+"""
+from typing import Dict, List
+
+import torch
+
+from . import cif as cifm
+from . import decoder as dec
+from . import emformer as em
+from .latency import average_lagging
+
+SHIFT_MS, WINDOW_MS = 10, 25
+
+
+class FrameSource:
+    def __init__(self, fbank):
+        self.fbank = fbank            # [T, 80]
+        self.pos = 0
+        self.finished = fbank.size(0) == 0
+
+    def read(self, n):
+        self.pos = min(self.pos + n, self.fbank.size(0))
+        self.finished = self.pos >= self.fbank.size(0)
+
+    def frames(self):
+        return self.fbank[:self.pos]
+
+    def elapsed_ms(self):
+        return 0 if self.pos == 0 else self.pos * SHIFT_MS + (WINDOW_MS - SHIFT_MS)
+
+    def total_ms(self):
+        return self.fbank.size(0) * SHIFT_MS + (WINDOW_MS - SHIFT_MS)
+
+
+def _first_chunk_frames(ecfg):
+    # agents/default_agent.py:367: (S + R) * stride_ms // SHIFT_SIZE
+    return (ecfg.segment_length + ecfg.right_context) * ecfg.stride * SHIFT_MS // SHIFT_MS
+
+
+def _next_chunk_frames(ecfg):
+    # agents/default_agent.py:407
+    return ecfg.segment_length * ecfg.stride * SHIFT_MS // SHIFT_MS
+
+
+def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=False):
+    """FairseqSimulSTAgent loop for wait-k / MMA (agents/default_agent.py:303-436).
+    Returns dict(tokens, delays_ms, actions ('R'/'W' string), AL, n_enc)."""
+    src = FrameSource(fbank)
+    enc_state = em.new_encoder_state()
+    dec_state = dec.new_decoder_state(dcfg)
+    enc_out = None
+    last_update = 0
+    expected = _first_chunk_frames(ecfg)
+    hyp: List[int] = []
+    delays: List[float] = []
+    actions = []
+    max_len = lambda n: min(max_len_a * n + max_len_b, dcfg.max_target_positions)  # noqa: E731
+
+    def update_encoder():
+        nonlocal enc_out, last_update
+        upd = src.pos - last_update
+        if upd == 0 and src.finished:
+            return
+        finish = (upd < expected) or src.finished
+        out = em.encoder_infer(w, "encoder", ecfg, src.frames().unsqueeze(0),
+                               torch.tensor([src.pos]), enc_state, finish=finish)
+        new = out["encoder_out"][0]
+        enc_out = new if enc_out is None else torch.cat([enc_out, new], dim=0)
+        last_update = src.pos
+
+    while True:
+        # ---- policy (agents/default_agent.py:364-413)
+        if enc_out is None:
+            expected = _first_chunk_frames(ecfg)
+            action = 0
+        else:
+            toks = torch.tensor([[dcfg.eos] + hyp])
+            dec_state["online"] = not src.finished
+            x, extra = dec.mma_decoder_step(w, "decoder", dcfg, toks,
+                                            {"encoder_out": [enc_out], "encoder_padding_mask": []},
+                                            dec_state)
+            action = extra["action"]
+            if action == 0:
+                expected = _next_chunk_frames(ecfg)
+        if action == 0:
+            actions.append("R")
+            if src.finished:          # nothing left to read: SimulEval would spin; guard
+                raise RuntimeError("READ after source finished")
+            src.read(expected)
+            update_encoder()
+            continue
+        # ---- predict (agents/default_agent.py:415-436)
+        actions.append("W")
+        idx = int(torch.log_softmax(x[:, -1:].float(), dim=-1).argmax(dim=-1)[0, 0])
+        if force_finish and idx == dcfg.eos and not src.finished:
+            dec.clear_cache(dec_state)
+            continue
+        hyp.append(idx)
+        delays.append(src.elapsed_ms())
+        # units_to_segment termination (agents/default_agent.py:268-271)
+        if idx == dcfg.eos or len(hyp) > max_len(src.pos):
+            break
+    return {"tokens": hyp, "delays_ms": delays, "actions": "".join(actions),
+            "AL": average_lagging(delays, src.total_ms()),
+            "n_enc": 0 if enc_out is None else enc_out.size(0)}
+
+
+def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot_weight=1.0):
+    """cif_agent.FairseqSimulSTAgent loop (agents/cif_agent.py:296-412)."""
+    src = FrameSource(fbank)
+    enc_state = em.new_encoder_state()
+    cif_state = cifm.new_cif_state()
+    dec_state = dec.new_decoder_state(dcfg)
+    states = None
+    last_update = 0
+    expected = _first_chunk_frames(ecfg)
+    hyp, delays, actions = [], [], []
+
+    def update_encoder():
+        nonlocal states, last_update
+        upd = src.pos - last_update
+        if upd == 0 and src.finished:
+            return
+        finish = (upd < expected) or src.finished
+        out = em.encoder_infer(w, "encoder", ecfg, src.frames().unsqueeze(0),
+                               torch.tensor([src.pos]), enc_state, finish=finish)
+        c = cifm.cif_layer_infer(w, "encoder.cif_layer", beta, out["encoder_out"][0], cif_state, finish)
+        if states is None:
+            states = {"cif_out": [c["cif_out"][0]], "cif_lengths": [c["cif_lengths"][0]]}
+        else:
+            states = {"cif_out": [torch.cat([states["cif_out"][0], c["cif_out"][0]], dim=0)],
+                      "cif_lengths": [states["cif_lengths"][0] + c["cif_lengths"][0]]}
+        assert states["cif_out"][0].size(0) == int(states["cif_lengths"][0])
+        last_update = src.pos
+
+    while True:
+        if states is None:
+            expected = _first_chunk_frames(ecfg)
+            read = True
+        else:
+            enc_len = int(states["cif_lengths"][0])
+            read = enc_len <= len(hyp) and not src.finished
+            if read:
+                expected = _next_chunk_frames(ecfg)
+        if read:
+            actions.append("R")
+            if src.finished:
+                raise RuntimeError("READ after source finished")
+            src.read(expected)
+            update_encoder()
+            continue
+        actions.append("W")
+        toks = torch.tensor([[dcfg.eos] + hyp])
+        x, _ = dec.cif_decoder_step(w, "decoder", dcfg, toks, states, dec_state, overshoot_weight)
+        idx = int(torch.log_softmax(x[:, -1:].float(), dim=-1).argmax(dim=-1)[0, 0])
+        hyp.append(idx)
+        delays.append(src.elapsed_ms())
+        if idx == dcfg.eos or len(hyp) > max_len_a * src.pos + max_len_b:
+            break
+    return {"tokens": hyp, "delays_ms": delays, "actions": "".join(actions),
+            "AL": average_lagging(delays, src.total_ms()),
+            "n_cif": 0 if states is None else int(states["cif_lengths"][0])}
+
+
+def greedy_offline(w, ecfg, dcfg, src_tokens, src_lengths, n_steps=None, mask_eos=False,
+                   max_len_a=0.1, max_len_b=10):
+    """Offline batched greedy decode: eval/generate.py:187-209 ->
+    task.inference_step -> SequenceGenerator(beam=1) semantics restated:
+    encoder._forward once, then decoder steps with 'online' unset (never READs,
+    mma_model.py:191-193); step cap int(0.1*T + 10) (exp/infer_st.yaml:3-5).
+    With ``mask_eos`` EOS is never chosen, so exactly n_steps tokens/utterance
+    (bench config 2: 110). Returns tokens [B, n] (eos-padded after finish), lengths [B]."""
+    B = src_tokens.size(0)
+    enc = em.encoder_forward(w, "encoder", ecfg, src_tokens, src_lengths)
+    pad = enc["encoder_padding_mask"][0]
+    enc_in = {"encoder_out": enc["encoder_out"], "encoder_padding_mask": [pad] if pad.any() else []}
+    if n_steps is None:
+        n_steps = int(max_len_a * src_tokens.size(1) + max_len_b)
+    st = dec.new_decoder_state(dcfg)
+    st["online"] = False
+    toks = torch.full((B, 1), dcfg.eos, dtype=torch.long)
+    done = torch.zeros(B, dtype=torch.bool)
+    lengths = torch.zeros(B, dtype=torch.long)
+    for step in range(n_steps):
+        logits, _ = dec.mma_decoder_step(w, "decoder", dcfg, toks, enc_in, st)
+        lp = torch.log_softmax(logits[:, -1].float(), dim=-1)
+        lp[:, dcfg.padding_idx] = -float("inf")
+        if mask_eos or step == 0:
+            lp[:, dcfg.eos] = -float("inf")
+        if not mask_eos and step == n_steps - 1:
+            lp[:, :dcfg.eos] = -float("inf")
+            lp[:, dcfg.eos + 1:] = -float("inf")
+        nxt = lp.argmax(dim=-1)
+        nxt = torch.where(done, torch.full_like(nxt, dcfg.eos), nxt)
+        lengths += (~done).long()
+        done = done | (nxt == dcfg.eos)
+        toks = torch.cat([toks, nxt.unsqueeze(1)], dim=1)
+        if bool(done.all()):
+            break
+    return toks[:, 1:], lengths, enc

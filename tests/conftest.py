@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """-> (arrays: dict name->torch tensor, weights: dict refname->torch tensor)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    arrs, w = {}, {}
+    for k in z.files:
+        v = torch.from_numpy(z[k])
+        if k.startswith("w:"):
+            w[k[2:]] = v
+        else:
+            arrs[k] = v
+    return arrs, w
+
+
+def split_weights(arrs, tag):
+    """weights stored as '<tag>.w:<name>' (fixtures holding several modules)."""
+    pre = tag + ".w:"
+    return {k[len(pre):]: v for k, v in arrs.items() if k.startswith(pre)}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
