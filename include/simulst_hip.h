@@ -1,0 +1,270 @@
+/*
+ * simulst_hip.h -- C ABI of libsimulst_hip.so: the MI355X (gfx950) hot path of
+ * streaming speech translation (conv subsampler -> Emformer -> wait-k / MMA /
+ * CIF policy + greedy decoder), drop-in behind the reference's Python surface.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned memory (the Python
+ *    host passes torch-ROCm tensor.data_ptr()); the library owns nothing but
+ *    the handle (a HIP stream + per-kernel-class event timers).
+ *  - all entry points are asynchronous on the handle's stream, return
+ *    0 on success, <0 for an invalid argument (SIMULST_E_*), >0 for a
+ *    hipError_t; they never throw and never exit.  simulst_last_error() gives
+ *    the message.  (The reference's only native precedent reports errors via
+ *    TORCH_CHECK -> RuntimeError, criterion/best_alignment/best_alignment.cu:233-238;
+ *    the Python binding turns a non-zero status into RuntimeError too.)
+ *  - dtype: activations/weights are SIMULST_F32 or SIMULST_BF16 (one dtype per
+ *    call); biases, LayerNorm affine parameters, probabilities, energies,
+ *    scan outputs and logits are always fp32; indices/lengths int32 unless
+ *    stated; accumulation is always fp32 and softmax is fp32 like
+ *    torchaudio_models/emformer.py:143-145.
+ *  - row-major everywhere; "rows" are batch-major (utterance b, then time).
+ *
+ * Each entry point cites the reference interface (file:line under
+ * /root/reference/codebase) it replaces.  INTEGRATION.md shows the binding.
+ */
+#ifndef SIMULST_HIP_H
+#define SIMULST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct simulst_handle simulst_handle;
+
+enum { SIMULST_F32 = 0, SIMULST_BF16 = 1 };
+
+enum {
+  SIMULST_OK = 0,
+  SIMULST_E_NULL = -1,     /* null pointer */
+  SIMULST_E_SHAPE = -2,    /* unsupported / inconsistent shape */
+  SIMULST_E_DTYPE = -3,    /* unknown dtype enum */
+  SIMULST_E_ARG = -4       /* other invalid argument */
+};
+
+/* GEMM epilogues (simulst_linear) */
+enum {
+  SIMULST_EPI_BIAS = 0,        /* C = A W^T + b                                   */
+  SIMULST_EPI_BIAS_GELU = 1,   /* C = gelu_erf(A W^T + b)                         */
+  SIMULST_EPI_BIAS_RES = 2,    /* C = A W^T + b + R                               */
+  SIMULST_EPI_GLU = 3,         /* C[:, j] = s * (a_j + b_j) * sigmoid(g_j + bg_j), W prepacked
+                                  in 64-row blocks [32 value rows | 32 gate rows]     */
+  SIMULST_EPI_EMF_OUT = 4,     /* Emformer out_proj: rows < n_main of each utterance: C = . + b + R;
+                                  summary rows: tanh(. + b) -> next layer's memory rows */
+  SIMULST_EPI_BIAS_F32OUT = 5  /* C (always fp32) = A W^T + b   (logits, energies)  */
+};
+
+/* monotonic attention flavours (modules/__init__.py:11-16 registry names minus the
+ * _fixed_pre_decision suffix, which is the `ratio` argument) */
+enum { SIMULST_ATTN_HARD = 0, SIMULST_ATTN_INFINITE_LOOKBACK = 1, SIMULST_ATTN_WAITK = 2,
+       SIMULST_ATTN_CHUNKWISE = 3 };
+
+/* kernel classes for simulst_timer_* (roofline accounting in bench.py) */
+enum { SIMULST_K_LINEAR = 0, SIMULST_K_LAYERNORM = 1, SIMULST_K_EMF_ATTN = 2, SIMULST_K_CONV_POS = 3,
+       SIMULST_K_DEC_SELF_ATTN = 4, SIMULST_K_DEC_CROSS_ATTN = 5, SIMULST_K_SCAN = 6,
+       SIMULST_K_ARGMAX = 7, SIMULST_K_MISC = 8, SIMULST_K_COUNT = 9 };
+
+/* ---- handle ------------------------------------------------------------------ */
+int simulst_create(simulst_handle** out, void* hip_stream);
+int simulst_destroy(simulst_handle* h);
+int simulst_set_stream(simulst_handle* h, void* hip_stream);
+const char* simulst_last_error(simulst_handle* h);
+int simulst_version(void);
+/* per-kernel-class HIP-event timing on the handle's stream (off by default) */
+int simulst_timer_enable(simulst_handle* h, int kernel_class, int on);
+int simulst_timer_read(simulst_handle* h, int kernel_class, double* total_ms, int64_t* launches);
+int simulst_timer_reset(simulst_handle* h);
+
+/* ---- dense contraction ----------------------------------------------------------
+ * C[r, :] = epi(A[r, :] . W^T) for logical rows r = b * rows_per_batch + i.
+ * A row address  = A + b*a_batch_stride + i*a_row_stride (elements), K contiguous;
+ *   elements whose offset (i*a_row_stride + k - a_lead) is negative read as 0
+ *   (left zero padding of a causal convolution).  A rows may OVERLAP
+ *   (a_row_stride < K): a stride-s causal Conv1d over channel-last input is this
+ *   GEMM with a_row_stride = s*C_in, K = k*C_in, a_lead = (k-1)*C_in and W laid
+ *   out [C_out][k][C_in].
+ * C row address  = C + b*c_batch_stride + i*c_row_stride.
+ * W is [N][K] (torch Linear layout). bias fp32 [N] or NULL.
+ * R (residual, EPI_BIAS_RES / EMF_OUT) addressed like C with r_* strides.
+ * EMF_OUT: n_main = rows per utterance that take the residual path; the remaining
+ *   rows_per_batch - n_main rows are summary rows s, written tanh'ed to
+ *   aux + b*aux_batch_stride + s*N for s < aux_rows (the LAST summary is dropped,
+ *   torchaudio_models/emformer.py:256,828).
+ * Replaces: nn.Linear / nn.Conv1d+GLU calls of modules/causal_conv.py:140-155,
+ * torchaudio_models/emformer.py:111-113,164-167,209,371-378, fairseq decoder
+ * projections (models/cif_transformer.py:391-537 witness). */
+typedef struct {
+  int32_t M_batches, rows_per_batch, N, K;
+  int64_t a_batch_stride, a_row_stride, a_lead;
+  int64_t c_batch_stride, c_row_stride;
+  int64_t r_batch_stride, r_row_stride;
+  int32_t epilogue, dtype;
+  float scale;                 /* GLU output scale (embed_scale), else unused */
+  int32_t n_main, aux_rows;    /* EMF_OUT only */
+  int64_t aux_batch_stride;    /* EMF_OUT only */
+} simulst_linear_desc;
+
+int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, const void* A, const void* W,
+                   const float* bias, const void* R, void* C, void* aux);
+
+/* ---- causal conv front-end ------------------------------------------------------
+ * conv-pos: y = x + gelu(causal grouped Conv1d(x)) then rows t >= lengths[b] zeroed.
+ * x, y [B][T][D] (+ optional `hist` [B][k-1][D] = the k-1 frames before x for streaming,
+ * NULL = zeros). W [D][D/groups][k] fp32/bf16 with weight-norm already folded.
+ * Replaces make_conv_pos(causal=True) + the add + masked_fill of
+ * models/s2t_transformer.py:114-143, models/s2t_emformer.py:140-151,208-215. */
+int simulst_conv_pos(simulst_handle* h, const void* x, const void* hist, const void* W,
+                     const float* bias, const int32_t* lengths, void* y,
+                     int32_t B, int32_t T, int32_t D, int32_t groups, int32_t k, int32_t dtype);
+
+/* ---- Emformer layer pieces ------------------------------------------------------
+ * Per-utterance row blocks of a layer buffer Z [B][n_mem + n_rc + T + n_sum][D]:
+ *   [memory rows | right-context block rows | utterance rows | summary rows].
+ * simulst_emformer_prenorm: LayerNorm rows of X [B][n_rc+T][D] into Z's rc|utt rows and
+ * write per-segment means of the normed utterance rows (AvgPool1d ceil_mode: a ragged last
+ * segment divides by its real frame count) into Z's summary rows.  `seg_len` = S.
+ * valid utterance frames of b = lengths[b] (NULL = T).
+ * Replaces _apply_pre_attention_layer_norm + memory_op (torchaudio_models/emformer.py:443-452,
+ * 368,472,497-498). */
+int simulst_emformer_prenorm(simulst_handle* h, const void* X, const float* gamma, const float* beta,
+                             const int32_t* lengths, void* Z, int32_t B, int32_t T, int32_t D,
+                             int32_t n_mem, int32_t n_rc, int32_t n_sum, int32_t seg_len, int32_t dtype);
+
+/* Plain row LayerNorm: Y[r] = LN(X[r]) (final_layer_norm, pos_ff.0, decoder norms). */
+int simulst_layernorm(simulst_handle* h, const void* X, const float* gamma, const float* beta, void* Y,
+                      int64_t rows, int32_t D, int64_t x_row_stride, int64_t y_row_stride, int32_t dtype);
+
+/* Segment means of RAW utterance rows -> first-layer memory (Emformer.forward mems,
+ * torchaudio_models/emformer.py:827-831; Emformer.infer mems :878-882). out [B][n_out][D]. */
+int simulst_segment_mean(simulst_handle* h, const void* X, const int32_t* lengths, void* out,
+                         int32_t B, int32_t T, int32_t D, int64_t x_batch_stride, int64_t out_batch_stride,
+                         int32_t seg_len, int32_t n_out, int32_t dtype);
+
+/* Block attention of one Emformer layer, all segments of all utterances in one launch.
+ * QKV [B][n_mem+n_rc+T+n_sum][3D] = (q|k|v) projections of Z rows.  For segment i of b:
+ *   queries: rc block i (R rows), utterance rows [iS, min((i+1)S, T)), summary i
+ *   keys   : memory [max(0,i-M), i) (hidden from the summary query), rc block i,
+ *            cached left-context K/V (streaming only), utterance [max(0,iS-Lc), min((i+1)S, len_b))
+ * CTX [B][n_rc+T+n_sum][D] receives softmax(QK^T/sqrt(d))V per head.
+ * Streaming (lc_k != NULL): n_seg == 1, memory rows come from the carried bank
+ * (n_mem_valid[b] newest rows valid), lc_k/lc_v [B][Lc][D] ring of the last Lc projected
+ * utterance rows of which lc_valid[b] are valid (oldest first).
+ * Replaces _EmformerAttention._forward_impl/_gen_attention_probs + the mask of
+ * Emformer._gen_attention_mask (torchaudio_models/emformer.py:127-219,259-318,711-793). */
+typedef struct {
+  int32_t B, T, D, H, S, R, Lc, M;
+  int32_t n_mem, n_seg;         /* rows in the memory block, segments (= rc blocks = summaries) */
+  int32_t use_summary;          /* 0 when max_memory_size == 0 */
+  int32_t dtype;
+} simulst_emf_attn_desc;
+
+int simulst_emformer_attention(simulst_handle* h, const simulst_emf_attn_desc* d, const void* QKV,
+                               const int32_t* lengths, const void* lc_k, const void* lc_v,
+                               const int32_t* lc_valid, const int32_t* n_mem_valid, void* CTX);
+
+/* ---- monotonic policies (scans) -------------------------------------------------
+ * wait-k step probability: p[bh][t][s] = (s == min(t0 + t + k - 1, online ? inf : key_len[bh]-1)).
+ * Replaces utils/p_choose_strategy.py:6-53. p fp32 {0,1}. key_len NULL = S. */
+int simulst_waitk_p_choose(simulst_handle* h, float* p, const int32_t* key_len, int32_t BH,
+                           int32_t tgt_len, int32_t tgt_offset, int32_t S, int32_t k, int32_t online);
+
+/* Inference step search: for each row bh, zero p below head_step, force 1 at the last
+ * allowed step, take the FIRST index with p >= 0.5.
+ * in : p [BH][S] fp32, head_step [BH] int64 (in/out), src_len [BH] int32 or NULL (= S)
+ * out: head_read [BH] uint8, alpha [BH][S] fp32 one-hot (may be NULL).
+ * Replaces modules/monotonic_multihead_attention.py:196-275. */
+int simulst_mma_step_search(simulst_handle* h, const float* p, int64_t* head_step, uint8_t* head_read,
+                            float* alpha, const int32_t* src_len, int32_t BH, int32_t S,
+                            int32_t mass_preservation);
+
+/* Expected alignment (train-mode forward): alpha [BH][U][S] from p_choose [BH][U][S], fp32,
+ * key padding via key_len [BH] (NULL = S): log-space exclusive cumprod along S, recurrence along U.
+ * Replaces utils/monotonic_attention.py:12-76 + utils/functions.py:20-66. */
+int simulst_expected_alignment(simulst_handle* h, const float* p, float* alpha, const int32_t* key_len,
+                               int32_t BH, int32_t U, int32_t S, float eps);
+
+/* alpha += residual mass on the last valid key (in place). utils/monotonic_attention.py:155-197. */
+int simulst_mass_preservation(simulst_handle* h, float* alpha, const int32_t* key_len,
+                              int32_t BH, int32_t U, int32_t S);
+
+/* Expected soft attention beta from alpha and soft energy; chunk_size <= 0 = infinite lookback.
+ * utils/monotonic_attention.py:79-152 (+ moving_sum utils/functions.py:69-125). */
+int simulst_expected_soft_attention(simulst_handle* h, const float* alpha, const float* energy,
+                                    float* beta, const int32_t* key_len, int32_t BH, int32_t U,
+                                    int32_t S, int32_t chunk_size, float eps);
+
+/* Step probabilities for ONE decode step of every utterance, with fixed pre-decision:
+ * p [B*H][S_cap] fp32 (zero beyond key_len[b]).
+ *   q     [B][D]  monotonic-energy query = q_proj(x) (1/sqrt(d) scaling applied inside)
+ *   Kmono [B][S_cap][D] = k_proj(encoder states), cached by the caller as the source grows.
+ *   Pooled key j = mean of Kmono frames [j*ratio, min((j+1)*ratio, len)): AvgPool1d(ceil_mode)
+ *   commutes with the affine k_proj, so pool -> k_proj of the reference
+ *   (modules/fixed_pre_decision.py:97-121) equals k_proj -> pool up to fp32 rounding; the pooled
+ *   count is floor-trimmed when `incremental` (:123-131); p_j = sigmoid(q.k_j/sqrt(d) + energy_bias)
+ *   (monotonic_multihead_attention.py:88-149, utils/p_choose_strategy.py:56-76, eval mode) is
+ *   upsampled by zero insertion to frame (j+1)*ratio-1, cropped/padded to len with the last
+ *   column overwritten when cropped (:85-95,143-159).  ratio == 1 = no pre-decision.
+ *   WAITK: p_j = (j == min(tgt_idx[b] + k - 1, online ? inf : P-1)) (p_choose_strategy.py:6-53),
+ *   q/Kmono unused.
+ * Per-utterance (B == 1) semantics for ragged batches: windows never mix padded frames. */
+int simulst_step_p_choose(simulst_handle* h, const void* q, const void* Kmono, float energy_bias,
+                          const int32_t* key_len, float* p, int32_t B, int32_t S_cap, int32_t H, int32_t d,
+                          int32_t ratio, int32_t incremental, int32_t attn_type, int32_t waitk_k,
+                          const int32_t* tgt_idx, int32_t online, int32_t dtype);
+
+/* ---- CIF integrate-and-fire -------------------------------------------------------
+ * x [B][S][C], alpha [B][S] fp32 -> out [B][T_cap][C] (zero beyond cif_len), cif_len [B] int32,
+ * delays [B][T_cap] fp32, tail_w [B] fp32, alpha_sum [B] fp32.  One wavefront prefix-sum of
+ * alpha per utterance, fire index floor(csum/beta), segmented weighted sum.
+ * Replaces torch_cif.cif_function as called from models/cif_transformer.py:171-178,228-233
+ * (inference form: no target_lengths). */
+int simulst_cif_integrate(simulst_handle* h, const void* x, const float* alpha, const int32_t* src_len,
+                          void* out, int32_t* cif_len, float* delays, float* tail_w, float* alpha_sum,
+                          int32_t B, int32_t S, int32_t C, int32_t T_cap, float beta, float tail_thres,
+                          int32_t dtype);
+
+/* CIF weight head: alpha[r] = sigmoid(w . gelu(LayerNorm(hidden[r])) + bias), hidden = output of
+ * the causal ConvTBC (itself a simulst_linear with overlapping rows).
+ * Replaces CIFLayer.alpha_proj[1:] + sigmoid (models/cif_transformer.py:124-130,160,211). */
+int simulst_cif_alpha_head(simulst_handle* h, const void* hidden, const float* gamma, const float* beta_ln,
+                           const void* w, float bias, float* alpha, int64_t rows, int32_t D, int32_t dtype);
+
+/* ---- decoder step ---------------------------------------------------------------
+ * token embedding * sqrt(D) + sinusoidal position row (padding_idx + n_prev) -> x [B][D].
+ * Replaces MMADecoder.pre_attention (models/mma_model.py:79-124). pos_table fp32 [rows][D]. */
+int simulst_embed_tokens(simulst_handle* h, const int64_t* tokens, const void* E, const float* pos_table,
+                         const int32_t* pos_row, void* x, int32_t B, int32_t D, float scale, int32_t dtype);
+
+/* Incremental self-attention: append this step's k,v (from qkv [B][3D]) at row n_prev[b] of the
+ * caches [B][H][cap][d], attend over n_prev[b]+1 keys. ctx [B][D].
+ * Replaces fairseq MultiheadAttention incremental self-attention + prev_key/prev_value cache
+ * (pruned at models/mma_model.py:34-54: a READ simply does not advance n_prev). */
+int simulst_decoder_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache,
+                                   const int32_t* n_prev, void* ctx, int32_t B, int32_t H, int32_t d,
+                                   int32_t cap, int32_t dtype);
+
+/* Monotonic cross-attention value aggregation for one decode step.
+ * q [B][D] (soft-energy query = q_proj(x), the 1/sqrt(d) scaling is applied inside), Kc/Vc [B][S_cap][D] cached
+ * projections of the encoder states, step [B*H] int64 = head_step after the search.
+ *   HARD : ctx = Vc[clamp(step)] (zero if !mass_preservation && step == len)
+ *   soft : ctx = softmax_{s <= step}(q.Kc[s]) Vc, zero if step == 0  (CHUNKWISE == INFINITE_LOOKBACK at
+ *          inference: the reference's inference softmax ignores the chunk size, :278-293)
+ * Replaces modules/monotonic_multihead_attention.py:278-297,401-409. */
+int simulst_decoder_cross_attention(simulst_handle* h, const void* q, const void* Kc, const void* Vc,
+                                    const int64_t* step, const int32_t* key_len, void* ctx, float* beta,
+                                    int32_t B, int32_t H, int32_t d, int32_t S_cap, int32_t attn_type,
+                                    int32_t mass_preservation, int32_t dtype);
+
+/* Greedy pick: argmax over fp32 logits [B][V] of log_softmax (== argmax of logits), with
+ * optional -inf at pad, optional -inf at eos, optional additive eos bias per row (CIF overshoot,
+ * models/cif_transformer.py:716-722). Ties resolve to the LOWEST index like torch.argmax.
+ * Replaces default_agent.predict (agents/default_agent.py:415-424). */
+int simulst_greedy_argmax(simulst_handle* h, const float* logits, const float* eos_bias, int64_t* out,
+                          int32_t B, int32_t V, int32_t pad_idx, int32_t eos_idx, int32_t mask_eos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMULST_HIP_H */

@@ -1,0 +1,142 @@
+"""ctypes binding of libsimulst_hip.so (the C ABI declared in include/simulst_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+returns a non-zero status, a RuntimeError is raised (the reference's native
+precedent surfaces TORCH_CHECK failures the same way,
+criterion/best_alignment/best_alignment.cu:233-238 -- but unlike
+criterion/best_alignment/__init__.py:18-20 a missing extension is never
+silently ignored).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimulst_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_GLU, EPI_EMF_OUT, EPI_BIAS_F32OUT = range(6)
+ATTN_HARD, ATTN_INFINITE_LOOKBACK, ATTN_WAITK, ATTN_CHUNKWISE = range(4)
+(K_LINEAR, K_LAYERNORM, K_EMF_ATTN, K_CONV_POS, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_SCAN, K_ARGMAX,
+ K_MISC, K_COUNT) = range(10)
+KERNEL_CLASS_NAMES = ["linear", "layernorm", "emformer_attention", "conv_pos", "decoder_self_attention",
+                      "decoder_cross_attention", "scan", "argmax", "misc"]
+
+ATTN_ENUM = {"hard_aligned": ATTN_HARD, "infinite_lookback": ATTN_INFINITE_LOOKBACK,
+             "waitk": ATTN_WAITK, "chunkwise": ATTN_CHUNKWISE}
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [("M_batches", C.c_int32), ("rows_per_batch", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("a_batch_stride", C.c_int64), ("a_row_stride", C.c_int64), ("a_lead", C.c_int64),
+                ("c_batch_stride", C.c_int64), ("c_row_stride", C.c_int64),
+                ("r_batch_stride", C.c_int64), ("r_row_stride", C.c_int64),
+                ("epilogue", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_float),
+                ("n_main", C.c_int32), ("aux_rows", C.c_int32), ("aux_batch_stride", C.c_int64)]
+
+
+class EmfAttnDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "T", "D", "H", "S", "R", "Lc", "M", "n_mem", "n_seg",
+                                         "use_summary", "dtype")]
+
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (restype is int unless noted); mirrors include/simulst_hip.h one to one
+SIGNATURES = {
+    "simulst_create": [C.POINTER(_vp), _vp],
+    "simulst_destroy": [_vp],
+    "simulst_set_stream": [_vp, _vp],
+    "simulst_last_error": [_vp],
+    "simulst_version": [],
+    "simulst_timer_enable": [_vp, C.c_int, C.c_int],
+    "simulst_timer_read": [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)],
+    "simulst_timer_reset": [_vp],
+    "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
+    "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
+    "simulst_emformer_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "simulst_layernorm": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i32],
+    "simulst_segment_mean": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _i32],
+    "simulst_emformer_attention": [_vp, C.POINTER(EmfAttnDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "simulst_waitk_p_choose": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
+    "simulst_mma_step_search": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    "simulst_expected_alignment": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32],
+    "simulst_mass_preservation": [_vp, _vp, _vp, _i32, _i32, _i32],
+    "simulst_expected_soft_attention": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32],
+    "simulst_step_p_choose": [_vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                              _vp, _i32, _i32],
+    "simulst_cif_integrate": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32],
+    "simulst_cif_alpha_head": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _i32],
+    "simulst_embed_tokens": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32],
+    "simulst_decoder_self_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
+    "simulst_decoder_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                        _i32, _i32],
+    "simulst_greedy_argmax": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once). Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"simulst_amd: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C simulst_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "simulst_last_error" else C.c_int
+    _lib = lib
+    return lib
+
+
+class Handle:
+    """Owns a simulst_handle bound to a HIP stream (default: torch's current stream)."""
+
+    def __init__(self, stream_ptr=None):
+        self.lib = load()
+        if stream_ptr is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise RuntimeError("simulst_amd: no HIP device visible; the hot path is GPU only "
+                                   "(no CPU fallback)")
+            stream_ptr = torch.cuda.current_stream().cuda_stream
+        self._h = _vp()
+        rc = self.lib.simulst_create(C.byref(self._h), _vp(stream_ptr))
+        if rc != 0:
+            raise RuntimeError(f"simulst_create failed: {rc}")
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.simulst_set_stream(self._h, _vp(stream_ptr)), "simulst_set_stream")
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.simulst_last_error(self._h)
+            raise RuntimeError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+    def timer_enable(self, kernel_class=-1, on=True):
+        self.check(self.lib.simulst_timer_enable(self._h, kernel_class, int(on)), "simulst_timer_enable")
+
+    def timer_reset(self):
+        self.check(self.lib.simulst_timer_reset(self._h), "simulst_timer_reset")
+
+    def timer_read(self, kernel_class):
+        ms, n = C.c_double(0), _i64(0)
+        self.check(self.lib.simulst_timer_read(self._h, kernel_class, C.byref(ms), C.byref(n)), "simulst_timer_read")
+        return ms.value, n.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.lib.simulst_destroy(self._h)
+                self._h = _vp()
+        except Exception:
+            pass

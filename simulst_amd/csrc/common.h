@@ -1,0 +1,130 @@
+// Shared device/host helpers for libsimulst_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/simulst_hip.h"
+
+typedef __hip_bfloat16 bf16;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct simulst_handle {
+  hipStream_t stream;
+  std::string err;
+  bool timer_on[SIMULST_K_COUNT];
+  double timer_ms[SIMULST_K_COUNT];
+  int64_t timer_n[SIMULST_K_COUNT];
+  hipEvent_t ev0, ev1;
+  bool ev_ready;
+};
+
+#define SL_CHECK_NULL(h, p)                                   \
+  do {                                                        \
+    if ((p) == nullptr) {                                     \
+      if (h) (h)->err = std::string("null pointer: ") + #p;   \
+      return SIMULST_E_NULL;                                  \
+    }                                                         \
+  } while (0)
+
+#define SL_REQUIRE(h, cond, code, msg)                        \
+  do {                                                        \
+    if (!(cond)) {                                            \
+      if (h) (h)->err = std::string(msg) + " [" #cond "]";    \
+      return (code);                                          \
+    }                                                         \
+  } while (0)
+
+// RAII-less timer scope: when the class timer is on, bracket the launch with events
+// and accumulate (synchronises -- measurement mode only, never on by default).
+struct KTimer {
+  simulst_handle* h;
+  int cls;
+  bool on;
+  KTimer(simulst_handle* h_, int cls_) : h(h_), cls(cls_), on(h_->timer_on[cls_]) {
+    if (on) {
+      if (!h->ev_ready) {
+        (void)hipEventCreate(&h->ev0);
+        (void)hipEventCreate(&h->ev1);
+        h->ev_ready = true;
+      }
+      (void)hipEventRecord(h->ev0, h->stream);
+    }
+  }
+  ~KTimer() {
+    if (on) {
+      (void)hipEventRecord(h->ev1, h->stream);
+      (void)hipEventSynchronize(h->ev1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+      h->timer_ms[cls] += ms;
+      h->timer_n[cls] += 1;
+    }
+  }
+};
+
+static inline int sl_launch_status(simulst_handle* h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    h->err = std::string(what) + ": " + hipGetErrorString(e);
+    return (int)e;
+  }
+  return SIMULST_OK;
+}
+
+// ---- dtype helpers ------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return __float2bfloat16(v); }
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned int)b) << 16);
+}
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ float wave_scan_incl(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// load 4 consecutive elements as floats (16B for f32, 8B for bf16); caller guarantees alignment
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void load4(const bf16* p, float (&o)[4]) {
+  ushort4 v = *reinterpret_cast<const ushort4*>(p);
+  o[0] = bf16_bits_to_f32(v.x); o[1] = bf16_bits_to_f32(v.y);
+  o[2] = bf16_bits_to_f32(v.z); o[3] = bf16_bits_to_f32(v.w);
+}
+__device__ __forceinline__ void store4(float* p, const float (&o)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void store4(bf16* p, const float (&o)[4]) {
+  bf16 t[4] = {__float2bfloat16(o[0]), __float2bfloat16(o[1]), __float2bfloat16(o[2]), __float2bfloat16(o[3])};
+  *reinterpret_cast<uint2*>(p) = *reinterpret_cast<uint2*>(t);
+}

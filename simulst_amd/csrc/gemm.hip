@@ -1,0 +1,300 @@
+// simulst_linear: MFMA contraction C = epi(A . W^T) for gfx950.
+//
+// One kernel template covers every dense contraction on the path: the two strided
+// causal convolutions of the subsampler (overlapping A rows over channel-last
+// frames + fused GLU), the Emformer QKV / out-proj / FFN projections and the
+// decoder projections.  fp32 operands use v_mfma_f32_32x32x2_f32 (exact fmaf chain),
+// bf16 operands v_mfma_f32_32x32x16_bf16; accumulation is fp32 in both.
+//
+// Block = 256 threads = 4 waves in a 2x2 grid; wave tile = (BM/2) x (BN/2) made of
+// 32x32 MFMA tiles.  Global -> registers -> LDS staging with the next K-tile's
+// global loads in flight during the MFMAs of the current one.
+//   fp32 LDS image: k-major [BK][BM+1] (stride == 1 mod 32 banks: conflict-free
+//                   transposed writes, conflict-free per-k reads)
+//   bf16 LDS image: row-major [BM][BK+8] (144-B rows: ds_read_b128 conflict-free)
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+namespace {
+
+template <typename T> struct Tile;
+template <> struct Tile<float> {
+  static constexpr int G = 4;            // elements per 16-B vector
+  static constexpr int BK = 32;
+};
+template <> struct Tile<bf16> {
+  static constexpr int G = 8;
+  static constexpr int BK = 64;
+};
+
+struct LinArgs {
+  int M, rpb, N, K;
+  long a_bs, a_rs, a_lead;
+  long c_bs, c_rs;
+  long r_bs, r_rs;
+  float scale;
+  int n_main, aux_rows;
+  long aux_bs;
+};
+
+template <typename T> struct Vec16 { uint4 v; };
+
+template <typename T>
+__device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// ---- LDS store of one 16-B vector belonging to (row m, k-group kq) ---------------
+template <int BMN>
+__device__ __forceinline__ void lds_store(float* s, int m, int kq, uint4 v) {
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s[(kq * 4 + j) * (BMN + 1) + m] = f[j];
+}
+template <int BMN>
+__device__ __forceinline__ void lds_store(bf16* s, int m, int kq, uint4 v) {
+  *reinterpret_cast<uint4*>(&s[m * (Tile<bf16>::BK + 8) + kq * 8]) = v;
+}
+
+template <typename TA, typename TC, int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ W,
+                                                     const float* __restrict__ bias,
+                                                     const TA* __restrict__ R, TC* __restrict__ C,
+                                                     TA* __restrict__ aux, LinArgs p) {
+  constexpr int G = Tile<TA>::G, BK = Tile<TA>::BK;
+  constexpr int WM = BM / 2, WN = BN / 2;      // wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 MFMA tiles per wave
+  constexpr int A_ITERS = BM / 32, W_ITERS = BN / 32;   // 16-B vectors per thread per K-tile
+  constexpr int LDS_A = std::is_same<TA, float>::value ? BK * (BM + 1) : BM * (BK + 8);
+  constexpr int LDS_W = std::is_same<TA, float>::value ? BK * (BN + 1) : BN * (BK + 8);
+  __shared__ __attribute__((aligned(16))) TA smem[LDS_A + LDS_W];
+  TA* As = smem;
+  TA* Ws = smem + LDS_A;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // XCD-aware block order: consecutive N-tiles of one M-tile share an XCD's L2 for A
+  const int nbn = (p.N + BN - 1) / BN;
+  const int bid = blockIdx.x;
+  const int bm = bid / nbn, bn = bid % nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const int kq = tid & 7;          // k-group inside the K-tile
+  const int lr = tid >> 3;         // 0..31 row inside a 32-row slab
+
+  // per-thread source rows (fixed over the K loop)
+  const TA* a_ptr[A_ITERS];
+  long a_koff[A_ITERS];            // (i*a_rs - a_lead): element offset used for the lead check
+  bool a_ok[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    int r = m0 + lr + 32 * i;
+    a_ok[i] = r < p.M;
+    int b = a_ok[i] ? r / p.rpb : 0;
+    int ii = a_ok[i] ? r - b * p.rpb : 0;
+    a_koff[i] = (long)ii * p.a_rs - p.a_lead;
+    a_ptr[i] = A + (long)b * p.a_bs + a_koff[i];
+  }
+  const TA* w_ptr[W_ITERS];
+  bool w_ok[W_ITERS];
+#pragma unroll
+  for (int i = 0; i < W_ITERS; ++i) {
+    int n = n0 + lr + 32 * i;
+    w_ok[i] = n < p.N;
+    w_ptr[i] = W + (long)(w_ok[i] ? n : 0) * p.K;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  uint4 ra[A_ITERS], rw[W_ITERS];
+  auto gload = [&](int k0) {
+    const int k = k0 + kq * G;
+    const bool kin = k < p.K;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      bool ok = a_ok[i] && kin && (a_koff[i] + k >= 0);
+      ra[i] = ok ? ld16(a_ptr[i] + k) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < W_ITERS; ++i) {
+      bool ok = w_ok[i] && kin;
+      rw[i] = ok ? ld16(w_ptr[i] + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0);
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) lds_store<BM>(As, lr + 32 * i, kq, ra[i]);
+#pragma unroll
+    for (int i = 0; i < W_ITERS; ++i) lds_store<BN>(Ws, lr + 32 * i, kq, rw[i]);
+    __syncthreads();
+    if (t + 1 < nk) gload((t + 1) * BK);
+
+    if constexpr (std::is_same<TA, float>::value) {
+      const int lm = lane & 31, lk = lane >> 5;
+#pragma unroll 4
+      for (int kk = 0; kk < BK; kk += 2) {
+        float af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = As[(kk + lk) * (BM + 1) + wr * WM + i * 32 + lm];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = Ws[(kk + lk) * (BN + 1) + wc * WN + j * 32 + lm];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const int lm = lane & 31, lk = lane >> 5;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 16) {
+        bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wr * WM + i * 32 + lm) * (BK + 8) + kk + lk * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8_t*>(&Ws[(wc * WN + j * 32 + lm) * (BK + 8) + kk + lk * 8]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: acc[i][j][e] is C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+  const int lcol = lane & 31, lhi = lane >> 5;
+  if constexpr (EPI == SIMULST_EPI_GLU) {
+    static_assert(TN == 2, "GLU epilogue pairs the two 32-column tiles of a wave");
+    const int nv = n0 + wc * WN + lcol;          // value column in the prepacked W
+    const int ng = nv + 32;                      // gate column
+    const int oc = (n0 + wc * WN) / 2 + lcol;    // output column
+    const bool cok = ng < p.N;
+    const float bv = (bias && cok) ? bias[nv] : 0.f, bg = (bias && cok) ? bias[ng] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int r = m0 + wr * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        if (r < p.M && cok) {
+          int b = r / p.rpb, ii = r - b * p.rpb;
+          float v = (acc[i][0][e] + bv) * sigmoidf_(acc[i][1][e] + bg) * p.scale;
+          C[(long)b * p.c_bs + (long)ii * p.c_rs + oc] = from_f32<TC>(v);
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int r = m0 + wr * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        if (r >= p.M) continue;
+        int b = r / p.rpb, ii = r - b * p.rpb;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          int c = n0 + wc * WN + j * 32 + lcol;
+          if (c >= p.N) continue;
+          float v = acc[i][j][e] + (bias ? bias[c] : 0.f);
+          if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_erf(v);
+          if constexpr (EPI == SIMULST_EPI_BIAS_RES)
+            v += to_f32(R[(long)b * p.r_bs + (long)ii * p.r_rs + c]);
+          if constexpr (EPI == SIMULST_EPI_EMF_OUT) {
+            if (ii < p.n_main) {
+              v += to_f32(R[(long)b * p.r_bs + (long)ii * p.r_rs + c]);
+              C[(long)b * p.c_bs + (long)ii * p.c_rs + c] = from_f32<TC>(v);
+            } else {
+              int s = ii - p.n_main;
+              if (s < p.aux_rows) aux[(long)b * p.aux_bs + (long)s * p.N + c] = from_f32<TA>(tanhf(v));
+            }
+          } else {
+            C[(long)b * p.c_bs + (long)ii * p.c_rs + c] = from_f32<TC>(v);
+          }
+        }
+      }
+  }
+}
+
+template <typename TA, typename TC, int BM, int BN, int EPI>
+void launch(simulst_handle* h, const void* A, const void* W, const float* bias, const void* R, void* C,
+            void* aux, const LinArgs& p) {
+  int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+  dim3 grid(nbm * nbn);
+  hipLaunchKernelGGL((linear_kernel<TA, TC, BM, BN, EPI>), grid, dim3(256), 0, h->stream,
+                     (const TA*)A, (const TA*)W, bias, (const TA*)R, (TC*)C, (TA*)aux, p);
+}
+
+template <typename TA, typename TC, int EPI>
+void launch_tiles(simulst_handle* h, const void* A, const void* W, const float* bias, const void* R,
+                  void* C, void* aux, const LinArgs& p) {
+  // tall problems get the 128x128 tile; short-M (decode step) problems the 64x64 one
+  if (EPI == SIMULST_EPI_GLU || p.M > 512)
+    launch<TA, TC, 128, 128, EPI>(h, A, W, bias, R, C, aux, p);
+  else {
+    if constexpr (EPI != SIMULST_EPI_GLU) launch<TA, TC, 64, 64, EPI>(h, A, W, bias, R, C, aux, p);
+  }
+}
+
+template <typename TA>
+int dispatch(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R,
+             void* C, void* aux, const LinArgs& p) {
+  switch (epi) {
+    case SIMULST_EPI_BIAS: launch_tiles<TA, TA, SIMULST_EPI_BIAS>(h, A, W, bias, R, C, aux, p); break;
+    case SIMULST_EPI_BIAS_GELU: launch_tiles<TA, TA, SIMULST_EPI_BIAS_GELU>(h, A, W, bias, R, C, aux, p); break;
+    case SIMULST_EPI_BIAS_RES: launch_tiles<TA, TA, SIMULST_EPI_BIAS_RES>(h, A, W, bias, R, C, aux, p); break;
+    case SIMULST_EPI_GLU: launch_tiles<TA, TA, SIMULST_EPI_GLU>(h, A, W, bias, R, C, aux, p); break;
+    case SIMULST_EPI_EMF_OUT: launch_tiles<TA, TA, SIMULST_EPI_EMF_OUT>(h, A, W, bias, R, C, aux, p); break;
+    case SIMULST_EPI_BIAS_F32OUT: launch_tiles<TA, float, SIMULST_EPI_BIAS>(h, A, W, bias, R, C, aux, p); break;
+    default: h->err = "simulst_linear: unknown epilogue"; return SIMULST_E_ARG;
+  }
+  return SIMULST_OK;
+}
+
+}  // namespace
+
+extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, const void* A, const void* W,
+                              const float* bias, const void* R, void* C, void* aux) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, d);
+  SL_CHECK_NULL(h, A);
+  SL_CHECK_NULL(h, W);
+  SL_CHECK_NULL(h, C);
+  SL_REQUIRE(h, d->dtype == SIMULST_F32 || d->dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_linear: dtype");
+  const int G = d->dtype == SIMULST_F32 ? 4 : 8;
+  SL_REQUIRE(h, d->M_batches >= 0 && d->rows_per_batch > 0 && d->N > 0 && d->K > 0, SIMULST_E_SHAPE,
+             "simulst_linear: non-positive shape");
+  SL_REQUIRE(h, d->K % G == 0 && d->a_row_stride % G == 0 && d->a_batch_stride % G == 0 && d->a_lead % G == 0,
+             SIMULST_E_SHAPE, "simulst_linear: K / A strides must be multiples of the 16-byte vector");
+  if (d->epilogue == SIMULST_EPI_BIAS_RES || d->epilogue == SIMULST_EPI_EMF_OUT) SL_CHECK_NULL(h, R);
+  if (d->epilogue == SIMULST_EPI_GLU)
+    SL_REQUIRE(h, d->N % 64 == 0, SIMULST_E_SHAPE, "simulst_linear: GLU needs N % 64 == 0 (prepacked pairs)");
+  if (d->epilogue == SIMULST_EPI_EMF_OUT) {
+    SL_CHECK_NULL(h, aux);
+    SL_REQUIRE(h, d->n_main >= 0 && d->n_main <= d->rows_per_batch && d->aux_rows >= 0, SIMULST_E_SHAPE,
+               "simulst_linear: EMF_OUT row split");
+  }
+  if (d->M_batches == 0) return SIMULST_OK;
+  long M = (long)d->M_batches * d->rows_per_batch;
+  SL_REQUIRE(h, M < (1L << 31), SIMULST_E_SHAPE, "simulst_linear: too many rows");
+  LinArgs p;
+  p.M = (int)M; p.rpb = d->rows_per_batch; p.N = d->N; p.K = d->K;
+  p.a_bs = d->a_batch_stride; p.a_rs = d->a_row_stride; p.a_lead = d->a_lead;
+  p.c_bs = d->c_batch_stride; p.c_rs = d->c_row_stride;
+  p.r_bs = d->r_batch_stride; p.r_rs = d->r_row_stride;
+  p.scale = d->scale; p.n_main = d->n_main; p.aux_rows = d->aux_rows; p.aux_bs = d->aux_batch_stride;
+  KTimer t(h, SIMULST_K_LINEAR);
+  int rc = d->dtype == SIMULST_F32 ? dispatch<float>(h, d->epilogue, A, W, bias, R, C, aux, p)
+                                   : dispatch<bf16>(h, d->epilogue, A, W, bias, R, C, aux, p);
+  if (rc != SIMULST_OK) return rc;
+  return sl_launch_status(h, "simulst_linear");
+}

@@ -1,0 +1,337 @@
+// Row-wise HBM-bound kernels: LayerNorm (+ Emformer segment summaries), segment means,
+// causal grouped conv-pos, token embedding, greedy argmax.  One wave (64 lanes) per row,
+// 16-byte (fp32) / 8-byte (bf16) vector accesses, fp32 statistics.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 4;   // row chunks of 4 elements per lane => D <= 1024
+
+// LayerNorm of one row by one wave. Returns normalized values in v[][4] (lane-local chunks).
+template <typename T>
+__device__ __forceinline__ void wave_layernorm_row(const T* __restrict__ x, const float* __restrict__ g,
+                                                   const float* __restrict__ bt, int D, int lane,
+                                                   float (&v)[MAXV][4], int& nv) {
+  nv = 0;
+  float s = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    load4(x + c, v[nv]);
+    s += v[nv][0] + v[nv][1] + v[nv][2] + v[nv][3];
+    ++nv;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = 0; i < nv; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float d = v[i][j] - mean;
+      q += d * d;
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+  int i = 0;
+  for (int c = lane * 4; c < D; c += 256, ++i) {
+    float gg[4], bb[4];
+    load4(g + c, gg);
+    load4(bt + c, bb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X, const float* __restrict__ g,
+                                                        const float* __restrict__ bt, T* __restrict__ Y,
+                                                        long rows, int D, long xs, long ys) {
+  const int lane = threadIdx.x & 63;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float v[MAXV][4];
+  int nv;
+  wave_layernorm_row(X + r * xs, g, bt, D, lane, v, nv);
+  int i = 0;
+  for (int c = lane * 4; c < D; c += 256, ++i) store4(Y + r * ys + c, v[i]);
+}
+
+// Emformer pre-attention LayerNorm. Block x in [0, n_seg): utterance segment x of utterance
+// blockIdx.y (rows [xS, xS+S)), also writes the segment's summary row. Block x >= n_seg:
+// 16 rows of the right-context block area.
+template <typename T>
+__global__ __launch_bounds__(256) void emformer_prenorm_kernel(
+    const T* __restrict__ X, const float* __restrict__ g, const float* __restrict__ bt,
+    const int* __restrict__ lengths, T* __restrict__ Z, int T_, int D, int n_mem, int n_rc, int n_sum,
+    int S, int n_seg) {
+  extern __shared__ float red[];   // [4][D] partial sums of the normalized rows
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long x_bs = (long)(n_rc + T_) * D;
+  const long z_bs = (long)(n_mem + n_rc + T_ + n_sum) * D;
+  const T* Xb = X + b * x_bs;
+  T* Zb = Z + b * z_bs + (long)n_mem * D;     // rc|utt|sum rows start here
+  float v[MAXV][4];
+  int nv;
+  if ((int)blockIdx.x >= n_seg) {             // right-context rows
+    int r0 = (blockIdx.x - n_seg) * 16;
+    for (int r = r0 + wave; r < min(r0 + 16, n_rc); r += 4) {
+      wave_layernorm_row(Xb + (long)r * D, g, bt, D, lane, v, nv);
+      int i = 0;
+      for (int c = lane * 4; c < D; c += 256, ++i) store4(Zb + (long)r * D + c, v[i]);
+    }
+    return;
+  }
+  const int seg = blockIdx.x;
+  const int len = lengths ? lengths[b] : T_;
+  const int t0 = seg * S, t1 = min(t0 + S, T_);
+  // AvgPool1d(ceil_mode): the ragged last window divides by its real frame count; in a padded
+  // batch the reference pools over padded rows too -- those summaries only feed segments
+  // that are themselves beyond `len`, so per-utterance (ragged) semantics are kept here.
+  const int cnt_rows = min(t1, max(len, t0 + 1)) - t0;   // >= 1
+  float acc[MAXV][4];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int t = t0 + wave; t < t1; t += 4) {
+    wave_layernorm_row(Xb + (long)(n_rc + t) * D, g, bt, D, lane, v, nv);
+    int i = 0;
+    for (int c = lane * 4; c < D; c += 256, ++i) {
+      store4(Zb + (long)(n_rc + t) * D + c, v[i]);
+      if (t - t0 < cnt_rows)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += v[i][j];
+    }
+  }
+  if (n_sum == 0) return;
+  {
+    int i = 0;
+    for (int c = lane * 4; c < D; c += 256, ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave * D + c + j] = acc[i][j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s = red[c] + red[D + c] + red[2 * D + c] + red[3 * D + c];
+    Zb[(long)(n_rc + T_ + seg) * D + c] = from_f32<T>(s / (float)cnt_rows);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void segment_mean_kernel(const T* __restrict__ X, const int* __restrict__ lengths,
+                                                           T* __restrict__ out, int T_, int D, long x_bs,
+                                                           long o_bs, int S, int n_out) {
+  const int b = blockIdx.y, seg = blockIdx.x;
+  if (seg >= n_out) return;
+  const int len = lengths ? lengths[b] : T_;
+  const int t0 = seg * S, t1 = min(t0 + S, T_);
+  const int cnt = min(t1, max(len, t0 + 1)) - t0;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s = 0.f;
+    for (int t = 0; t < cnt; ++t) s += to_f32(X[b * x_bs + (long)(t0 + t) * D + c]);
+    out[b * o_bs + (long)seg * D + c] = from_f32<T>(s / (float)cnt);
+  }
+}
+
+// ---- conv-pos: y = x + gelu(causal grouped conv(x)), zero beyond lengths -----------------
+// block = (time tile of 64, group, utterance); thread = (out channel o, 4 consecutive frames).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pos_kernel(const T* __restrict__ x, const T* __restrict__ hist,
+                                                       const T* __restrict__ W, const float* __restrict__ bias,
+                                                       const int* __restrict__ lengths, T* __restrict__ y,
+                                                       int T_, int D, int cpg, int k) {
+  extern __shared__ float sm[];
+  const int TT = 64;
+  const int b = blockIdx.z, g = blockIdx.y, t_base = blockIdx.x * TT;
+  const int win = TT + k - 1, xstride = win + 1;
+  float* Wl = sm;                       // [k][cpg_in][cpg_out]
+  float* xs = sm + k * cpg * cpg;       // [cpg][xstride]
+  const int tid = threadIdx.x;
+  // weights W[D][cpg][k] -> Wl[tau][c][o]
+  for (int i = tid; i < k * cpg * cpg; i += 256) {
+    int tau = i % k, c = (i / k) % cpg, o = i / (k * cpg);
+    Wl[(tau * cpg + c) * cpg + o] = to_f32(W[((long)(g * cpg + o) * cpg + c) * k + tau]);
+  }
+  // input window frames [t_base-(k-1), t_base+TT)
+  for (int i = tid; i < win * cpg; i += 256) {
+    int c = i % cpg, w = i / cpg;
+    int t = t_base - (k - 1) + w;
+    float v = 0.f;
+    if (t >= 0) {
+      if (t < T_) v = to_f32(x[((long)b * T_ + t) * D + g * cpg + c]);
+    } else if (hist) {
+      v = to_f32(hist[((long)b * (k - 1) + (k - 1 + t)) * D + g * cpg + c]);
+    }
+    xs[c * xstride + w] = v;
+  }
+  __syncthreads();
+  const int o = tid % cpg, tq = tid / cpg;
+  const int nq = 256 / cpg;             // thread groups along time
+  const int len = lengths ? lengths[b] : T_;
+  for (int q = tq; q * 4 < TT; q += nq) {
+    const int tl = q * 4;               // local frame of the first of 4 outputs
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c = 0; c < cpg; ++c) {
+      const float* xr = xs + c * xstride + tl;
+      float x0 = xr[0], x1 = xr[1], x2 = xr[2];
+      for (int tau = 0; tau < k; ++tau) {
+        float x3 = xr[tau + 3];
+        float w = Wl[(tau * cpg + c) * cpg + o];
+        a0 = fmaf(w, x0, a0); a1 = fmaf(w, x1, a1); a2 = fmaf(w, x2, a2); a3 = fmaf(w, x3, a3);
+        x0 = x1; x1 = x2; x2 = x3;
+      }
+    }
+    float av[4] = {a0, a1, a2, a3};
+    const float bo = bias[g * cpg + o];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int t = t_base + tl + j;
+      if (t < T_) {
+        float xin = xs[o * xstride + (k - 1) + tl + j];
+        float v = (t < len) ? xin + gelu_erf(av[j] + bo) : 0.f;
+        y[((long)b * T_ + t) * D + g * cpg + o] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void embed_kernel(const long* __restrict__ tokens, const T* __restrict__ E,
+                             const float* __restrict__ pos, const int* __restrict__ pos_row,
+                             T* __restrict__ x, int D, float scale) {
+  const int b = blockIdx.x;
+  const long tok = tokens[b];
+  const long pr = pos_row[b];
+  for (int c = threadIdx.x; c < D; c += blockDim.x)
+    x[(long)b * D + c] = from_f32<T>(scale * to_f32(E[tok * D + c]) + pos[pr * D + c]);
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits,
+                                                     const float* __restrict__ eos_bias,
+                                                     long* __restrict__ out, int V, int pad_idx, int eos_idx,
+                                                     int mask_eos) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* row = logits + (long)b * V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = tid; c < V; c += 256) {
+    float v = row[c];
+    if (c == eos_idx && eos_bias) v += eos_bias[b];
+    if (c == pad_idx || (mask_eos && c == eos_idx)) v = -INFINITY;
+    if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    out[b] = bi == 0x7fffffff ? 0 : bi;
+  }
+}
+
+}  // namespace
+
+#define DT_SWITCH(dtype, ...)                               \
+  if ((dtype) == SIMULST_F32) { using T = float; __VA_ARGS__; } \
+  else { using T = bf16; __VA_ARGS__; }
+
+extern "C" int simulst_layernorm(simulst_handle* h, const void* X, const float* gamma, const float* beta,
+                                 void* Y, int64_t rows, int32_t D, int64_t xs, int64_t ys, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, X); SL_CHECK_NULL(h, gamma); SL_CHECK_NULL(h, beta); SL_CHECK_NULL(h, Y);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_layernorm: dtype");
+  SL_REQUIRE(h, D > 0 && D % 4 == 0 && D <= 1024 && xs % 4 == 0 && ys % 4 == 0, SIMULST_E_SHAPE,
+             "simulst_layernorm: D must be a multiple of 4, <= 1024");
+  if (rows <= 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_LAYERNORM);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                      h->stream, (const T*)X, gamma, beta, (T*)Y, (long)rows, D, (long)xs, (long)ys));
+  return sl_launch_status(h, "simulst_layernorm");
+}
+
+extern "C" int simulst_emformer_prenorm(simulst_handle* h, const void* X, const float* gamma, const float* beta,
+                                        const int32_t* lengths, void* Z, int32_t B, int32_t T_, int32_t D,
+                                        int32_t n_mem, int32_t n_rc, int32_t n_sum, int32_t seg_len, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, X); SL_CHECK_NULL(h, gamma); SL_CHECK_NULL(h, beta); SL_CHECK_NULL(h, Z);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_emformer_prenorm: dtype");
+  SL_REQUIRE(h, D > 0 && D % 4 == 0 && D <= 1024 && seg_len > 0 && T_ > 0 && n_mem >= 0 && n_rc >= 0,
+             SIMULST_E_SHAPE, "simulst_emformer_prenorm: shape");
+  const int n_seg = (T_ + seg_len - 1) / seg_len;
+  SL_REQUIRE(h, n_sum == 0 || n_sum == n_seg, SIMULST_E_SHAPE, "simulst_emformer_prenorm: n_sum must be 0 or ceil(T/S)");
+  if (B <= 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_LAYERNORM);
+  dim3 grid(n_seg + (n_rc + 15) / 16, B);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(emformer_prenorm_kernel<T>, grid, dim3(256), 4 * D * sizeof(float), h->stream,
+                                      (const T*)X, gamma, beta, lengths, (T*)Z, T_, D, n_mem, n_rc, n_sum, seg_len, n_seg));
+  return sl_launch_status(h, "simulst_emformer_prenorm");
+}
+
+extern "C" int simulst_segment_mean(simulst_handle* h, const void* X, const int32_t* lengths, void* out,
+                                    int32_t B, int32_t T_, int32_t D, int64_t x_bs, int64_t o_bs,
+                                    int32_t seg_len, int32_t n_out, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, X); SL_CHECK_NULL(h, out);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_segment_mean: dtype");
+  SL_REQUIRE(h, D > 0 && seg_len > 0 && T_ > 0 && n_out >= 0 && (long)n_out * seg_len < (long)T_ + seg_len,
+             SIMULST_E_SHAPE, "simulst_segment_mean: shape");
+  if (B <= 0 || n_out == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_MISC);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(segment_mean_kernel<T>, dim3(n_out, B), dim3(256), 0, h->stream,
+                                      (const T*)X, lengths, (T*)out, T_, D, (long)x_bs, (long)o_bs, seg_len, n_out));
+  return sl_launch_status(h, "simulst_segment_mean");
+}
+
+extern "C" int simulst_conv_pos(simulst_handle* h, const void* x, const void* hist, const void* W,
+                                const float* bias, const int32_t* lengths, void* y, int32_t B, int32_t T_,
+                                int32_t D, int32_t groups, int32_t k, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, W); SL_CHECK_NULL(h, bias); SL_CHECK_NULL(h, y);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_conv_pos: dtype");
+  SL_REQUIRE(h, groups > 0 && D % groups == 0 && k > 0, SIMULST_E_SHAPE, "simulst_conv_pos: D % groups");
+  const int cpg = D / groups;
+  SL_REQUIRE(h, cpg <= 256 && 256 % cpg == 0, SIMULST_E_SHAPE, "simulst_conv_pos: channels/group must divide 256");
+  const size_t lds = ((size_t)k * cpg * cpg + (size_t)cpg * (64 + k)) * sizeof(float);
+  SL_REQUIRE(h, lds <= 160 * 1024, SIMULST_E_SHAPE, "simulst_conv_pos: kernel too large for LDS");
+  if (B <= 0 || T_ <= 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_CONV_POS);
+  dim3 grid((T_ + 63) / 64, groups, B);
+  DT_SWITCH(dtype, {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_pos_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_pos_kernel<T>, grid, dim3(256), lds, h->stream, (const T*)x, (const T*)hist,
+                       (const T*)W, bias, lengths, (T*)y, T_, D, cpg, k);
+  });
+  return sl_launch_status(h, "simulst_conv_pos");
+}
+
+extern "C" int simulst_embed_tokens(simulst_handle* h, const int64_t* tokens, const void* E, const float* pos_table,
+                                    const int32_t* pos_row, void* x, int32_t B, int32_t D, float scale, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, tokens); SL_CHECK_NULL(h, E); SL_CHECK_NULL(h, pos_table); SL_CHECK_NULL(h, pos_row); SL_CHECK_NULL(h, x);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_embed_tokens: dtype");
+  if (B <= 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_MISC);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(embed_kernel<T>, dim3(B), dim3(256), 0, h->stream, (const long*)tokens,
+                                      (const T*)E, pos_table, pos_row, (T*)x, D, scale));
+  return sl_launch_status(h, "simulst_embed_tokens");
+}
+
+extern "C" int simulst_greedy_argmax(simulst_handle* h, const float* logits, const float* eos_bias, int64_t* out,
+                                     int32_t B, int32_t V, int32_t pad_idx, int32_t eos_idx, int32_t mask_eos) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, logits); SL_CHECK_NULL(h, out);
+  SL_REQUIRE(h, V > 0, SIMULST_E_SHAPE, "simulst_greedy_argmax: V");
+  if (B <= 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_ARGMAX);
+  hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, h->stream, logits, eos_bias, (long*)out, V, pad_idx,
+                     eos_idx, mask_eos);
+  return sl_launch_status(h, "simulst_greedy_argmax");
+}

@@ -1,0 +1,487 @@
+// Monotonic-policy scans and the CIF integrate-and-fire scan (gfx950).
+// All fp32; one 64-lane wavefront owns one row and walks it in 64-wide chunks with a carried
+// prefix (wavefront prefix scan by __shfl_up); integer decisions (first p >= 0.5,
+// floor(csum / beta)) are thresholded in fp32 exactly like the reference.
+#include "common.h"
+
+namespace {
+
+// ---- wait-k one-hot p_choose (utils/p_choose_strategy.py:6-53) -------------------------
+__global__ void waitk_p_choose_kernel(float* __restrict__ p, const int* __restrict__ key_len, int tgt_len,
+                                      int tgt_offset, int S, int k, int online) {
+  const int bh = blockIdx.y, t = blockIdx.x;
+  const int eos = (key_len ? key_len[bh] : S) - 1;
+  int step = tgt_offset + t + k - 1;
+  if (!online) step = min(step, eos);
+  float* row = p + ((long)bh * tgt_len + t) * S;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) row[s] = (s == step) ? 1.f : 0.f;
+}
+
+// ---- inference step search (monotonic_multihead_attention.py:196-275) -----------------
+__global__ __launch_bounds__(256) void step_search_kernel(const float* __restrict__ p, long* __restrict__ head_step,
+                                                          unsigned char* __restrict__ head_read,
+                                                          float* __restrict__ alpha, const int* __restrict__ src_len,
+                                                          int BH, int S, int mass_pres) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= BH) return;
+  const float* pr = p + (long)r * S;
+  const int len = src_len ? src_len[r] : S;
+  const long hs = head_step[r];
+  const int max_steps = mass_pres ? len - 1 : len;
+  const int n = mass_pres ? S : S + 1;           // length of the searched row
+  int found = -1;
+  for (int j0 = 0; j0 < n && found < 0; j0 += 64) {
+    const int j = j0 + lane;
+    float v = 0.f;
+    if (j < n) {
+      v = (j < S) ? pr[j] : 0.f;
+      if ((long)j < hs) v = 0.f;                 // mask the past
+      if (j == max_steps) v = 1.f;               // force stop at the end
+    }
+    const unsigned long long m = __ballot(j < n && v >= 0.5f);
+    if (m) found = j0 + __ffsll((long long)m) - 1;
+  }
+  if (found < 0) found = 0;                      // unreachable: the forced 1.0 always hits
+  const int clampi = min(max(found, 0), len - 1);
+  const float p_i = pr[clampi];
+  const bool dead = (!mass_pres) && found == max_steps;
+  if (alpha)
+    for (int j = lane; j < S; j += 64) alpha[(long)r * S + j] = (j == clampi && !dead) ? 1.f : 0.f;
+  if (lane == 0) {
+    head_step[r] = found;
+    head_read[r] = (found == max_steps && p_i < 0.5f) ? 1 : 0;
+  }
+}
+
+// ---- expected alignment (utils/monotonic_attention.py:12-76) ----------------------------
+// one wave per row bh; sequential over targets, two wavefront scans over the source per target.
+__global__ __launch_bounds__(256) void expected_alignment_kernel(const float* __restrict__ p,
+                                                                 float* __restrict__ alpha,
+                                                                 const int* __restrict__ key_len, int BH, int U,
+                                                                 int S, float eps) {
+  extern __shared__ float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= BH) return;
+  float* prev = sm + wave * S;                   // alpha_{i-1}
+  const int len = key_len ? key_len[r] : S;
+  for (int s = lane; s < S; s += 64) prev[s] = (s == 0) ? 1.f : 0.f;
+  const float lead = logf(1.0f + eps);           // the prepended 1 also passes through log(. + eps)
+  for (int i = 0; i < U; ++i) {
+    const float* pi = p + ((long)r * U + i) * S;
+    float* ai = alpha + ((long)r * U + i) * S;
+    float carry_log = lead, carry_sum = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      const bool in = s < S;
+      float pv = (in && s < len) ? pi[s] : 0.f;
+      float lg = in ? logf(1.0f - pv + eps) : 0.f;
+      float incl = wave_scan_incl(lg, lane);
+      float cp = expf(carry_log + incl - lg);    // exclusive cumprod of (1 - p)
+      carry_log += __shfl(incl, 63, 64);
+      float cpc = fminf(fmaxf(cp, eps), 1.0f);
+      float term = in ? prev[s] / cpc : 0.f;
+      float tin = wave_scan_incl(term, lane);
+      float a = pv * cp * (carry_sum + tin);
+      carry_sum += __shfl(tin, 63, 64);
+      a = fminf(fmaxf(a, 0.f), 1.f);
+      __builtin_amdgcn_wave_barrier();
+      if (in) { ai[s] = a; }
+      // prev[s] for this chunk is consumed; overwrite for the next target row
+      if (in) prev[s] = a;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- mass preservation (utils/monotonic_attention.py:155-197) ----------------------------
+__global__ __launch_bounds__(256) void mass_preservation_kernel(float* __restrict__ alpha,
+                                                                const int* __restrict__ key_len, int rows, int U,
+                                                                int S) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* a = alpha + r * S;
+  if (!key_len) {
+    float s = 0.f;
+    for (int j = lane; j < S - 1; j += 64) s += a[j];
+    s = wave_sum(s);
+    if (lane == 0) a[S - 1] = 1.f - fminf(fmaxf(s, 0.f), 1.f);
+  } else {
+    const int len = key_len[r / U];
+    float s = 0.f;
+    for (int j = lane; j < S; j += 64) {
+      if (j >= len) a[j] = 0.f; else s += a[j];
+    }
+    s = wave_sum(s);
+    if (lane == 0) a[len - 1] += 1.f - fminf(fmaxf(s, 0.f), 1.f);
+  }
+}
+
+// ---- expected soft attention (utils/monotonic_attention.py:79-152) ------------------------
+__global__ __launch_bounds__(256) void soft_attention_kernel(const float* __restrict__ alpha,
+                                                             const float* __restrict__ energy,
+                                                             float* __restrict__ beta,
+                                                             const int* __restrict__ key_len, int rows, int U, int S,
+                                                             int chunk, float eps) {
+  extern __shared__ float sm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  float* ex = sm + wave * 2 * S;                 // exp(e - max) + eps
+  float* inner = ex + S;
+  const float* a = alpha + r * S;
+  const float* e = energy + r * S;
+  const int len = key_len ? key_len[r / U] : S;
+  float mx = -INFINITY;
+  for (int j = lane; j < S; j += 64) mx = fmaxf(mx, j < len ? e[j] : -1e8f);
+  mx = wave_max(mx);
+  for (int j = lane; j < S; j += 64) ex[j] = expf((j < len ? e[j] : -1e8f) - mx) + eps;
+  __builtin_amdgcn_wave_barrier();
+  if (chunk > 0) {
+    for (int j = lane; j < S; j += 64) {
+      float d = 0.f;                              // moving_sum(ex, chunk, 1)[j]
+      for (int m = max(0, j - chunk + 1); m <= j; ++m) d += ex[m];
+      inner[j] = (j < len ? a[j] : 0.f) / (eps + d);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < S; j += 64) {
+      float s = 0.f;                              // moving_sum(inner, 1, chunk)[j]
+      for (int m = j; m < min(S, j + chunk); ++m) s += inner[m];
+      float b = (j < len) ? ex[j] * s : 0.f;
+      beta[r * S + j] = fminf(fmaxf(b, 0.f), 1.f);
+    }
+  } else {
+    float carry = 0.f;
+    for (int j0 = 0; j0 < S; j0 += 64) {          // cumsum(ex)
+      const int j = j0 + lane;
+      float v = j < S ? ex[j] : 0.f;
+      float inc = wave_scan_incl(v, lane);
+      if (j < S) inner[j] = (j < len ? a[j] : 0.f) / (eps + carry + inc);
+      carry += __shfl(inc, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    carry = 0.f;
+    const int nch = (S + 63) / 64;
+    for (int c = 0; c < nch; ++c) {               // reverse cumsum(inner): walk from the end
+      const int j = S - 1 - (c * 64 + lane);
+      float v = j >= 0 ? inner[j] : 0.f;
+      float inc = wave_scan_incl(v, lane);
+      if (j >= 0) {
+        float b = (j < len) ? ex[j] * (carry + inc) : 0.f;
+        beta[r * S + j] = fminf(fmaxf(b, 0.f), 1.f);
+      }
+      carry += __shfl(inc, 63, 64);
+    }
+  }
+}
+
+// ---- step probabilities for one decode step, with fixed pre-decision pooling --------------
+// p[b*H+h][s] for s < S: zero-inserted pooled probabilities (fixed_pre_decision.py:85-167).
+// Pooled key j = mean of frames [j*ratio, min((j+1)*ratio, len)) of Kmono (k_proj already
+// applied: mean and the affine projection commute). One wave per (b, h).
+template <typename T>
+__global__ __launch_bounds__(256) void step_p_choose_kernel(const T* __restrict__ q, const T* __restrict__ Km,
+                                                            float energy_bias, const int* __restrict__ key_len,
+                                                            float* __restrict__ p, int S_cap, int H, int d,
+                                                            int ratio, int incremental, int attn_type, int waitk_k,
+                                                            const int* __restrict__ tgt_idx, int online) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D = H * d;
+  const int len = key_len ? key_len[b] : S_cap;
+  float* pp = sm + wave * S_cap;                             // pooled probabilities of this wave's head
+  for (int h = wave; h < H; h += 4) {
+    float* pr = p + ((long)b * H + h) * S_cap;
+    int P = (len + ratio - 1) / ratio;                       // ceil pooling
+    if (incremental) P = min(P, max(1, len / ratio));        // floor at inference, at least 1
+    const float qv = (attn_type != SIMULST_ATTN_WAITK && lane < d)
+                         ? to_f32(q[(long)b * D + h * d + lane]) * rsqrtf((float)d) : 0.f;
+    if (attn_type == SIMULST_ATTN_WAITK) {
+      int wk_step = tgt_idx[b] + waitk_k - 1;
+      if (!online) wk_step = min(wk_step, P - 1);
+      for (int j = lane; j < P; j += 64) pp[j] = (j == wk_step) ? 1.f : 0.f;
+    } else {
+      for (int j = 0; j < P; ++j) {
+        const int f0 = j * ratio, f1 = min(f0 + ratio, len);
+        float acc = 0.f;
+        if (lane < d)
+          for (int f = f0; f < f1; ++f) acc += to_f32(Km[((long)b * S_cap + f) * D + h * d + lane]);
+        acc = acc / (float)(f1 - f0) * qv;
+        const float en = wave_sum(acc) + energy_bias;
+        if (lane == 0) pp[j] = 1.0f / (1.0f + expf(-en));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // zero insertion: pooled j lands on frame (j+1)*ratio-1; if the upsampled row reaches past the
+    // source it is cropped and the LAST column takes the last pooled value (fixed_pre_decision.py:143-159)
+    for (int s = lane; s < S_cap; s += 64) {
+      float v = 0.f;
+      if (s < len) {
+        if ((s + 1) % ratio == 0 && (s + 1) / ratio - 1 < P) v = pp[(s + 1) / ratio - 1];
+        if (s == len - 1 && P * ratio >= len) v = pp[P - 1];
+      }
+      pr[s] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- CIF integrate-and-fire ---------------------------------------------------------------
+// grid (ceil(C/64), B), one wave per block: phase 1 wavefront prefix-sum of alpha -> per-frame
+// (left slot, fire count, left weight, right weight) in LDS; phase 2 lane = channel walks the
+// source once, emitting a slot each time it fires.
+template <typename T>
+__global__ __launch_bounds__(64) void cif_kernel(const T* __restrict__ x, const float* __restrict__ alpha,
+                                                 const int* __restrict__ src_len, T* __restrict__ out,
+                                                 int* __restrict__ cif_len, float* __restrict__ delays,
+                                                 float* __restrict__ tail_w, float* __restrict__ alpha_sum, int S,
+                                                 int C, int T_cap, float beta, float tail_thres) {
+  extern __shared__ float sm[];
+  float* lw = sm;                    // [S] left weight
+  float* rw = sm + S;                // [S] right weight
+  int* li = (int*)(sm + 2 * S);      // [S] left slot index
+  int* fn = li + S;                  // [S] fires
+  const int b = blockIdx.y, lane = threadIdx.x;
+  const int len = src_len ? src_len[b] : S;
+  const float* al = alpha + (long)b * S;
+  float carry = 0.f;
+  int prev_right = 0;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const float a = (s < S && s < len) ? al[s] : 0.f;
+    const float cs = carry + wave_scan_incl(a, lane);
+    const int ri = (int)floorf(cs / beta);
+    int left = __shfl_up(ri, 1, 64);
+    if (lane == 0) left = prev_right;
+    const int fires = ri - left;
+    const float r_w = fires > 0 ? cs - (float)ri * beta : 0.f;
+    const float l_w = a - r_w - (float)max(fires - 1, 0) * beta;
+    if (s < S) { lw[s] = l_w; rw[s] = r_w; li[s] = left; fn[s] = fires; }
+    carry = __shfl(cs, 63, 64);
+    prev_right = __shfl(ri, 63, 64);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float total = carry;
+  int n_full = (int)floorf(total / beta);      // feat_lengths before the tail decision
+  // phase 2
+  const int c = blockIdx.x * 64 + lane;
+  const bool cin = c < C;
+  const T* xb = x + (long)b * S * C;
+  T* ob = out + (long)b * T_cap * C;
+  float acc = 0.f, dacc = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float xv = cin ? to_f32(xb[(long)s * C + c]) : 0.f;
+    const float pos = (float)(s + 1);
+    acc = fmaf(lw[s], xv, acc);
+    dacc += lw[s] * pos / beta;
+    const int f = fn[s];
+    if (f > 0) {
+      int slot = li[s];
+      if (slot < T_cap) {
+        if (cin) ob[(long)slot * C + c] = from_f32<T>(acc);
+        if (blockIdx.x == 0 && lane == 0) delays[(long)b * T_cap + slot] = dacc;
+      }
+      for (int e = 1; e < f; ++e) {            // whole-beta slots (alpha > beta)
+        ++slot;
+        if (slot < T_cap) {
+          if (cin) ob[(long)slot * C + c] = from_f32<T>(xv * beta);
+          if (blockIdx.x == 0 && lane == 0) delays[(long)b * T_cap + slot] = pos;
+        }
+      }
+      acc = rw[s] * xv;
+      dacc = rw[s] * pos / beta;
+    }
+  }
+  // tail: leftover weight in slot n_full
+  const float tw = total - (float)n_full * beta;
+  // the reference sums the contributions that landed in slot n_full; that is acc's weight.
+  // Recompute it from the per-frame weights for bit-for-bit agreement of the threshold test.
+  float twsum = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    float v = 0.f;
+    if (fn[s] > 0 && li[s] + fn[s] == n_full) v += rw[s];
+    if (li[s] == n_full) v += lw[s];
+    twsum += v;
+  }
+  twsum = wave_sum(twsum);
+  (void)tw;
+  const bool extend = twsum >= tail_thres;
+  int n_out = n_full;
+  if (extend) {
+    if (n_full < T_cap) {
+      if (cin) ob[(long)n_full * C + c] = from_f32<T>(acc * (beta / twsum));
+      if (blockIdx.x == 0 && lane == 0) delays[(long)b * T_cap + n_full] = dacc;
+    }
+    n_out = n_full + 1;
+  }
+  for (int t = min(n_out, T_cap); t < T_cap; ++t) {
+    if (cin) ob[(long)t * C + c] = from_f32<T>(0.f);
+    if (blockIdx.x == 0 && lane == 0) delays[(long)b * T_cap + t] = 0.f;
+  }
+  if (blockIdx.x == 0 && lane == 0) {
+    cif_len[b] = n_out;
+    tail_w[b] = twsum;
+    alpha_sum[b] = total;
+  }
+}
+
+// alpha head: alpha[r] = sigmoid(w . gelu(LN(h[r])) + b)  (cif_transformer.py:124-130 minus the conv)
+template <typename T>
+__global__ __launch_bounds__(256) void cif_alpha_head_kernel(const T* __restrict__ H_, const float* __restrict__ g,
+                                                             const float* __restrict__ bt,
+                                                             const T* __restrict__ w, float bias,
+                                                             float* __restrict__ alpha, long rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const T* x = H_ + r * D;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += to_f32(x[c]);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int c = lane; c < D; c += 64) { float dd = to_f32(x[c]) - mean; q += dd * dd; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+  float acc = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    float v = (to_f32(x[c]) - mean) * rstd * g[c] + bt[c];
+    acc = fmaf(gelu_erf(v), to_f32(w[c]), acc);
+  }
+  acc = wave_sum(acc) + bias;
+  if (lane == 0) alpha[r] = 1.0f / (1.0f + expf(-acc));
+}
+
+}  // namespace
+
+extern "C" int simulst_waitk_p_choose(simulst_handle* h, float* p, const int32_t* key_len, int32_t BH,
+                                      int32_t tgt_len, int32_t tgt_offset, int32_t S, int32_t k, int32_t online) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, p);
+  SL_REQUIRE(h, k > 0 && S > 0 && tgt_len >= 0 && BH >= 0, SIMULST_E_SHAPE, "simulst_waitk_p_choose: shape");
+  if (BH == 0 || tgt_len == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_SCAN);
+  hipLaunchKernelGGL(waitk_p_choose_kernel, dim3(tgt_len, BH), dim3(64), 0, h->stream, p, key_len, tgt_len,
+                     tgt_offset, S, k, online);
+  return sl_launch_status(h, "simulst_waitk_p_choose");
+}
+
+extern "C" int simulst_mma_step_search(simulst_handle* h, const float* p, int64_t* head_step, uint8_t* head_read,
+                                       float* alpha, const int32_t* src_len, int32_t BH, int32_t S,
+                                       int32_t mass_preservation) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, p); SL_CHECK_NULL(h, head_step); SL_CHECK_NULL(h, head_read);
+  SL_REQUIRE(h, S > 0 && BH >= 0, SIMULST_E_SHAPE, "simulst_mma_step_search: shape");
+  if (BH == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_SCAN);
+  hipLaunchKernelGGL(step_search_kernel, dim3((BH + 3) / 4), dim3(256), 0, h->stream, p, (long*)head_step,
+                     head_read, alpha, src_len, BH, S, mass_preservation);
+  return sl_launch_status(h, "simulst_mma_step_search");
+}
+
+extern "C" int simulst_expected_alignment(simulst_handle* h, const float* p, float* alpha, const int32_t* key_len,
+                                          int32_t BH, int32_t U, int32_t S, float eps) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, p); SL_CHECK_NULL(h, alpha);
+  SL_REQUIRE(h, S > 0 && U >= 0 && BH >= 0 && (size_t)4 * S * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE,
+             "simulst_expected_alignment: shape (S <= 4096)");
+  if (BH == 0 || U == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_SCAN);
+  hipLaunchKernelGGL(expected_alignment_kernel, dim3((BH + 3) / 4), dim3(256), 4 * S * sizeof(float), h->stream, p,
+                     alpha, key_len, BH, U, S, eps);
+  return sl_launch_status(h, "simulst_expected_alignment");
+}
+
+extern "C" int simulst_mass_preservation(simulst_handle* h, float* alpha, const int32_t* key_len, int32_t BH,
+                                         int32_t U, int32_t S) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, alpha);
+  SL_REQUIRE(h, S > 0 && U >= 0 && BH >= 0, SIMULST_E_SHAPE, "simulst_mass_preservation: shape");
+  const long rows = (long)BH * U;
+  if (rows == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_SCAN);
+  hipLaunchKernelGGL(mass_preservation_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->stream, alpha,
+                     key_len, (int)rows, U, S);
+  return sl_launch_status(h, "simulst_mass_preservation");
+}
+
+extern "C" int simulst_expected_soft_attention(simulst_handle* h, const float* alpha, const float* energy,
+                                               float* beta, const int32_t* key_len, int32_t BH, int32_t U, int32_t S,
+                                               int32_t chunk_size, float eps) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, alpha); SL_CHECK_NULL(h, energy); SL_CHECK_NULL(h, beta);
+  SL_REQUIRE(h, S > 0 && U >= 0 && BH >= 0 && (size_t)8 * S * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE,
+             "simulst_expected_soft_attention: shape (S <= 2048)");
+  const long rows = (long)BH * U;
+  if (rows == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_SCAN);
+  hipLaunchKernelGGL(soft_attention_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 8 * S * sizeof(float),
+                     h->stream, alpha, energy, beta, key_len, (int)rows, U, S, chunk_size, eps);
+  return sl_launch_status(h, "simulst_expected_soft_attention");
+}
+
+extern "C" int simulst_step_p_choose(simulst_handle* h, const void* q, const void* Kmono, float energy_bias,
+                                     const int32_t* key_len, float* p, int32_t B, int32_t S_cap, int32_t H,
+                                     int32_t d, int32_t ratio, int32_t incremental, int32_t attn_type,
+                                     int32_t waitk_k, const int32_t* tgt_idx, int32_t online, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, p);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_step_p_choose: dtype");
+  SL_REQUIRE(h, attn_type >= SIMULST_ATTN_HARD && attn_type <= SIMULST_ATTN_CHUNKWISE, SIMULST_E_ARG,
+             "simulst_step_p_choose: attn_type");
+  if (attn_type == SIMULST_ATTN_WAITK) { SL_CHECK_NULL(h, tgt_idx); SL_REQUIRE(h, waitk_k > 0, SIMULST_E_ARG, "simulst_step_p_choose: waitk lagging"); }
+  else { SL_CHECK_NULL(h, q); SL_CHECK_NULL(h, Kmono); }
+  SL_REQUIRE(h, ratio >= 1 && S_cap > 0 && H > 0 && d > 0 && d <= 64 && S_cap <= 4096, SIMULST_E_SHAPE,
+             "simulst_step_p_choose: shape (head_dim <= 64, S_cap <= 4096)");
+  if (B <= 0) return SIMULST_OK;
+  const size_t lds = (size_t)4 * S_cap * sizeof(float);
+  KTimer t(h, SIMULST_K_SCAN);
+  if (dtype == SIMULST_F32)
+    hipLaunchKernelGGL(step_p_choose_kernel<float>, dim3(B), dim3(256), lds, h->stream, (const float*)q,
+                       (const float*)Kmono, energy_bias, key_len, p, S_cap, H, d, ratio, incremental, attn_type,
+                       waitk_k, tgt_idx, online);
+  else
+    hipLaunchKernelGGL(step_p_choose_kernel<bf16>, dim3(B), dim3(256), lds, h->stream, (const bf16*)q,
+                       (const bf16*)Kmono, energy_bias, key_len, p, S_cap, H, d, ratio, incremental, attn_type,
+                       waitk_k, tgt_idx, online);
+  return sl_launch_status(h, "simulst_step_p_choose");
+}
+
+extern "C" int simulst_cif_integrate(simulst_handle* h, const void* x, const float* alpha, const int32_t* src_len,
+                                     void* out, int32_t* cif_len, float* delays, float* tail_w, float* alpha_sum,
+                                     int32_t B, int32_t S, int32_t C, int32_t T_cap, float beta, float tail_thres,
+                                     int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, alpha); SL_CHECK_NULL(h, out); SL_CHECK_NULL(h, cif_len);
+  SL_CHECK_NULL(h, delays); SL_CHECK_NULL(h, tail_w); SL_CHECK_NULL(h, alpha_sum);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_cif_integrate: dtype");
+  SL_REQUIRE(h, S > 0 && C > 0 && T_cap > 0 && beta > 0.f, SIMULST_E_SHAPE, "simulst_cif_integrate: shape");
+  SL_REQUIRE(h, (size_t)4 * S * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE, "simulst_cif_integrate: S <= 4096");
+  if (B <= 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_SCAN);
+  dim3 grid((C + 63) / 64, B);
+  const size_t lds = (size_t)4 * S * sizeof(float);
+  if (dtype == SIMULST_F32)
+    hipLaunchKernelGGL(cif_kernel<float>, grid, dim3(64), lds, h->stream, (const float*)x, alpha, src_len, (float*)out,
+                       cif_len, delays, tail_w, alpha_sum, S, C, T_cap, beta, tail_thres);
+  else
+    hipLaunchKernelGGL(cif_kernel<bf16>, grid, dim3(64), lds, h->stream, (const bf16*)x, alpha, src_len, (bf16*)out,
+                       cif_len, delays, tail_w, alpha_sum, S, C, T_cap, beta, tail_thres);
+  return sl_launch_status(h, "simulst_cif_integrate");
+}
+
+extern "C" int simulst_cif_alpha_head(simulst_handle* h, const void* hidden, const float* gamma, const float* beta_ln,
+                                      const void* w, float bias, float* alpha, int64_t rows, int32_t D, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, hidden); SL_CHECK_NULL(h, gamma); SL_CHECK_NULL(h, beta_ln); SL_CHECK_NULL(h, w); SL_CHECK_NULL(h, alpha);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_cif_alpha_head: dtype");
+  if (rows <= 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_SCAN);
+  if (dtype == SIMULST_F32)
+    hipLaunchKernelGGL(cif_alpha_head_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->stream,
+                       (const float*)hidden, gamma, beta_ln, (const float*)w, bias, alpha, (long)rows, D);
+  else
+    hipLaunchKernelGGL(cif_alpha_head_kernel<bf16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, h->stream,
+                       (const bf16*)hidden, gamma, beta_ln, (const bf16*)w, bias, alpha, (long)rows, D);
+  return sl_launch_status(h, "simulst_cif_alpha_head");
+}

@@ -1,0 +1,215 @@
+"""S2TEmformerEncoder on MI355X: host-side mirror of models/s2t_emformer.py.
+
+Same constructor inputs (a ModelConfig carrying the reference's flags), same
+methods (`forward`, `infer`, `conv_layer_stride`) and the same output dict
+(`encoder_out` [T x B x C], `encoder_padding_mask` [B x T], `encoder_states`,
+`ctc_logits`), but every tensor op is a HIP kernel from libsimulst_hip.so:
+
+  fbank [B,T,80] --causal conv k5 s2 + GLU (MFMA, overlapping-row GEMM)--> [B,T/2,512]
+        --causal conv k5 s2 + GLU, * sqrt(D)--> [B,T/4,D] --conv-pos + mask--> x
+  12 x { prenorm+summaries -> fused QKV GEMM -> block attention -> out-proj(+residual,
+         tanh memories) -> LN -> FFN1+GELU -> FFN2+residual } -> final LN
+
+Data layout in HBM (batch-major, channel-last, one dtype per model: fp32 or bf16):
+  X   [B][n_rc + T][D]                 layer activations: right-context block rows, then utterance rows
+  Z   [B][n_mem + n_rc + T + n_sum][D] normed rows + memory rows in front + summary rows behind, so the
+                                       K/V input [mem|rc|utt] and the Q input [rc|utt|sum] of
+                                       torchaudio_models/emformer.py:163-167 are two overlapping row
+                                       windows of ONE buffer and QKV is ONE GEMM
+  QKV [B][rows(Z)][3D], CTX [B][n_rc+T+n_sum][D]
+Ragged batches keep per-utterance semantics (= the reference at B == 1, which is also what
+the reference computes for the valid frames of a padded batch).
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .config import ModelConfig
+from .ops import Ops, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_EMF_OUT
+
+
+def prepack_glu_conv(weight: torch.Tensor, bias: torch.Tensor):
+    """Conv1d weight [C_out, C_in, k] -> GEMM weight [C_out, k*C_in] with rows permuted into
+    64-row blocks [32 value rows | 32 gate rows] (GLU pairs channel c with c + C_out/2,
+    modules/causal_conv.py:152)."""
+    C_out, C_in, k = weight.shape
+    half = C_out // 2
+    assert half % 32 == 0, "GLU prepack needs C_out/2 to be a multiple of 32"
+    w = weight.permute(0, 2, 1).reshape(C_out, k * C_in)
+    idx = torch.arange(half).view(-1, 32)
+    perm = torch.cat([idx, idx + half], dim=1).reshape(-1)
+    return w[perm].contiguous(), bias[perm].contiguous()
+
+
+class EncoderWeights:
+    """Device copies of the encoder parameters, re-laid out once for the kernels."""
+
+    def __init__(self, w: Dict[str, torch.Tensor], cfg: ModelConfig, device, dtype, prefix="encoder"):
+        f32 = dict(device=device, dtype=torch.float32)
+        act = dict(device=device, dtype=dtype)
+        p = prefix
+        self.conv = []
+        for i, k in enumerate(cfg.conv_kernel_sizes):
+            wp, bp = prepack_glu_conv(w[f"{p}.subsample.conv_layers.{i}.weight"].float(),
+                                      w[f"{p}.subsample.conv_layers.{i}.bias"].float())
+            self.conv.append((wp.to(**act), bp.to(**f32), k))
+        g, v = w[f"{p}.embed_positions.conv.weight_g"].float(), w[f"{p}.embed_positions.conv.weight_v"].float()
+        # weight_norm(dim=2) folded once (models/s2t_transformer.py:120)
+        wpos = v * (g / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        self.pos_w = wpos.contiguous().to(**act)
+        self.pos_b = w[f"{p}.embed_positions.conv.bias"].float().to(**f32)
+        self.layers = []
+        for l in range(cfg.encoder_layers):
+            lp = f"{p}.emformer_blocks.emformer_layers.{l}"
+            L = {}
+            L["wqkv"] = torch.cat([w[lp + ".attention.emb_to_query.weight"],
+                                   w[lp + ".attention.emb_to_key_value.weight"]], 0).contiguous().to(**act)
+            L["bqkv"] = torch.cat([w[lp + ".attention.emb_to_query.bias"],
+                                   w[lp + ".attention.emb_to_key_value.bias"]], 0).float().to(**f32)
+            L["wo"] = w[lp + ".attention.out_proj.weight"].contiguous().to(**act)
+            L["bo"] = w[lp + ".attention.out_proj.bias"].float().to(**f32)
+            L["ln_in_g"] = w[lp + ".layer_norm_input.weight"].float().to(**f32)
+            L["ln_in_b"] = w[lp + ".layer_norm_input.bias"].float().to(**f32)
+            L["ln_ff_g"] = w[lp + ".pos_ff.0.weight"].float().to(**f32)
+            L["ln_ff_b"] = w[lp + ".pos_ff.0.bias"].float().to(**f32)
+            L["w1"] = w[lp + ".pos_ff.1.weight"].contiguous().to(**act)
+            L["b1"] = w[lp + ".pos_ff.1.bias"].float().to(**f32)
+            L["w2"] = w[lp + ".pos_ff.4.weight"].contiguous().to(**act)
+            L["b2"] = w[lp + ".pos_ff.4.bias"].float().to(**f32)
+            self.layers.append(L)
+        self.final_g = w[f"{p}.emformer_blocks.final_layer_norm.weight"].float().to(**f32)
+        self.final_b = w[f"{p}.emformer_blocks.final_layer_norm.bias"].float().to(**f32)
+        self.ctc = w[f"{p}.ctc_layer.weight"].contiguous().to(**act) if f"{p}.ctc_layer.weight" in w else None
+
+
+class S2TEmformerEncoder:
+    """Mirror of models/s2t_emformer.py:S2TEmformerEncoder (inference only)."""
+
+    def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda", dtype=torch.float32,
+                 ops: Optional[Ops] = None, prefix="encoder"):
+        assert cfg.tanh_on_mem, "only --tanh-on-mem memories are implemented (arch default, s2t_emformer.py:410)"
+        self.cfg = cfg
+        self.device, self.dtype = torch.device(device), dtype
+        self.ops = ops or Ops()
+        self.w = EncoderWeights(weights, cfg, self.device, dtype, prefix)
+        self.embed_dim = cfg.embed_dim
+        self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(cfg.embed_dim)
+        # same public attributes the agent reads (agents/default_agent.py:163-165)
+        self.stride = cfg.stride
+        self.left_context, self.right_context, self.segment_length = cfg.Lc, cfg.R, cfg.S
+        self.max_memory_size = cfg.M
+
+    def conv_layer_stride(self):
+        return self.stride
+
+    # ---------------------------------------------------------------- front-end
+    @staticmethod
+    def out_lengths(lengths: torch.Tensor, n_layers: int) -> torch.Tensor:
+        """CausalConv1dSubsampler.get_out_seq_lens_tensor (modules/causal_conv.py:133-138)."""
+        out = lengths.clone()
+        for _ in range(n_layers):
+            out = torch.div(out - 1, 2, rounding_mode="floor") + 1
+        return out.clamp(min=0)
+
+    def _subsample(self, x: torch.Tensor, lead: bool) -> torch.Tensor:
+        """x [B,T,C] channel-last. lead=True: zero left padding (utterance start, a_lead);
+        lead=False: x already carries k-1 context frames in front."""
+        ops = self.ops
+        n = len(self.w.conv)
+        for i, (wp, bp, k) in enumerate(self.w.conv):
+            B, T, Cin = x.shape
+            N = wp.shape[0]
+            T_out = ((T - 1) // 2 + 1) if lead else ((T - k) // 2 + 1)
+            y = torch.empty(B, max(T_out, 0), N // 2, device=x.device, dtype=x.dtype)
+            if T_out > 0:
+                ops.linear_raw(x, wp, bp, y, M_batches=B, rows_per_batch=T_out, N=N, K=k * Cin,
+                               a_bs=T * Cin, a_rs=2 * Cin, a_lead=(k - 1) * Cin if lead else 0,
+                               c_bs=T_out * (N // 2), c_rs=N // 2, epilogue=_lib.EPI_GLU,
+                               scale=self.embed_scale if i == n - 1 else 1.0)
+            x = y
+        return x
+
+    # ---------------------------------------------------------------- Emformer
+    def _rc_index(self, T: int, device):
+        """Row gather for the right-context blocks (Emformer._gen_right_context,
+        torchaudio_models/emformer.py:700-709) over an input extended by one all-zero row T."""
+        S, R = self.cfg.S, self.cfg.R
+        N = math.ceil(T / S)
+        idx = torch.full((N * R,), T, dtype=torch.long)
+        for i in range(N - 1):
+            for r in range(R):
+                t = (i + 1) * S + r
+                if t < T:
+                    idx[i * R + r] = t
+        return idx.to(device), N
+
+    def _emformer_layers(self, X, lengths_i32, T, N, mems0):
+        """X [B][N*R + T][D] activations; mems0 [B][N-1][D] first-layer memory. Returns X_out."""
+        cfg, ops, W = self.cfg, self.ops, self.w
+        B, _, D = X.shape
+        R, S = cfg.R, cfg.S
+        use_mem = cfg.M > 0
+        n_mem = (N - 1) if use_mem else 0
+        n_rc, n_sum = N * R, (N if use_mem else 0)
+        rows_z = n_mem + n_rc + T + n_sum
+        rows_c = n_rc + T + n_sum
+        rows_x = n_rc + T
+        Za = torch.zeros(B, rows_z, D, device=X.device, dtype=X.dtype)
+        Zb = torch.zeros_like(Za)
+        if n_mem > 0:
+            Za[:, :n_mem] = mems0
+        QKV = torch.empty(B, rows_z, 3 * D, device=X.device, dtype=X.dtype)
+        CTX = torch.zeros(B, rows_c, D, device=X.device, dtype=X.dtype)
+        X1 = torch.empty_like(X)
+        Y = torch.empty_like(X)
+        Hf = torch.empty(B * rows_x, cfg.ffn_dim, device=X.device, dtype=X.dtype)
+        states = []
+        for l, L in enumerate(W.layers):
+            Z, Zn = (Za, Zb) if l % 2 == 0 else (Zb, Za)
+            ops.emformer_prenorm(X, L["ln_in_g"], L["ln_in_b"], lengths_i32, Z, T=T, n_mem=n_mem, n_rc=n_rc,
+                                 n_sum=n_sum, seg_len=S)
+            ops.linear(Z.view(B * rows_z, D), L["wqkv"], L["bqkv"], out=QKV.view(B * rows_z, 3 * D))
+            ops.emformer_attention(QKV, lengths_i32, CTX, B=B, T=T, D=D, H=cfg.num_heads, S=S, R=R, Lc=cfg.Lc,
+                                   M=cfg.M, n_mem=n_mem, n_seg=N, use_summary=use_mem)
+            ops.linear_raw(CTX, L["wo"], L["bo"], X1, M_batches=B, rows_per_batch=rows_c, N=D, K=D,
+                           a_bs=rows_c * D, a_rs=D, c_bs=rows_x * D, c_rs=D, epilogue=EPI_EMF_OUT, R=X,
+                           r_bs=rows_x * D, r_rs=D, n_main=rows_x, aux=Zn, aux_rows=n_mem, aux_bs=rows_z * D)
+            ops.layernorm(X1, L["ln_ff_g"], L["ln_ff_b"], out=Y)
+            ops.linear(Y.view(B * rows_x, D), L["w1"], L["b1"], epilogue=EPI_BIAS_GELU, out=Hf)
+            ops.linear(Hf, L["w2"], L["b2"], epilogue=EPI_BIAS_RES, residual=X1.view(B * rows_x, D),
+                       out=X.view(B * rows_x, D))
+            states.append(None)
+        return X
+
+    def forward(self, src_tokens: torch.Tensor, src_lengths: torch.Tensor):
+        """S2TEmformerEncoder._forward (models/s2t_emformer.py:125-177), eval mode.
+        src_tokens [B,T,80] on device (self.dtype), src_lengths [B] int64."""
+        cfg, ops = self.cfg, self.ops
+        src_tokens = src_tokens.to(self.dtype).contiguous()
+        B = src_tokens.size(0)
+        x = self._subsample(src_tokens, lead=True)                    # [B,Te,D], scaled
+        enc_len = self.out_lengths(src_lengths, len(self.w.conv))
+        Te = x.size(1)
+        len_i32 = enc_len.to(torch.int32)
+        x = ops.conv_pos(x, None, self.w.pos_w, self.w.pos_b, len_i32, cfg.conv_pos_groups)
+        D, R, S = cfg.embed_dim, cfg.R, cfg.S
+        idx, N = self._rc_index(Te, x.device)
+        xz = torch.cat([x, x.new_zeros(B, 1, D)], dim=1)
+        X = torch.cat([xz.index_select(1, idx), x], dim=1).contiguous()     # [rc blocks | utterance]
+        mems0 = None
+        if cfg.M > 0 and N > 1:
+            mems0 = torch.empty(B, N - 1, D, device=x.device, dtype=x.dtype)
+            ops.segment_mean(x, len_i32, mems0, T=Te, x_bs=Te * D, o_bs=(N - 1) * D, seg_len=S, n_out=N - 1)
+        X = self._emformer_layers(X, len_i32, Te, N, mems0)
+        # final LayerNorm (rows are independent: norm every row, return the utterance rows as a view)
+        Yall = ops.layernorm(X, self.w.final_g, self.w.final_b)
+        out = Yall[:, N * R:]                                          # [B,Te,D], batch stride (N*R+Te)*D
+        pad = torch.arange(Te, device=x.device).unsqueeze(0) >= enc_len.to(x.device).unsqueeze(1)
+        res = {"encoder_out": [out.transpose(0, 1)], "encoder_padding_mask": [pad], "encoder_embedding": [],
+               "encoder_states": [], "src_tokens": [], "src_lengths": [], "ctc_logits": [],
+               "encoder_out_btd": out, "encoder_lengths": enc_len}
+        if self.w.ctc is not None:
+            res["ctc_logits"] = [ops.linear(out.reshape(B * Te, D), self.w.ctc).view(B, Te, -1)]
+        return res

@@ -1,0 +1,245 @@
+"""Tensor-level wrappers over the C ABI: validate torch-ROCm tensors, pass data_ptr()s.
+
+PyTorch is plumbing here (device memory + the current stream); every op below
+runs a hand-written HIP kernel from libsimulst_hip.so.  No fallbacks.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ATTN_ENUM, BF16, EPI_BIAS, EPI_BIAS_F32OUT, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_EMF_OUT,
+                   EPI_GLU, F32, EmfAttnDesc, LinearDesc)
+
+_vp = C.c_void_p
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"simulst_amd: unsupported dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return _vp(0)
+    if not t.is_cuda:
+        raise RuntimeError("simulst_amd: tensors must live on the HIP device (no CPU fallback)")
+    return _vp(t.data_ptr())
+
+
+def _chk_contig(*ts):
+    for t in ts:
+        if t is not None and not t.is_contiguous():
+            raise ValueError("simulst_amd: tensor must be contiguous")
+
+
+class Ops:
+    """All kernels, bound to one Handle (one HIP stream)."""
+
+    def __init__(self, handle: Optional[_lib.Handle] = None):
+        self.h = handle or _lib.Handle()
+        self.lib = self.h.lib
+
+    # ------------------------------------------------------------------ dense
+    def linear_raw(self, A, W, bias, C_out, *, M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead=0,
+                   c_bs, c_rs, epilogue=EPI_BIAS, R=None, r_bs=0, r_rs=0, scale=1.0, n_main=0, aux=None,
+                   aux_rows=0, aux_bs=0):
+        d = LinearDesc(M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead, c_bs, c_rs, r_bs, r_rs,
+                       epilogue, dt(A), scale, n_main, aux_rows, aux_bs)
+        self.h.check(self.lib.simulst_linear(self.h.ptr, C.byref(d), _p(A), _p(W), _p(bias), _p(R), _p(C_out),
+                                             _p(aux)), "simulst_linear")
+        return C_out
+
+    def linear(self, x, W, bias=None, *, epilogue=EPI_BIAS, residual=None, out=None):
+        """y[rows, N] = epi(x[rows, K] @ W[N, K]^T + bias). x 2-D contiguous."""
+        _chk_contig(x, W, residual, out)
+        rows, K = x.shape
+        N = W.shape[0]
+        assert W.shape[1] == K
+        if out is None:
+            odt = torch.float32 if epilogue == EPI_BIAS_F32OUT else x.dtype
+            out = torch.empty(rows, N, device=x.device, dtype=odt)
+        return self.linear_raw(x, W, bias, out, M_batches=1, rows_per_batch=rows, N=N, K=K, a_bs=0, a_rs=K,
+                               c_bs=0, c_rs=N, epilogue=epilogue, R=residual, r_bs=0, r_rs=N)
+
+    def causal_conv1d_glu(self, x, Wp, bp, *, ksize, stride, scale=1.0, out=None):
+        """Strided causal Conv1d + GLU over channel-last frames.
+        x [B, T_in, C_in] whose first (ksize-1) frames are LEFT CONTEXT (zeros at utterance start,
+        the cached tail when streaming); Wp [2*C_out prepacked][ksize*C_in]; output
+        [B, (T_in-(ksize-1))//stride ... ] frames t_out -> input window ending at frame
+        (ksize-1) + stride*t_out ... see subsampler() for the framing."""
+        _chk_contig(x, Wp, out)
+        B, T_in, Cin = x.shape
+        N = Wp.shape[0]
+        T_out = (T_in - ksize) // stride + 1
+        if out is None:
+            out = torch.empty(B, T_out, N // 2, device=x.device, dtype=x.dtype)
+        if T_out <= 0:
+            return out
+        return self.linear_raw(x, Wp, bp, out, M_batches=B, rows_per_batch=T_out, N=N, K=ksize * Cin,
+                               a_bs=T_in * Cin, a_rs=stride * Cin, a_lead=0, c_bs=T_out * (N // 2),
+                               c_rs=N // 2, epilogue=EPI_GLU, scale=scale)
+
+    # ------------------------------------------------------------------ row ops
+    def layernorm(self, x, gamma, beta, out=None):
+        _chk_contig(x, out)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        if out is None:
+            out = torch.empty_like(x)
+        self.h.check(self.lib.simulst_layernorm(self.h.ptr, _p(x), _p(gamma), _p(beta), _p(out), rows, D, D, D,
+                                                dt(x)), "simulst_layernorm")
+        return out
+
+    def emformer_prenorm(self, X, gamma, beta, lengths, Z, *, T, n_mem, n_rc, n_sum, seg_len):
+        B, _, D = X.shape
+        self.h.check(self.lib.simulst_emformer_prenorm(self.h.ptr, _p(X), _p(gamma), _p(beta), _p(lengths), _p(Z),
+                                                       B, T, D, n_mem, n_rc, n_sum, seg_len, dt(X)),
+                     "simulst_emformer_prenorm")
+        return Z
+
+    def segment_mean(self, X, lengths, out, *, T, x_bs, o_bs, seg_len, n_out):
+        B = out.shape[0]
+        D = out.shape[-1]
+        self.h.check(self.lib.simulst_segment_mean(self.h.ptr, _p(X), _p(lengths), _p(out), B, T, D, x_bs, o_bs,
+                                                   seg_len, n_out, dt(out)), "simulst_segment_mean")
+        return out
+
+    def conv_pos(self, x, hist, W, bias, lengths, groups, out=None):
+        _chk_contig(x, hist, W, out)
+        B, T, D = x.shape
+        k = W.shape[2]
+        if out is None:
+            out = torch.empty_like(x)
+        self.h.check(self.lib.simulst_conv_pos(self.h.ptr, _p(x), _p(hist), _p(W), _p(bias), _p(lengths), _p(out),
+                                               B, T, D, groups, k, dt(x)), "simulst_conv_pos")
+        return out
+
+    def emformer_attention(self, QKV, lengths, CTX, *, B, T, D, H, S, R, Lc, M, n_mem, n_seg, use_summary,
+                           lc_k=None, lc_v=None, lc_valid=None, n_mem_valid=None):
+        d = EmfAttnDesc(B, T, D, H, S, R, Lc, M, n_mem, n_seg, int(use_summary), dt(QKV))
+        self.h.check(self.lib.simulst_emformer_attention(self.h.ptr, C.byref(d), _p(QKV), _p(lengths), _p(lc_k),
+                                                         _p(lc_v), _p(lc_valid), _p(n_mem_valid), _p(CTX)),
+                     "simulst_emformer_attention")
+        return CTX
+
+    # ------------------------------------------------------------------ scans
+    def waitk_p_choose(self, BH, tgt_len, S, k, *, key_len=None, tgt_offset=0, online=False, device="cuda"):
+        p = torch.empty(BH, tgt_len, S, device=device, dtype=torch.float32)
+        self.h.check(self.lib.simulst_waitk_p_choose(self.h.ptr, _p(p), _p(key_len), BH, tgt_len, tgt_offset, S, k,
+                                                     int(online)), "simulst_waitk_p_choose")
+        return p
+
+    def mma_step_search(self, p, head_step, *, src_len=None, mass_preservation=True, want_alpha=True):
+        """p [BH,S] fp32; head_step [BH] int64 updated IN PLACE. -> head_read uint8 [BH], alpha."""
+        _chk_contig(p, head_step)
+        BH, S = p.shape
+        head_read = torch.empty(BH, device=p.device, dtype=torch.uint8)
+        alpha = torch.empty(BH, S, device=p.device, dtype=torch.float32) if want_alpha else None
+        self.h.check(self.lib.simulst_mma_step_search(self.h.ptr, _p(p), _p(head_step), _p(head_read), _p(alpha),
+                                                      _p(src_len), BH, S, int(mass_preservation)),
+                     "simulst_mma_step_search")
+        return head_read, alpha
+
+    def expected_alignment(self, p, key_len=None, eps=1e-6):
+        _chk_contig(p)
+        BH, U, S = p.shape
+        alpha = torch.empty_like(p)
+        self.h.check(self.lib.simulst_expected_alignment(self.h.ptr, _p(p), _p(alpha), _p(key_len), BH, U, S, eps),
+                     "simulst_expected_alignment")
+        return alpha
+
+    def mass_preservation(self, alpha, key_len=None):
+        _chk_contig(alpha)
+        BH, U, S = alpha.shape
+        self.h.check(self.lib.simulst_mass_preservation(self.h.ptr, _p(alpha), _p(key_len), BH, U, S),
+                     "simulst_mass_preservation")
+        return alpha
+
+    def expected_soft_attention(self, alpha, energy, key_len=None, chunk_size=None, eps=1e-10):
+        _chk_contig(alpha, energy)
+        BH, U, S = alpha.shape
+        beta = torch.empty_like(alpha)
+        self.h.check(self.lib.simulst_expected_soft_attention(self.h.ptr, _p(alpha), _p(energy), _p(beta),
+                                                              _p(key_len), BH, U, S, int(chunk_size or 0), eps),
+                     "simulst_expected_soft_attention")
+        return beta
+
+    def step_p_choose(self, q, Kmono, p, *, B, S_cap, H, d, ratio, incremental, attn_type, key_len=None,
+                      energy_bias=0.0, waitk_k=0, tgt_idx=None, online=False, dtype=None):
+        dd = dtype if dtype is not None else dt(Kmono if Kmono is not None else q)
+        self.h.check(self.lib.simulst_step_p_choose(self.h.ptr, _p(q), _p(Kmono), float(energy_bias), _p(key_len),
+                                                    _p(p), B, S_cap, H, d, ratio, int(incremental), attn_type,
+                                                    waitk_k, _p(tgt_idx), int(online), dd),
+                     "simulst_step_p_choose")
+        return p
+
+    def cif_integrate(self, x, alpha, *, beta, tail_thres, src_len=None, T_cap=None):
+        _chk_contig(x, alpha)
+        B, S, Cc = x.shape
+        if T_cap is None:
+            T_cap = int(S / beta) + 2
+        out = torch.empty(B, T_cap, Cc, device=x.device, dtype=x.dtype)
+        cif_len = torch.empty(B, device=x.device, dtype=torch.int32)
+        delays = torch.empty(B, T_cap, device=x.device, dtype=torch.float32)
+        tail_w = torch.empty(B, device=x.device, dtype=torch.float32)
+        alpha_sum = torch.empty(B, device=x.device, dtype=torch.float32)
+        self.h.check(self.lib.simulst_cif_integrate(self.h.ptr, _p(x), _p(alpha), _p(src_len), _p(out), _p(cif_len),
+                                                    _p(delays), _p(tail_w), _p(alpha_sum), B, S, Cc, T_cap,
+                                                    float(beta), float(tail_thres), dt(x)), "simulst_cif_integrate")
+        return out, cif_len, delays, tail_w, alpha_sum
+
+    def cif_alpha_head(self, hidden, gamma, beta_ln, w, bias):
+        _chk_contig(hidden, w)
+        D = hidden.shape[-1]
+        rows = hidden.numel() // D
+        alpha = torch.empty(hidden.shape[:-1], device=hidden.device, dtype=torch.float32)
+        self.h.check(self.lib.simulst_cif_alpha_head(self.h.ptr, _p(hidden), _p(gamma), _p(beta_ln), _p(w),
+                                                     float(bias), _p(alpha), rows, D, dt(hidden)),
+                     "simulst_cif_alpha_head")
+        return alpha
+
+    # ------------------------------------------------------------------ decoder step
+    def embed_tokens(self, tokens, E, pos_table, pos_row, scale, out=None):
+        B = tokens.shape[0]
+        D = E.shape[1]
+        if out is None:
+            out = torch.empty(B, D, device=E.device, dtype=E.dtype)
+        self.h.check(self.lib.simulst_embed_tokens(self.h.ptr, _p(tokens), _p(E), _p(pos_table), _p(pos_row), _p(out),
+                                                   B, D, float(scale), dt(E)), "simulst_embed_tokens")
+        return out
+
+    def decoder_self_attention(self, qkv, k_cache, v_cache, n_prev, out=None):
+        B, H, cap, d = k_cache.shape
+        if out is None:
+            out = torch.empty(B, H * d, device=qkv.device, dtype=qkv.dtype)
+        self.h.check(self.lib.simulst_decoder_self_attention(self.h.ptr, _p(qkv), _p(k_cache), _p(v_cache),
+                                                             _p(n_prev), _p(out), B, H, d, cap, dt(qkv)),
+                     "simulst_decoder_self_attention")
+        return out
+
+    def decoder_cross_attention(self, q, Kc, Vc, step, *, H, attn_type, mass_preservation, key_len=None,
+                                want_beta=False, out=None):
+        B, S_cap, D = Vc.shape
+        d = D // H
+        if out is None:
+            out = torch.empty(B, D, device=Vc.device, dtype=Vc.dtype)
+        beta = torch.empty(B * H, S_cap, device=Vc.device, dtype=torch.float32) if want_beta else None
+        self.h.check(self.lib.simulst_decoder_cross_attention(self.h.ptr, _p(q), _p(Kc), _p(Vc), _p(step),
+                                                              _p(key_len), _p(out), _p(beta), B, H, d, S_cap,
+                                                              attn_type, int(mass_preservation), dt(Vc)),
+                     "simulst_decoder_cross_attention")
+        return out, beta
+
+    def greedy_argmax(self, logits, *, pad_idx, eos_idx, mask_eos=False, eos_bias=None, out=None):
+        _chk_contig(logits)
+        B, V = logits.shape
+        if out is None:
+            out = torch.empty(B, device=logits.device, dtype=torch.int64)
+        self.h.check(self.lib.simulst_greedy_argmax(self.h.ptr, _p(logits), _p(eos_bias), _p(out), B, V, pad_idx,
+                                                    eos_idx, int(mask_eos)), "simulst_greedy_argmax")
+        return out

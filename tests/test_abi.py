@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads here (no GPU) and exports
+every symbol include/simulst_hip.h declares; argument validation never touches the device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "simulst_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(simulst_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from simulst_amd import _lib
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/simulst_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert lib.simulst_version() >= 100
+
+
+def test_null_handle_and_null_pointer_statuses():
+    from simulst_amd import _lib
+    lib = _lib.load()
+    assert lib.simulst_destroy(None) == -1
+    d = _lib.LinearDesc()
+    assert lib.simulst_linear(None, ctypes.byref(d), None, None, None, None, None, None) == -1
+    h = ctypes.c_void_p()
+    assert lib.simulst_create(ctypes.byref(h), None) == 0
+    assert lib.simulst_linear(h, ctypes.byref(d), None, None, None, None, None, None) == -1
+    assert b"null pointer" in lib.simulst_last_error(h)
+    assert lib.simulst_timer_enable(h, 99, 1) == -4
+    assert lib.simulst_destroy(h) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from simulst_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    """The product package must not route through the CPU oracle (tier rule 3)."""
+    pkg = os.path.join(ROOT, "simulst_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f

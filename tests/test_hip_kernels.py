@@ -1,0 +1,399 @@
+"""Parity of every HIP kernel (called through the C ABI) against the oracle / golden
+vectors.  GPU only (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simulst_amd.ops import Ops
+    return Ops()
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def close(a, b, atol=2e-5, rtol=1e-4):
+    torch.testing.assert_close(a.float().cpu(), b.float().cpu(), atol=atol, rtol=rtol)
+
+
+# ------------------------------------------------------------------ dense contraction
+@pytest.mark.parametrize("rows,K,N", [(1, 32, 32), (64, 256, 256), (64, 256, 4096), (300, 256, 768),
+                                      (1000, 400, 192), (515, 2048, 256), (130, 64, 96)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_bias(ops, rows, K, N, dtype):
+    from simulst_amd import _lib
+    g = torch.Generator().manual_seed(rows * 7 + K + N)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    xd, wd = dev(x, dtype), dev(w, dtype)
+    ref = torch.nn.functional.linear(xd.float().cpu(), wd.float().cpu(), b)
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=2e-2)
+    y = ops.linear(xd, wd, dev(b))
+    close(y, ref, **tol)
+    y = ops.linear(xd, wd, dev(b), epilogue=_lib.EPI_BIAS_GELU)
+    close(y, torch.nn.functional.gelu(ref), **tol)
+    r = torch.randn(rows, N, generator=g)
+    y = ops.linear(xd, wd, dev(b), epilogue=_lib.EPI_BIAS_RES, residual=dev(r, dtype))
+    close(y, ref + dev(r, dtype).float().cpu(), **tol)
+    y = ops.linear(xd, wd, dev(b), epilogue=_lib.EPI_BIAS_F32OUT)
+    assert y.dtype == torch.float32
+    close(y, ref, **(tol if dtype == torch.float32 else dict(atol=1e-3, rtol=1e-3)))
+
+
+def test_linear_a_equals_identity_asymmetric(ops):
+    """A = I with an asymmetric W catches a transposed C write (guide section 3)."""
+    n = 64
+    w = torch.arange(n * n, dtype=torch.float32).view(n, n) / 100.0
+    y = ops.linear(dev(torch.eye(n)), dev(w))
+    close(y, w.t())
+
+
+def test_linear_rejects_bad_args(ops):
+    x = torch.zeros(4, 6, device="cuda")
+    w = torch.zeros(8, 6, device="cuda")
+    with pytest.raises(RuntimeError, match="16-byte"):
+        ops.linear(x, w)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.linear(torch.zeros(4, 8), torch.zeros(8, 8))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_g1_subsampler_as_overlapping_gemm(ops, dtype):
+    """Causal strided Conv1d+GLU x2 == GEMM over overlapping channel-last rows (golden g1)."""
+    from simulst_amd.config import tiny
+    from simulst_amd.encoder import S2TEmformerEncoder
+    a, w = load_golden("g1_subsampler")
+    g11, w11 = load_golden("g11_encoder")
+    wfull = dict(w11)
+    for k, v in w.items():
+        wfull["encoder." + k] = v
+    cfg = tiny(no_scale_embedding=True)
+    enc = S2TEmformerEncoder(cfg, wfull, dtype=dtype, ops=ops)
+    y = enc._subsample(dev(a["x"], dtype), lead=True)           # [B,Te,D]
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=5e-2, rtol=5e-2)
+    ref = a["y"].permute(1, 0, 2)
+    for b, L in enumerate(a["out_lengths"].tolist()):
+        close(y[b, :L], ref[b, :L], **tol)
+    assert torch.equal(enc.out_lengths(a["lengths"], 2), a["out_lengths"])
+
+
+# ------------------------------------------------------------------ row ops
+@pytest.mark.parametrize("D", [32, 256, 1024])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm(ops, D, dtype):
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(77, D, generator=g) * 3 + 1
+    gm, bt = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    xd = dev(x, dtype)
+    ref = torch.nn.functional.layer_norm(xd.float().cpu(), (D,), gm, bt, 1e-5)
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=2e-2)
+    close(ops.layernorm(xd, dev(gm), dev(bt)), ref, **tol)
+
+
+def test_g2_conv_pos(ops):
+    from oracle import causal_conv as occ
+    a, w = load_golden("g2_conv_pos")
+    g = int(a["groups"])
+    wt = occ.weight_norm_weight(w["embed_positions.conv.weight_g"], w["embed_positions.conv.weight_v"])
+    x = a["x"]                                            # [B,C,T]
+    xcl = x.permute(0, 2, 1).contiguous()                 # channel-last
+    lengths = torch.tensor([50, 37], dtype=torch.int32)
+    y = ops.conv_pos(dev(xcl), None, dev(wt.contiguous()), dev(w["embed_positions.conv.bias"]), dev(lengths), g)
+    ref = (x + a["y"]).permute(0, 2, 1)
+    close(y[0], ref[0])
+    close(y[1, :37], ref[1, :37])
+    assert float(y[1, 37:].abs().max()) == 0.0
+    # streaming: history of k-1 frames instead of zero padding
+    k = wt.shape[2]
+    y2 = ops.conv_pos(dev(xcl[:, 20:]), dev(xcl[:, 20 - (k - 1):20].contiguous()), dev(wt.contiguous()),
+                      dev(w["embed_positions.conv.bias"]), None, g)
+    close(y2, ref[:, 20:])
+
+
+@pytest.mark.parametrize("T,S", [(23, 4), (250, 16), (5, 16)])
+def test_prenorm_and_segment_mean(ops, T, S):
+    from oracle import emformer as oem
+    g = torch.Generator().manual_seed(T)
+    B, D, R = 3, 64, 2
+    N = math.ceil(T / S)
+    n_rc, n_mem, n_sum = N * R, N - 1, N
+    X = torch.randn(B, n_rc + T, D, generator=g)
+    gm, bt = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    lengths = torch.tensor([T, max(1, T - 3), max(1, T // 2)], dtype=torch.int32)
+    Z = torch.zeros(B, n_mem + n_rc + T + n_sum, D, device="cuda")
+    ops.emformer_prenorm(dev(X), dev(gm), dev(bt), dev(lengths), Z, T=T, n_mem=n_mem, n_rc=n_rc, n_sum=n_sum,
+                         seg_len=S)
+    ref = torch.nn.functional.layer_norm(X, (D,), gm, bt, 1e-5)
+    close(Z[:, n_mem:n_mem + n_rc + T], ref)
+    for b in range(B):
+        L = int(lengths[b])
+        pooled = oem.avg_pool_ceil(ref[b:b + 1, n_rc:n_rc + L].transpose(0, 1), S)[:, 0]   # ragged semantics
+        close(Z[b, n_mem + n_rc + T:n_mem + n_rc + T + pooled.size(0)], pooled)
+    out = torch.zeros(B, max(N - 1, 1), D, device="cuda")
+    if N > 1:
+        ops.segment_mean(dev(X[:, n_rc:].contiguous()), dev(lengths), out, T=T, x_bs=T * D, o_bs=(N - 1) * D,
+                         seg_len=S, n_out=N - 1)
+        full = oem.avg_pool_ceil(X[:1, n_rc:].transpose(0, 1), S)[:, 0]
+        close(out[0], full[:N - 1])
+
+
+# ------------------------------------------------------------------ encoder (offline) vs golden + oracle
+def test_g11_encoder_forward_golden(ops):
+    from simulst_amd.config import tiny
+    from simulst_amd.encoder import S2TEmformerEncoder
+    a, w = load_golden("g11_encoder")
+    enc = S2TEmformerEncoder(tiny(), w, dtype=torch.float32, ops=ops)
+    out = enc.forward(dev(a["fbank"]), a["lengths"])
+    y = out["encoder_out"][0]                              # [T,B,D]
+    assert torch.equal(out["encoder_padding_mask"][0].cpu(), a["pad_mask"])
+    for b in range(3):
+        L = int((~a["pad_mask"][b]).sum())
+        close(y[:L, b], a["enc_out"][:L, b], atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_forward_full_size_vs_oracle(ops, dtype):
+    """Full s2t_emformer_s dims, ragged batch of 3, T up to 420 frames."""
+    from oracle import emformer as oem
+    from oracle.configs import from_model_config
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.encoder import S2TEmformerEncoder
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=3, decoder_layers=1)
+    w = init_model(cfg, seed=999)
+    if dtype == torch.bfloat16:
+        w = {k: v.to(torch.bfloat16).float() for k, v in w.items()}
+    ecfg, _ = from_model_config(cfg)
+    g = torch.Generator().manual_seed(1000)
+    fb = torch.randn(3, 420, 80, generator=g)
+    L = torch.tensor([420, 333, 131])
+    for b in range(3):
+        fb[b, L[b]:] = 0
+    if dtype == torch.bfloat16:
+        fb = fb.to(torch.bfloat16).float()
+    ref = oem.encoder_forward(w, "encoder", ecfg, fb, L)["encoder_out"][0]
+    enc = S2TEmformerEncoder(cfg, w, dtype=dtype, ops=ops)
+    out = enc.forward(dev(fb, dtype), L)
+    y = out["encoder_out"][0]
+    tol = dict(atol=2e-4, rtol=1e-3) if dtype == torch.float32 else dict(atol=0.15, rtol=0.1)
+    for b in range(3):
+        n = int(out["encoder_lengths"][b])
+        close(y[:n, b], ref[:n, b], **tol)
+
+
+# ------------------------------------------------------------------ scans
+def test_g9_expected_alignment_and_soft_attention(ops):
+    a, _ = load_golden("g9_alignment")
+    p, pm, e = a["p"], a["padmask"], a["energy"]
+    klen = (~pm).sum(1).to(torch.int32)
+    for tag, kl in (("nopad", None), ("pad", klen)):
+        al = ops.expected_alignment(dev(p), None if kl is None else dev(kl), 1e-6)
+        close(al, a[f"alpha.{tag}"], atol=1e-5, rtol=1e-4)
+        amp = ops.mass_preservation(al.clone(), None if kl is None else dev(kl))
+        close(amp, a[f"alpha_mp.{tag}"], atol=1e-5, rtol=1e-4)
+        amp_ref = dev(a[f"alpha_mp.{tag}"])
+        b_il = ops.expected_soft_attention(amp_ref, dev(e), None if kl is None else dev(kl), None, 1e-6)
+        close(b_il, a[f"beta_il.{tag}"], atol=1e-5, rtol=1e-4)
+        b_ck = ops.expected_soft_attention(amp_ref, dev(e), None if kl is None else dev(kl), 3, 1e-6)
+        close(b_ck, a[f"beta_chunk3.{tag}"], atol=1e-5, rtol=1e-4)
+    close(ops.expected_alignment(dev(a["p_extreme"]), None, 1e-6), a["alpha_extreme"], atol=1e-5, rtol=1e-3)
+
+
+def test_expected_alignment_long_rows_vs_oracle(ops):
+    """S > 64 exercises the carried multi-chunk wavefront scan; config-2 shape (1536,110,32) too."""
+    from oracle import monotonic as omo
+    g = torch.Generator().manual_seed(3)
+    for shape in ((5, 9, 250), (1536, 110, 32), (2, 3, 64), (2, 3, 65)):
+        p = torch.sigmoid(torch.randn(*shape, generator=g) * 2)
+        ref = omo.expected_alignment_from_p_choose(p, None, 1e-6)
+        close(ops.expected_alignment(dev(p), None, 1e-6), ref, atol=1e-5, rtol=1e-3)
+
+
+def test_g6_waitk_p_choose_exact(ops):
+    a, _ = load_golden("g6_waitk")
+    for k in (1, 3, 5):
+        for online in (True, False):
+            for pad in (False, True):
+                kl = None
+                if pad:
+                    kl = torch.tensor([9, 9, 6, 6], dtype=torch.int32)
+                for tl in (1, 4, 8):
+                    ref = a[f"k{k}.on{int(online)}.pad{int(pad)}.t{tl}"]       # last row only
+                    p = ops.waitk_p_choose(4, tl, 9, k, key_len=None if kl is None else dev(kl), online=online)
+                    assert torch.equal(p[:, -1:].cpu() > 0.5, ref), (k, online, pad, tl)
+
+
+@pytest.mark.parametrize("mp", [True, False])
+def test_step_search_exact_vs_oracle(ops, mp):
+    from oracle import monotonic as omo
+    g = torch.Generator().manual_seed(11 + int(mp))
+    for S in (1, 7, 64, 65, 250):
+        BH = 37
+        p = torch.rand(BH, S, generator=g)
+        p[::3] *= 0.4                                    # rows that never fire -> forced stop / READ
+        hs = torch.randint(0, S, (BH,), generator=g)
+        lens = torch.randint(1, S + 1, (BH,), generator=g)
+        ns, hr, al = omo.step_search(p, hs, lens, mp)
+        hsd = dev(hs.clone())
+        hr_d, al_d = ops.mma_step_search(dev(p), hsd, src_len=dev(lens.to(torch.int32)), mass_preservation=mp)
+        assert torch.equal(hsd.cpu(), ns), S
+        assert torch.equal(hr_d.cpu().bool(), hr), S
+        assert torch.equal(al_d.cpu(), al), S
+
+
+@pytest.mark.parametrize("name", ["hard_aligned_fixed_pre_decision", "infinite_lookback_fixed_pre_decision",
+                                  "waitk_fixed_pre_decision", "hard_aligned", "waitk"])
+def test_g7_step_p_choose_vs_golden(ops, name):
+    """Fixed pre-decision p_choose for one decode step (pool and k_proj commuted)."""
+    from simulst_amd import _lib
+    a, _ = load_golden("g7_predecision")
+    g10, _ = load_golden("g10_mma_forward")
+    w = split_weights(g10, f"{name}.mp1")
+    H, d, D = 2, 16, 32
+    ratio = 2 if name.endswith("fixed_pre_decision") else 1
+    base = name.replace("_fixed_pre_decision", "")
+    q, keys = a["q"], a["keys"]                            # [1,2,32], [21,2,32]
+    if base != "waitk":
+        qp = torch.nn.functional.linear(q[0], w["q_proj.weight"], w["q_proj.bias"])           # [B,D]
+        km = torch.nn.functional.linear(keys, w["k_proj.weight"], w["k_proj.bias"]).transpose(0, 1).contiguous()
+    for sl in (1, 2, 3, 4, 5, 8, 9, 21):
+        S_cap = 24
+        p = torch.full((2 * H, S_cap), -1.0, device="cuda")
+        kl = torch.tensor([sl, sl], dtype=torch.int32)
+        if base == "waitk":
+            if not name.endswith("fixed_pre_decision"):
+                continue
+            ops.step_p_choose(None, None, p, B=2, S_cap=S_cap, H=H, d=d, ratio=ratio, incremental=True,
+                              attn_type=_lib.ATTN_WAITK, key_len=dev(kl), waitk_k=3,
+                              tgt_idx=dev(torch.zeros(2, dtype=torch.int32)), online=True, dtype=_lib.F32)
+        else:
+            kmp = torch.zeros(2, S_cap, D)
+            kmp[:, :21] = km
+            ops.step_p_choose(dev(qp), dev(kmp), p, B=2, S_cap=S_cap, H=H, d=d, ratio=ratio, incremental=True,
+                              attn_type=_lib.ATTN_ENUM[base], key_len=dev(kl))
+        if name.endswith("fixed_pre_decision"):
+            ref = a[f"{name}.incr.{sl}"][:, 0]             # [BH, sl]
+            close(p[:, :sl], ref, atol=1e-5, rtol=1e-4)
+        assert float(p[:, sl:].abs().max()) == 0.0
+
+
+def test_cif_integrate_vs_oracle(ops):
+    from oracle import cif as ocif
+    g = torch.Generator().manual_seed(21)
+    for (B, S, Cc, beta, thres) in ((2, 37, 32, 1.0, 0.5), (3, 250, 256, 1.0, 0.0), (3, 130, 64, 0.8, 0.4),
+                                    (2, 70, 40, 0.3, 0.15)):
+        x = torch.randn(B, S, Cc, generator=g)
+        al = torch.rand(B, S, generator=g)
+        lens = torch.tensor([S, max(1, S - 5), max(1, S // 2)][:B])
+        for b in range(B):
+            al[b, lens[b]:] = 0
+        out, n, delays, tw, asum = ops.cif_integrate(dev(x), dev(al), beta=beta, tail_thres=thres,
+                                                     src_len=dev(lens.to(torch.int32)))
+        for b in range(B):
+            L = int(lens[b])
+            ref = ocif.cif_function(x[b:b + 1, :L], al[b:b + 1, :L], beta=beta, tail_thres=thres)
+            nb = int(ref["cif_lengths"][0])
+            assert int(n[b]) == nb, (B, S, beta, b)
+            close(out[b, :nb], ref["cif_out"][0][0], atol=1e-4, rtol=1e-3)
+            assert float(out[b, nb:].abs().max()) == 0.0
+            close(delays[b, :nb], ref["delays"][0][0], atol=1e-3, rtol=1e-4)
+            close(tw[b], ref["tail_weights"][0][0], atol=1e-4, rtol=1e-3)
+            close(asum[b], ref["alpha_sum"][0][0], atol=1e-4, rtol=1e-5)
+
+
+def test_cif_known_answer(ops):
+    h = torch.eye(4).unsqueeze(0).cuda()
+    al = torch.tensor([[0.6, 0.7, 0.2, 0.9]]).cuda()
+    out, n, delays, tw, _ = ops.cif_integrate(h, al, beta=1.0, tail_thres=0.5)
+    assert int(n[0]) == 2
+    close(out[0, :2], torch.tensor([[0.6, 0.4, 0, 0], [0, 0.3, 0.2, 0.5]]), atol=1e-6)
+    close(delays[0, :2], torch.tensor([1.4, 3.2]), atol=1e-6)
+    close(tw, torch.tensor([0.4]), atol=1e-6)
+
+
+# ------------------------------------------------------------------ decoder step pieces
+def test_greedy_argmax_ties_and_masks(ops):
+    g = torch.Generator().manual_seed(5)
+    lg = torch.randn(9, 4096, generator=g)
+    lg[0, 7] = lg[0, 100] = 50.0                          # tie -> lowest index
+    lg[1, 1] = 60.0                                       # pad is never chosen
+    lg[2, 2] = 60.0                                       # eos chosen unless masked
+    out = ops.greedy_argmax(dev(lg), pad_idx=1, eos_idx=2)
+    ref = lg.clone()
+    ref[:, 1] = -float("inf")
+    assert torch.equal(out.cpu(), ref.argmax(-1))
+    assert int(out[0]) == 7 and int(out[2]) == 2
+    out = ops.greedy_argmax(dev(lg), pad_idx=1, eos_idx=2, mask_eos=True)
+    ref[:, 2] = -float("inf")
+    assert torch.equal(out.cpu(), ref.argmax(-1))
+    bias = torch.zeros(9)
+    bias[3] = 1000.0
+    out = ops.greedy_argmax(dev(lg), pad_idx=1, eos_idx=2, eos_bias=dev(bias))
+    assert int(out[3]) == 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decoder_self_attention_steps(ops, dtype):
+    g = torch.Generator().manual_seed(8)
+    B, H, d, cap = 5, 4, 64, 130
+    D = H * d
+    kc = torch.zeros(B, H, cap, d, device="cuda", dtype=dtype)
+    vc = torch.zeros_like(kc)
+    n_prev = torch.zeros(B, dtype=torch.int32)
+    ks, vs = [], []
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
+    for step in range(70):
+        qkv = dev(torch.randn(B, 3 * D, generator=g), dtype)
+        ctx = ops.decoder_self_attention(qkv, kc, vc, dev(n_prev))
+        f = qkv.float().cpu()
+        ks.append(f[:, D:2 * D].view(B, H, 1, d))
+        vs.append(f[:, 2 * D:].view(B, H, 1, d))
+        K, V = torch.cat(ks, 2), torch.cat(vs, 2)
+        q = f[:, :D].view(B, H, 1, d) * d ** -0.5
+        ref = (torch.softmax(q @ K.transpose(-1, -2), -1) @ V).view(B, D)
+        close(ctx, ref, **tol)
+        n_prev += 1
+
+
+@pytest.mark.parametrize("attn", ["hard_aligned", "infinite_lookback", "waitk"])
+def test_decoder_cross_attention(ops, attn):
+    from simulst_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    B, H, d, S = 4, 4, 64, 250
+    D = H * d
+    q, Kc, Vc = torch.randn(B, D, generator=g), torch.randn(B, S, D, generator=g), torch.randn(B, S, D, generator=g)
+    lens = torch.tensor([250, 100, 31, 1], dtype=torch.int32)
+    step = torch.stack([torch.randint(0, int(l) + 1, (H,), generator=g) for l in lens]).view(-1)
+    step[0] = 0
+    for mp in (True, False):
+        ctx, beta = ops.decoder_cross_attention(dev(q), dev(Kc), dev(Vc), dev(step), H=H,
+                                                attn_type=_lib.ATTN_ENUM[attn], mass_preservation=mp,
+                                                key_len=dev(lens), want_beta=True)
+        for b in range(B):
+            L = int(lens[b])
+            for h in range(H):
+                st = int(step[b * H + h])
+                v = Vc[b, :L, h * d:(h + 1) * d]
+                if attn == "hard_aligned":
+                    ref = torch.zeros(d) if (not mp and st == L) else v[min(max(st, 0), L - 1)]
+                else:
+                    if st == 0:
+                        ref = torch.zeros(d)
+                    else:
+                        n = min(st, L - 1) + 1
+                        e = (q[b, h * d:(h + 1) * d] * d ** -0.5) @ Kc[b, :n, h * d:(h + 1) * d].t()
+                        pr = torch.softmax(e, -1)
+                        ref = pr @ v[:n]
+                        close(beta[b * H + h, :n], pr, atol=1e-5, rtol=1e-4)
+                close(ctx[b, h * d:(h + 1) * d], ref, atol=1e-4, rtol=1e-3)
