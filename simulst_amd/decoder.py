@@ -1,0 +1,233 @@
+"""MMADecoder on MI355X: host-side mirror of models/mma_model.py (MMADecoderLayer, MMADecoder)
+over fairseq's TransformerDecoder dataflow (in-repo witness models/cif_transformer.py:391-537).
+
+All state lives in device tensors owned by the caller-visible ``incremental_state`` dict
+(the reference keeps it in ``states.dec_incremental_states``, agents/default_agent.py:237-238):
+  self-attention K/V caches [B][H][cap][d] per layer (a READ does not advance ``n_prev``, which is
+  what MMADecoderLayer.prune_incremental_state achieves by popping rows, mma_model.py:34-54),
+  ``head_step`` [B*H] int64 per layer (monotonic buffer), ``n_prev`` [B] int32 = tokens written
+  (= the reference's tgt_len - 1).
+Cross-attention K/V projections of the encoder states are computed ONCE per new encoder frame
+and cached (the reference re-projects the whole source every decode step,
+modules/monotonic_multihead_attention.py:401); results are identical.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .config import ModelConfig
+from .ops import Ops, EPI_BIAS, EPI_BIAS_F32OUT, EPI_BIAS_GELU, EPI_BIAS_RES
+
+
+def sinusoidal_table(n: int, dim: int, padding_idx: int) -> torch.Tensor:
+    """fairseq SinusoidalPositionalEmbedding.get_embedding (external)."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(n, dtype=torch.float).unsqueeze(1) * freq.unsqueeze(0)
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    if dim % 2 == 1:
+        tab = torch.cat([tab, torch.zeros(n, 1)], dim=1)
+    tab[padding_idx] = 0
+    return tab
+
+
+class DecoderWeights:
+    def __init__(self, w: Dict[str, torch.Tensor], cfg: ModelConfig, device, dtype, prefix="decoder"):
+        f32 = dict(device=device, dtype=torch.float32)
+        act = dict(device=device, dtype=dtype)
+        p = prefix
+
+        def W(name):
+            return w[name].contiguous().to(**act)
+
+        def Bv(name):
+            return w[name].float().contiguous().to(**f32)
+
+        self.E = W(f"{p}.embed_tokens.weight")
+        self.out_proj = W(f"{p}.output_projection.weight")
+        self.pos = sinusoidal_table(cfg.max_target_positions + cfg.padding_idx + 2, cfg.embed_dim,
+                                    cfg.padding_idx).to(**f32)
+        self.ln_g, self.ln_b = Bv(f"{p}.layer_norm.weight"), Bv(f"{p}.layer_norm.bias")
+        self.layers = []
+        cif = cfg.model == "cif_transformer"
+        for l in range(cfg.decoder_layers):
+            lp = f"{p}.layers.{l}"
+            L = {}
+            L["wqkv"] = torch.cat([w[f"{lp}.self_attn.{n}.weight"] for n in ("q_proj", "k_proj", "v_proj")],
+                                  0).contiguous().to(**act)
+            L["bqkv"] = torch.cat([w[f"{lp}.self_attn.{n}.bias"] for n in ("q_proj", "k_proj", "v_proj")],
+                                  0).float().to(**f32)
+            L["wo"], L["bo"] = W(f"{lp}.self_attn.out_proj.weight"), Bv(f"{lp}.self_attn.out_proj.bias")
+            for n, key in (("self_attn_layer_norm", "ln1"), ("encoder_attn_layer_norm", "ln2"),
+                           ("final_layer_norm", "ln3")):
+                L[key + "_g"], L[key + "_b"] = Bv(f"{lp}.{n}.weight"), Bv(f"{lp}.{n}.bias")
+            ea = f"{lp}.encoder_attn"
+            if cif:
+                L["c_wq"] = W(f"{ea}.q_proj.weight")
+                L["c_wk"], L["c_bk"] = W(f"{ea}.k_proj.weight"), Bv(f"{ea}.k_proj.bias")
+                L["c_wo"], L["c_bo"] = W(f"{ea}.out_proj.weight"), Bv(f"{ea}.out_proj.bias")
+            else:
+                L["c_wq"], L["c_bq"] = W(f"{ea}.q_proj.weight"), Bv(f"{ea}.q_proj.bias")
+                L["c_wk"], L["c_bk"] = W(f"{ea}.k_proj.weight"), Bv(f"{ea}.k_proj.bias")
+                L["c_wv"], L["c_bv"] = W(f"{ea}.v_proj.weight"), Bv(f"{ea}.v_proj.bias")
+                L["c_wo"], L["c_bo"] = W(f"{ea}.out_proj.weight"), Bv(f"{ea}.out_proj.bias")
+                if cfg.attn_type in ("infinite_lookback", "chunkwise"):
+                    L["c_wq_soft"], L["c_bq_soft"] = W(f"{ea}.q_proj_soft.weight"), Bv(f"{ea}.q_proj_soft.bias")
+                    L["c_wk_soft"], L["c_bk_soft"] = W(f"{ea}.k_proj_soft.weight"), Bv(f"{ea}.k_proj_soft.bias")
+                L["energy_bias"] = float(w[f"{ea}.energy_bias"][0]) if cfg.energy_bias else 0.0
+            L["fc1"], L["b1"] = W(f"{lp}.fc1.weight"), Bv(f"{lp}.fc1.bias")
+            L["fc2"], L["b2"] = W(f"{lp}.fc2.weight"), Bv(f"{lp}.fc2.bias")
+            self.layers.append(L)
+
+
+class DecoderState:
+    """Device-resident incremental state of one hypothesis batch."""
+
+    def __init__(self, cfg: ModelConfig, B: int, cap: int, S_cap: int, device, dtype):
+        H, d, D, Ld = cfg.num_heads, cfg.head_dim, cfg.embed_dim, cfg.decoder_layers
+        self.B, self.cap, self.S_cap = B, cap, S_cap
+        self.k_cache = [torch.zeros(B, H, cap, d, device=device, dtype=dtype) for _ in range(Ld)]
+        self.v_cache = [torch.zeros(B, H, cap, d, device=device, dtype=dtype) for _ in range(Ld)]
+        self.head_step = [torch.zeros(B * H, device=device, dtype=torch.int64) for _ in range(Ld)]
+        self.head_read = [None] * Ld
+        self.n_prev = torch.zeros(B, device=device, dtype=torch.int32)
+        self.n_prev_host = 0                 # lockstep batches: every row has written this many tokens
+        # cached cross-attention projections of the encoder states, per layer
+        self.Kmono = [torch.zeros(B, S_cap, D, device=device, dtype=dtype) for _ in range(Ld)]
+        self.Ksoft = None
+        self.V = [torch.zeros(B, S_cap, D, device=device, dtype=dtype) for _ in range(Ld)]
+        self.enc_len = torch.zeros(B, device=device, dtype=torch.int32)
+        self.enc_len_bh = torch.zeros(B * H, device=device, dtype=torch.int32)
+        self.enc_rows = 0                    # rows of the source already projected (lockstep)
+        self.online = False
+
+
+class MMADecoder:
+    """Mirror of models/mma_model.py:MMADecoder (inference, incremental)."""
+
+    def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda", dtype=torch.float32,
+                 ops: Optional[Ops] = None, prefix="decoder"):
+        self.cfg = cfg
+        self.device, self.dtype = torch.device(device), dtype
+        self.ops = ops or Ops()
+        self.w = DecoderWeights(weights, cfg, self.device, dtype, prefix)
+        self.attn_enum = _lib.ATTN_ENUM[cfg.attn_type]
+        self.soft = cfg.attn_type != "hard_aligned"
+        self.separate_soft = cfg.attn_type in ("infinite_lookback", "chunkwise")
+        self.embed_scale = math.sqrt(cfg.embed_dim)
+
+    # the agent reads decoder.layers[0].encoder_attn.pre_decision_ratio (agents/default_agent.py:157-161)
+    @property
+    def pre_decision_ratio(self):
+        return self.cfg.pre_decision_ratio
+
+    def max_positions(self):
+        return self.cfg.max_target_positions
+
+    def new_state(self, B: int, cap: int = 128, S_cap: int = 256) -> DecoderState:
+        st = DecoderState(self.cfg, B, cap, S_cap, self.device, self.dtype)
+        if self.separate_soft:
+            st.Ksoft = [torch.zeros(B, S_cap, self.cfg.embed_dim, device=self.device, dtype=self.dtype)
+                        for _ in range(self.cfg.decoder_layers)]
+        return st
+
+    # ------------------------------------------------------------------ source side
+    def append_encoder_out(self, st: DecoderState, enc_new: torch.Tensor, enc_len: torch.Tensor):
+        """Project NEW encoder rows (enc_new [B,n,D], any batch stride, rows contiguous) for every layer
+        and append them to the cached cross-attention K/V; enc_len [B] = valid source rows so far."""
+        ops, cfg = self.ops, self.cfg
+        B, n, D = enc_new.shape
+        r0 = st.enc_rows
+        assert r0 + n <= st.S_cap, "source longer than the state's S_cap"
+        if n > 0:
+            a_bs = enc_new.stride(0)
+            assert enc_new.stride(2) == 1 and enc_new.stride(1) == D
+            for l, L in enumerate(self.w.layers):
+                jobs = [(L["c_wk"], L["c_bk"], st.Kmono[l]), (L["c_wv"], L["c_bv"], st.V[l])]
+                if self.separate_soft:
+                    jobs.append((L["c_wk_soft"], L["c_bk_soft"], st.Ksoft[l]))
+                for Wt, bt, dst in jobs:
+                    ops.linear_raw(enc_new, Wt, bt, dst[:, r0:], M_batches=B, rows_per_batch=n, N=D, K=D,
+                                   a_bs=a_bs, a_rs=D, c_bs=st.S_cap * D, c_rs=D, epilogue=EPI_BIAS)
+        st.enc_rows = r0 + n
+        st.enc_len = enc_len.to(device=self.device, dtype=torch.int32)
+        st.enc_len_bh = st.enc_len.repeat_interleave(cfg.num_heads).contiguous()
+
+    # ------------------------------------------------------------------ one decode step
+    def step(self, st: DecoderState, last_tokens: torch.Tensor, stop_on_read: bool = False):
+        """One target position for every row. last_tokens [B] int64 (the newest of [eos]+hyp).
+        Returns (logits [B,V] fp32 or None, action): action 0 = READ (some head of some layer wants
+        more source while ``st.online``; only with stop_on_read, which host-syncs per layer like the
+        reference's head_read.any(), mma_model.py:196-210), 1 = WRITE."""
+        ops, cfg, Wd = self.ops, self.cfg, self.w
+        B, D, H, d = st.B, cfg.embed_dim, cfg.num_heads, cfg.head_dim
+        pos_row = (st.n_prev + (cfg.padding_idx + 1)).contiguous()
+        x = ops.embed_tokens(last_tokens, Wd.E, Wd.pos, pos_row, self.embed_scale)
+        incremental = True
+        for l, L in enumerate(Wd.layers):
+            y = ops.layernorm(x, L["ln1_g"], L["ln1_b"])
+            qkv = ops.linear(y, L["wqkv"], L["bqkv"])
+            ctx = ops.decoder_self_attention(qkv, st.k_cache[l], st.v_cache[l], st.n_prev)
+            x = ops.linear(ctx, L["wo"], L["bo"], epilogue=EPI_BIAS_RES, residual=x)
+            y = ops.layernorm(x, L["ln2_g"], L["ln2_b"])
+            p = torch.empty(B * H, st.S_cap, device=self.device, dtype=torch.float32)
+            q = None
+            if cfg.attn_type == "waitk":
+                ops.step_p_choose(None, None, p, B=B, S_cap=st.S_cap, H=H, d=d, ratio=cfg.pre_decision_ratio,
+                                  incremental=incremental, attn_type=_lib.ATTN_WAITK, key_len=st.enc_len,
+                                  waitk_k=cfg.waitk_lagging, tgt_idx=st.n_prev, online=st.online,
+                                  dtype=_lib.F32)
+                q = ops.linear(y, L["c_wq"], L["c_bq"])            # soft energy shares the monotonic projections
+            else:
+                qm = ops.linear(y, L["c_wq"], L["c_bq"])
+                ops.step_p_choose(qm, st.Kmono[l], p, B=B, S_cap=st.S_cap, H=H, d=d,
+                                  ratio=cfg.pre_decision_ratio, incremental=incremental,
+                                  attn_type=self.attn_enum, key_len=st.enc_len, energy_bias=L["energy_bias"])
+                if self.separate_soft:
+                    q = ops.linear(y, L["c_wq_soft"], L["c_bq_soft"])
+            head_read, _ = ops.mma_step_search(p, st.head_step[l], src_len=st.enc_len_bh,
+                                               mass_preservation=cfg.mass_preservation, want_alpha=False)
+            st.head_read[l] = head_read
+            Ks = st.Ksoft[l] if self.separate_soft else st.Kmono[l]
+            ctx, _ = ops.decoder_cross_attention(q, Ks, st.V[l], st.head_step[l], H=H, attn_type=self.attn_enum,
+                                                 mass_preservation=cfg.mass_preservation, key_len=st.enc_len)
+            x = ops.linear(ctx, L["c_wo"], L["c_bo"], epilogue=EPI_BIAS_RES, residual=x)
+            y = ops.layernorm(x, L["ln3_g"], L["ln3_b"])
+            hdn = ops.linear(y, L["fc1"], L["b1"], epilogue=EPI_BIAS_GELU)
+            x = ops.linear(hdn, L["fc2"], L["b2"], epilogue=EPI_BIAS_RES, residual=x)
+            if stop_on_read and st.online and bool(head_read.any()):
+                return None, 0          # n_prev not advanced == clear_cache(i + 1)
+        y = ops.layernorm(x, Wd.ln_g, Wd.ln_b)
+        logits = ops.linear(y, Wd.out_proj, None, epilogue=EPI_BIAS_F32OUT)
+        return logits, 1
+
+    def commit(self, st: DecoderState):
+        """Advance the target position after a WRITE (the K/V row appended by step() becomes permanent)."""
+        st.n_prev += 1
+        st.n_prev_host += 1
+        assert st.n_prev_host < st.cap, "decoder state capacity exceeded"
+
+    def clear_cache(self, st: DecoderState):
+        """MMADecoder.clear_cache after a completed forward whose token is discarded (force_finish,
+        agents/default_agent.py:426-434): step() never advanced n_prev, so nothing to undo."""
+        return None
+
+    # ------------------------------------------------------------------ offline greedy (generate.py semantics)
+    def greedy_offline(self, enc_btd: torch.Tensor, enc_len: torch.Tensor, n_steps: int, mask_eos: bool = True):
+        """Batched greedy decode with 'online' unset (never READs, mma_model.py:191-193). Tokens stay on
+        the device between steps. Returns tokens [B, n_steps] int64."""
+        cfg, ops = self.cfg, self.ops
+        B, S, D = enc_btd.shape
+        st = self.new_state(B, cap=n_steps + 2, S_cap=max(S, 1))
+        st.online = False
+        self.append_encoder_out(st, enc_btd, enc_len)
+        toks = torch.full((B,), cfg.eos, device=self.device, dtype=torch.int64)
+        out = torch.empty(n_steps, B, device=self.device, dtype=torch.int64)
+        for s in range(n_steps):
+            logits, _ = self.step(st, toks)
+            toks = ops.greedy_argmax(logits, pad_idx=cfg.padding_idx, eos_idx=cfg.eos,
+                                     mask_eos=mask_eos or s == 0, out=out[s])
+            self.commit(st)
+        return out.t().contiguous(), st

@@ -190,7 +190,7 @@ class S2TEmformerEncoder:
         src_tokens = src_tokens.to(self.dtype).contiguous()
         B = src_tokens.size(0)
         x = self._subsample(src_tokens, lead=True)                    # [B,Te,D], scaled
-        enc_len = self.out_lengths(src_lengths, len(self.w.conv))
+        enc_len = self.out_lengths(src_lengths.to(x.device), len(self.w.conv))
         Te = x.size(1)
         len_i32 = enc_len.to(torch.int32)
         x = ops.conv_pos(x, None, self.w.pos_w, self.w.pos_b, len_i32, cfg.conv_pos_groups)
@@ -206,7 +206,7 @@ class S2TEmformerEncoder:
         # final LayerNorm (rows are independent: norm every row, return the utterance rows as a view)
         Yall = ops.layernorm(X, self.w.final_g, self.w.final_b)
         out = Yall[:, N * R:]                                          # [B,Te,D], batch stride (N*R+Te)*D
-        pad = torch.arange(Te, device=x.device).unsqueeze(0) >= enc_len.to(x.device).unsqueeze(1)
+        pad = torch.arange(Te, device=x.device).unsqueeze(0) >= enc_len.unsqueeze(1)
         res = {"encoder_out": [out.transpose(0, 1)], "encoder_padding_mask": [pad], "encoder_embedding": [],
                "encoder_states": [], "src_tokens": [], "src_lengths": [], "ctc_logits": [],
                "encoder_out_btd": out, "encoder_lengths": enc_len}
