@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded target tokens/sec of the streaming-ST hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Emformer encoder + wait-k=5 decoder (mma_model_s,
+waitk_fixed_pre_decision ratio 8), bf16, synthetic 80x1000 fbank, batch 64 per GPU, 110 forced
+greedy steps (EOS masked) => 7040 tokens per step per GPU.  One "step" = one pass of the hot
+path (encoder forward + 110 decoder steps + argmax) over one batch already resident in HBM, the
+stopwatch placement of eval/generate.py:200-209.  Utterance batches shard across ranks with no
+data-path collective (weak scaling); the only RCCL traffic is the all_gather of hypotheses.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel class by device time in an instrumented replay of one step
+                  (HIP events on the handle's stream around every launch of each class)
+  cpu_baseline -- the CPU oracle (oracle/, "port") timed on this box's host cores on a bounded
+                  sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+B_PER_GPU, T_FRAMES, N_STEPS_DECODE, WAITK = 64, 1000, 110, 5
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+
+
+def algorithmic_work(cfg, B, T, U):
+    """Algorithmic FLOPs / bytes of one step (DESIGN.md 'Roofline accounting')."""
+    D, F, H, V = cfg.embed_dim, cfg.ffn_dim, cfg.num_heads, cfg.vocab
+    S, R, Lc, M = cfg.S, cfg.R, cfg.Lc, cfg.M
+    T1 = (T - 1) // 2 + 1
+    Te = (T1 - 1) // 2 + 1
+    N = -(-Te // S)
+    rows_x, rows_z, rows_c = N * R + Te, (N - 1) + N * R + Te + N, N * R + Te + N
+    fl = {}
+    fl["conv"] = 2 * B * (T1 * cfg.conv_channels * 5 * cfg.input_feat + Te * 2 * D * 5 * (cfg.conv_channels // 2))
+    fl["enc_linear"] = cfg.encoder_layers * 2 * B * (rows_z * 3 * D * D + rows_c * D * D + 2 * rows_x * D * F)
+    kpl = M + R + Lc + S
+    fl["enc_attn"] = cfg.encoder_layers * B * N * H * 2 * 2 * (R + S + 1) * kpl * (D // H)
+    per_tok = cfg.decoder_layers * 2 * (3 * D * D + D * D + D * D + D * D + 2 * D * F) + 2 * D * V
+    fl["dec_linear"] = B * U * per_tok
+    fl["dec_cross_kv"] = cfg.decoder_layers * 2 * 2 * B * Te * D * D
+    return fl, dict(T1=T1, Te=Te, N=N, rows_x=rows_x, rows_z=rows_z, rows_c=rows_c)
+
+
+def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps):
+    """Oracle (CPU restatement, kind 'port') on a bounded sample: sample_B utterances x T_FRAMES
+    frames, n_steps forced decode steps, all host cores."""
+    from oracle import agent as oag
+    from oracle.configs import from_model_config
+    ecfg, dcfg = from_model_config(cfg)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    fb = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + i))
+                      for i in range(sample_B)])
+    L = torch.full((sample_B,), T_FRAMES)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        toks, _, _ = oag.greedy_offline(weights_f32, ecfg, dcfg, fb, L, n_steps=n_steps, mask_eos=True)
+        dt = time.perf_counter() - t0
+    return {"value": round(toks.numel() / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_B} utterances x {T_FRAMES} frames, {n_steps} forced greedy steps "
+                      f"({toks.numel()} tokens) in {dt:.1f} s, torch fp32, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from simulst_amd import _lib
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.sharding import gather_hypotheses
+    from simulst_amd.weights import init_model
+
+    cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=WAITK, fixed_pre_decision_ratio=8)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    weights = init_model(cfg, seed=999)
+    model = SimulSTModel(cfg, weights, device=f"cuda:{local}", dtype=dtype)
+    B = args.batch
+    # synthetic fbank, seed 999 + global utterance id, resident in HBM before the clock starts
+    fb = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + rank * B + i))
+                      for i in range(B)]).to(device=f"cuda:{local}", dtype=dtype)
+    L = torch.full((B,), T_FRAMES, device=f"cuda:{local}")
+
+    def one_step():
+        toks, _ = model.generate_offline(fb, L, n_steps=N_STEPS_DECODE, mask_eos=True)
+        if dist is not None:
+            toks = gather_hypotheses(toks, dist)
+        return toks
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            one_step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            toks = one_step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=f"cuda:{local}", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    tokens_per_step = B * N_STEPS_DECODE * world
+    value = tokens_per_step * args.steps / elapsed
+
+    roofline, cpu_base = None, None
+    if rank == 0:
+        # ---- instrumented replay of ONE step: HIP events around every launch, per kernel class
+        h = model.ops.h
+        h.timer_reset()
+        h.timer_enable(-1, True)
+        with torch.no_grad():
+            model.generate_offline(fb, L, n_steps=N_STEPS_DECODE, mask_eos=True)
+        torch.cuda.synchronize()
+        h.timer_enable(-1, False)
+        per_class = {_lib.KERNEL_CLASS_NAMES[c]: h.timer_read(c) for c in range(_lib.K_COUNT)}
+        dom = max(per_class, key=lambda k: per_class[k][0])
+        dom_ms, dom_n = per_class[dom]
+        fl, dims = algorithmic_work(cfg, B, T_FRAMES, N_STEPS_DECODE)
+        if dom == "linear":
+            flops = fl["conv"] + fl["enc_linear"] + fl["dec_linear"] + fl["dec_cross_kv"]
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            ach = flops / (dom_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 5), "traffic": None}
+        else:
+            esz = 2 if args.dtype == "bf16" else 4
+            D, H = cfg.embed_dim, cfg.num_heads
+            if dom == "emformer_attention":
+                byts = cfg.encoder_layers * B * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
+            elif dom == "decoder_cross_attention":
+                byts = cfg.decoder_layers * N_STEPS_DECODE * B * (2 * dims["Te"] * D + 2 * D) * esz
+            elif dom == "decoder_self_attention":
+                byts = cfg.decoder_layers * B * sum((2 * (u + 1) * D + 4 * D) for u in range(N_STEPS_DECODE)) * esz
+            elif dom == "layernorm":
+                byts = (cfg.encoder_layers * 2 * B * dims["rows_x"] * 2 * D
+                        + cfg.decoder_layers * 3 * N_STEPS_DECODE * B * 2 * D) * esz
+            else:
+                byts = 0
+            ach = byts / (dom_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None}
+        roofline["kernel"] = dom
+        roofline["launches_per_step"] = dom_n
+        roofline["avg_launch_us"] = round(dom_ms * 1e3 / max(dom_n, 1), 3)
+        roofline["class_ms_per_step"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_base = run_cpu_baseline(cfg, weights, args.cpu_sample, N_STEPS_DECODE)
+        out = {
+            "metric": "decoded tgt tokens/sec (Emformer encoder + wait-k=5 greedy decode, MuST-C en-de shape)",
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic N(0,1) fbank seed 999+utt_id; random-init weights seed 999",
+            "config": {"workload": "configs[1]: Emformer enc (12L) + wait-k=5 dec (6L), 80x1000 fbank, "
+                                   "batch 64/GPU, 110 forced greedy steps",
+                       "batch_per_gpu": B, "frames": T_FRAMES, "decode_steps": N_STEPS_DECODE,
+                       "tokens_per_step": tokens_per_step, "sharding": f"utterance-sharded x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu_base,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

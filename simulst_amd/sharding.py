@@ -1,0 +1,66 @@
+"""Utterance sharding across GPUs + the single collective of the path.
+
+The reference shards evaluation data as independent dataset shards with no collective
+(eval/generate.py:151-152: num_shards=distributed_world_size, shard_id=distributed_rank).  Here:
+utterances are sorted by length and dealt round-robin to ranks (balances the summed frames per
+rank), every rank holds a full weight replica and decodes its shard, and ONE all_gather of
+fixed-width hypothesis records brings the results together (RCCL over xGMI when the backend is
+"nccl"; gloo in the CPU tests).  There is no data-path collective.
+"""
+from typing import List, Sequence
+
+import torch
+
+
+def shard_utterances(lengths: Sequence[int], world_size: int, rank: int) -> List[int]:
+    """Indices of the utterances rank `rank` decodes: sort by length (desc, stable), deal round-robin,
+    alternating direction every round so the per-rank frame sums stay balanced."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    mine = []
+    for pos, idx in enumerate(order):
+        rnd, slot = divmod(pos, world_size)
+        owner = slot if rnd % 2 == 0 else world_size - 1 - slot
+        if owner == rank:
+            mine.append(idx)
+    return mine
+
+
+def gather_hypotheses(tokens: torch.Tensor, dist, group=None) -> torch.Tensor:
+    """all_gather of equally-shaped token tensors [B, U] -> [world*B, U] (rank-major)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return tokens
+    tokens = tokens.contiguous()
+    out = torch.empty((world,) + tuple(tokens.shape), device=tokens.device, dtype=tokens.dtype)
+    dist.all_gather_into_tensor(out.view(world * tokens.shape[0], *tokens.shape[1:]), tokens, group=group)
+    return out.view(world * tokens.shape[0], *tokens.shape[1:])
+
+
+def gather_records(utt_ids: torch.Tensor, n_tok: torch.Tensor, tokens: torch.Tensor, delays_ms: torch.Tensor,
+                   dist, width: int, group=None):
+    """Fixed-width hypothesis records {utt_id, n_tok, tokens[width], delays_ms[width]} (int32) from every
+    rank. Shards may differ in size by one utterance: records are padded to the max
+    shard size with utt_id = -1 and dropped after the gather. Returns a dict keyed by utterance id."""
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([utt_ids.numel()], device=tokens.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    n_max = int(max(int(s.item()) for s in sizes))
+    rec = torch.full((n_max, 2 + 2 * width), -1, device=tokens.device, dtype=torch.int32)
+    n = utt_ids.numel()
+    if n > 0:
+        rec[:n, 0] = utt_ids.to(torch.int32)
+        rec[:n, 1] = n_tok.to(torch.int32)
+        w = min(width, tokens.shape[1])
+        rec[:n, 2:2 + w] = tokens[:, :w].to(torch.int32)
+        rec[:n, 2 + width:2 + width + w] = delays_ms[:, :w].to(torch.int32)
+    allrec = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(allrec, rec, group=group)
+    out = {}
+    for r in torch.cat(allrec, 0).cpu():
+        uid = int(r[0])
+        if uid >= 0:
+            k = int(r[1])
+            out[uid] = {"tokens": r[2:2 + min(k, width)].tolist(),
+                        "delays_ms": r[2 + width:2 + width + min(k, width)].tolist()}
+    return out
