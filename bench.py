@@ -60,8 +60,11 @@ def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps):
     from oracle import agent as oag
     from oracle.configs import from_model_config
     ecfg, dcfg = from_model_config(cfg)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)   # the oracle's small ops stop scaling well before this
     torch.set_num_threads(cores)
+    with torch.no_grad():                  # spin up the thread pool outside the timed sample
+        oag.greedy_offline(weights_f32, ecfg, dcfg, torch.randn(1, 200, 80), torch.tensor([200]), n_steps=2,
+                           mask_eos=True)
     fb = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + i))
                       for i in range(sample_B)])
     L = torch.full((sample_B,), T_FRAMES)
@@ -74,6 +77,13 @@ def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps):
                       f"({toks.numel()} tokens) in {dt:.1f} s, torch fp32, {cores} threads"}
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,7 +92,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4)
+    ap.add_argument("--cpu-sample", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -120,9 +130,12 @@ def main():
             toks = gather_hypotheses(toks, dist)
         return toks
 
+    log(f"model + inputs resident on cuda:{local}; host cores {os.cpu_count()}")
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for i in range(args.warmup):
             one_step()
+            torch.cuda.synchronize()
+            log(f"warmup step {i} done")
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -139,6 +152,7 @@ def main():
         elapsed = float(tmax.item())
     tokens_per_step = B * N_STEPS_DECODE * world
     value = tokens_per_step * args.steps / elapsed
+    log(f"timed region: {elapsed:.3f} s for {args.steps} steps -> {value:.0f} tokens/s")
 
     roofline, cpu_base = None, None
     if rank == 0:
@@ -150,6 +164,7 @@ def main():
             model.generate_offline(fb, L, n_steps=N_STEPS_DECODE, mask_eos=True)
         torch.cuda.synchronize()
         h.timer_enable(-1, False)
+        log("instrumented replay done")
         per_class = {_lib.KERNEL_CLASS_NAMES[c]: h.timer_read(c) for c in range(_lib.K_COUNT)}
         dom = max(per_class, key=lambda k: per_class[k][0])
         dom_ms, dom_n = per_class[dom]
@@ -183,6 +198,7 @@ def main():
         roofline["class_ms_per_step"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
         if world == 1 and not args.no_cpu_baseline:
             cpu_base = run_cpu_baseline(cfg, weights, args.cpu_sample, N_STEPS_DECODE)
+            log("cpu baseline done")
         out = {
             "metric": "decoded tgt tokens/sec (Emformer encoder + wait-k=5 greedy decode, MuST-C en-de shape)",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
