@@ -104,6 +104,9 @@ typedef struct {
   float scale;                 /* GLU output scale (embed_scale), else unused */
   int32_t n_main, aux_rows;    /* EMF_OUT only */
   int64_t aux_batch_stride;    /* EMF_OUT only */
+  const float* ln_gamma;       /* optional LayerNorm PROLOGUE: A rows are normalised (eps 1e-5, fp32 stats,   */
+  const float* ln_beta;        /* rounded to the operand dtype) before the contraction; NULL = none.          */
+                               /* Supported when M <= 128 and rows do not overlap (decode-step shapes).       */
 } simulst_linear_desc;
 
 int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, const void* A, const void* W,
@@ -263,6 +266,62 @@ int simulst_decoder_cross_attention(simulst_handle* h, const void* q, const void
  * Replaces default_agent.predict (agents/default_agent.py:415-424). */
 int simulst_greedy_argmax(simulst_handle* h, const float* logits, const float* eos_bias, int64_t* out,
                           int32_t B, int32_t V, int32_t pad_idx, int32_t eos_idx, int32_t mask_eos);
+
+/* ---- whole decode steps on the device ----------------------------------------------
+ * Runs n_steps consecutive WRITE steps of the MMA / wait-k decoder for a batch in lockstep with no
+ * host round trip: embed -> n_layers x { LN+QKV, self-attention, out-proj+res, LN+q-proj,
+ * policy (p_choose + step search) + cross-attention, out-proj+res, LN+fc1+GELU, fc2+res } -> LN+logits
+ * -> greedy pick, which feeds the next step's embedding.  This is the offline loop of
+ * eval/generate.py:187-209 ('online' unset => never READs, models/mma_model.py:191-193); with
+ * n_steps == 1 it is one policy()/predict() pair of agents/default_agent.py:378-424 after which the
+ * caller inspects head_read.  Pointers per layer in simulst_dec_layer, shared ones in
+ * simulst_decoder_desc; all device memory is caller-owned. */
+typedef struct {
+  const void* wqkv; const float* bqkv;           /* self-attention [3D][D] (q|k|v) */
+  const void* wo; const float* bo;
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+  const void* c_wq; const float* c_bq;           /* monotonic-energy query projection */
+  const void* c_wq_soft; const float* c_bq_soft; /* soft-energy query projection (NULL: shares c_wq) */
+  const void* c_wo; const float* c_bo;
+  const void* fc1; const float* b1; const void* fc2; const float* b2;
+  float energy_bias;
+  void *k_cache, *v_cache;                       /* [B][H][cap][d] */
+  int64_t* head_step;                            /* [B*H] in/out */
+  uint8_t* head_read;                            /* [B*H] out */
+  const void *Kmono, *Ksoft, *V;                 /* [B][S_cap][D] cached projections of the encoder states */
+} simulst_dec_layer;
+
+typedef struct {
+  int32_t B, D, H, F, V, n_layers, cap, S_cap, dtype;
+  int32_t attn_type, ratio, waitk_k, mass_preservation, online;
+  int32_t pad_idx, eos_idx;
+  int32_t n_prev_uniform;                        /* >= 0: every row has written exactly this many tokens (lockstep
+                                                    batches; saves a dependent device read per kernel); -1: use n_prev[] */
+  float embed_scale;
+  const void* E;                                 /* [V][D] token embedding */
+  const void* out_proj;                          /* [V][D] output projection (shared with E in the reference runs) */
+  const float* pos_table;                        /* [rows][D] sinusoidal table */
+  const float *ln_g, *ln_b;                      /* final LayerNorm */
+  const int32_t* enc_len;                        /* [B] valid source rows */
+  int32_t* n_prev;                               /* [B] in/out: tokens written so far */
+  void *x, *qkv, *ctx, *q, *q2, *hidden;         /* workspace: [B][D], [B][3D], [B][D], [B][D], [B][D], [B][F] */
+  float* logits;                                 /* workspace [B][V] */
+} simulst_decoder_desc;
+
+/* tokens_io [B] int64: in = newest token of [eos]+hyp, out = last token picked.
+ * out_tokens [n_steps][B] int64.  EOS is masked when mask_eos != 0 or while n_prev == 0
+ * (SequenceGenerator min_len = 1). */
+int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,
+                       int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos);
+
+/* policy + cross-attention of one layer for one step in ONE launch (simulst_step_p_choose +
+ * simulst_mma_step_search + simulst_decoder_cross_attention, same results). qm/qs: monotonic / soft
+ * queries [B][D] (qm unused for WAITK, qs unused for HARD). */
+int simulst_policy_cross_attention(simulst_handle* h, const void* qm, const void* qs, const void* Kmono,
+                                   const void* Ksoft, const void* Vc, float energy_bias, const int32_t* key_len,
+                                   const int32_t* tgt_idx, int64_t* head_step, uint8_t* head_read, void* ctx,
+                                   int32_t B, int32_t H, int32_t d, int32_t S_cap, int32_t ratio, int32_t attn_type,
+                                   int32_t waitk_k, int32_t online, int32_t mass_preservation, int32_t dtype);
 
 #ifdef __cplusplus
 }

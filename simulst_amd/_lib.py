@@ -31,7 +31,8 @@ class LinearDesc(C.Structure):
                 ("c_batch_stride", C.c_int64), ("c_row_stride", C.c_int64),
                 ("r_batch_stride", C.c_int64), ("r_row_stride", C.c_int64),
                 ("epilogue", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_float),
-                ("n_main", C.c_int32), ("aux_rows", C.c_int32), ("aux_batch_stride", C.c_int64)]
+                ("n_main", C.c_int32), ("aux_rows", C.c_int32), ("aux_batch_stride", C.c_int64),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p)]
 
 
 class EmfAttnDesc(C.Structure):
@@ -40,6 +41,22 @@ class EmfAttnDesc(C.Structure):
 
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class DecLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g",
+                                          "ln3_b", "c_wq", "c_bq", "c_wq_soft", "c_bq_soft", "c_wo", "c_bo", "fc1",
+                                          "b1", "fc2", "b2")] + [("energy_bias", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("k_cache", "v_cache", "head_step", "head_read", "Kmono", "Ksoft", "V")]
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "D", "H", "F", "V", "n_layers", "cap", "S_cap", "dtype", "attn_type",
+                                         "ratio", "waitk_k", "mass_preservation", "online", "pad_idx", "eos_idx",
+                                         "n_prev_uniform")] + \
+               [("embed_scale", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("E", "out_proj", "pos_table", "ln_g", "ln_b", "enc_len", "n_prev", "x", "qkv",
+                                          "ctx", "q", "q2", "hidden", "logits")]
 
 # name -> argtypes (restype is int unless noted); mirrors include/simulst_hip.h one to one
 SIGNATURES = {
@@ -71,6 +88,9 @@ SIGNATURES = {
     "simulst_decoder_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                         _i32, _i32],
     "simulst_greedy_argmax": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
+    "simulst_mma_decode": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, _vp, _i32, _i32],
+    "simulst_policy_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
+                                       _i32, _i32, _i32, _i32, _i32, _i32, _i32],
 }
 
 _lib = None

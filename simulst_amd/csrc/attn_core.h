@@ -1,0 +1,179 @@
+// Single-latency attention core shared by the decoder step kernels (gfx950).
+//
+// One 256-thread workgroup per (head, utterance).  Every dependent memory round trip costs ~1 us
+// at decode-step sizes, so ALL global loads are issued before anything is consumed:
+//   attn_prefetch : q (broadcast), one K row per thread, this thread's share of V rows -> registers
+//   attn_finish   : q.K per thread -> fp32 scores in LDS -> block max / exp / sum -> PV from the
+//                   preloaded V registers (4 channels per lane, 256/(d/4) rows per pass) -> LDS reduce
+// Fast path covers n <= 256 keys (cross-attention over <= 256 encoder frames, self-attention over
+// <= 256 target positions); longer rows take the looped path attn_looped.
+#pragma once
+#include "common.h"
+
+namespace attn {
+
+template <typename T> struct VL;
+template <> struct VL<float> {
+  static constexpr int W = 4;       // elements per 16-byte vector
+  static __device__ __forceinline__ void cvt(const uint4& v, float (&o)[4]) {
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+  }
+};
+template <> struct VL<bf16> {
+  static constexpr int W = 8;
+  static __device__ __forceinline__ void cvt(const uint4& v, float (&o)[8]) {
+    const unsigned int u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(u[i] << 16);
+      o[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+    }
+  }
+};
+
+__device__ __forceinline__ float blk_max(float v, float* scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+}
+__device__ __forceinline__ float blk_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+constexpr int MAXD = 64;
+
+template <typename T> struct Regs {
+  static constexpr int NQ = MAXD / VL<T>::W;     // 16-byte vectors per head row
+  uint4 q[NQ];
+  uint4 k[NQ];
+  float v[16][4];                                // up to 16 V rows x 4 channels per thread
+};
+
+// issue every load; rows >= n_max are clamped to row 0 (values unused)
+template <typename T>
+__device__ __forceinline__ void prefetch(Regs<T>& r, const T* qp, const T* Kb, long ks, const T* Vb, long vs,
+                                         int n_max, int d, int j_new, const T* k_new, const T* v_new) {
+  constexpr int W = VL<T>::W;
+  const int tid = threadIdx.x;
+  const int jk = tid < n_max ? tid : 0;
+  const T* kr = (jk == j_new) ? k_new : Kb + (long)jk * ks;
+#pragma unroll
+  for (int c = 0; c < Regs<T>::NQ; ++c) {
+    const int cc = c * W < d ? c * W : 0;
+    r.q[c] = *reinterpret_cast<const uint4*>(qp + cc);
+    r.k[c] = *reinterpret_cast<const uint4*>(kr + cc);
+  }
+  const int lpr = d >> 2, c4 = tid % lpr, rw = tid / lpr, RR = 256 / lpr;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int j = rw + RR * i;
+    if (i >= lpr || j >= n_max) j = 0;
+    const T* vr = ((j == j_new) ? v_new : Vb + (long)j * vs) + c4 * 4;
+    load4(vr, r.v[i]);
+  }
+}
+
+// softmax(q.K[0..n)) V from the prefetched registers. n <= n_max <= 256. Threads tid < d return ctx[tid].
+template <typename T>
+__device__ __forceinline__ float finish(const Regs<T>& r, int n, int d, float qscale, float* sc, float* red,
+                                        float* beta) {
+  constexpr int W = VL<T>::W;
+  const int tid = threadIdx.x;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < Regs<T>::NQ; ++c) {
+    if (c * W < d) {
+      float qa[W], ka[W];
+      VL<T>::cvt(r.q[c], qa);
+      VL<T>::cvt(r.k[c], ka);
+#pragma unroll
+      for (int i = 0; i < W; ++i) s = fmaf(qa[i] * qscale, ka[i], s);
+    }
+  }
+  const bool live = tid < n;
+  const float mx = blk_max(live ? s : -INFINITY, red + 1024);
+  const float e = live ? expf(s - mx) : 0.f;
+  sc[tid] = e;
+  const float inv = 1.0f / blk_sum(e, red + 1024);          // barrier inside also publishes sc[]
+  const int lpr = d >> 2, c4 = tid % lpr, rw = tid / lpr, RR = 256 / lpr;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = rw + RR * i;
+    if (i < lpr && j < n) {
+      const float pj = sc[j];
+      a0 = fmaf(pj, r.v[i][0], a0); a1 = fmaf(pj, r.v[i][1], a1);
+      a2 = fmaf(pj, r.v[i][2], a2); a3 = fmaf(pj, r.v[i][3], a3);
+    }
+  }
+  float* rr = red + rw * d + c4 * 4;
+  rr[0] = a0; rr[1] = a1; rr[2] = a2; rr[3] = a3;
+  __syncthreads();
+  float o = 0.f;
+  if (tid < d) {
+    for (int k = 0; k < RR; ++k) o += red[k * d + tid];
+    o *= inv;
+  }
+  if (beta && tid < n) beta[tid] = e * inv;
+  return o;
+}
+
+// looped variant for n > 256 (q_s: LDS [d] scaled query, sc: LDS [>= n])
+template <typename T>
+__device__ __forceinline__ float looped(const float* q_s, const T* Kb, long ks, const T* Vb, long vs, int n, int d,
+                                        int j_new, const T* k_new, const T* v_new, float* sc, float* red,
+                                        float* beta) {
+  constexpr int W = VL<T>::W;
+  const int tid = threadIdx.x;
+  float lmax = -INFINITY;
+  for (int j = tid; j < n; j += 256) {
+    const T* kr = (j == j_new) ? k_new : Kb + (long)j * ks;
+    float s = 0.f;
+    for (int c = 0; c < d; c += W) {
+      float kv[W];
+      VL<T>::cvt(*reinterpret_cast<const uint4*>(kr + c), kv);
+#pragma unroll
+      for (int i = 0; i < W; ++i) s = fmaf(q_s[c + i], kv[i], s);
+    }
+    sc[j] = s;
+    lmax = fmaxf(lmax, s);
+  }
+  const float mx = blk_max(lmax, red + 1024);
+  float lsum = 0.f;
+  for (int j = tid; j < n; j += 256) {
+    float e = expf(sc[j] - mx);
+    sc[j] = e;
+    lsum += e;
+  }
+  const float inv = 1.0f / blk_sum(lsum, red + 1024);
+  const int lpr = d >> 2, c4 = tid % lpr, rw = tid / lpr, RR = 256 / lpr;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int j = rw; j < n; j += RR) {
+    const T* vr = ((j == j_new) ? v_new : Vb + (long)j * vs) + c4 * 4;
+    float v4[4];
+    load4(vr, v4);
+    const float pj = sc[j];
+    a0 = fmaf(pj, v4[0], a0); a1 = fmaf(pj, v4[1], a1); a2 = fmaf(pj, v4[2], a2); a3 = fmaf(pj, v4[3], a3);
+  }
+  float* rr = red + rw * d + c4 * 4;
+  rr[0] = a0; rr[1] = a1; rr[2] = a2; rr[3] = a3;
+  __syncthreads();
+  float o = 0.f;
+  if (tid < d) {
+    for (int k = 0; k < RR; ++k) o += red[k * d + tid];
+    o *= inv;
+  }
+  if (beta)
+    for (int j = tid; j < n; j += 256) beta[j] = sc[j] * inv;
+  return o;
+}
+
+}  // namespace attn

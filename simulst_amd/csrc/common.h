@@ -128,3 +128,8 @@ __device__ __forceinline__ void store4(bf16* p, const float (&o)[4]) {
   bf16 t[4] = {__float2bfloat16(o[0]), __float2bfloat16(o[1]), __float2bfloat16(o[2]), __float2bfloat16(o[3])};
   *reinterpret_cast<uint2*>(p) = *reinterpret_cast<uint2*>(t);
 }
+
+// internal (not exported): self-attention with a host-known uniform n_prev (np_uniform >= 0) or the
+// device array (np_uniform < 0)
+int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev,
+                      int np_uniform, void* ctx, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t dtype);

@@ -1,0 +1,309 @@
+// Device-resident decode loop (gfx950): simulst_mma_decode launches every kernel of n_steps
+// greedy WRITE steps back to back on the handle's stream -- no host round trip between steps
+// (the greedy pick of step s feeds the embedding of step s+1 on the device) -- plus the two
+// step-level fusions that make that loop short:
+//   policy_cross_attn_kernel : step probabilities (fixed pre-decision) + first-p>=0.5 search +
+//                              monotonic cross-attention in one launch per layer
+//   argmax_embed_kernel      : greedy pick + commit (n_prev += 1) + next token's embedding
+// LayerNorms ride as prologues of the following skinny GEMM (simulst_linear_desc.ln_gamma).
+#include "attn_core.h"
+
+namespace {
+
+using attn::VL;
+
+// One workgroup per (head, utterance).
+//  1. pooled step probabilities pp[j] (thread per pooled key), zero-inserted into p[] in LDS
+//     (modules/fixed_pre_decision.py:85-167; wait-k one-hot utils/p_choose_strategy.py:6-53)
+//  2. wave 0: mask the past, force the stop, first index with p >= 0.5
+//     (modules/monotonic_multihead_attention.py:196-257) -> head_step, head_read
+//  3. hard gather / softmax over keys <= step (:261-297), PV
+template <typename T>
+__global__ __launch_bounds__(256) void policy_cross_attn_kernel(
+    const T* __restrict__ qm, const T* __restrict__ qs, const T* __restrict__ Km, const T* __restrict__ Ks,
+    const T* __restrict__ Vc, float energy_bias, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
+    long* __restrict__ head_step, unsigned char* __restrict__ head_read, T* __restrict__ ctx, int H, int d,
+    int S_cap, int ratio, int attn_type, int waitk_k, int online, int mass_pres) {
+  constexpr int W = VL<T>::W;
+  extern __shared__ float sm[];
+  float* q_s = sm;                 // [64]
+  float* red = sm + 64;            // [1024 + 8]
+  float* sc = red + 1032;          // [max(S_cap,256)] scores
+  float* pl = sc + (S_cap > 256 ? S_cap : 256);   // [S_cap + 1] step probabilities
+  float* pp = pl + S_cap + 1;      // [S_cap] pooled probabilities
+  __shared__ int s_found;
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int D = H * d;
+  const int len = key_len ? key_len[b] : S_cap;
+  const int r = b * H + h;
+  int P = (len + ratio - 1) / ratio;
+  P = min(P, max(1, len / ratio));           // inference: floor-trimmed, at least one (:123-131)
+  // ---- 0. every load of the value-aggregation phase goes out first (soft attention over <= 256 keys):
+  //         the policy below then runs under their latency
+  const T* Vh = Vc + (long)b * S_cap * D + h * d;
+  const T* Kh = Ks ? Ks + (long)b * S_cap * D + h * d : nullptr;
+  const bool soft = attn_type != SIMULST_ATTN_HARD;
+  const bool fast = soft && S_cap <= 256;     // rows >= len exist (zero-filled) and are masked by n <= len
+  attn::Regs<T> rg;
+  if (fast) attn::prefetch<T>(rg, qs + (long)b * D + h * d, Kh, D, Vh, D, S_cap, d, -1, nullptr, nullptr);
+  const int tg = tgt_idx ? tgt_idx[b] : 0;    // scalar inputs of the policy: issued with the prefetch
+  const long hs = head_step[r];
+  // ---- 1. pooled probabilities
+  if (attn_type == SIMULST_ATTN_WAITK) {
+    int wk = tg + waitk_k - 1;
+    if (!online) wk = min(wk, P - 1);
+    for (int j = tid; j < P; j += 256) pp[j] = (j == wk) ? 1.f : 0.f;
+  } else {
+    if (tid < d) q_s[tid] = to_f32(qm[(long)b * D + h * d + tid]) * rsqrtf((float)d);
+    __syncthreads();
+    for (int j = tid; j < P; j += 256) {
+      const int f0 = j * ratio, f1 = min(f0 + ratio, len);
+      float en = 0.f;
+      for (int c = 0; c < d; c += W) {
+        float accv[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) accv[i] = 0.f;
+        for (int f = f0; f < f1; ++f) {
+          float kv[W];
+          VL<T>::cvt(*reinterpret_cast<const uint4*>(Km + ((long)b * S_cap + f) * D + h * d + c), kv);
+#pragma unroll
+          for (int i = 0; i < W; ++i) accv[i] += kv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W; ++i) en = fmaf(accv[i] / (float)(f1 - f0), q_s[c + i], en);
+      }
+      pp[j] = 1.0f / (1.0f + expf(-(en + energy_bias)));
+    }
+  }
+  __syncthreads();
+  for (int s = tid; s < S_cap; s += 256) {
+    float v = 0.f;
+    if (s < len) {
+      if ((s + 1) % ratio == 0 && (s + 1) / ratio - 1 < P) v = pp[(s + 1) / ratio - 1];
+      if (s == len - 1 && P * ratio >= len) v = pp[P - 1];
+    }
+    pl[s] = v;
+  }
+  __syncthreads();
+  // ---- 2. step search (wave 0)
+  if (tid < 64) {
+    const int max_steps = mass_pres ? len - 1 : len;
+    const int n = mass_pres ? S_cap : S_cap + 1;
+    int found = -1;
+    for (int j0 = 0; j0 < n && found < 0; j0 += 64) {
+      const int j = j0 + lane;
+      float v = 0.f;
+      if (j < n) {
+        v = (j < S_cap) ? pl[j] : 0.f;
+        if ((long)j < hs) v = 0.f;
+        if (j == max_steps) v = 1.f;
+      }
+      const unsigned long long m = __ballot(j < n && v >= 0.5f);
+      if (m) found = j0 + __ffsll((long long)m) - 1;
+    }
+    if (found < 0) found = 0;
+    if (lane == 0) {
+      const int clampi = min(max(found, 0), len - 1);
+      head_step[r] = found;
+      head_read[r] = (found == max_steps && pl[clampi] < 0.5f) ? 1 : 0;
+      s_found = found;
+    }
+  }
+  __syncthreads();
+  const long st = s_found;
+  // ---- 3. value aggregation
+  float o = 0.f;
+  if (!soft) {
+    const long scl = st < 0 ? 0 : (st > len - 1 ? len - 1 : st);
+    const bool dead = (!mass_pres) && st == len;
+    if (!dead && tid < d) o = to_f32(Vh[scl * D + tid]);
+  } else {
+    const int n = (int)(st < len - 1 ? st : len - 1) + 1;
+    if (st > 0 && n > 0) {
+      if (fast) {
+        o = attn::finish<T>(rg, n, d, rsqrtf((float)d), sc, red, nullptr);
+      } else {
+        __syncthreads();
+        if (tid < d) q_s[tid] = to_f32(qs[(long)b * D + h * d + tid]) * rsqrtf((float)d);
+        __syncthreads();
+        o = attn::looped<T>(q_s, Kh, D, Vh, D, n, d, -1, nullptr, nullptr, sc, red, nullptr);
+      }
+    }
+  }
+  if (tid < d) ctx[(long)b * D + h * d + tid] = from_f32<T>(o);
+}
+
+// greedy pick (lowest index on ties, pad never, eos masked on request / at the first position),
+// commit, and the next step's input embedding.
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restrict__ logits, long* __restrict__ tokens,
+                                                           long* __restrict__ out_tokens, int* __restrict__ n_prev,
+                                                           const T* __restrict__ E, const float* __restrict__ pos,
+                                                           T* __restrict__ x, int V, int D, int pad_idx, int eos_idx,
+                                                           int mask_eos, float scale) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  __shared__ int s_tok;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* row = logits + (long)b * V;
+  const int np = n_prev[b];
+  const bool no_eos = mask_eos || np == 0;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = tid; c < V; c += 256) {
+    float v = row[c];
+    if (c == pad_idx || (no_eos && c == eos_idx)) v = -INFINITY;
+    if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    if (bi == 0x7fffffff) bi = 0;
+    tokens[b] = bi;
+    out_tokens[b] = bi;
+    n_prev[b] = np + 1;
+    s_tok = bi;
+  }
+  __syncthreads();
+  const long tok = s_tok;
+  const long pr = pad_idx + 1 + (np + 1);          // position row of the NEXT input token
+  for (int c = tid; c < D; c += 256)
+    x[(long)b * D + c] = from_f32<T>(scale * to_f32(E[tok * D + c]) + pos[pr * D + c]);
+}
+
+template <typename T>
+__global__ void embed_first_kernel(const long* __restrict__ tokens, const T* __restrict__ E,
+                                   const float* __restrict__ pos, const int* __restrict__ n_prev, T* __restrict__ x,
+                                   int D, int pad_idx, float scale) {
+  const int b = blockIdx.x;
+  const long tok = tokens[b];
+  const long pr = pad_idx + 1 + n_prev[b];
+  for (int c = threadIdx.x; c < D; c += blockDim.x)
+    x[(long)b * D + c] = from_f32<T>(scale * to_f32(E[tok * D + c]) + pos[pr * D + c]);
+}
+
+int lin(simulst_handle* h, int dtype, int B, int N, int K, const void* A, const void* W, const float* bias,
+        const void* R, void* C, int epi, const float* ln_g, const float* ln_b) {
+  simulst_linear_desc d;
+  d.M_batches = 1; d.rows_per_batch = B; d.N = N; d.K = K;
+  d.a_batch_stride = 0; d.a_row_stride = K; d.a_lead = 0;
+  d.c_batch_stride = 0; d.c_row_stride = N;
+  d.r_batch_stride = 0; d.r_row_stride = N;
+  d.epilogue = epi; d.dtype = dtype; d.scale = 1.f; d.n_main = 0; d.aux_rows = 0; d.aux_batch_stride = 0;
+  d.ln_gamma = ln_g; d.ln_beta = ln_b;
+  return simulst_linear(h, &d, A, W, bias, R, C, nullptr);
+}
+
+template <typename T>
+int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const void* Km, const void* Ks,
+                        const void* Vc, float energy_bias, const int32_t* key_len, const int32_t* tgt_idx,
+                        int64_t* head_step, uint8_t* head_read, void* ctx, int B, int H, int d, int S_cap, int ratio,
+                        int attn_type, int waitk_k, int online, int mass_pres) {
+  const size_t lds = (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1) * sizeof(float);
+  KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
+  hipLaunchKernelGGL(policy_cross_attn_kernel<T>, dim3(H, B), dim3(256), lds, h->stream, (const T*)qm, (const T*)qs,
+                     (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx, (long*)head_step,
+                     head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres);
+  return sl_launch_status(h, "simulst_policy_cross_attention");
+}
+
+}  // namespace
+
+extern "C" int simulst_policy_cross_attention(simulst_handle* h, const void* qm, const void* qs, const void* Kmono,
+                                              const void* Ksoft, const void* Vc, float energy_bias,
+                                              const int32_t* key_len, const int32_t* tgt_idx, int64_t* head_step,
+                                              uint8_t* head_read, void* ctx, int32_t B, int32_t H, int32_t d,
+                                              int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k,
+                                              int32_t online, int32_t mass_preservation, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, Vc); SL_CHECK_NULL(h, head_step); SL_CHECK_NULL(h, head_read); SL_CHECK_NULL(h, ctx);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_policy_cross_attention: dtype");
+  SL_REQUIRE(h, attn_type >= SIMULST_ATTN_HARD && attn_type <= SIMULST_ATTN_CHUNKWISE, SIMULST_E_ARG,
+             "simulst_policy_cross_attention: attn_type");
+  if (attn_type == SIMULST_ATTN_WAITK) { SL_CHECK_NULL(h, tgt_idx); SL_REQUIRE(h, waitk_k > 0, SIMULST_E_ARG, "simulst_policy_cross_attention: lagging"); }
+  else { SL_CHECK_NULL(h, qm); SL_CHECK_NULL(h, Kmono); }
+  if (attn_type != SIMULST_ATTN_HARD) { SL_CHECK_NULL(h, qs); SL_CHECK_NULL(h, Ksoft); }
+  SL_REQUIRE(h, H > 0 && d >= 8 && d <= 64 && d % 8 == 0 && S_cap > 0 && ratio >= 1, SIMULST_E_SHAPE,
+             "simulst_policy_cross_attention: head_dim must be a multiple of 8, <= 64");
+  SL_REQUIRE(h, (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1) * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE,
+             "simulst_policy_cross_attention: source too long for the LDS rows");
+  if (B <= 0) return SIMULST_OK;
+  if (dtype == SIMULST_F32)
+    return launch_policy_cross<float>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
+                                      ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation);
+  return launch_policy_cross<bf16>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
+                                   ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation);
+}
+
+extern "C" int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
+                                  int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos) {
+  const int np_uniform = dd ? dd->n_prev_uniform : -1;
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, dd); SL_CHECK_NULL(h, layers); SL_CHECK_NULL(h, tokens_io); SL_CHECK_NULL(h, out_tokens);
+  SL_CHECK_NULL(h, dd->E); SL_CHECK_NULL(h, dd->out_proj); SL_CHECK_NULL(h, dd->pos_table);
+  SL_CHECK_NULL(h, dd->n_prev); SL_CHECK_NULL(h, dd->enc_len);
+  SL_CHECK_NULL(h, dd->x); SL_CHECK_NULL(h, dd->qkv); SL_CHECK_NULL(h, dd->ctx); SL_CHECK_NULL(h, dd->q);
+  SL_CHECK_NULL(h, dd->q2); SL_CHECK_NULL(h, dd->hidden); SL_CHECK_NULL(h, dd->logits);
+  SL_REQUIRE(h, dd->dtype == SIMULST_F32 || dd->dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_mma_decode: dtype");
+  SL_REQUIRE(h, dd->B > 0 && dd->D > 0 && dd->H > 0 && dd->D % dd->H == 0 && dd->n_layers > 0 && n_steps >= 0,
+             SIMULST_E_SHAPE, "simulst_mma_decode: shape");
+  const int B = dd->B, D = dd->D, H = dd->H, F = dd->F, V = dd->V, d = D / H, dt = dd->dtype;
+  int rc;
+  {
+    KTimer t(h, SIMULST_K_MISC);
+    if (dt == SIMULST_F32)
+      hipLaunchKernelGGL(embed_first_kernel<float>, dim3(B), dim3(256), 0, h->stream, (const long*)tokens_io,
+                         (const float*)dd->E, dd->pos_table, dd->n_prev, (float*)dd->x, D, dd->pad_idx, dd->embed_scale);
+    else
+      hipLaunchKernelGGL(embed_first_kernel<bf16>, dim3(B), dim3(256), 0, h->stream, (const long*)tokens_io,
+                         (const bf16*)dd->E, dd->pos_table, dd->n_prev, (bf16*)dd->x, D, dd->pad_idx, dd->embed_scale);
+    if ((rc = sl_launch_status(h, "simulst_mma_decode(embed)")) != 0) return rc;
+  }
+  for (int s = 0; s < n_steps; ++s) {
+    for (int l = 0; l < dd->n_layers; ++l) {
+      const simulst_dec_layer& L = layers[l];
+      if ((rc = lin(h, dt, B, 3 * D, D, dd->x, L.wqkv, L.bqkv, nullptr, dd->qkv, SIMULST_EPI_BIAS, L.ln1_g, L.ln1_b))) return rc;
+      if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
+                                  dd->ctx, B, H, d, dd->cap, dt))) return rc;
+      if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
+      // queries of the monotonic (and, when separate, the soft) energy from LN2(x)
+      const void* qm = dd->q;
+      const void* qs = dd->q;
+      if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq, L.c_bq, nullptr, dd->q, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b))) return rc;
+      if (L.c_wq_soft) {
+        if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq_soft, L.c_bq_soft, nullptr, dd->q2, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b))) return rc;
+        qs = dd->q2;
+      }
+      if ((rc = simulst_policy_cross_attention(h, qm, qs, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias,
+                                               dd->enc_len, dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d,
+                                               dd->S_cap, dd->ratio, dd->attn_type, dd->waitk_k, dd->online,
+                                               dd->mass_preservation, dt))) return rc;
+      if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
+      if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b))) return rc;
+      if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
+    }
+    if ((rc = lin(h, dt, B, V, D, dd->x, dd->out_proj, nullptr, nullptr, dd->logits, SIMULST_EPI_BIAS_F32OUT, dd->ln_g,
+                  dd->ln_b))) return rc;
+    {
+      KTimer t(h, SIMULST_K_ARGMAX);
+      if (dt == SIMULST_F32)
+        hipLaunchKernelGGL(argmax_embed_kernel<float>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
+                           (long*)out_tokens + (long)s * B, dd->n_prev, (const float*)dd->E, dd->pos_table,
+                           (float*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale);
+      else
+        hipLaunchKernelGGL(argmax_embed_kernel<bf16>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
+                           (long*)out_tokens + (long)s * B, dd->n_prev, (const bf16*)dd->E, dd->pos_table,
+                           (bf16*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale);
+      if ((rc = sl_launch_status(h, "simulst_mma_decode(argmax)")) != 0) return rc;
+    }
+  }
+  return SIMULST_OK;
+}

@@ -102,6 +102,7 @@ class DecoderState:
         self.enc_len_bh = torch.zeros(B * H, device=device, dtype=torch.int32)
         self.enc_rows = 0                    # rows of the source already projected (lockstep)
         self.online = False
+        self.lockstep = True                 # every row has written n_prev_host tokens
 
 
 class MMADecoder:
@@ -214,8 +215,57 @@ class MMADecoder:
         agents/default_agent.py:426-434): step() never advanced n_prev, so nothing to undo."""
         return None
 
+    # ------------------------------------------------------------------ device-resident step loop
+    def _layer_structs(self, st: DecoderState):
+        arr = (_lib.DecLayer * self.cfg.decoder_layers)()
+        st.head_read = [torch.zeros(st.B * self.cfg.num_heads, device=self.device, dtype=torch.uint8)
+                        if hr is None else hr for hr in st.head_read]
+        for l, L in enumerate(self.w.layers):
+            a = arr[l]
+            for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b", "c_wq",
+                      "c_bq", "c_wo", "c_bo", "fc1", "b1", "fc2", "b2"):
+                setattr(a, n, L[n].data_ptr())
+            a.c_wq_soft = L["c_wq_soft"].data_ptr() if self.separate_soft else None
+            a.c_bq_soft = L["c_bq_soft"].data_ptr() if self.separate_soft else None
+            a.energy_bias = L["energy_bias"]
+            a.k_cache, a.v_cache = st.k_cache[l].data_ptr(), st.v_cache[l].data_ptr()
+            a.head_step, a.head_read = st.head_step[l].data_ptr(), st.head_read[l].data_ptr()
+            a.Kmono, a.V = st.Kmono[l].data_ptr(), st.V[l].data_ptr()
+            a.Ksoft = st.Ksoft[l].data_ptr() if self.separate_soft else None
+        return arr
+
+    def decode_steps(self, st: DecoderState, last_tokens: torch.Tensor, n_steps: int, mask_eos: bool):
+        """n_steps WRITE steps entirely on the device (simulst_mma_decode). last_tokens [B] int64 is
+        updated in place; returns tokens [n_steps, B]."""
+        cfg, ops = self.cfg, self.ops
+        B, D = st.B, cfg.embed_dim
+        dev, dt_ = self.device, self.dtype
+        if not hasattr(st, "ws"):
+            st.ws = {"x": torch.empty(B, D, device=dev, dtype=dt_), "qkv": torch.empty(B, 3 * D, device=dev, dtype=dt_),
+                     "ctx": torch.empty(B, D, device=dev, dtype=dt_), "q": torch.empty(B, D, device=dev, dtype=dt_),
+                     "q2": torch.empty(B, D, device=dev, dtype=dt_),
+                     "hidden": torch.empty(B, cfg.ffn_dim, device=dev, dtype=dt_),
+                     "logits": torch.empty(B, cfg.vocab, device=dev, dtype=torch.float32)}
+            st.layer_structs = self._layer_structs(st)
+        assert st.n_prev_host + n_steps < st.cap, "decoder state capacity exceeded"
+        ws = st.ws
+        d = _lib.DecoderDesc(B, D, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st.cap, st.S_cap,
+                             _lib.F32 if dt_ == torch.float32 else _lib.BF16, self.attn_enum, cfg.pre_decision_ratio,
+                             cfg.waitk_lagging, int(cfg.mass_preservation), int(st.online), cfg.padding_idx, cfg.eos,
+                             st.n_prev_host if st.lockstep else -1, self.embed_scale, self.w.E.data_ptr(), self.w.out_proj.data_ptr(), self.w.pos.data_ptr(),
+                             self.w.ln_g.data_ptr(), self.w.ln_b.data_ptr(), st.enc_len.data_ptr(),
+                             st.n_prev.data_ptr(), ws["x"].data_ptr(), ws["qkv"].data_ptr(), ws["ctx"].data_ptr(),
+                             ws["q"].data_ptr(), ws["q2"].data_ptr(), ws["hidden"].data_ptr(), ws["logits"].data_ptr())
+        out = torch.empty(n_steps, B, device=dev, dtype=torch.int64)
+        import ctypes as C
+        ops.h.check(ops.lib.simulst_mma_decode(ops.h.ptr, C.byref(d), st.layer_structs, last_tokens.data_ptr(),
+                                               out.data_ptr(), n_steps, int(mask_eos)), "simulst_mma_decode")
+        st.n_prev_host += n_steps
+        return out
+
     # ------------------------------------------------------------------ offline greedy (generate.py semantics)
-    def greedy_offline(self, enc_btd: torch.Tensor, enc_len: torch.Tensor, n_steps: int, mask_eos: bool = True):
+    def greedy_offline(self, enc_btd: torch.Tensor, enc_len: torch.Tensor, n_steps: int, mask_eos: bool = True,
+                       fused: bool = True):
         """Batched greedy decode with 'online' unset (never READs, mma_model.py:191-193). Tokens stay on
         the device between steps. Returns tokens [B, n_steps] int64."""
         cfg, ops = self.cfg, self.ops
@@ -224,10 +274,13 @@ class MMADecoder:
         st.online = False
         self.append_encoder_out(st, enc_btd, enc_len)
         toks = torch.full((B,), cfg.eos, device=self.device, dtype=torch.int64)
-        out = torch.empty(n_steps, B, device=self.device, dtype=torch.int64)
-        for s in range(n_steps):
-            logits, _ = self.step(st, toks)
-            toks = ops.greedy_argmax(logits, pad_idx=cfg.padding_idx, eos_idx=cfg.eos,
-                                     mask_eos=mask_eos or s == 0, out=out[s])
-            self.commit(st)
+        if fused:
+            out = self.decode_steps(st, toks, n_steps, mask_eos)
+        else:       # per-op launches from the host (reference-shaped control flow; kept for parity tests)
+            out = torch.empty(n_steps, B, device=self.device, dtype=torch.int64)
+            for s in range(n_steps):
+                logits, _ = self.step(st, toks)
+                toks = ops.greedy_argmax(logits, pad_idx=cfg.padding_idx, eos_idx=cfg.eos,
+                                         mask_eos=mask_eos or s == 0, out=out[s])
+                self.commit(st)
         return out.t().contiguous(), st

@@ -31,14 +31,15 @@ class SimulSTModel:
     def max_decoder_positions(self):
         return self.cfg.max_target_positions
 
-    def generate_offline(self, src_tokens, src_lengths, n_steps=None, mask_eos=False):
+    def generate_offline(self, src_tokens, src_lengths, n_steps=None, mask_eos=False, fused=True):
         """task.inference_step with beam 1 (eval/generate.py:200-209; exp/infer_st.yaml:2-5):
         encoder._forward once, greedy decoder steps with 'online' unset. Returns tokens [B,n] and
         a dict with the encoder output."""
         enc = self.encoder.forward(src_tokens, src_lengths)
         if n_steps is None:
             n_steps = int(0.1 * src_tokens.size(1) + 10)
-        toks, st = self.decoder.greedy_offline(enc["encoder_out_btd"], enc["encoder_lengths"], n_steps, mask_eos)
+        toks, st = self.decoder.greedy_offline(enc["encoder_out_btd"], enc["encoder_lengths"], n_steps, mask_eos,
+                                               fused=fused)
         return toks, {"encoder": enc, "state": st}
 
 

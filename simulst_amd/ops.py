@@ -47,15 +47,17 @@ class Ops:
     # ------------------------------------------------------------------ dense
     def linear_raw(self, A, W, bias, C_out, *, M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead=0,
                    c_bs, c_rs, epilogue=EPI_BIAS, R=None, r_bs=0, r_rs=0, scale=1.0, n_main=0, aux=None,
-                   aux_rows=0, aux_bs=0):
+                   aux_rows=0, aux_bs=0, ln=None):
         d = LinearDesc(M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead, c_bs, c_rs, r_bs, r_rs,
-                       epilogue, dt(A), scale, n_main, aux_rows, aux_bs)
+                       epilogue, dt(A), scale, n_main, aux_rows, aux_bs,
+                       ln[0].data_ptr() if ln is not None else None, ln[1].data_ptr() if ln is not None else None)
         self.h.check(self.lib.simulst_linear(self.h.ptr, C.byref(d), _p(A), _p(W), _p(bias), _p(R), _p(C_out),
                                              _p(aux)), "simulst_linear")
         return C_out
 
-    def linear(self, x, W, bias=None, *, epilogue=EPI_BIAS, residual=None, out=None):
-        """y[rows, N] = epi(x[rows, K] @ W[N, K]^T + bias). x 2-D contiguous."""
+    def linear(self, x, W, bias=None, *, epilogue=EPI_BIAS, residual=None, out=None, ln=None):
+        """y[rows, N] = epi(LN?(x)[rows, K] @ W[N, K]^T + bias). x 2-D contiguous. ln = (gamma, beta) fuses a
+        LayerNorm prologue (decode-step shapes only)."""
         _chk_contig(x, W, residual, out)
         rows, K = x.shape
         N = W.shape[0]
@@ -64,7 +66,7 @@ class Ops:
             odt = torch.float32 if epilogue == EPI_BIAS_F32OUT else x.dtype
             out = torch.empty(rows, N, device=x.device, dtype=odt)
         return self.linear_raw(x, W, bias, out, M_batches=1, rows_per_batch=rows, N=N, K=K, a_bs=0, a_rs=K,
-                               c_bs=0, c_rs=N, epilogue=epilogue, R=residual, r_bs=0, r_rs=N)
+                               c_bs=0, c_rs=N, epilogue=epilogue, R=residual, r_bs=0, r_rs=N, ln=ln)
 
     def causal_conv1d_glu(self, x, Wp, bp, *, ksize, stride, scale=1.0, out=None):
         """Strided causal Conv1d + GLU over channel-last frames.
@@ -234,6 +236,20 @@ class Ops:
                                                               attn_type, int(mass_preservation), dt(Vc)),
                      "simulst_decoder_cross_attention")
         return out, beta
+
+    def policy_cross_attention(self, qm, qs, Kmono, Ksoft, V, head_step, *, H, ratio, attn_type, key_len,
+                               tgt_idx=None, energy_bias=0.0, waitk_k=0, online=False, mass_preservation=True,
+                               out=None):
+        B, S_cap, D = V.shape
+        d = D // H
+        if out is None:
+            out = torch.empty(B, D, device=V.device, dtype=V.dtype)
+        head_read = torch.empty(B * H, device=V.device, dtype=torch.uint8)
+        self.h.check(self.lib.simulst_policy_cross_attention(
+            self.h.ptr, _p(qm), _p(qs), _p(Kmono), _p(Ksoft), _p(V), float(energy_bias), _p(key_len), _p(tgt_idx),
+            _p(head_step), _p(head_read), _p(out), B, H, d, S_cap, ratio, attn_type, waitk_k, int(online),
+            int(mass_preservation), dt(V)), "simulst_policy_cross_attention")
+        return out, head_read
 
     def greedy_argmax(self, logits, *, pad_idx, eos_idx, mask_eos=False, eos_bias=None, out=None):
         _chk_contig(logits)

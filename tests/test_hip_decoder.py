@@ -112,3 +112,32 @@ def test_greedy_offline_bf16_agreement(ops):
     agree = (toks.cpu() == ref_toks).float().mean().item()
     print(f"bf16 token agreement: first-step {first:.2f}, all {agree:.2f}")
     assert first >= 0.5
+
+
+@pytest.mark.parametrize("attn", ["waitk_fixed_pre_decision", "hard_aligned_fixed_pre_decision",
+                                  "infinite_lookback_fixed_pre_decision", "infinite_lookback", "hard_aligned"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_device_resident_decode_equals_per_op_path(ops, attn, dtype):
+    """simulst_mma_decode (fused policy+cross-attention, LN prologues, argmax->embed, no host round trip)
+    must reproduce the per-op host loop: same tokens, same head steps."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=1, decoder_layers=3, simul_attn_type=attn, waitk_lagging=3,
+                      mass_preservation=attn != "hard_aligned")
+    w = init_model(cfg, seed=5)
+    for l in range(3):      # spread the monotonic energies so learned policies move at different rates
+        w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 6
+    model = SimulSTModel(cfg, w, dtype=dtype, ops=ops)
+    fb = torch.randn(5, 360, 80, generator=torch.Generator().manual_seed(3))
+    L = torch.tensor([360, 301, 222, 150, 64])
+    for b in range(5):
+        fb[b, L[b]:] = 0
+    t1, i1 = model.generate_offline(fb.cuda().to(dtype), L, n_steps=14, mask_eos=False, fused=False)
+    t2, i2 = model.generate_offline(fb.cuda().to(dtype), L, n_steps=14, mask_eos=False, fused=True)
+    if dtype == torch.float32:
+        assert torch.equal(t1, t2)
+        for a, b in zip(i1["state"].head_step, i2["state"].head_step):
+            assert torch.equal(a, b)
+    else:
+        assert (t1 == t2).float().mean().item() > 0.7
