@@ -1,0 +1,145 @@
+"""FairseqSimulSTAgent on MI355X: mirror of agents/default_agent.py (wait-k / MMA policies).
+
+Same method names and control flow as the reference agent -- ``initialize_states``,
+``update_states_read``, ``update_model_encoder``, ``policy``, ``predict`` -- with the model calls
+going to the HIP encoder/decoder.  SimulEval (the process that drives the agent through
+READ/WRITE actions) is third-party and absent from the images; ``FrameSource`` + ``run_utterance``
+below stand in for its client/server loop at fbank-frame granularity (DESIGN.md "Synthetic
+harness"): a READ releases the next ``expected_frames`` frames (fewer at the end, raising
+``finish_read`` with the last ones) and every committed token is stamped with the source
+milliseconds released so far.
+"""
+from typing import List, Optional
+
+import torch
+
+READ_ACTION, WRITE_ACTION = 0, 1
+SHIFT_SIZE, WINDOW_SIZE = 10, 25
+
+
+class FrameSource:
+    def __init__(self, fbank: torch.Tensor):
+        self.fbank = fbank
+        self.pos = 0
+        self.finished = fbank.size(0) == 0
+
+    def read(self, n: int):
+        self.pos = min(self.pos + n, self.fbank.size(0))
+        self.finished = self.pos >= self.fbank.size(0)
+
+    def elapsed_ms(self):
+        return 0 if self.pos == 0 else self.pos * SHIFT_SIZE + (WINDOW_SIZE - SHIFT_SIZE)
+
+    def total_ms(self):
+        return self.fbank.size(0) * SHIFT_SIZE + (WINDOW_SIZE - SHIFT_SIZE)
+
+
+class States:
+    """The slice of SimulEval's SpeechStates the agent touches."""
+
+    def __init__(self, source: FrameSource):
+        self.source = source
+        self.target: List[Optional[int]] = []
+        self.enc_incremental_states = {}
+        self.dec_incremental_states = {}
+        self.last_update_source_len = 0
+
+    def finish_read(self):
+        return self.source.finished
+
+
+class FairseqSimulSTAgent:
+    def __init__(self, model, max_len_a: float = 1, max_len_b: int = 0, force_finish: bool = False):
+        self.model = model
+        enc = model.encoder
+        # agents/default_agent.py:157-175
+        self.pre_decision_ratio = model.decoder.pre_decision_ratio
+        self.stride_ms = enc.conv_layer_stride() * SHIFT_SIZE
+        self.right_context, self.segment_length = enc.right_context, enc.segment_length
+        self.max_len = lambda x: min(max_len_a * x + max_len_b, model.max_decoder_positions())
+        self.force_finish = force_finish
+        self.eos = model.cfg.eos
+
+    def initialize_states(self, states: States):
+        states.enc_incremental_states = {}
+        states.dec_incremental_states = {}
+
+    # ---- agents/default_agent.py:303-342
+    def update_model_encoder(self, states: States):
+        src = states.source
+        update_len = src.pos - states.last_update_source_len
+        if update_len == 0 and states.finish_read():
+            return
+        finish = (update_len < self.expected_frames) or states.finish_read()
+        frames = src.fbank[:src.pos].unsqueeze(0)
+        out = self.model.encoder.infer(frames, torch.tensor([src.pos]), states.enc_incremental_states, finish=finish)
+        new = out["encoder_out_btd"]
+        dec = self.model.decoder
+        if "dec" not in states.dec_incremental_states:
+            cap = int(self.max_len(src.fbank.size(0))) + 4
+            s_cap = (src.fbank.size(0) // self.model.encoder.stride) + 2 * self.right_context + 8
+            states.dec_incremental_states["dec"] = dec.new_state(1, cap=cap, S_cap=s_cap)
+        st = states.dec_incremental_states["dec"]
+        dec.append_encoder_out(st, new, torch.tensor([st.enc_rows + new.size(1)]))
+        states.has_encoder_states = True
+        states.last_update_source_len = src.pos
+
+    def update_states_read(self, states: States):
+        self.update_model_encoder(states)
+
+    # ---- agents/default_agent.py:364-413
+    def policy(self, states: States):
+        if not getattr(states, "has_encoder_states", False):
+            self.expected_frames = (self.segment_length + self.right_context) * self.stride_ms // SHIFT_SIZE
+            if states.finish_read():
+                self.update_states_read(states)
+            return READ_ACTION
+        st = states.dec_incremental_states["dec"]
+        st.online = not states.finish_read()
+        last = ([self.eos] + [t for t in states.target if t is not None])[-1]
+        logits, action = self.model.decoder.step(st, torch.tensor([last], device=self.model.device),
+                                                 stop_on_read=True)
+        states.decoder_out = logits
+        if action == 0:
+            self.expected_frames = self.segment_length * self.stride_ms // SHIFT_SIZE
+            return READ_ACTION
+        return WRITE_ACTION
+
+    # ---- agents/default_agent.py:415-436
+    def predict(self, states: States):
+        lprobs = self.model.get_normalized_probs([states.decoder_out], log_probs=True)
+        index = int(lprobs.argmax(dim=-1)[0].item())
+        if self.force_finish and index == self.eos and not states.finish_read():
+            self.model.decoder.clear_cache(states.dec_incremental_states["dec"])
+            return None
+        return index
+
+    # ---- the loop SimulEval runs around the agent
+    def run_utterance(self, fbank: torch.Tensor):
+        from .latency import average_lagging
+        src = FrameSource(fbank)
+        states = States(src)
+        self.initialize_states(states)
+        actions, delays = [], []
+        while True:
+            action = self.policy(states)
+            if action == READ_ACTION:
+                actions.append("R")
+                if src.finished:
+                    raise RuntimeError("READ after source finished")
+                src.read(self.expected_frames)
+                self.update_states_read(states)
+                continue
+            actions.append("W")
+            tok = self.predict(states)
+            if tok is None:
+                continue
+            states.target.append(tok)
+            self.model.decoder.commit(states.dec_incremental_states["dec"])
+            delays.append(src.elapsed_ms())
+            # units_to_segment termination (agents/default_agent.py:268-271)
+            if tok == self.eos or len(states.target) > self.max_len(src.pos):
+                break
+        st = states.dec_incremental_states.get("dec")
+        return {"tokens": list(states.target), "delays_ms": delays, "actions": "".join(actions),
+                "AL": average_lagging(delays, src.total_ms()), "n_enc": st.enc_rows if st is not None else 0}

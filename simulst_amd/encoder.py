@@ -213,3 +213,151 @@ class S2TEmformerEncoder:
         if self.w.ctc is not None:
             res["ctc_logits"] = [ops.linear(out.reshape(B * Te, D), self.w.ctc).view(B, Te, -1)]
         return res
+
+
+    # ================================================================== streaming (Emformer.infer)
+    def new_stream_state(self, B: int):
+        """enc_incremental_states content (agents/default_agent.py:237): subsampler conv caches (the last
+        k-1 input frames of each conv -- the reference keeps the whole history, modules/causal_conv.py:62-69,
+        with identical outputs), conv-pos history, the carried look-ahead frames and the per-layer Emformer
+        state [memory bank M, left-context K/V Lc, past_length] (torchaudio_models/emformer.py:397-429)."""
+        cfg, dev, dt_ = self.cfg, self.device, self.dtype
+        D = cfg.embed_dim
+        st = {"prev_len": 0, "past": 0, "carry": None}
+        cin = cfg.input_feat
+        st["conv"] = []
+        for i, (wp, bp, k) in enumerate(self.w.conv):
+            st["conv"].append(torch.zeros(B, k - 1, cin, device=dev, dtype=dt_))
+            cin = wp.shape[0] // 2
+        kp = self.w.pos_w.shape[2]
+        st["pos_hist"] = torch.zeros(B, kp - 1, D, device=dev, dtype=dt_)
+        L = cfg.encoder_layers
+        st["bank"] = [torch.zeros(B, max(cfg.M, 1), D, device=dev, dtype=dt_) for _ in range(L)]
+        st["lc_k"] = [torch.zeros(B, max(cfg.Lc, 1), D, device=dev, dtype=dt_) for _ in range(L)]
+        st["lc_v"] = [torch.zeros(B, max(cfg.Lc, 1), D, device=dev, dtype=dt_) for _ in range(L)]
+        return st
+
+    def _subsample_stream(self, new_frames: torch.Tensor, st) -> torch.Tensor:
+        """Incremental CausalConv1dSubsampler (modules/causal_conv.py:140-155): only new frames are
+        convolved, left context comes from the k-1 cached frames."""
+        ops = self.ops
+        x = new_frames
+        n = len(self.w.conv)
+        for i, (wp, bp, k) in enumerate(self.w.conv):
+            xc = torch.cat([st["conv"][i], x], dim=1).contiguous()
+            B, T, Cin = xc.shape
+            N = wp.shape[0]
+            T_out = (T - k) // 2 + 1
+            y = torch.empty(B, max(T_out, 0), N // 2, device=x.device, dtype=x.dtype)
+            if T_out > 0:
+                ops.linear_raw(xc, wp, bp, y, M_batches=B, rows_per_batch=T_out, N=N, K=k * Cin, a_bs=T * Cin,
+                               a_rs=2 * Cin, a_lead=0, c_bs=T_out * (N // 2), c_rs=N // 2, epilogue=_lib.EPI_GLU,
+                               scale=self.embed_scale if i == n - 1 else 1.0)
+            st["conv"][i] = xc[:, T - (k - 1):].contiguous()
+            x = y
+        return x
+
+    def _emformer_infer(self, chunk: torch.Tensor, st) -> torch.Tensor:
+        """Emformer.infer over one chunk [B, n_utt + R, D] (torchaudio_models/emformer.py:842-896 and
+        _EmformerLayer.infer :561-606). Returns [B, n_utt, D]; updates the per-layer state."""
+        cfg, ops, W = self.cfg, self.ops, self.w
+        B, n, D = chunk.shape
+        R, S, M, Lc = cfg.R, cfg.S, cfg.M, cfg.Lc
+        T = n - R
+        assert 0 < T <= S, "streaming chunks carry at most one segment"
+        use_mem = M > 0
+        n_mem = M if use_mem else 0
+        n_sum = 1 if use_mem else 0
+        rows_z, rows_c, rows_x = n_mem + R + T + n_sum, R + T + n_sum, R + T
+        past = st["past"]
+        n_mem_valid = torch.full((B,), min(M, -(-past // S)), device=chunk.device, dtype=torch.int32)
+        lc_valid = torch.full((B,), min(Lc, past), device=chunk.device, dtype=torch.int32)
+        X = torch.cat([chunk[:, T:], chunk[:, :T]], dim=1).contiguous()          # [rc | utt]
+        mems_in = None
+        if use_mem:
+            mems_in = torch.empty(B, 1, D, device=chunk.device, dtype=chunk.dtype)
+            ops.segment_mean(chunk, None, mems_in, T=T, x_bs=n * D, o_bs=D, seg_len=S, n_out=1)
+        Z = torch.zeros(B, rows_z, D, device=chunk.device, dtype=chunk.dtype)
+        QKV = torch.empty(B, rows_z, 3 * D, device=chunk.device, dtype=chunk.dtype)
+        CTX = torch.zeros(B, rows_c, D, device=chunk.device, dtype=chunk.dtype)
+        X1 = torch.empty_like(X)
+        Y = torch.empty_like(X)
+        Hf = torch.empty(B * rows_x, cfg.ffn_dim, device=chunk.device, dtype=chunk.dtype)
+        for l, L in enumerate(W.layers):
+            if use_mem:
+                Z[:, :n_mem] = st["bank"][l]
+            ops.emformer_prenorm(X, L["ln_in_g"], L["ln_in_b"], None, Z, T=T, n_mem=n_mem, n_rc=R, n_sum=n_sum,
+                                 seg_len=max(S, T))
+            ops.linear(Z.view(B * rows_z, D), L["wqkv"], L["bqkv"], out=QKV.view(B * rows_z, 3 * D))
+            ops.emformer_attention(QKV, None, CTX, B=B, T=T, D=D, H=cfg.num_heads, S=max(S, T), R=R, Lc=Lc, M=M,
+                                   n_mem=n_mem, n_seg=1, use_summary=use_mem, lc_k=st["lc_k"][l],
+                                   lc_v=st["lc_v"][l], lc_valid=lc_valid, n_mem_valid=n_mem_valid)
+            mems_out = torch.empty(B, 1, D, device=chunk.device, dtype=chunk.dtype)
+            ops.linear_raw(CTX, L["wo"], L["bo"], X1, M_batches=B, rows_per_batch=rows_c, N=D, K=D, a_bs=rows_c * D,
+                           a_rs=D, c_bs=rows_x * D, c_rs=D, epilogue=EPI_EMF_OUT, R=X, r_bs=rows_x * D, r_rs=D,
+                           n_main=rows_x, aux=mems_out, aux_rows=n_sum, aux_bs=D)
+            # _pack_state (:415-429): roll the memory bank with this layer's INPUT memory, the
+            # left-context K/V with the utterance rows' projections
+            if use_mem:
+                st["bank"][l] = torch.cat([st["bank"][l], mems_in], dim=1)[:, -M:].contiguous()
+                mems_in = mems_out
+            if Lc > 0:
+                u0 = n_mem + R
+                st["lc_k"][l] = torch.cat([st["lc_k"][l], QKV[:, u0:u0 + T, D:2 * D]], dim=1)[:, -Lc:].contiguous()
+                st["lc_v"][l] = torch.cat([st["lc_v"][l], QKV[:, u0:u0 + T, 2 * D:]], dim=1)[:, -Lc:].contiguous()
+            ops.layernorm(X1, L["ln_ff_g"], L["ln_ff_b"], out=Y)
+            ops.linear(Y.view(B * rows_x, D), L["w1"], L["b1"], epilogue=EPI_BIAS_GELU, out=Hf)
+            ops.linear(Hf, L["w2"], L["b2"], epilogue=EPI_BIAS_RES, residual=X1.view(B * rows_x, D),
+                       out=X.view(B * rows_x, D))
+        st["past"] = past + T
+        Yall = ops.layernorm(X, W.final_g, W.final_b)
+        return Yall[:, R:]
+
+    def infer(self, src_tokens: torch.Tensor, src_lengths: torch.Tensor, incremental_state: dict, finish=False):
+        """S2TEmformerEncoder.infer (models/s2t_emformer.py:199-278). src_tokens holds ALL frames so far
+        [B,T,80]; the reference asserts B == 1 (:200) -- here a batch of streams advancing in lockstep
+        (same frame counts) is accepted too and equals B independent calls."""
+        cfg, ops = self.cfg, self.ops
+        key = "simulst_amd.encoder_state"
+        B = src_tokens.size(0)
+        if key not in incremental_state:
+            incremental_state[key] = self.new_stream_state(B)
+        st = incremental_state[key]
+        S, R, D = cfg.S, cfg.R, cfg.embed_dim
+        update_len = src_tokens.size(1) - st["prev_len"]
+        if finish and update_len == 0:
+            x = torch.zeros(B, 0, D, device=self.device, dtype=self.dtype)
+        else:
+            assert update_len > 0
+            new = src_tokens[:, st["prev_len"]:].to(device=self.device, dtype=self.dtype).contiguous()
+            st["prev_len"] = src_tokens.size(1)
+            x = self._subsample_stream(new, st)
+            if x.size(1) > 0:
+                y = ops.conv_pos(x, st["pos_hist"], self.w.pos_w, self.w.pos_b, None, cfg.conv_pos_groups)
+                kp1 = st["pos_hist"].size(1)
+                st["pos_hist"] = torch.cat([st["pos_hist"], x], dim=1)[:, -kp1:].contiguous()
+                x = y
+        n_in = x.size(1)
+        if finish:
+            x = torch.cat([x, x.new_zeros(B, R, D)], dim=1)
+        block_len = n_in
+        if st["carry"] is not None:
+            block_len = n_in + st["carry"].size(1)
+            x = torch.cat([st["carry"], x], dim=1)
+        carry = x[:, S:]
+        carry_len = 0
+        if block_len > S:
+            carry_len = block_len - S
+            x = x[:, :S + R]
+        outs = []
+        if x.size(1) > R:
+            outs.append(self._emformer_infer(x.contiguous(), st))
+        st["carry"] = carry.contiguous()
+        if finish and carry_len > 0:
+            outs.append(self._emformer_infer(st["carry"], st))
+        out = torch.cat(outs, dim=1) if outs else torch.zeros(B, 0, D, device=self.device, dtype=self.dtype)
+        n_out = out.size(1)
+        pad = torch.zeros(B, n_out, dtype=torch.bool, device=self.device)
+        return {"encoder_out": [out.transpose(0, 1)], "encoder_padding_mask": [pad], "encoder_embedding": [],
+                "encoder_states": [], "src_tokens": [], "src_lengths": [], "ctc_logits": [],
+                "encoder_out_btd": out}

@@ -1,0 +1,96 @@
+"""Streaming path on the GPU: encoder.infer vs golden g11, the agent loop vs the oracle's agent loop
+(identical READ/WRITE actions, tokens, delays => identical Average Lagging). GPU only."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from simulst_amd.ops import Ops
+    return Ops()
+
+
+def test_g11_streaming_encoder_golden(ops):
+    from simulst_amd.config import tiny
+    from simulst_amd.encoder import S2TEmformerEncoder
+    a, w = load_golden("g11_encoder")
+    cfg = tiny()
+    enc = S2TEmformerEncoder(cfg, w, dtype=torch.float32, ops=ops)
+    first = (cfg.S + cfg.R) * cfg.stride
+    nxt = cfg.S * cfg.stride
+    for b in range(3):
+        T = int(a["lengths"][b])
+        inc, pos, outs, sched, expected = {}, 0, [], [], first
+        while pos < T:
+            n = min(expected, T - pos)
+            pos += n
+            finish = (n < expected) or pos >= T
+            o = enc.infer(a["fbank"][b:b + 1, :pos].cuda(), torch.tensor([pos]), inc, finish=finish)
+            outs.append(o["encoder_out"][0])
+            sched.append((n, int(finish), o["encoder_out"][0].size(0)))
+            expected = nxt
+        assert sched == [tuple(r) for r in a[f"stream{b}.sched"].tolist()]
+        torch.testing.assert_close(torch.cat(outs, 0).cpu(), a[f"stream{b}.enc_out"], atol=1e-4, rtol=1e-3)
+    T = int(a["flush.T"])
+    inc, outs = {}, []
+    for pos, fin in ((first, False), (first + nxt, False), (T, False), (T, True)):
+        o = enc.infer(a["fbank"][:1, :pos].cuda(), torch.tensor([pos]), inc, finish=fin)
+        outs.append(o["encoder_out"][0])
+    torch.testing.assert_close(torch.cat(outs, 0).cpu(), a["flush.enc_out"], atol=1e-4, rtol=1e-3)
+
+
+def test_streaming_batch_equals_single(ops):
+    """Batched lockstep streaming (absent from the reference, models/s2t_emformer.py:200) equals B=1 calls."""
+    from simulst_amd.config import tiny
+    from simulst_amd.encoder import S2TEmformerEncoder
+    a, w = load_golden("g11_encoder")
+    cfg = tiny()
+    enc = S2TEmformerEncoder(cfg, w, dtype=torch.float32, ops=ops)
+    fb = a["fbank"][:, :105].cuda()
+    chunks = [24, 16, 16, 16, 16, 16, 1]
+    outs_b, inc, pos = [], {}, 0
+    for i, n in enumerate(chunks):
+        pos += n
+        outs_b.append(enc.infer(fb[:, :pos], torch.tensor([pos] * 3), inc, finish=i == len(chunks) - 1)["encoder_out_btd"])
+    full = torch.cat(outs_b, 1)
+    for b in range(3):
+        outs, inc, pos = [], {}, 0
+        for i, n in enumerate(chunks):
+            pos += n
+            outs.append(enc.infer(fb[b:b + 1, :pos], torch.tensor([pos]), inc, finish=i == len(chunks) - 1)["encoder_out_btd"])
+        torch.testing.assert_close(torch.cat(outs, 1)[0], full[b], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("attn,kw", [("waitk_fixed_pre_decision", dict(waitk_lagging=3)),
+                                     ("hard_aligned_fixed_pre_decision", {}),
+                                     ("infinite_lookback_fixed_pre_decision", {})])
+def test_agent_actions_tokens_al_identical_to_oracle(ops, attn, kw):
+    """BASELINE config 1 shape at reduced depth: B=1 streaming through the agent schedule; READ/WRITE
+    sequence, greedy tokens and per-token delays must be IDENTICAL to the CPU oracle => identical AL."""
+    from oracle import agent as oag
+    from oracle.configs import from_model_config
+    from simulst_amd.agent import FairseqSimulSTAgent
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, simul_attn_type=attn, max_target_positions=24, **kw)
+    w = init_model(cfg, seed=999)
+    if "waitk" not in attn:
+        for l in range(2):
+            w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 8
+    ecfg, dcfg = from_model_config(cfg)
+    model = SimulSTModel(cfg, w, dtype=torch.float32, ops=ops)
+    agent = FairseqSimulSTAgent(model)
+    for utt, T in enumerate((312, 498, 640)):
+        fb = torch.randn(T, 80, generator=torch.Generator().manual_seed(999 + utt))
+        ref = oag.simulate_mma(w, ecfg, dcfg, fb)
+        got = agent.run_utterance(fb.cuda())
+        assert got["actions"] == ref["actions"], (attn, T)
+        assert got["tokens"] == ref["tokens"], (attn, T)
+        assert got["delays_ms"] == ref["delays_ms"]
+        assert got["AL"] == ref["AL"]
+        assert got["n_enc"] == ref["n_enc"]
