@@ -53,7 +53,8 @@ enum {
                                   in 64-row blocks [32 value rows | 32 gate rows]     */
   SIMULST_EPI_EMF_OUT = 4,     /* Emformer out_proj: rows < n_main of each utterance: C = . + b + R;
                                   summary rows: tanh(. + b) -> next layer's memory rows */
-  SIMULST_EPI_BIAS_F32OUT = 5  /* C (always fp32) = A W^T + b   (logits, energies)  */
+  SIMULST_EPI_BIAS_F32OUT = 5, /* C (always fp32) = A W^T + b   (logits, energies)  */
+  SIMULST_EPI_BIAS_RES_GELU = 6 /* C = gelu_erf(A W^T + b + R)   (CIF FakeCrossAttn, models/cif_transformer.py:357-362) */
 };
 
 /* monotonic attention flavours (modules/__init__.py:11-16 registry names minus the

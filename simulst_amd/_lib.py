@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsimulst_hip.so")
 
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_GLU, EPI_EMF_OUT, EPI_BIAS_F32OUT = range(6)
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_GLU, EPI_EMF_OUT, EPI_BIAS_F32OUT, EPI_BIAS_RES_GELU = range(7)
 ATTN_HARD, ATTN_INFINITE_LOOKBACK, ATTN_WAITK, ATTN_CHUNKWISE = range(4)
 (K_LINEAR, K_LAYERNORM, K_EMF_ATTN, K_CONV_POS, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_SCAN, K_ARGMAX,
  K_MISC, K_COUNT) = range(10)

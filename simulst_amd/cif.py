@@ -1,0 +1,261 @@
+"""CIF adaptive-policy model on MI355X: mirror of models/cif_transformer.py (CIFLayer, CIFEncoder,
+FakeCrossAttn/CIFDecoderLayer/CIFDecoder) and agents/cif_agent.py.
+
+The integrate-and-fire scan itself (``torch_cif.cif_function`` in the reference -- an un-vendored
+submodule) is the HIP kernel ``simulst_cif_integrate``: wavefront prefix-sum of alpha, fire index
+floor(csum / beta), segmented weighted sum in one pass over the source.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .agent import READ_ACTION, WRITE_ACTION, FrameSource, States
+from .config import ModelConfig
+from .decoder import DecoderWeights
+from .encoder import S2TEmformerEncoder
+from .ops import Ops, EPI_BIAS, EPI_BIAS_F32OUT, EPI_BIAS_GELU, EPI_BIAS_RES
+from .registry import register_model
+
+
+class CIFLayer:
+    """models/cif_transformer.py:111-261 (alpha_proj = CausalConvTBC -> LN -> GELU -> Linear -> sigmoid)."""
+
+    def __init__(self, cfg: ModelConfig, w: Dict[str, torch.Tensor], ops: Ops, device, dtype,
+                 prefix="encoder.cif_layer"):
+        self.cfg, self.ops, self.device, self.dtype = cfg, ops, device, dtype
+        self.beta = cfg.cif_beta
+        self.tail_thres = cfg.cif_beta / 2
+        cw = w[prefix + ".alpha_proj.0.weight"]                 # ConvTBC [k, C_in, C_out]
+        self.k = cw.shape[0]
+        # GEMM over overlapping channel-last rows: W[o][tau*C + c] = cw[tau][c][o]
+        self.conv_w = cw.permute(2, 0, 1).reshape(cw.shape[2], -1).contiguous().to(device=device, dtype=dtype)
+        self.conv_b = w[prefix + ".alpha_proj.0.bias"].float().to(device)
+        self.ln_g = w[prefix + ".alpha_proj.1.weight"].float().to(device)
+        self.ln_b = w[prefix + ".alpha_proj.1.bias"].float().to(device)
+        self.out_w = w[prefix + ".alpha_proj.4.weight"].reshape(-1).contiguous().to(device=device, dtype=dtype)
+        self.out_b = float(w[prefix + ".alpha_proj.4.bias"][0])
+
+    def _alpha(self, x_btd: torch.Tensor, hist: Optional[torch.Tensor]):
+        """sigmoid(alpha_proj(x)). x [B,T,D]; hist [B,k-1,D] = frames before x (None: zero left pad)."""
+        ops = self.ops
+        B, T, D = x_btd.shape
+        k = self.k
+        if hist is not None:
+            xc = torch.cat([hist, x_btd], dim=1).contiguous()
+            lead = 0
+        else:
+            xc = x_btd.contiguous()
+            lead = (k - 1) * D
+        Tc = xc.size(1)
+        h = torch.empty(B, T, D, device=x_btd.device, dtype=x_btd.dtype)
+        ops.linear_raw(xc, self.conv_w, self.conv_b, h, M_batches=B, rows_per_batch=T, N=D, K=k * D, a_bs=Tc * D,
+                       a_rs=D, a_lead=lead, c_bs=T * D, c_rs=D, epilogue=EPI_BIAS)
+        return ops.cif_alpha_head(h, self.ln_g, self.ln_b, self.out_w, self.out_b)
+
+    def forward(self, x_btd: torch.Tensor, lengths: torch.Tensor):
+        """CIFLayer.forward (:141-186), inference (no target_lengths). x [B,T,D], lengths [B]."""
+        alpha = self._alpha(x_btd, None)
+        len_i32 = lengths.to(device=self.device, dtype=torch.int32)
+        out, n, delays, tail_w, asum = self.ops.cif_integrate(x_btd.contiguous(), alpha, beta=self.beta,
+                                                               tail_thres=self.tail_thres, src_len=len_i32)
+        return {"cif_out": [out.transpose(0, 1)], "cif_lengths": [n.to(torch.int64)], "alpha": [alpha],
+                "delays": [delays], "alpha_sum": [asum], "tail_weights": [tail_w], "cif_out_btd": out}
+
+    def new_state(self, B: int, D: int):
+        return {"conv_hist": torch.zeros(B, self.k - 1, D, device=self.device, dtype=self.dtype),
+                "prev_feat": None, "prev_weight": None}
+
+    def infer(self, x_btd: torch.Tensor, st: dict, finish: bool = False):
+        """CIFLayer.infer (:188-261): B == 1; the un-fired tail (weight, feature / beta) is carried as a
+        pseudo source frame in front of the next chunk."""
+        B, T, D = x_btd.shape
+        if B > 1:
+            raise NotImplementedError("batched infer not supported for now.")
+        if T > 0:
+            alpha = self._alpha(x_btd, st["conv_hist"])
+            st["conv_hist"] = torch.cat([st["conv_hist"], x_btd], dim=1)[:, -(self.k - 1):].contiguous()
+        else:
+            alpha = torch.zeros(B, 0, device=self.device, dtype=torch.float32)
+        x = x_btd
+        if st["prev_weight"] is not None:
+            alpha = torch.cat([st["prev_weight"], alpha], dim=1).contiguous()
+            x = torch.cat([st["prev_feat"], x], dim=1).contiguous()
+        out, n, delays, tail_w, asum = self.ops.cif_integrate(x.contiguous(), alpha, beta=self.beta,
+                                                               tail_thres=self.tail_thres if finish else 0.0)
+        n_host = int(n[0].item())
+        if not finish:
+            st["prev_feat"] = (out[:, n_host - 1:n_host].float() / self.beta).to(self.dtype)
+            st["prev_weight"] = tail_w.view(B, 1)
+            n_host -= 1
+        else:
+            st["prev_feat"] = st["prev_weight"] = None
+        feats = out[:, :n_host]
+        return {"cif_out": [feats.transpose(0, 1)], "cif_lengths": [torch.tensor([n_host])], "alpha": [alpha],
+                "delays": [delays], "alpha_sum": [asum], "tail_weights": [tail_w], "cif_out_btd": feats}
+
+
+class CIFEncoder(S2TEmformerEncoder):
+    """models/cif_transformer.py:264-321."""
+
+    def __init__(self, cfg, weights, device="cuda", dtype=torch.float32, ops=None):
+        super().__init__(cfg, weights, device, dtype, ops)
+        self.cif_layer = CIFLayer(cfg, weights, self.ops, self.device, dtype)
+
+    def forward(self, src_tokens, src_lengths):
+        enc = super().forward(src_tokens, src_lengths)
+        enc.update(self.cif_layer.forward(enc["encoder_out_btd"].contiguous(), enc["encoder_lengths"]))
+        return enc
+
+    def infer(self, src_tokens, src_lengths, incremental_state, finish=False):
+        enc = super().infer(src_tokens, src_lengths, incremental_state, finish=finish)
+        key = "simulst_amd.cif_state"
+        if key not in incremental_state:
+            incremental_state[key] = self.cif_layer.new_state(src_tokens.size(0), self.cfg.embed_dim)
+        enc.update(self.cif_layer.infer(enc["encoder_out_btd"].contiguous(), incremental_state[key], finish))
+        return enc
+
+
+class CIFDecoder:
+    """models/cif_transformer.py:540-724: position-synchronous decoding; the 'cross attention' is
+    FakeCrossAttn out_proj(gelu(q_proj(x) + k_proj(cif_t))) (:340-362)."""
+
+    def __init__(self, cfg: ModelConfig, weights, device="cuda", dtype=torch.float32, ops=None, prefix="decoder"):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.ops = ops or Ops()
+        self.w = DecoderWeights(weights, cfg, self.device, dtype, prefix)
+        self.embed_scale = math.sqrt(cfg.embed_dim)
+        self.pre_decision_ratio = 1
+
+    def max_positions(self):
+        return self.cfg.max_target_positions
+
+    def new_state(self, B: int, cap: int = 128):
+        cfg = self.cfg
+        H, d = cfg.num_heads, cfg.head_dim
+        return {"k": [torch.zeros(B, H, cap, d, device=self.device, dtype=self.dtype) for _ in range(cfg.decoder_layers)],
+                "v": [torch.zeros(B, H, cap, d, device=self.device, dtype=self.dtype) for _ in range(cfg.decoder_layers)],
+                "n_prev": torch.zeros(B, device=self.device, dtype=torch.int32), "n_prev_host": 0, "cap": cap}
+
+    def step(self, st, last_tokens, cif_btd, cif_lengths, overshoot_weight=1.0):
+        """CIFDecoder.forward with incremental_state (:692-724). cif_btd [B,n,D], cif_lengths [B] (host or
+        device ints). Returns logits [B,V] fp32 with the EOS overshoot bias applied."""
+        ops, cfg, Wd = self.ops, self.cfg, self.w
+        B = last_tokens.size(0)
+        u = st["n_prev_host"] + 1                             # len([eos] + hyp)
+        cl = cif_lengths.to(self.device).to(torch.int64)
+        idx = (cl.clamp(max=u) - 1).clamp(min=0)
+        cif_t = cif_btd[torch.arange(B, device=self.device), idx].contiguous()          # [B,D] gather (:622-628)
+        pos_row = (st["n_prev"] + (cfg.padding_idx + 1)).contiguous()
+        x = ops.embed_tokens(last_tokens, Wd.E, Wd.pos, pos_row, self.embed_scale)
+        for l, L in enumerate(Wd.layers):
+            qkv = ops.linear(x, L["wqkv"], L["bqkv"], ln=(L["ln1_g"], L["ln1_b"]))
+            ctx = ops.decoder_self_attention(qkv, st["k"][l], st["v"][l], st["n_prev"])
+            x = ops.linear(ctx, L["wo"], L["bo"], epilogue=EPI_BIAS_RES, residual=x)
+            kk = ops.linear(cif_t, L["c_wk"], L["c_bk"])
+            hdn = ops.linear(x, L["c_wq"], None, epilogue=_lib.EPI_BIAS_RES_GELU, residual=kk,
+                             ln=(L["ln2_g"], L["ln2_b"]))
+            x = ops.linear(hdn, L["c_wo"], L["c_bo"], epilogue=EPI_BIAS_RES, residual=x)
+            hdn = ops.linear(x, L["fc1"], L["b1"], epilogue=EPI_BIAS_GELU, ln=(L["ln3_g"], L["ln3_b"]))
+            x = ops.linear(hdn, L["fc2"], L["b2"], epilogue=EPI_BIAS_RES, residual=x)
+        if cfg.cif_highway:
+            y = ops.layernorm(x, Wd.ln_g, Wd.ln_b)
+            y = (y.float() + cif_t.float()).to(self.dtype)
+            logits = ops.linear(y, Wd.out_proj, None, epilogue=EPI_BIAS_F32OUT)
+        else:
+            logits = ops.linear(x, Wd.out_proj, None, epilogue=EPI_BIAS_F32OUT, ln=(Wd.ln_g, Wd.ln_b))
+        overshoot = (u - cl).clamp(min=0).to(torch.float32) * overshoot_weight       # (:716-722)
+        return logits, overshoot
+
+    def commit(self, st):
+        st["n_prev"] += 1
+        st["n_prev_host"] += 1
+        assert st["n_prev_host"] < st["cap"]
+
+
+@register_model("cif_transformer")
+class CIFTransformerModel:
+    def __init__(self, cfg: ModelConfig, weights, device="cuda", dtype=torch.float32, ops=None):
+        self.cfg = cfg
+        self.ops = ops or Ops()
+        self.device, self.dtype = torch.device(device), dtype
+        self.encoder = CIFEncoder(cfg, weights, device, dtype, self.ops)
+        self.decoder = CIFDecoder(cfg, weights, device, dtype, self.ops)
+
+    def get_normalized_probs(self, net_output, log_probs=True):
+        lg = net_output[0].float()
+        return torch.log_softmax(lg, -1) if log_probs else torch.softmax(lg, -1)
+
+    def max_decoder_positions(self):
+        return self.cfg.max_target_positions
+
+
+class CIFAgent:
+    """agents/cif_agent.py: READ while cif_lengths <= len(hyp) and the source has not ended (:385-389),
+    otherwise one decoder step and WRITE; cif_out / cif_lengths accumulate across READs (:327-343)."""
+
+    def __init__(self, model: CIFTransformerModel, max_len_a: int = 1, max_len_b: int = 0,
+                 overshoot_weight: float = 1.0):
+        self.model = model
+        enc = model.encoder
+        self.stride_ms = enc.conv_layer_stride() * 10
+        self.right_context, self.segment_length = enc.right_context, enc.segment_length
+        self.max_len = lambda x: max_len_a * x + max_len_b
+        self.overshoot_weight = overshoot_weight
+        self.eos = model.cfg.eos
+
+    def update_model_encoder(self, states: States):
+        src = states.source
+        update_len = src.pos - states.last_update_source_len
+        if update_len == 0 and states.finish_read():
+            return
+        finish = (update_len < self.expected_frames) or states.finish_read()
+        out = self.model.encoder.infer(src.fbank[:src.pos].unsqueeze(0), torch.tensor([src.pos]),
+                                       states.enc_incremental_states, finish=finish)
+        if getattr(states, "cif_out", None) is None:
+            states.cif_out, states.cif_len = out["cif_out_btd"], int(out["cif_lengths"][0])
+        else:
+            states.cif_out = torch.cat([states.cif_out, out["cif_out_btd"]], dim=1)
+            states.cif_len += int(out["cif_lengths"][0])
+        assert states.cif_out.size(1) == states.cif_len, "length mismatch"
+        states.last_update_source_len = src.pos
+
+    def run_utterance(self, fbank: torch.Tensor):
+        from .latency import average_lagging
+        src = FrameSource(fbank)
+        states = States(src)
+        states.cif_out = None
+        dec = self.model.decoder
+        dst = dec.new_state(1, cap=int(self.max_len(fbank.size(0))) + 4)
+        actions, delays = [], []
+        first = (self.segment_length + self.right_context) * self.stride_ms // 10
+        nxt = self.segment_length * self.stride_ms // 10
+        while True:
+            if states.cif_out is None:
+                self.expected_frames = first
+                read = True
+            else:
+                read = states.cif_len <= len(states.target) and not states.finish_read()
+                if read:
+                    self.expected_frames = nxt
+            if read:
+                actions.append("R")
+                if src.finished:
+                    raise RuntimeError("READ after source finished")
+                src.read(self.expected_frames)
+                self.update_model_encoder(states)
+                continue
+            actions.append("W")
+            last = ([self.eos] + states.target)[-1]
+            logits, overshoot = dec.step(dst, torch.tensor([last], device=self.model.device), states.cif_out,
+                                         torch.tensor([states.cif_len]), self.overshoot_weight)
+            tok = int(self.model.ops.greedy_argmax(logits, pad_idx=-1, eos_idx=self.eos,
+                                                   eos_bias=overshoot.contiguous())[0].item())
+            states.target.append(tok)
+            dec.commit(dst)
+            delays.append(src.elapsed_ms())
+            if tok == self.eos or len(states.target) > self.max_len(src.pos):
+                break
+        return {"tokens": list(states.target), "delays_ms": delays, "actions": "".join(actions),
+                "AL": average_lagging(delays, src.total_ms()), "n_cif": states.cif_len}

@@ -213,8 +213,9 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
           if (c >= p.N) continue;
           float v = acc[i][j][e] + (bias ? bias[c] : 0.f);
           if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_erf(v);
-          if constexpr (EPI == SIMULST_EPI_BIAS_RES)
+          if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU)
             v += to_f32(R[(long)b * p.r_bs + (long)ii * p.r_rs + c]);
+          if constexpr (EPI == SIMULST_EPI_BIAS_RES_GELU) v = gelu_erf(v);
           if constexpr (EPI == SIMULST_EPI_EMF_OUT) {
             if (ii < p.n_main) {
               v += to_f32(R[(long)b * p.r_bs + (long)ii * p.r_rs + c]);
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
   float resv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) resv[e] = 0.f;
-  if constexpr (EPI == SIMULST_EPI_BIAS_RES) {
+  if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) {
     const TA* rp = R + (long)eb * p.r_bs + (long)ei * p.r_rs + n0 + ec;
     if (e_ok && n0 + ec + 8 <= p.N) {
       if constexpr (F32) {
@@ -431,7 +432,8 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
     const int c = n0 + ec + e;
     v += (bias && c < p.N) ? bias[c] : 0.f;
     if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_erf(v);
-    if constexpr (EPI == SIMULST_EPI_BIAS_RES) v += resv[e];
+    if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) v += resv[e];
+    if constexpr (EPI == SIMULST_EPI_BIAS_RES_GELU) v = gelu_erf(v);
     outv[e] = v;
   }
   TC* cp = C + (long)eb * p.c_bs + (long)ei * p.c_rs + n0 + ec;
@@ -503,6 +505,7 @@ int dispatch(simulst_handle* h, int epi, const void* A, const void* W, const flo
     case SIMULST_EPI_GLU: launch_tiles<TA, TA, SIMULST_EPI_GLU>(h, A, W, bias, R, C, aux, p); break;
     case SIMULST_EPI_EMF_OUT: launch_tiles<TA, TA, SIMULST_EPI_EMF_OUT>(h, A, W, bias, R, C, aux, p); break;
     case SIMULST_EPI_BIAS_F32OUT: launch_tiles<TA, float, SIMULST_EPI_BIAS>(h, A, W, bias, R, C, aux, p); break;
+    case SIMULST_EPI_BIAS_RES_GELU: launch_tiles<TA, TA, SIMULST_EPI_BIAS_RES_GELU>(h, A, W, bias, R, C, aux, p); break;
     default: h->err = "simulst_linear: unknown epilogue"; return SIMULST_E_ARG;
   }
   return SIMULST_OK;
@@ -523,7 +526,8 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
              "simulst_linear: non-positive shape");
   SL_REQUIRE(h, d->K % G == 0 && d->a_row_stride % G == 0 && d->a_batch_stride % G == 0 && d->a_lead % G == 0,
              SIMULST_E_SHAPE, "simulst_linear: K / A strides must be multiples of the 16-byte vector");
-  if (d->epilogue == SIMULST_EPI_BIAS_RES || d->epilogue == SIMULST_EPI_EMF_OUT) SL_CHECK_NULL(h, R);
+  if (d->epilogue == SIMULST_EPI_BIAS_RES || d->epilogue == SIMULST_EPI_EMF_OUT ||
+      d->epilogue == SIMULST_EPI_BIAS_RES_GELU) SL_CHECK_NULL(h, R);
   if (d->epilogue == SIMULST_EPI_GLU)
     SL_REQUIRE(h, d->N % 64 == 0, SIMULST_E_SHAPE, "simulst_linear: GLU needs N % 64 == 0 (prepacked pairs)");
   if (d->epilogue == SIMULST_EPI_EMF_OUT) {
