@@ -21,6 +21,8 @@ struct simulst_handle {
   int64_t timer_n[SIMULST_K_COUNT];
   hipEvent_t ev0, ev1;
   bool ev_ready;
+  void* ws;            // library-owned scratch (split-K partial tiles), grown on demand
+  size_t ws_bytes;
 };
 
 #define SL_CHECK_NULL(h, p)                                   \

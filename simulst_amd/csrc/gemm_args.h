@@ -1,0 +1,25 @@
+// Shared argument block of the contraction kernels (gemm.hip, gemm_skinny.hip).
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct LinArgs {
+  int M, rpb, N, K;
+  long a_bs, a_rs, a_lead;
+  long c_bs, c_rs;
+  long r_bs, r_rs;
+  float scale;
+  int n_main, aux_rows;
+  long aux_bs;
+  const float* ln_g;
+  const float* ln_b;
+};
+
+
+template <typename T>
+__device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// decode-step (M <= 128) contraction, defined in gemm_skinny.hip
+int sl_launch_skinny(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
+                     const void* R, void* C, const LinArgs& p);

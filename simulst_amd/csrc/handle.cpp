@@ -9,6 +9,8 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (!h) return SIMULST_E_ARG;
   h->stream = (hipStream_t)hip_stream;
   h->ev_ready = false;
+  h->ws = nullptr;
+  h->ws_bytes = 0;
   for (int i = 0; i < SIMULST_K_COUNT; ++i) { h->timer_on[i] = false; h->timer_ms[i] = 0.0; h->timer_n[i] = 0; }
   *out = h;
   return SIMULST_OK;
@@ -17,6 +19,7 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
 extern "C" int simulst_destroy(simulst_handle* h) {
   if (!h) return SIMULST_E_NULL;
   if (h->ev_ready) { (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); }
+  if (h->ws) (void)hipFree(h->ws);
   delete h;
   return SIMULST_OK;
 }
