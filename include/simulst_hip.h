@@ -77,6 +77,11 @@ int simulst_version(void);
 int simulst_timer_enable(simulst_handle* h, int kernel_class, int on);
 int simulst_timer_read(simulst_handle* h, int kernel_class, double* total_ms, int64_t* launches);
 int simulst_timer_reset(simulst_handle* h);
+/* hipGraph replay of simulst_mma_decode: when on (and the handle's stream is not the null stream and no
+ * timer is enabled) the kernel sequence of a call is captured once and replayed whenever the call repeats
+ * with identical arguments (same buffers, steps, flags) -- removes the per-launch host cost and about a
+ * microsecond of dependent-kernel gap per kernel. */
+int simulst_graph_enable(simulst_handle* h, int on);
 
 /* ---- dense contraction ----------------------------------------------------------
  * C[r, :] = epi(A[r, :] . W^T) for logical rows r = b * rows_per_batch + i.

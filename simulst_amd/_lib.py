@@ -68,6 +68,7 @@ SIGNATURES = {
     "simulst_timer_enable": [_vp, C.c_int, C.c_int],
     "simulst_timer_read": [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)],
     "simulst_timer_reset": [_vp],
+    "simulst_graph_enable": [_vp, C.c_int],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_emformer_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
@@ -144,6 +145,9 @@ class Handle:
 
     def timer_enable(self, kernel_class=-1, on=True):
         self.check(self.lib.simulst_timer_enable(self._h, kernel_class, int(on)), "simulst_timer_enable")
+
+    def graph_enable(self, on=True):
+        self.check(self.lib.simulst_graph_enable(self._h, int(on)), "simulst_graph_enable")
 
     def timer_reset(self):
         self.check(self.lib.simulst_timer_reset(self._h), "simulst_timer_reset")

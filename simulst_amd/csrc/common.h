@@ -4,6 +4,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/simulst_hip.h"
 
@@ -19,10 +20,16 @@ struct simulst_handle {
   bool timer_on[SIMULST_K_COUNT];
   double timer_ms[SIMULST_K_COUNT];
   int64_t timer_n[SIMULST_K_COUNT];
-  hipEvent_t ev0, ev1;
-  bool ev_ready;
+  struct EvPair { hipEvent_t a, b; int cls; };
+  std::vector<EvPair> ev_pool;   // pooled event pairs of the timed launches since the last read
+  int ev_used;
   void* ws;            // library-owned scratch (split-K partial tiles), grown on demand
   size_t ws_bytes;
+  // cached hipGraph of the last simulst_mma_decode call (replayed when the call repeats exactly)
+  bool graph_on;
+  bool capturing;
+  hipGraphExec_t graph_exec;
+  uint64_t graph_key;
 };
 
 #define SL_CHECK_NULL(h, p)                                   \
@@ -41,31 +48,33 @@ struct simulst_handle {
     }                                                         \
   } while (0)
 
-// RAII-less timer scope: when the class timer is on, bracket the launch with events
-// and accumulate (synchronises -- measurement mode only, never on by default).
+// Timer scope: when the class timer is on, ONE pooled HIP event is recorded on the handle's stream after
+// the launch (plus one in front of the first timed launch). Nothing is synchronised here -- launches stay
+// back to back -- and simulst_timer_read() attributes each interval between consecutive events to the class
+// of the launch that closed it: on an in-order stream that is the kernel's dispatch-to-end time (the
+// quantity rocprofv3 --kernel-trace reports) plus the cost of one event record, which the caller removes
+// by comparing the instrumented pass with an un-instrumented one (bench.py does). Work issued
+// by others between two timed launches (torch copies/fills) is attributed to the next timed launch.
+// Measurement mode only, never on by default.
 struct KTimer {
   simulst_handle* h;
   int cls;
-  bool on;
-  KTimer(simulst_handle* h_, int cls_) : h(h_), cls(cls_), on(h_->timer_on[cls_]) {
-    if (on) {
-      if (!h->ev_ready) {
-        (void)hipEventCreate(&h->ev0);
-        (void)hipEventCreate(&h->ev1);
-        h->ev_ready = true;
-      }
-      (void)hipEventRecord(h->ev0, h->stream);
+  int slot;
+  KTimer(simulst_handle* h_, int cls_) : h(h_), cls(cls_), slot(-1) {
+    if (!h->timer_on[cls_] || h->capturing) return;
+    if (h->ev_used >= (int)h->ev_pool.size()) {
+      if (h->ev_pool.size() >= 40000) return;            // cap: later launches stay untimed
+      simulst_handle::EvPair p;
+      if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+      p.cls = cls_;
+      h->ev_pool.push_back(p);
     }
+    slot = h->ev_used++;
+    h->ev_pool[slot].cls = cls_;
+    if (slot == 0) (void)hipEventRecord(h->ev_pool[0].a, h->stream);
   }
   ~KTimer() {
-    if (on) {
-      (void)hipEventRecord(h->ev1, h->stream);
-      (void)hipEventSynchronize(h->ev1);
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-      h->timer_ms[cls] += ms;
-      h->timer_n[cls] += 1;
-    }
+    if (slot >= 0) (void)hipEventRecord(h->ev_pool[slot].b, h->stream);
   }
 };
 

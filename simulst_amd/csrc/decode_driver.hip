@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
     const T* __restrict__ qm, const T* __restrict__ qs, const T* __restrict__ Km, const T* __restrict__ Ks,
     const T* __restrict__ Vc, float energy_bias, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
     long* __restrict__ head_step, unsigned char* __restrict__ head_read, T* __restrict__ ctx, int H, int d,
-    int S_cap, int ratio, int attn_type, int waitk_k, int online, int mass_pres) {
+    int S_cap, int ratio, int attn_type, int waitk_k, int online, int mass_pres, int n_hint) {
   constexpr int W = VL<T>::W;
   extern __shared__ float sm[];
   float* q_s = sm;                 // [64]
@@ -45,9 +45,12 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
   const bool soft = attn_type != SIMULST_ATTN_HARD;
   const bool fast = soft && S_cap <= 256;     // rows >= len exist (zero-filled) and are masked by n <= len
   attn::Regs<T> rg;
-  if (fast) attn::prefetch<T>(rg, qs + (long)b * D + h * d, Kh, D, Vh, D, S_cap, d, -1, nullptr, nullptr);
+  // n_hint: upper bound on the keys this step can attend to: host-known (wait-k in lockstep), derived from
+  // the device-side target index (n_hint < 0, wait-k: target t sees at most (t + k) * ratio frames), else S_cap
   const int tg = tgt_idx ? tgt_idx[b] : 0;    // scalar inputs of the policy: issued with the prefetch
   const long hs = head_step[r];
+  if (n_hint < 0) n_hint = attn_type == SIMULST_ATTN_WAITK ? (tg + waitk_k) * ratio : S_cap;
+  if (fast) attn::prefetch<T>(rg, qs + (long)b * D + h * d, Kh, D, Vh, D, min(S_cap, n_hint), d, -1, nullptr, nullptr);
   // ---- 1. pooled probabilities
   if (attn_type == SIMULST_ATTN_WAITK) {
     int wk = tg + waitk_k - 1;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
                                                            long* __restrict__ out_tokens, int* __restrict__ n_prev,
                                                            const T* __restrict__ E, const float* __restrict__ pos,
                                                            T* __restrict__ x, int V, int D, int pad_idx, int eos_idx,
-                                                           int mask_eos, float scale) {
+                                                           int mask_eos, float scale, int B_, int np_base) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int s_tok;
@@ -168,7 +171,9 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
       if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
     if (bi == 0x7fffffff) bi = 0;
     tokens[b] = bi;
-    out_tokens[b] = bi;
+    // np_base >= 0: out_tokens is the [n_steps][B] buffer and the row is derived from the device-side
+    // position (one captured step graph serves every step); else out_tokens already points at the row
+    if (np_base >= 0) out_tokens[(long)(np - np_base) * B_ + b] = bi; else out_tokens[b] = bi;
     n_prev[b] = np + 1;
     s_tok = bi;
   }
@@ -206,16 +211,22 @@ template <typename T>
 int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const void* Km, const void* Ks,
                         const void* Vc, float energy_bias, const int32_t* key_len, const int32_t* tgt_idx,
                         int64_t* head_step, uint8_t* head_read, void* ctx, int B, int H, int d, int S_cap, int ratio,
-                        int attn_type, int waitk_k, int online, int mass_pres) {
+                        int attn_type, int waitk_k, int online, int mass_pres, int n_hint) {
   const size_t lds = (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1) * sizeof(float);
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
   hipLaunchKernelGGL(policy_cross_attn_kernel<T>, dim3(H, B), dim3(256), lds, h->stream, (const T*)qm, (const T*)qs,
                      (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx, (long*)head_step,
-                     head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres);
+                     head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres, n_hint);
   return sl_launch_status(h, "simulst_policy_cross_attention");
 }
 
 }  // namespace
+
+static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const void* Kmono, const void* Ksoft,
+                        const void* Vc, float energy_bias, const int32_t* key_len, const int32_t* tgt_idx,
+                        int64_t* head_step, uint8_t* head_read, void* ctx, int32_t B, int32_t H, int32_t d,
+                        int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k, int32_t online,
+                        int32_t mass_preservation, int32_t dtype, int32_t n_hint);
 
 extern "C" int simulst_policy_cross_attention(simulst_handle* h, const void* qm, const void* qs, const void* Kmono,
                                               const void* Ksoft, const void* Vc, float energy_bias,
@@ -223,6 +234,15 @@ extern "C" int simulst_policy_cross_attention(simulst_handle* h, const void* qm,
                                               uint8_t* head_read, void* ctx, int32_t B, int32_t H, int32_t d,
                                               int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k,
                                               int32_t online, int32_t mass_preservation, int32_t dtype) {
+  return policy_cross(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read, ctx, B, H, d,
+                      S_cap, ratio, attn_type, waitk_k, online, mass_preservation, dtype, S_cap);
+}
+
+static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const void* Kmono, const void* Ksoft,
+                        const void* Vc, float energy_bias, const int32_t* key_len, const int32_t* tgt_idx,
+                        int64_t* head_step, uint8_t* head_read, void* ctx, int32_t B, int32_t H, int32_t d,
+                        int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k, int32_t online,
+                        int32_t mass_preservation, int32_t dtype, int32_t n_hint) {
   if (!h) return SIMULST_E_NULL;
   SL_CHECK_NULL(h, Vc); SL_CHECK_NULL(h, head_step); SL_CHECK_NULL(h, head_read); SL_CHECK_NULL(h, ctx);
   SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_policy_cross_attention: dtype");
@@ -238,14 +258,67 @@ extern "C" int simulst_policy_cross_attention(simulst_handle* h, const void* qm,
   if (B <= 0) return SIMULST_OK;
   if (dtype == SIMULST_F32)
     return launch_policy_cross<float>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
-                                      ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation);
+                                      ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint);
   return launch_policy_cross<bf16>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
-                                   ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation);
+                                   ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint);
+}
+
+static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
+                      int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos, bool do_embed,
+                      bool device_indexed);
+
+static uint64_t fnv(uint64_t hsh, const void* p, size_t n) {
+  const unsigned char* c = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) { hsh ^= c[i]; hsh *= 1099511628211ull; }
+  return hsh;
 }
 
 extern "C" int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
                                   int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos) {
-  const int np_uniform = dd ? dd->n_prev_uniform : -1;
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, dd); SL_CHECK_NULL(h, layers);
+  bool timers = false;
+  for (int i = 0; i < SIMULST_K_COUNT; ++i) timers |= h->timer_on[i];
+  if (!h->graph_on || timers || h->stream == nullptr || n_steps <= 0 || dd->n_prev_uniform < 0)
+    return run_decode(h, dd, layers, tokens_io, out_tokens, n_steps, mask_eos, true, false);
+  uint64_t key = 1469598103934665603ull;
+  key = fnv(key, dd, sizeof(*dd));
+  key = fnv(key, layers, sizeof(simulst_dec_layer) * dd->n_layers);
+  key = fnv(key, &tokens_io, sizeof(tokens_io));
+  key = fnv(key, &out_tokens, sizeof(out_tokens));
+  key = fnv(key, &mask_eos, sizeof(mask_eos));
+  // ONE step is captured (positions are read from the device-side n_prev[], so the same 50-kernel graph
+  // serves every step) and replayed n_steps times; the first embedding runs eagerly
+  int rc0 = run_decode(h, dd, layers, tokens_io, out_tokens, 0, mask_eos, true, true);
+  if (rc0 != SIMULST_OK) return rc0;
+  if (!h->graph_exec || h->graph_key != key) {
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { h->err = std::string("simulst_mma_decode: begin capture: ") + hipGetErrorString(e); return (int)e; }
+    h->capturing = true;
+    int rc = run_decode(h, dd, layers, tokens_io, out_tokens, 1, mask_eos, false, true);
+    h->capturing = false;
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(h->stream, &g);
+    if (rc != SIMULST_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) { h->err = std::string("simulst_mma_decode: end capture: ") + hipGetErrorString(e); return (int)e; }
+    e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { h->graph_exec = nullptr; h->err = std::string("simulst_mma_decode: instantiate: ") + hipGetErrorString(e); return (int)e; }
+    h->graph_key = key;
+  }
+  for (int s = 0; s < n_steps; ++s) {
+    hipError_t e = hipGraphLaunch(h->graph_exec, h->stream);
+    if (e != hipSuccess) { h->err = std::string("simulst_mma_decode: graph launch: ") + hipGetErrorString(e); return (int)e; }
+  }
+  return SIMULST_OK;
+}
+
+static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
+                      int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos, bool do_embed,
+                      bool device_indexed) {
+  const int np_uniform = (dd && !device_indexed) ? dd->n_prev_uniform : -1;
+  const int np_base = device_indexed ? dd->n_prev_uniform : -1;
   if (!h) return SIMULST_E_NULL;
   SL_CHECK_NULL(h, dd); SL_CHECK_NULL(h, layers); SL_CHECK_NULL(h, tokens_io); SL_CHECK_NULL(h, out_tokens);
   SL_CHECK_NULL(h, dd->E); SL_CHECK_NULL(h, dd->out_proj); SL_CHECK_NULL(h, dd->pos_table);
@@ -257,7 +330,7 @@ extern "C" int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc*
              SIMULST_E_SHAPE, "simulst_mma_decode: shape");
   const int B = dd->B, D = dd->D, H = dd->H, F = dd->F, V = dd->V, d = D / H, dt = dd->dtype;
   int rc;
-  {
+  if (do_embed) {
     KTimer t(h, SIMULST_K_MISC);
     if (dt == SIMULST_F32)
       hipLaunchKernelGGL(embed_first_kernel<float>, dim3(B), dim3(256), 0, h->stream, (const long*)tokens_io,
@@ -282,10 +355,13 @@ extern "C" int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc*
         if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq_soft, L.c_bq_soft, nullptr, dd->q2, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b))) return rc;
         qs = dd->q2;
       }
-      if ((rc = simulst_policy_cross_attention(h, qm, qs, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias,
-                                               dd->enc_len, dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d,
-                                               dd->S_cap, dd->ratio, dd->attn_type, dd->waitk_k, dd->online,
-                                               dd->mass_preservation, dt))) return rc;
+      // wait-k in lockstep: target t can attend to at most (t + k) * ratio frames
+      const int n_hint = device_indexed ? -1
+                         : (dd->attn_type == SIMULST_ATTN_WAITK && np_uniform >= 0)
+                               ? (np_uniform + s + dd->waitk_k) * dd->ratio : dd->S_cap;
+      if ((rc = policy_cross(h, qm, qs, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
+                             dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
+                             dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint))) return rc;
       if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
       if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b))) return rc;
       if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
@@ -296,12 +372,14 @@ extern "C" int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc*
       KTimer t(h, SIMULST_K_ARGMAX);
       if (dt == SIMULST_F32)
         hipLaunchKernelGGL(argmax_embed_kernel<float>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
-                           (long*)out_tokens + (long)s * B, dd->n_prev, (const float*)dd->E, dd->pos_table,
-                           (float*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale);
+                           (long*)out_tokens + (device_indexed ? 0 : (long)s * B), dd->n_prev, (const float*)dd->E,
+                           dd->pos_table, (float*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, B,
+                           np_base);
       else
         hipLaunchKernelGGL(argmax_embed_kernel<bf16>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
-                           (long*)out_tokens + (long)s * B, dd->n_prev, (const bf16*)dd->E, dd->pos_table,
-                           (bf16*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale);
+                           (long*)out_tokens + (device_indexed ? 0 : (long)s * B), dd->n_prev, (const bf16*)dd->E,
+                           dd->pos_table, (bf16*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, B,
+                           np_base);
       if ((rc = sl_launch_status(h, "simulst_mma_decode(argmax)")) != 0) return rc;
     }
   }

@@ -248,6 +248,7 @@ int launch_all(simulst_handle* h, const void* A, const void* W, const float* bia
   if (splits > 1) {
     const size_t need = (size_t)splits * p.M * p.N * sizeof(float);
     if (h->ws_bytes < need) {
+      if (h->capturing) { h->err = "simulst_linear: scratch too small while capturing a graph"; return SIMULST_E_ARG; }
       if (h->ws) (void)hipFree(h->ws);
       h->ws = nullptr; h->ws_bytes = 0;
       hipError_t e = hipMalloc(&h->ws, need);

@@ -8,9 +8,13 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   simulst_handle* h = new (std::nothrow) simulst_handle();
   if (!h) return SIMULST_E_ARG;
   h->stream = (hipStream_t)hip_stream;
-  h->ev_ready = false;
+  h->ev_used = 0;
   h->ws = nullptr;
   h->ws_bytes = 0;
+  h->graph_on = false;
+  h->capturing = false;
+  h->graph_exec = nullptr;
+  h->graph_key = 0;
   for (int i = 0; i < SIMULST_K_COUNT; ++i) { h->timer_on[i] = false; h->timer_ms[i] = 0.0; h->timer_n[i] = 0; }
   *out = h;
   return SIMULST_OK;
@@ -18,8 +22,9 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
 
 extern "C" int simulst_destroy(simulst_handle* h) {
   if (!h) return SIMULST_E_NULL;
-  if (h->ev_ready) { (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); }
+  for (auto& p : h->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (h->ws) (void)hipFree(h->ws);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   delete h;
   return SIMULST_OK;
 }
@@ -40,9 +45,25 @@ extern "C" int simulst_timer_enable(simulst_handle* h, int cls, int on) {
   return SIMULST_OK;
 }
 
+#include <algorithm>
+static void resolve_events(simulst_handle* h) {
+  if (h->ev_used == 0) return;
+  (void)hipStreamSynchronize(h->stream);
+  for (int i = 0; i < h->ev_used; ++i) {
+    float ms = 0.f;
+    hipEvent_t from = i == 0 ? h->ev_pool[0].a : h->ev_pool[i - 1].b;
+    if (hipEventElapsedTime(&ms, from, h->ev_pool[i].b) == hipSuccess) {
+      h->timer_ms[h->ev_pool[i].cls] += ms;
+      h->timer_n[h->ev_pool[i].cls] += 1;
+    }
+  }
+  h->ev_used = 0;
+}
+
 extern "C" int simulst_timer_read(simulst_handle* h, int cls, double* total_ms, int64_t* launches) {
   if (!h) return SIMULST_E_NULL;
   SL_REQUIRE(h, cls >= 0 && cls < SIMULST_K_COUNT, SIMULST_E_ARG, "simulst_timer_read: kernel class");
+  resolve_events(h);
   if (total_ms) *total_ms = h->timer_ms[cls];
   if (launches) *launches = h->timer_n[cls];
   return SIMULST_OK;
@@ -50,6 +71,21 @@ extern "C" int simulst_timer_read(simulst_handle* h, int cls, double* total_ms, 
 
 extern "C" int simulst_timer_reset(simulst_handle* h) {
   if (!h) return SIMULST_E_NULL;
+  resolve_events(h);
   for (int i = 0; i < SIMULST_K_COUNT; ++i) { h->timer_ms[i] = 0.0; h->timer_n[i] = 0; }
+  return SIMULST_OK;
+}
+
+extern "C" int simulst_graph_enable(simulst_handle* h, int on) {
+  if (!h) return SIMULST_E_NULL;
+  h->graph_on = on != 0;
+  if (!h->graph_on && h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; h->graph_key = 0; }
+  if (h->graph_on && h->ws_bytes < (size_t)(16u << 20)) {     // no allocation may happen inside a capture
+    if (h->ws) (void)hipFree(h->ws);
+    h->ws = nullptr; h->ws_bytes = 0;
+    hipError_t e = hipMalloc(&h->ws, (size_t)(16u << 20));
+    if (e != hipSuccess) { h->err = "simulst_graph_enable: scratch allocation failed"; return (int)e; }
+    h->ws_bytes = (size_t)(16u << 20);
+  }
   return SIMULST_OK;
 }

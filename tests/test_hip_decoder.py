@@ -141,3 +141,32 @@ def test_device_resident_decode_equals_per_op_path(ops, attn, dtype):
             assert torch.equal(a, b)
     else:
         assert (t1 == t2).float().mean().item() > 0.7
+
+
+def test_graph_replay_equals_eager():
+    """hipGraph replay of simulst_mma_decode on a non-null stream: same tokens as eager launches,
+    and a second batch through the cached graph gives that batch's own result."""
+    from simulst_amd import _lib
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.ops import Ops
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=1, decoder_layers=2, waitk_lagging=3)
+    w = init_model(cfg, seed=11)
+    g = torch.Generator().manual_seed(4)
+    fbs = [torch.randn(3, 400, 80, generator=g) for _ in range(2)]
+    L = torch.tensor([400, 400, 400])
+    eager = SimulSTModel(cfg, w, dtype=torch.float32, ops=Ops())
+    ref = [eager.generate_offline(fb.cuda(), L, n_steps=10, mask_eos=True)[0].clone() for fb in fbs]
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ops = Ops(_lib.Handle())
+        ops.h.graph_enable(True)
+        m = SimulSTModel(cfg, w, dtype=torch.float32, ops=ops)
+        got = []
+        for rep in range(2):
+            for fb in fbs:
+                got.append(m.generate_offline(fb.cuda(), L, n_steps=10, mask_eos=True)[0].clone())
+        stream.synchronize()
+    for i, t in enumerate(got):
+        assert torch.equal(t, ref[i % 2]), i
