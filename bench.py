@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run encoder and decode loop of each batch strictly one after the other")
     ap.add_argument("--graph", action="store_true",
                     help="replay the decode step as a hipGraph (measured neutral on MI355X: the step is bound by "
                          "kernel bodies, not by launch cost)")
@@ -138,18 +140,32 @@ def main():
             toks = gather_hypotheses(toks, dist)
         return toks
 
+    pipe = None
+    if not args.no_pipeline:
+        from simulst_amd.model import OfflinePipeline
+        pipe = OfflinePipeline(model)
+
+    def run_steps(k):
+        """k passes of the hot path. Pipelined mode overlaps the encoder of batch i+1 with the greedy loop of
+        batch i (two HIP streams); every batch still runs the full encoder + 110 decode steps."""
+        if pipe is None:
+            for _ in range(k):
+                one_step()
+            return
+        gather = (lambda t: gather_hypotheses(t, dist)) if dist is not None else None
+        pipe.run([(fb, L)] * k, N_STEPS_DECODE, mask_eos=True, on_tokens=gather)
+
     log(f"model + inputs resident on cuda:{local}; host cores {os.cpu_count()}")
     with torch.no_grad():
-        for i in range(args.warmup):
-            one_step()
+        if args.warmup > 0:
+            run_steps(args.warmup)
             torch.cuda.synchronize()
-            log(f"warmup step {i} done")
+            log(f"{args.warmup} warmup steps done")
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            toks = one_step()
+        run_steps(args.steps)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -221,9 +237,19 @@ def main():
             ach = byts / (dom_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None}
+        # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate runs of this same command; profiles/*_pmc_traffic.json says how it was corrected)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")))
+            if dom in pmc:
+                roofline["traffic"] = pmc[dom]["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline["kernel"] = dom
         roofline["launches_per_step"] = dom_n
         roofline["avg_launch_us"] = round(dom_ms * 1e3 / max(dom_n, 1), 3)
+        roofline["algorithmic_bytes_per_launch" if roofline["bound"] == "hbm" else "algorithmic_flop_per_launch"] = \
+            round((byts if roofline["bound"] == "hbm" else flops) / max(dom_n, 1))
         roofline["class_ms_per_step"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
         # the MFMA-bound encoder contractions, reported beside the dominant class
         lin_ms = per_class["linear"][0]
@@ -242,7 +268,8 @@ def main():
             "config": {"workload": "configs[1]: Emformer enc (12L) + wait-k=5 dec (6L), 80x1000 fbank, "
                                    "batch 64/GPU, 110 forced greedy steps",
                        "batch_per_gpu": B, "frames": T_FRAMES, "decode_steps": N_STEPS_DECODE,
-                       "tokens_per_step": tokens_per_step, "sharding": f"utterance-sharded x{world}"},
+                       "tokens_per_step": tokens_per_step, "sharding": f"utterance-sharded x{world}",
+                       "schedule": "serial" if args.no_pipeline else "encoder(i+1) overlapped with decode(i) on 2 streams"},
             "roofline": roofline, "cpu_baseline": cpu_base,
         }
         print(json.dumps(out))

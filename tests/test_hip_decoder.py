@@ -170,3 +170,21 @@ def test_graph_replay_equals_eager():
         stream.synchronize()
     for i, t in enumerate(got):
         assert torch.equal(t, ref[i % 2]), i
+
+
+def test_offline_pipeline_equals_serial(ops):
+    """Two-stream encoder/decoder pipelining across batches returns exactly the per-batch serial results."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import OfflinePipeline, SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, waitk_lagging=3)
+    model = SimulSTModel(cfg, init_model(cfg, seed=21), dtype=torch.float32, ops=ops)
+    g = torch.Generator().manual_seed(8)
+    L = torch.tensor([400, 400, 400])
+    batches = [(torch.randn(3, 400, 80, generator=g).cuda(), L) for _ in range(4)]
+    ref = [model.generate_offline(fb, ln, n_steps=9, mask_eos=True)[0].clone() for fb, ln in batches]
+    torch.cuda.synchronize()
+    got = OfflinePipeline(model).run(batches, 9, mask_eos=True)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
