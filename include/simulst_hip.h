@@ -82,6 +82,8 @@ int simulst_timer_reset(simulst_handle* h);
  * with identical arguments (same buffers, steps, flags) -- removes the per-launch host cost and about a
  * microsecond of dependent-kernel gap per kernel. */
 int simulst_graph_enable(simulst_handle* h, int on);
+/* test hook: route bf16 Emformer attention through the fp32-VALU kernel instead of the MFMA one */
+int simulst_debug_force_valu_attention(simulst_handle* h, int on);
 
 /* ---- dense contraction ----------------------------------------------------------
  * C[r, :] = epi(A[r, :] . W^T) for logical rows r = b * rows_per_batch + i.

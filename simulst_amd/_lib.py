@@ -69,6 +69,7 @@ SIGNATURES = {
     "simulst_timer_read": [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)],
     "simulst_timer_reset": [_vp],
     "simulst_graph_enable": [_vp, C.c_int],
+    "simulst_debug_force_valu_attention": [_vp, C.c_int],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_emformer_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],

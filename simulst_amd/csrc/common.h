@@ -28,6 +28,7 @@ struct simulst_handle {
   // cached hipGraph of the last simulst_mma_decode call (replayed when the call repeats exactly)
   bool graph_on;
   bool capturing;
+  bool force_valu_attention;   // test hook: route bf16 Emformer attention through the VALU kernel
   hipGraphExec_t graph_exec;
   uint64_t graph_key;
 };
@@ -144,3 +145,7 @@ __device__ __forceinline__ void store4(bf16* p, const float (&o)[4]) {
 // device array (np_uniform < 0)
 int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev,
                       int np_uniform, void* ctx, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t dtype);
+
+int sl_emformer_attention_mfma(simulst_handle* h, const simulst_emf_attn_desc* d, const void* QKV,
+                               const int32_t* lengths, const void* lc_k, const void* lc_v, const int32_t* lc_valid,
+                               const int32_t* n_mem_valid, void* CTX);

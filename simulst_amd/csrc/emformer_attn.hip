@@ -147,6 +147,12 @@ extern "C" int simulst_emformer_attention(simulst_handle* h, const simulst_emf_a
   const int nk_max = (d->use_summary ? d->M : 0) + d->R + d->Lc + d->S;
   SL_REQUIRE(h, nk_max <= 128, SIMULST_E_SHAPE, "simulst_emformer_attention: M+R+Lc+S must be <= 128");
   if (d->B <= 0) return SIMULST_OK;
+  // bf16, head_dim 64, <= 32 queries x <= 64 keys per segment: the MFMA kernel (emformer_attn_mfma.hip)
+  {
+    const int nq_max = d->R + d->S + (d->use_summary ? 1 : 0);
+    if (d->dtype == SIMULST_BF16 && d->D / d->H == 64 && nq_max <= 32 && nk_max <= 64 && !h->force_valu_attention)
+      return sl_emformer_attention_mfma(h, d, QKV, lengths, lc_k, lc_v, lc_valid, n_mem_valid, CTX);
+  }
   EmfArgs a;
   a.T = d->T; a.D = d->D; a.H = d->H; a.d = d->D / d->H; a.S = d->S; a.R = d->R; a.Lc = d->Lc; a.M = d->M;
   a.n_mem = d->n_mem; a.n_seg = d->n_seg; a.use_summary = d->use_summary;

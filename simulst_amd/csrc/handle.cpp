@@ -13,6 +13,7 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->ws_bytes = 0;
   h->graph_on = false;
   h->capturing = false;
+  h->force_valu_attention = false;
   h->graph_exec = nullptr;
   h->graph_key = 0;
   for (int i = 0; i < SIMULST_K_COUNT; ++i) { h->timer_on[i] = false; h->timer_ms[i] = 0.0; h->timer_n[i] = 0; }
@@ -87,5 +88,11 @@ extern "C" int simulst_graph_enable(simulst_handle* h, int on) {
     if (e != hipSuccess) { h->err = "simulst_graph_enable: scratch allocation failed"; return (int)e; }
     h->ws_bytes = (size_t)(16u << 20);
   }
+  return SIMULST_OK;
+}
+
+extern "C" int simulst_debug_force_valu_attention(simulst_handle* h, int on) {
+  if (!h) return SIMULST_E_NULL;
+  h->force_valu_attention = on != 0;
   return SIMULST_OK;
 }

@@ -397,3 +397,34 @@ def test_decoder_cross_attention(ops, attn):
                         ref = pr @ v[:n]
                         close(beta[b * H + h, :n], pr, atol=1e-5, rtol=1e-4)
                 close(ctx[b, h * d:(h + 1) * d], ref, atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("streaming", [False, True])
+def test_emformer_attention_mfma_equals_valu(ops, streaming):
+    """bf16 Emformer block attention: the MFMA kernel (S^T = K.Q^T, P^T reused from the accumulators, V
+    transposed in LDS) against the fp32-VALU kernel on the same bf16 inputs."""
+    g = torch.Generator().manual_seed(31 + int(streaming))
+    B, D, H, S, R, Lc, M = 5, 256, 4, 16, 8, 32, 5
+    if streaming:
+        T, N, n_mem = 11, 1, M
+    else:
+        T, N = 250, 16
+        n_mem = N - 1
+    rows_z, rows_c = n_mem + N * R + T + N, N * R + T + N
+    QKV = (torch.randn(B, rows_z, 3 * D, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    lengths = None if streaming else torch.tensor([250, 249, 131, 17, 1], dtype=torch.int32).cuda()
+    kw = dict(B=B, T=T, D=D, H=H, S=S, R=R, Lc=Lc, M=M, n_mem=n_mem, n_seg=N, use_summary=True)
+    if streaming:
+        kw.update(lc_k=(torch.randn(B, Lc, D, generator=g)).to(torch.bfloat16).cuda(),
+                  lc_v=(torch.randn(B, Lc, D, generator=g)).to(torch.bfloat16).cuda(),
+                  lc_valid=torch.tensor([32, 16, 0, 5, 32], dtype=torch.int32).cuda(),
+                  n_mem_valid=torch.tensor([5, 2, 0, 1, 3], dtype=torch.int32).cuda())
+    out = {}
+    for force in (1, 0):
+        ops.h.check(ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, force), "force")
+        CTX = torch.zeros(B, rows_c, D, device="cuda", dtype=torch.bfloat16)
+        ops.emformer_attention(QKV, lengths, CTX, **kw)
+        out[force] = CTX.float().cpu()
+    ops.h.check(ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, 0), "force")
+    torch.testing.assert_close(out[0], out[1], atol=2e-2, rtol=2e-2)
+    assert float(out[1].abs().max()) > 0.1
