@@ -182,6 +182,12 @@ def main():
     if rank == 0:
         # ---- instrumented replay of ONE step: HIP events around every launch, per kernel class
         h = model.ops.h
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        with torch.no_grad():                  # one SERIAL un-instrumented pass: the reference for the event cost
+            model.generate_offline(fb, L, n_steps=N_STEPS_DECODE, mask_eos=True)
+        torch.cuda.synchronize()
+        serial_s = time.perf_counter() - ts0
         h.timer_reset()
         h.timer_enable(-1, True)
         torch.cuda.synchronize()
@@ -195,7 +201,7 @@ def main():
         # every timed launch carries one extra event record; its cost = (instrumented pass - plain pass)
         # spread over the launches, removed from each class
         n_launch = sum(v[1] for v in raw.values())
-        plain_s = elapsed / args.steps
+        plain_s = serial_s
         ovh_ms = max(0.0, (replay_s - plain_s) * 1e3 / max(n_launch, 1))
         per_class = {k: (max(0.0, v[0] - ovh_ms * v[1]), v[1]) for k, v in raw.items()}
         log(f"instrumented replay done: {replay_s * 1e3:.1f} ms vs {plain_s * 1e3:.1f} ms plain, "
