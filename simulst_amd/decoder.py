@@ -268,19 +268,20 @@ class MMADecoder:
 
     # ------------------------------------------------------------------ offline greedy (generate.py semantics)
     def greedy_offline(self, enc_btd: torch.Tensor, enc_len: torch.Tensor, n_steps: int, mask_eos: bool = True,
-                       fused: bool = True):
+                       fused: bool = True, s_cap: Optional[int] = None, cap: Optional[int] = None):
         """Batched greedy decode with 'online' unset (never READs, mma_model.py:191-193). Tokens stay on
         the device between steps. Returns tokens [B, n_steps] int64."""
         cfg, ops = self.cfg, self.ops
         B, S, D = enc_btd.shape
         # the state (and with it every buffer address) is reused across batches of the same shape, so a
         # cached hipGraph of the step loop can be replayed; only the small per-batch fields are reset
-        key = (B, n_steps + 2, max(S, 1))
+        # s_cap / cap: round the state's capacities up so ragged workloads reuse a few cached states
+        key = (B, max(cap or 0, n_steps + 2), max(s_cap or 0, S, 1))
         if not hasattr(self, "_offline_states"):
             self._offline_states = {}
         st = self._offline_states.get(key)
         if st is None:
-            st = self._offline_states[key] = self.new_state(B, cap=n_steps + 2, S_cap=max(S, 1))
+            st = self._offline_states[key] = self.new_state(B, cap=key[1], S_cap=key[2])
             st.tok_buf = torch.empty(B, device=self.device, dtype=torch.int64)
         else:
             for hs in st.head_step:

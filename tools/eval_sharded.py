@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: batched offline evaluation of a large synthetic test set, utterance-sharded over the GPUs
+of one node (eval/generate.py:141-155 semantics: independent shards, no data-path collective), hypotheses
+gathered once at the end over RCCL.
+
+    python tools/eval_sharded.py --utterances 512                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        tools/eval_sharded.py --utterances 40000
+
+Lengths: fixed log-normal clipped to [100, 3000] frames, seed 999. Each rank
+sorts its shard by length, batches 64 neighbours (ragged batch, per-utterance semantics), decodes
+int(0.1 * T + 10) tokens per utterance (exp/infer_st.yaml:3-5) and the ranks all_gather fixed-width records.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utterances", type=int, default=40000)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--waitk", type=int, default=3)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.sharding import gather_records, shard_utterances
+    from simulst_amd.weights import init_model
+
+    g = torch.Generator().manual_seed(999)
+    lengths = torch.exp(torch.randn(args.utterances, generator=g) * 0.55 + 6.6).clamp(100, 3000).long().tolist()
+    mine = shard_utterances(lengths, world, rank)
+    mine.sort(key=lambda i: -lengths[i])
+    cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=args.waitk)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dev = f"cuda:{local}"
+    model = SimulSTModel(cfg, init_model(cfg, seed=999), device=dev, dtype=dtype)
+    width = int(0.1 * 3000 + 10)
+    ids, ntok, toks_all = [], [], []
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n_tokens = 0
+    with torch.no_grad():
+        for s in range(0, len(mine), args.batch):
+            idx = mine[s:s + args.batch]
+            L = torch.tensor([lengths[i] for i in idx])
+            Tmax = int(L.max())
+            Tpad = (Tmax + 255) // 256 * 256
+            gen = torch.Generator(device=dev).manual_seed(999 + idx[0])
+            fb = torch.randn(len(idx), Tpad, 80, device=dev, generator=gen).to(dtype)
+            fb = fb * (torch.arange(Tpad, device=dev).view(1, -1, 1) < L.to(dev).view(-1, 1, 1))
+            steps = int(0.1 * Tmax + 10)
+            enc = model.encoder.forward(fb, L.to(dev))
+            toks, _ = model.decoder.greedy_offline(enc["encoder_out_btd"], enc["encoder_lengths"], steps, False,
+                                                   s_cap=Tpad // 4 + 1, cap=(steps + 2 + 31) // 32 * 32)
+            n_b = (0.1 * L.float() + 10).long().clamp(max=steps)
+            # a hypothesis ends at its first EOS or at its own length cap
+            is_eos = toks.cpu() == cfg.eos
+            first = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, n_b)
+            n_b = torch.minimum(n_b, first)
+            pad = torch.full((len(idx), width), cfg.padding_idx, dtype=torch.int64)
+            pad[:, :steps] = toks.cpu()
+            ids += idx
+            ntok.append(n_b)
+            toks_all.append(pad)
+            n_tokens += int(n_b.sum())
+    torch.cuda.synchronize()
+    local_s = time.perf_counter() - t0
+    ids_t = torch.tensor(ids, device=dev)
+    ntok_t = torch.cat(ntok).to(dev) if ntok else torch.zeros(0, dtype=torch.int64, device=dev)
+    toks_t = torch.cat(toks_all).to(dev) if toks_all else torch.zeros(0, width, dtype=torch.int64, device=dev)
+    if dist is not None:
+        recs = gather_records(ids_t, ntok_t, toks_t, torch.zeros_like(toks_t), dist, width=width)
+        tt = torch.tensor([local_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        total_s = float(tt.item())
+        tk = torch.tensor([n_tokens], device=dev, dtype=torch.int64)
+        dist.all_reduce(tk)
+        total_tokens = int(tk.item())
+    else:
+        recs = {int(i): None for i in ids}
+        total_s, total_tokens = local_s, n_tokens
+    if rank == 0:
+        assert len(recs) == args.utterances, (len(recs), args.utterances)
+        print(json.dumps({"workload": "configs[4]: batched offline eval, utterance-sharded", "utterances": args.utterances,
+                          "n_gpus": world, "tokens": total_tokens, "seconds": round(total_s, 3),
+                          "tokens_per_s": round(total_tokens / total_s, 1),
+                          "utterances_per_s": round(args.utterances / total_s, 1), "dtype": args.dtype}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
