@@ -251,6 +251,9 @@ def main():
                 roofline["traffic"] = pmc[dom]["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
+        # whole-path HBM model of SURVEY.md 8(d): 2.135 MB of algorithmic traffic per token at batch 64 x 110 steps
+        roofline["path_hbm_model"] = {"bytes_per_token": 2.135e6, "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / 2.135e6),
+                                      "frac": round(value / world / (HBM_PEAK_GBS * 1e9 / 2.135e6), 5)}
         roofline["kernel"] = dom
         roofline["launches_per_step"] = dom_n
         roofline["avg_launch_us"] = round(dom_ms * 1e3 / max(dom_n, 1), 3)
