@@ -11,7 +11,7 @@
 //   * LayerNorm prologue: row moments from the fragments already in registers, exchanged through
 //     LDS; normalised, rounded to the operand dtype, then fed to the MFMA (same rounding points as
 //     the unfused LayerNorm kernel)
-//   * SPLITK > 1 (K >= 1024): fp32 partial tiles to the handle's scratch, summed in a FIXED order by
+//   * SPLITK > 1 (K >= 4096): fp32 partial tiles to the handle's scratch, summed in a FIXED order by
 //     splitk_epilogue_kernel (deterministic; no atomics)
 #include "gemm_args.h"
 
@@ -233,8 +233,10 @@ int launch_all(simulst_handle* h, const void* A, const void* W, const float* bia
   const int bn = wide ? 32 : 16;
   const int nt = (p.N + bn - 1) / bn;
   int splits = 1;
-  if (!p.ln_g && p.K >= 1024) {
-    splits = p.K / 512;
+  // measured on MI355X (bench.py, K = 2048 fc2): one 16x16-tile launch streaming 128 KB per workgroup is as
+  // fast end to end as 4-way split-K + epilogue launch, so splitting starts only at K >= 4096
+  if (!p.ln_g && p.K >= 4096) {
+    splits = p.K / 1024;
     while (splits > 1 && (long)mt * nt * splits > 1024) splits >>= 1;
   }
   int kps = (p.K + splits - 1) / splits;

@@ -109,11 +109,11 @@ class MMADecoder:
     """Mirror of models/mma_model.py:MMADecoder (inference, incremental)."""
 
     def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda", dtype=torch.float32,
-                 ops: Optional[Ops] = None, prefix="decoder"):
+                 ops: Optional[Ops] = None, prefix="decoder", shared_weights: Optional[DecoderWeights] = None):
         self.cfg = cfg
         self.device, self.dtype = torch.device(device), dtype
         self.ops = ops or Ops()
-        self.w = DecoderWeights(weights, cfg, self.device, dtype, prefix)
+        self.w = shared_weights if shared_weights is not None else DecoderWeights(weights, cfg, self.device, dtype, prefix)
         self.attn_enum = _lib.ATTN_ENUM[cfg.attn_type]
         self.soft = cfg.attn_type != "hard_aligned"
         self.separate_soft = cfg.attn_type in ("infinite_lookback", "chunkwise")

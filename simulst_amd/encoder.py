@@ -88,12 +88,12 @@ class S2TEmformerEncoder:
     """Mirror of models/s2t_emformer.py:S2TEmformerEncoder (inference only)."""
 
     def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda", dtype=torch.float32,
-                 ops: Optional[Ops] = None, prefix="encoder"):
+                 ops: Optional[Ops] = None, prefix="encoder", shared_weights: Optional[EncoderWeights] = None):
         assert cfg.tanh_on_mem, "only --tanh-on-mem memories are implemented (arch default, s2t_emformer.py:410)"
         self.cfg = cfg
         self.device, self.dtype = torch.device(device), dtype
         self.ops = ops or Ops()
-        self.w = EncoderWeights(weights, cfg, self.device, dtype, prefix)
+        self.w = shared_weights if shared_weights is not None else EncoderWeights(weights, cfg, self.device, dtype, prefix)
         self.embed_dim = cfg.embed_dim
         self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(cfg.embed_dim)
         # same public attributes the agent reads (agents/default_agent.py:163-165)

@@ -17,12 +17,16 @@ class SimulSTModel:
     394-406,418-420): .encoder, .decoder, get_normalized_probs, max_decoder_positions."""
 
     def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda", dtype=torch.float32,
-                 ops: Optional[Ops] = None):
+                 ops: Optional[Ops] = None, share_with: Optional["SimulSTModel"] = None):
+        """share_with: another instance whose device weights are reused (replicas that differ only in their
+        HIP stream / handle / decoder state, for concurrent batches)."""
         self.cfg = cfg
         self.ops = ops or Ops()
         self.device, self.dtype = torch.device(device), dtype
-        self.encoder = S2TEmformerEncoder(cfg, weights, device, dtype, self.ops)
-        self.decoder = MMADecoder(cfg, weights, device, dtype, self.ops)
+        self.encoder = S2TEmformerEncoder(cfg, weights, device, dtype, self.ops,
+                                          shared_weights=share_with.encoder.w if share_with else None)
+        self.decoder = MMADecoder(cfg, weights, device, dtype, self.ops,
+                                  shared_weights=share_with.decoder.w if share_with else None)
 
     def get_normalized_probs(self, net_output, log_probs=True):
         logits = net_output[0]
@@ -102,4 +106,59 @@ class OfflinePipeline:
         cur.wait_stream(self.s_dec)
         cur.wait_stream(self.s_enc)
         m.ops.h.set_stream(cur.cuda_stream)
+        return out
+
+
+class ConcurrentOffline:
+    """C batches in flight on C HIP streams, one host thread per stream (ctypes and torch release the GIL while
+    they enqueue): the greedy loop of one 64-utterance batch is a chain of ~5700 small dependent kernels that
+    leaves the chip mostly idle, so independent batches -- which the offline evaluation of a test set has
+    plenty of (eval/generate.py:187-209 iterates over them) -- fill it.  Each batch runs exactly the kernels of
+    generate_offline; replicas share the device weights and own their stream, handle and decoder state."""
+
+    def __init__(self, model: SimulSTModel, weights, concurrency: int = 4, graph: bool = False):
+        from . import _lib
+        self.models, self.streams = [], []
+        dev = model.device
+        for c in range(concurrency):
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                ops = Ops(_lib.Handle(st.cuda_stream))
+                if graph:
+                    ops.h.graph_enable(True)
+                self.models.append(SimulSTModel(model.cfg, weights, device=dev, dtype=model.dtype, ops=ops,
+                                                share_with=model))
+            self.streams.append(st)
+
+    def run(self, batches, n_steps: int, mask_eos: bool = False, on_tokens=None):
+        import threading
+        batches = list(batches)
+        out = [None] * len(batches)
+        errs = []
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(cur)
+        dev_index = self.models[0].device.index
+
+        def worker(c):
+            try:
+                if dev_index is not None:
+                    torch.cuda.set_device(dev_index)
+                with torch.no_grad(), torch.cuda.stream(self.streams[c]):
+                    for i in range(c, len(batches), len(self.models)):
+                        toks, _ = self.models[c].generate_offline(*batches[i], n_steps=n_steps, mask_eos=mask_eos)
+                        toks = toks.clone()
+                        out[i] = on_tokens(toks) if on_tokens is not None else toks
+            except Exception as e:          # surfaced to the caller below
+                errs.append(e)
+
+        threads = [threading.Thread(target=worker, args=(c,)) for c in range(len(self.models))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for st in self.streams:
+            cur.wait_stream(st)
+        if errs:
+            raise errs[0]
         return out

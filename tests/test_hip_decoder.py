@@ -188,3 +188,22 @@ def test_offline_pipeline_equals_serial(ops):
     torch.cuda.synchronize()
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+def test_concurrent_batches_equal_serial(ops):
+    """C batches in flight on C streams / host threads give exactly the serial per-batch results."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import ConcurrentOffline, SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, waitk_lagging=3)
+    w = init_model(cfg, seed=23)
+    model = SimulSTModel(cfg, w, dtype=torch.float32, ops=ops)
+    g = torch.Generator().manual_seed(9)
+    L = torch.tensor([400, 400, 400]).cuda()
+    batches = [(torch.randn(3, 400, 80, generator=g).cuda(), L) for _ in range(7)]
+    ref = [model.generate_offline(fb, ln, n_steps=9, mask_eos=True)[0].clone() for fb, ln in batches]
+    torch.cuda.synchronize()
+    got = ConcurrentOffline(model, w, concurrency=3).run(batches, 9, mask_eos=True)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
