@@ -28,6 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# more hardware queues for the HIP runtime: with the default (4) at most 2 kernels from different streams
+# execute concurrently on this stack (tools/microbench_streams.hip); 8 lets 3-4 independent decode chains overlap.
+# Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch  # noqa: E402
 
 B_PER_GPU, T_FRAMES, N_STEPS_DECODE, WAITK = 64, 1000, 110, 5
@@ -87,12 +92,12 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=9)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--concurrency", type=int, default=2,
+    ap.add_argument("--concurrency", type=int, default=3,
                     help="independent 64-utterance batches in flight (one HIP stream + host thread each)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode loop of each batch strictly one after the other")
