@@ -121,6 +121,17 @@ __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, two orders below bf16 resolution),
+// one v_exp + one v_rcp instead of the ~30-instruction erff
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
+                              0.254829592f);
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  const float erf = x < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * x * (1.0f + erf);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // load 4 consecutive elements as floats (16B for f32, 8B for bf16); caller guarantees alignment

@@ -181,6 +181,43 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
           C[(long)b * p.c_bs + (long)ii * p.c_rs + oc] = from_f32<TC>(v);
         }
       }
+  } else if constexpr ((EPI == SIMULST_EPI_BIAS || EPI == SIMULST_EPI_BIAS_GELU) && std::is_same<TC, bf16>::value &&
+                       std::is_same<TA, bf16>::value) {
+    // bf16 output without residual (QKV, FFN1): bias / GELU in registers, tile staged through LDS (the operand
+    // buffers are free now) and written with 16-byte row-contiguous stores instead of 64 two-byte ones per lane
+    constexpr int CS = BN + 8;                       // bf16 elements per staged row
+    static_assert(BM * CS <= LDS_A + LDS_W, "staging tile must fit in the operand buffers");
+    __syncthreads();
+    bf16* Cs = smem;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cl = wc * WN + j * 32 + lcol;
+      const int c = n0 + cl;
+      const float bv = (bias && c < p.N) ? bias[c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = wr * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+          float v = acc[i][j][e] + bv;
+          if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast(v);
+          Cs[rl * CS + cl] = __float2bfloat16(v);
+        }
+    }
+    __syncthreads();
+    constexpr int CHUNKS = BM * BN / 8;              // 16-byte chunks in the tile
+    for (int ch = tid; ch < CHUNKS; ch += 256) {
+      const int rl = ch / (BN / 8), c8 = (ch % (BN / 8)) * 8;
+      const int r = m0 + rl, c = n0 + c8;
+      if (r >= p.M || c >= p.N) continue;
+      const int b = r / p.rpb, ii = r - b * p.rpb;
+      TC* dst = C + (long)b * p.c_bs + (long)ii * p.c_rs + c;
+      if (c + 8 <= p.N && ((p.c_rs | p.c_bs) & 7) == 0) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&Cs[rl * CS + c8]);
+      } else {
+        for (int q = 0; q < 8 && c + q < p.N; ++q) dst[q] = Cs[rl * CS + c8 + q];
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
