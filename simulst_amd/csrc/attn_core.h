@@ -81,10 +81,32 @@ __device__ __forceinline__ void prefetch(Regs<T>& r, const T* qp, const T* Kb, l
   }
 }
 
+// K/V-only prefetch (the query is produced inside the kernel and read from LDS later)
+template <typename T>
+__device__ __forceinline__ void prefetch_kv(Regs<T>& r, const T* Kb, long ks, const T* Vb, long vs, int n_max, int d) {
+  constexpr int W = VL<T>::W;
+  const int tid = threadIdx.x;
+  const int jk = tid < n_max ? tid : 0;
+  const T* kr = Kb + (long)jk * ks;
+#pragma unroll
+  for (int c = 0; c < Regs<T>::NQ; ++c) {
+    const int cc = c * W < d ? c * W : 0;
+    r.k[c] = *reinterpret_cast<const uint4*>(kr + cc);
+  }
+  const int lpr = d >> 2, c4 = tid % lpr, rw = tid / lpr, RR = 256 / lpr;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int j = rw + RR * i;
+    if (i >= lpr || j >= n_max) j = 0;
+    load4(Vb + (long)j * vs + c4 * 4, r.v[i]);
+  }
+}
+
 // softmax(q.K[0..n)) V from the prefetched registers. n <= n_max <= 256. Threads tid < d return ctx[tid].
+// q_lds != nullptr: the (already scaled) query is read from LDS instead of the prefetched registers.
 template <typename T>
 __device__ __forceinline__ float finish(const Regs<T>& r, int n, int d, float qscale, float* sc, float* red,
-                                        float* beta) {
+                                        float* beta, const float* q_lds = nullptr) {
   constexpr int W = VL<T>::W;
   const int tid = threadIdx.x;
   float s = 0.f;
@@ -92,10 +114,15 @@ __device__ __forceinline__ float finish(const Regs<T>& r, int n, int d, float qs
   for (int c = 0; c < Regs<T>::NQ; ++c) {
     if (c * W < d) {
       float qa[W], ka[W];
-      VL<T>::cvt(r.q[c], qa);
       VL<T>::cvt(r.k[c], ka);
+      if (q_lds) {
 #pragma unroll
-      for (int i = 0; i < W; ++i) s = fmaf(qa[i] * qscale, ka[i], s);
+        for (int i = 0; i < W; ++i) s = fmaf(q_lds[c * W + i], ka[i], s);
+      } else {
+        VL<T>::cvt(r.q[c], qa);
+#pragma unroll
+        for (int i = 0; i < W; ++i) s = fmaf(qa[i] * qscale, ka[i], s);
+      }
     }
   }
   const bool live = tid < n;

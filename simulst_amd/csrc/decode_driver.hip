@@ -23,7 +23,12 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
     const T* __restrict__ qm, const T* __restrict__ qs, const T* __restrict__ Km, const T* __restrict__ Ks,
     const T* __restrict__ Vc, float energy_bias, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
     long* __restrict__ head_step, unsigned char* __restrict__ head_read, T* __restrict__ ctx, int H, int d,
-    int S_cap, int ratio, int attn_type, int waitk_k, int online, int mass_pres, int n_hint) {
+    int S_cap, int ratio, int attn_type, int waitk_k, int online, int mass_pres, int n_hint,
+    // fused query projection (xres != nullptr): q = W . LayerNorm(xres[b]) + bias for this head, replacing the
+    // separate LN2 + q-proj GEMM launch; qm / qs are then ignored
+    const T* __restrict__ xres, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+    const T* __restrict__ Wqm, const float* __restrict__ bqm, const T* __restrict__ Wqs,
+    const float* __restrict__ bqs) {
   constexpr int W = VL<T>::W;
   extern __shared__ float sm[];
   float* q_s = sm;                 // [64]
@@ -31,6 +36,8 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
   float* sc = red + 1032;          // [max(S_cap,256)] scores
   float* pl = sc + (S_cap > 256 ? S_cap : 256);   // [S_cap + 1] step probabilities
   float* pp = pl + S_cap + 1;      // [S_cap] pooled probabilities
+  float* xn = pp + S_cap;          // [D] normalised residual row (fused projection only)
+  float* qsoft_s = xn + H * d;     // [64] scaled soft-energy query (fused projection only)
   __shared__ int s_found;
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int D = H * d;
@@ -50,15 +57,58 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
   const int tg = tgt_idx ? tgt_idx[b] : 0;    // scalar inputs of the policy: issued with the prefetch
   const long hs = head_step[r];
   if (n_hint < 0) n_hint = attn_type == SIMULST_ATTN_WAITK ? (tg + waitk_k) * ratio : S_cap;
-  if (fast) attn::prefetch<T>(rg, qs + (long)b * D + h * d, Kh, D, Vh, D, min(S_cap, n_hint), d, -1, nullptr, nullptr);
+  const bool fusedq = xres != nullptr;
+  if (fast) {
+    if (fusedq) attn::prefetch_kv<T>(rg, Kh, D, Vh, D, min(S_cap, n_hint), d);
+    else attn::prefetch<T>(rg, qs + (long)b * D + h * d, Kh, D, Vh, D, min(S_cap, n_hint), d, -1, nullptr, nullptr);
+  }
+  if (fusedq) {
+    // LayerNorm of the residual row (fp32 stats, rounded to the activation dtype like the unfused path), then
+    // 4 threads per output channel: 16-byte loads along K, shuffle-reduce, bias, round, scale
+    float ps = 0.f;
+    for (int k = tid; k < D; k += 256) ps += to_f32(xres[(long)b * D + k]);
+    const float mean = attn::blk_sum(ps, red + 1024) / (float)D;
+    float pq = 0.f;
+    for (int k = tid; k < D; k += 256) { const float dd = to_f32(xres[(long)b * D + k]) - mean; pq += dd * dd; }
+    const float rstd = 1.0f / sqrtf(attn::blk_sum(pq, red + 1024) / (float)D + 1e-5f);
+    for (int k = tid; k < D; k += 256)
+      xn[k] = to_f32(from_f32<T>((to_f32(xres[(long)b * D + k]) - mean) * rstd * ln_g[k] + ln_b[k]));
+    __syncthreads();
+    const int o = tid >> 2, part = tid & 3, kq = D >> 2;        // output channel, quarter of K
+    const float scl = rsqrtf((float)d);
+    for (int pass = 0; pass < 2; ++pass) {
+      const T* Wp = pass == 0 ? Wqm : Wqs;
+      const float* bp = pass == 0 ? bqm : bqs;
+      if (!Wp) continue;
+      float acc = 0.f;
+      if (o < d) {
+        const T* wr = Wp + (long)(h * d + o) * D + part * kq;
+        for (int k = 0; k < kq; k += W) {
+          float wv[W];
+          VL<T>::cvt(*reinterpret_cast<const uint4*>(wr + k), wv);
+#pragma unroll
+          for (int i = 0; i < W; ++i) acc = fmaf(wv[i], xn[part * kq + k + i], acc);
+        }
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (o < d && part == 0) {
+        const float qv = to_f32(from_f32<T>(acc + (bp ? bp[h * d + o] : 0.f))) * scl;
+        if (pass == 0) q_s[o] = qv; else qsoft_s[o] = qv;
+      }
+    }
+    __syncthreads();
+  }
   // ---- 1. pooled probabilities
   if (attn_type == SIMULST_ATTN_WAITK) {
     int wk = tg + waitk_k - 1;
     if (!online) wk = min(wk, P - 1);
     for (int j = tid; j < P; j += 256) pp[j] = (j == wk) ? 1.f : 0.f;
   } else {
-    if (tid < d) q_s[tid] = to_f32(qm[(long)b * D + h * d + tid]) * rsqrtf((float)d);
-    __syncthreads();
+    if (!fusedq) {
+      if (tid < d) q_s[tid] = to_f32(qm[(long)b * D + h * d + tid]) * rsqrtf((float)d);
+      __syncthreads();
+    }
     for (int j = tid; j < P; j += 256) {
       const int f0 = j * ratio, f1 = min(f0 + ratio, len);
       float en = 0.f;
@@ -123,13 +173,16 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
   } else {
     const int n = (int)(st < len - 1 ? st : len - 1) + 1;
     if (st > 0 && n > 0) {
+      const float* qfused = fusedq ? (Wqs ? qsoft_s : q_s) : nullptr;
       if (fast) {
-        o = attn::finish<T>(rg, n, d, rsqrtf((float)d), sc, red, nullptr);
+        o = attn::finish<T>(rg, n, d, rsqrtf((float)d), sc, red, nullptr, qfused);
       } else {
         __syncthreads();
-        if (tid < d) q_s[tid] = to_f32(qs[(long)b * D + h * d + tid]) * rsqrtf((float)d);
-        __syncthreads();
-        o = attn::looped<T>(q_s, Kh, D, Vh, D, n, d, -1, nullptr, nullptr, sc, red, nullptr);
+        if (!fusedq) {
+          if (tid < d) q_s[tid] = to_f32(qs[(long)b * D + h * d + tid]) * rsqrtf((float)d);
+          __syncthreads();
+        }
+        o = attn::looped<T>(fusedq ? qfused : q_s, Kh, D, Vh, D, n, d, -1, nullptr, nullptr, sc, red, nullptr);
       }
     }
   }
@@ -211,12 +264,15 @@ template <typename T>
 int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const void* Km, const void* Ks,
                         const void* Vc, float energy_bias, const int32_t* key_len, const int32_t* tgt_idx,
                         int64_t* head_step, uint8_t* head_read, void* ctx, int B, int H, int d, int S_cap, int ratio,
-                        int attn_type, int waitk_k, int online, int mass_pres, int n_hint) {
-  const size_t lds = (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1) * sizeof(float);
+                        int attn_type, int waitk_k, int online, int mass_pres, int n_hint, const void* xres,
+                        const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
+                        const float* bqs) {
+  const size_t lds = (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
   hipLaunchKernelGGL(policy_cross_attn_kernel<T>, dim3(H, B), dim3(256), lds, h->stream, (const T*)qm, (const T*)qs,
                      (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx, (long*)head_step,
-                     head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres, n_hint);
+                     head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres, n_hint,
+                     (const T*)xres, ln_g, ln_b, (const T*)Wqm, bqm, (const T*)Wqs, bqs);
   return sl_launch_status(h, "simulst_policy_cross_attention");
 }
 
@@ -226,7 +282,9 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         const void* Vc, float energy_bias, const int32_t* key_len, const int32_t* tgt_idx,
                         int64_t* head_step, uint8_t* head_read, void* ctx, int32_t B, int32_t H, int32_t d,
                         int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k, int32_t online,
-                        int32_t mass_preservation, int32_t dtype, int32_t n_hint);
+                        int32_t mass_preservation, int32_t dtype, int32_t n_hint, const void* xres = nullptr,
+                        const float* ln_g = nullptr, const float* ln_b = nullptr, const void* Wqm = nullptr,
+                        const float* bqm = nullptr, const void* Wqs = nullptr, const float* bqs = nullptr);
 
 extern "C" int simulst_policy_cross_attention(simulst_handle* h, const void* qm, const void* qs, const void* Kmono,
                                               const void* Ksoft, const void* Vc, float energy_bias,
@@ -242,25 +300,31 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         const void* Vc, float energy_bias, const int32_t* key_len, const int32_t* tgt_idx,
                         int64_t* head_step, uint8_t* head_read, void* ctx, int32_t B, int32_t H, int32_t d,
                         int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k, int32_t online,
-                        int32_t mass_preservation, int32_t dtype, int32_t n_hint) {
+                        int32_t mass_preservation, int32_t dtype, int32_t n_hint, const void* xres,
+                        const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
+                        const float* bqs) {
   if (!h) return SIMULST_E_NULL;
   SL_CHECK_NULL(h, Vc); SL_CHECK_NULL(h, head_step); SL_CHECK_NULL(h, head_read); SL_CHECK_NULL(h, ctx);
   SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_policy_cross_attention: dtype");
   SL_REQUIRE(h, attn_type >= SIMULST_ATTN_HARD && attn_type <= SIMULST_ATTN_CHUNKWISE, SIMULST_E_ARG,
              "simulst_policy_cross_attention: attn_type");
   if (attn_type == SIMULST_ATTN_WAITK) { SL_CHECK_NULL(h, tgt_idx); SL_REQUIRE(h, waitk_k > 0, SIMULST_E_ARG, "simulst_policy_cross_attention: lagging"); }
-  else { SL_CHECK_NULL(h, qm); SL_CHECK_NULL(h, Kmono); }
-  if (attn_type != SIMULST_ATTN_HARD) { SL_CHECK_NULL(h, qs); SL_CHECK_NULL(h, Ksoft); }
+  else { if (!xres) SL_CHECK_NULL(h, qm); SL_CHECK_NULL(h, Kmono); }
+  if (attn_type != SIMULST_ATTN_HARD) { if (!xres) SL_CHECK_NULL(h, qs); SL_CHECK_NULL(h, Ksoft); }
+  if (xres) { SL_CHECK_NULL(h, ln_g); SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, Wqm);
+              SL_REQUIRE(h, (H * d) % 32 == 0, SIMULST_E_SHAPE, "simulst_policy_cross_attention: D % 32 for the fused projection"); }
   SL_REQUIRE(h, H > 0 && d >= 8 && d <= 64 && d % 8 == 0 && S_cap > 0 && ratio >= 1, SIMULST_E_SHAPE,
              "simulst_policy_cross_attention: head_dim must be a multiple of 8, <= 64");
-  SL_REQUIRE(h, (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1) * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE,
+  SL_REQUIRE(h, (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE,
              "simulst_policy_cross_attention: source too long for the LDS rows");
   if (B <= 0) return SIMULST_OK;
   if (dtype == SIMULST_F32)
     return launch_policy_cross<float>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
-                                      ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint);
+                                      ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint,
+                                      xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs);
   return launch_policy_cross<bf16>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
-                                   ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint);
+                                   ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint,
+                                   xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs);
 }
 
 static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
@@ -347,21 +411,15 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
       if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
                                   dd->ctx, B, H, d, dd->cap, dt))) return rc;
       if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
-      // queries of the monotonic (and, when separate, the soft) energy from LN2(x)
-      const void* qm = dd->q;
-      const void* qs = dd->q;
-      if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq, L.c_bq, nullptr, dd->q, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b))) return rc;
-      if (L.c_wq_soft) {
-        if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq_soft, L.c_bq_soft, nullptr, dd->q2, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b))) return rc;
-        qs = dd->q2;
-      }
-      // wait-k in lockstep: target t can attend to at most (t + k) * ratio frames
+      // LN2 + query projection(s) + policy + cross-attention in ONE launch: each (head, utterance) workgroup
+      // normalises its residual row and projects its own 64 query channels (32 KB of W per workgroup)
       const int n_hint = device_indexed ? -1
                          : (dd->attn_type == SIMULST_ATTN_WAITK && np_uniform >= 0)
                                ? (np_uniform + s + dd->waitk_k) * dd->ratio : dd->S_cap;
-      if ((rc = policy_cross(h, qm, qs, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
+      if ((rc = policy_cross(h, nullptr, nullptr, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
                              dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
-                             dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint))) return rc;
+                             dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, dd->x, L.ln2_g,
+                             L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft))) return rc;
       if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
       if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b))) return rc;
       if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
