@@ -237,7 +237,7 @@ def main():
                 # weights N*K + activations M*K in, M*N out.
                 def gb(n, k):
                     return (n * k + B * k + B * n) * esz
-                per_layer = gb(3 * D, D) + 3 * gb(D, D) + gb(F, D) + gb(D, F)
+                per_layer = gb(3 * D, D) + 2 * gb(D, D) + gb(F, D) + gb(D, F)   # q-proj lives in the cross-attention launch
                 byts = U * (Ld * per_layer + gb(V, D))
             elif dom == "emformer_attention":
                 byts = cfg.encoder_layers * B * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
@@ -257,7 +257,7 @@ def main():
         # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate runs of this same command; profiles/*_pmc_traffic.json says how it was corrected)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")))
             if dom in pmc:
                 roofline["traffic"] = pmc[dom]["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
