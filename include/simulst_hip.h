@@ -322,6 +322,27 @@ typedef struct {
 int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,
                        int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos);
 
+/* BATCHED STREAMING decode steps (no counterpart in the reference, which asserts B == 1 when streaming,
+ * models/s2t_emformer.py:200): n_iter policy()/predict() rounds for every row of a batch whose rows decide
+ * READ / WRITE independently.  Per row and round: the layers run until one wants more source while the row is
+ * online (models/mma_model.py:191-210) -- then the row is parked (active = 0) with its target position not
+ * advanced -- else the greedy token (plain argmax, agents/default_agent.py:415-424) is committed to hyp, stamped
+ * with cur_ms, and the row finishes on EOS or when it holds more than max_len_now tokens
+ * (agents/default_agent.py:268-271).  The host re-activates parked rows after feeding the next source chunk.
+ * Device arrays of length B unless noted; dd->n_prev_uniform must be -1. */
+typedef struct {
+  uint8_t* active;        /* in/out */
+  uint8_t* read_flag;     /* scratch, zero before the first call */
+  const uint8_t* online;  /* row's source has not ended */
+  uint8_t* done;          /* out: hypothesis finished */
+  int32_t* delays_ms;     /* [B][cap] or NULL */
+  int64_t* hyp;           /* [B][cap] committed tokens */
+  int32_t cap, cur_ms, max_len_now;
+} simulst_stream_ctl;
+
+int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,
+                             int64_t* tokens_io, const simulst_stream_ctl* ctl, int32_t n_iter);
+
 /* policy + cross-attention of one layer for one step in ONE launch (simulst_step_p_choose +
  * simulst_mma_step_search + simulst_decoder_cross_attention, same results). qm/qs: monotonic / soft
  * queries [B][D] (qm unused for WAITK, qs unused for HARD). */

@@ -58,6 +58,11 @@ class DecoderDesc(C.Structure):
                [(n, C.c_void_p) for n in ("E", "out_proj", "pos_table", "ln_g", "ln_b", "enc_len", "n_prev", "x", "qkv",
                                           "ctx", "q", "q2", "hidden", "logits")]
 
+class StreamCtl(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("active", "read_flag", "online", "done", "delays_ms", "hyp")] + \
+               [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now")]
+
+
 # name -> argtypes (restype is int unless noted); mirrors include/simulst_hip.h one to one
 SIGNATURES = {
     "simulst_create": [C.POINTER(_vp), _vp],
@@ -91,6 +96,7 @@ SIGNATURES = {
                                         _i32, _i32],
     "simulst_greedy_argmax": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
     "simulst_mma_decode": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, _vp, _i32, _i32],
+    "simulst_mma_stream_steps": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, C.POINTER(StreamCtl), _i32],
     "simulst_policy_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                        _i32, _i32, _i32, _i32, _i32, _i32, _i32],
 }

@@ -143,3 +143,84 @@ class FairseqSimulSTAgent:
         st = states.dec_incremental_states.get("dec")
         return {"tokens": list(states.target), "delays_ms": delays, "actions": "".join(actions),
                 "AL": average_lagging(delays, src.total_ms()), "n_enc": st.enc_rows if st is not None else 0}
+
+
+class BatchedStreamingAgent(FairseqSimulSTAgent):
+    """B simultaneous streams through ONE encoder/decoder batch, each row taking its own READ / WRITE
+    decisions.  The reference streams one utterance per process (models/s2t_emformer.py:200 asserts B == 1);
+    this is the MI355X-shaped version of the same protocol: the sources advance in lockstep (every stream is
+    offered the next chunk at the same time, as microphones do), between chunks the decoder repeats masked
+    steps (simulst_mma_stream_steps) until every row is either waiting for source or finished.  Because a
+    row's decisions depend only on its own state and on the source released so far, each row's tokens,
+    delays and action string are those of ``FairseqSimulSTAgent.run_utterance`` on that utterance alone
+    (tests/test_hip_streaming.py::test_batched_streaming_*).
+    """
+
+    def __init__(self, model, max_len_a: float = 1, max_len_b: int = 0, steps_per_call: int = 4):
+        super().__init__(model, max_len_a, max_len_b, force_finish=False)
+        self.steps_per_call = steps_per_call
+
+    def run_batch(self, fbank: torch.Tensor):
+        """fbank [B, T, 80] (equal lengths).  Returns one record per row, same keys as run_utterance."""
+        import ctypes as C
+        from . import _lib
+        from .latency import average_lagging
+        model, dec, enc = self.model, self.model.decoder, self.model.encoder
+        cfg, dev = model.cfg, model.device
+        B, T = fbank.size(0), fbank.size(1)
+        fbank = fbank.to(dev)
+        cap = int(self.max_len(T)) + 4
+        s_cap = T // enc.stride + 2 * self.right_context + 8
+        st = dec.new_state(B, cap=cap, S_cap=s_cap)
+        st.lockstep = False
+        u8 = dict(device=dev, dtype=torch.uint8)
+        active, read_flag = torch.zeros(B, **u8), torch.zeros(B, **u8)
+        online, done = torch.ones(B, **u8), torch.zeros(B, **u8)
+        hyp = torch.zeros(B, cap, device=dev, dtype=torch.int64)
+        delays = torch.zeros(B, cap, device=dev, dtype=torch.int32)
+        tokens = torch.full((B,), cfg.eos, device=dev, dtype=torch.int64)
+        enc_state = {}
+        src = FrameSource(fbank[0])
+        actions = [[] for _ in range(B)]
+        n_written = [0] * B
+        last_update = 0
+        expected = (self.segment_length + self.right_context) * self.stride_ms // SHIFT_SIZE
+        alive = list(range(B))
+        while alive:
+            # ---- READ phase: every unfinished stream takes the next chunk (agents/default_agent.py:303-342)
+            for b in alive:
+                actions[b].append("R")
+            if src.finished:
+                raise RuntimeError("READ after source finished")
+            src.read(expected)
+            update_len = src.pos - last_update
+            finish = update_len < expected or src.finished
+            out = enc.infer(fbank[:, :src.pos], torch.full((B,), src.pos), enc_state, finish=finish)
+            new = out["encoder_out_btd"]
+            dec.append_encoder_out(st, new, torch.full((B,), st.enc_rows + new.size(1)))
+            last_update = src.pos
+            expected = self.segment_length * self.stride_ms // SHIFT_SIZE
+            # ---- WRITE phase: masked decoder steps until every row waits for source or is finished
+            online.fill_(0 if src.finished else 1)
+            active.copy_(1 - done)
+            ctl = _lib.StreamCtl(active.data_ptr(), read_flag.data_ptr(), online.data_ptr(), done.data_ptr(),
+                                 delays.data_ptr(), hyp.data_ptr(), cap, src.elapsed_ms(),
+                                 int(self.max_len(src.pos)))
+            while True:
+                dec.stream_steps(st, tokens, ctl, self.steps_per_call)
+                if not bool(active.any().item()):
+                    break
+            n_prev = st.n_prev.tolist()
+            done_h = done.tolist()
+            for b in alive:
+                actions[b].extend("W" * (n_prev[b] - n_written[b]))
+                n_written[b] = n_prev[b]
+            alive = [b for b in alive if not done_h[b]]
+        hyp_h, delays_h = hyp.tolist(), delays.tolist()
+        recs = []
+        for b in range(B):
+            n = n_written[b]
+            d = [int(x) for x in delays_h[b][:n]]
+            recs.append({"tokens": hyp_h[b][:n], "delays_ms": d, "actions": "".join(actions[b]),
+                         "AL": average_lagging(d, src.total_ms()), "n_enc": st.enc_rows})
+        return recs

@@ -12,6 +12,25 @@ namespace {
 
 using attn::VL;
 
+// Per-row control of BATCHED STREAMING decode (absent from the reference, models/s2t_emformer.py:200,
+// models/cif_transformer.py:199-200): rows of a batch take READ/WRITE decisions independently.
+//   active[b]    row takes part in the current step (0: waiting for source, or finished)
+//   read_flag[b] set (to the layer id) by any layer/head that wants more source while the row is online
+//                (models/mma_model.py:191-210); the layers after it skip the row, the commit kernel turns it
+//                into active = 0 and clears it
+//   online[b]    the row's source has not ended (agents/default_agent.py:392)
+// All null for lockstep offline decode.
+struct StreamCtl {
+  unsigned char* active;
+  unsigned char* read_flag;
+  const unsigned char* online;
+  unsigned char* done;
+  int* delays;          // [B][cap] source milliseconds at commit, may be null
+  long* hyp;            // [B][cap] committed tokens
+  int cap, cur_ms, max_len_now;
+  int layer;            // 1-based id of the launching layer: read_flag holds the id of the layer that fired
+};
+
 // One workgroup per (head, utterance).
 //  1. pooled step probabilities pp[j] (thread per pooled key), zero-inserted into p[] in LDS
 //     (modules/fixed_pre_decision.py:85-167; wait-k one-hot utils/p_choose_strategy.py:6-53)
@@ -28,8 +47,13 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
     // separate LN2 + q-proj GEMM launch; qm / qs are then ignored
     const T* __restrict__ xres, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
     const T* __restrict__ Wqm, const float* __restrict__ bqm, const T* __restrict__ Wqs,
-    const float* __restrict__ bqs) {
+    const float* __restrict__ bqs, StreamCtl ctl) {
   constexpr int W = VL<T>::W;
+  if (ctl.active) {   // row parked / finished, or an EARLIER layer asked for source (heads of one layer all run)
+    const unsigned char rf = ctl.read_flag[blockIdx.y];
+    if (!ctl.active[blockIdx.y] || (rf && rf != ctl.layer)) return;
+  }
+  if (ctl.online) online = ctl.online[blockIdx.y];
   extern __shared__ float sm[];
   float* q_s = sm;                 // [64]
   float* red = sm + 64;            // [1024 + 8]
@@ -157,8 +181,10 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
     if (found < 0) found = 0;
     if (lane == 0) {
       const int clampi = min(max(found, 0), len - 1);
+      const bool hr = found == max_steps && pl[clampi] < 0.5f;
       head_step[r] = found;
-      head_read[r] = (found == max_steps && pl[clampi] < 0.5f) ? 1 : 0;
+      head_read[r] = hr ? 1 : 0;
+      if (ctl.read_flag && hr && online) ctl.read_flag[b] = (unsigned char)ctl.layer;   // same-value race between heads
       s_found = found;
     }
   }
@@ -196,19 +222,22 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
                                                            long* __restrict__ out_tokens, int* __restrict__ n_prev,
                                                            const T* __restrict__ E, const float* __restrict__ pos,
                                                            T* __restrict__ x, int V, int D, int pad_idx, int eos_idx,
-                                                           int mask_eos, float scale, int B_, int np_base) {
+                                                           int mask_eos, float scale, int B_, int np_base,
+                                                           StreamCtl ctl) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int s_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* row = logits + (long)b * V;
   const int np = n_prev[b];
-  const bool no_eos = mask_eos || np == 0;
+  // streaming commit follows agent.predict (agents/default_agent.py:415-424): plain argmax, nothing masked
+  const bool streaming = ctl.active != nullptr;
+  const bool no_eos = !streaming && (mask_eos || np == 0);
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int c = tid; c < V; c += 256) {
     float v = row[c];
-    if (c == pad_idx || (no_eos && c == eos_idx)) v = -INFINITY;
+    if ((!streaming && c == pad_idx) || (no_eos && c == eos_idx)) v = -INFINITY;
     if (v > best || (v == best && c < bi)) { best = v; bi = c; }
   }
 #pragma unroll
@@ -223,16 +252,37 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
     for (int w = 1; w < 4; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
     if (bi == 0x7fffffff) bi = 0;
+    if (streaming) {
+      const bool act = ctl.active[b] != 0, rd = ctl.read_flag[b] != 0;
+      int tok_next = (int)tokens[b], np_next = np;
+      if (act && !rd) {                                   // WRITE: commit, stamp, maybe finish
+        if (np < ctl.cap) {
+          ctl.hyp[(long)b * ctl.cap + np] = bi;
+          if (ctl.delays) ctl.delays[(long)b * ctl.cap + np] = ctl.cur_ms;
+        }
+        tok_next = bi; np_next = np + 1;
+        tokens[b] = bi;
+        n_prev[b] = np_next;
+        if (bi == eos_idx || np_next > ctl.max_len_now) { ctl.done[b] = 1; ctl.active[b] = 0; }
+      } else if (act && rd) {
+        ctl.active[b] = 0;                                // READ: wait for the next source chunk
+      }
+      ctl.read_flag[b] = 0;
+      s_tok = tok_next;
+      sv[0] = __int_as_float(np_next);
+    } else {
     tokens[b] = bi;
     // np_base >= 0: out_tokens is the [n_steps][B] buffer and the row is derived from the device-side
     // position (one captured step graph serves every step); else out_tokens already points at the row
     if (np_base >= 0) out_tokens[(long)(np - np_base) * B_ + b] = bi; else out_tokens[b] = bi;
     n_prev[b] = np + 1;
     s_tok = bi;
+    sv[0] = __int_as_float(np + 1);
+    }
   }
   __syncthreads();
   const long tok = s_tok;
-  const long pr = pad_idx + 1 + (np + 1);          // position row of the NEXT input token
+  const long pr = pad_idx + 1 + __float_as_int(sv[0]);   // position row of the NEXT input token
   for (int c = tid; c < D; c += 256)
     x[(long)b * D + c] = from_f32<T>(scale * to_f32(E[tok * D + c]) + pos[pr * D + c]);
 }
@@ -266,13 +316,13 @@ int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int64_t* head_step, uint8_t* head_read, void* ctx, int B, int H, int d, int S_cap, int ratio,
                         int attn_type, int waitk_k, int online, int mass_pres, int n_hint, const void* xres,
                         const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
-                        const float* bqs) {
+                        const float* bqs, const StreamCtl& ctl) {
   const size_t lds = (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
   hipLaunchKernelGGL(policy_cross_attn_kernel<T>, dim3(H, B), dim3(256), lds, h->stream, (const T*)qm, (const T*)qs,
                      (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx, (long*)head_step,
                      head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres, n_hint,
-                     (const T*)xres, ln_g, ln_b, (const T*)Wqm, bqm, (const T*)Wqs, bqs);
+                     (const T*)xres, ln_g, ln_b, (const T*)Wqm, bqm, (const T*)Wqs, bqs, ctl);
   return sl_launch_status(h, "simulst_policy_cross_attention");
 }
 
@@ -284,7 +334,8 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k, int32_t online,
                         int32_t mass_preservation, int32_t dtype, int32_t n_hint, const void* xres = nullptr,
                         const float* ln_g = nullptr, const float* ln_b = nullptr, const void* Wqm = nullptr,
-                        const float* bqm = nullptr, const void* Wqs = nullptr, const float* bqs = nullptr);
+                        const float* bqm = nullptr, const void* Wqs = nullptr, const float* bqs = nullptr,
+                        const StreamCtl* ctl = nullptr);
 
 extern "C" int simulst_policy_cross_attention(simulst_handle* h, const void* qm, const void* qs, const void* Kmono,
                                               const void* Ksoft, const void* Vc, float energy_bias,
@@ -302,8 +353,10 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k, int32_t online,
                         int32_t mass_preservation, int32_t dtype, int32_t n_hint, const void* xres,
                         const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
-                        const float* bqs) {
+                        const float* bqs, const StreamCtl* ctlp) {
   if (!h) return SIMULST_E_NULL;
+  StreamCtl ctl = {};
+  if (ctlp) ctl = *ctlp;
   SL_CHECK_NULL(h, Vc); SL_CHECK_NULL(h, head_step); SL_CHECK_NULL(h, head_read); SL_CHECK_NULL(h, ctx);
   SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_policy_cross_attention: dtype");
   SL_REQUIRE(h, attn_type >= SIMULST_ATTN_HARD && attn_type <= SIMULST_ATTN_CHUNKWISE, SIMULST_E_ARG,
@@ -321,15 +374,15 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
   if (dtype == SIMULST_F32)
     return launch_policy_cross<float>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
                                       ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint,
-                                      xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs);
+                                      xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl);
   return launch_policy_cross<bf16>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
                                    ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint,
-                                   xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs);
+                                   xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl);
 }
 
 static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
                       int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos, bool do_embed,
-                      bool device_indexed);
+                      bool device_indexed, const StreamCtl* ctlp = nullptr);
 
 static uint64_t fnv(uint64_t hsh, const void* p, size_t n) {
   const unsigned char* c = (const unsigned char*)p;
@@ -380,11 +433,14 @@ extern "C" int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc*
 
 static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
                       int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos, bool do_embed,
-                      bool device_indexed) {
+                      bool device_indexed, const StreamCtl* ctlp) {
+  StreamCtl ctl = {};
+  if (ctlp) ctl = *ctlp;
   const int np_uniform = (dd && !device_indexed) ? dd->n_prev_uniform : -1;
   const int np_base = device_indexed ? dd->n_prev_uniform : -1;
   if (!h) return SIMULST_E_NULL;
-  SL_CHECK_NULL(h, dd); SL_CHECK_NULL(h, layers); SL_CHECK_NULL(h, tokens_io); SL_CHECK_NULL(h, out_tokens);
+  SL_CHECK_NULL(h, dd); SL_CHECK_NULL(h, layers); SL_CHECK_NULL(h, tokens_io);
+  if (!ctlp) SL_CHECK_NULL(h, out_tokens);
   SL_CHECK_NULL(h, dd->E); SL_CHECK_NULL(h, dd->out_proj); SL_CHECK_NULL(h, dd->pos_table);
   SL_CHECK_NULL(h, dd->n_prev); SL_CHECK_NULL(h, dd->enc_len);
   SL_CHECK_NULL(h, dd->x); SL_CHECK_NULL(h, dd->qkv); SL_CHECK_NULL(h, dd->ctx); SL_CHECK_NULL(h, dd->q);
@@ -416,10 +472,11 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
       const int n_hint = device_indexed ? -1
                          : (dd->attn_type == SIMULST_ATTN_WAITK && np_uniform >= 0)
                                ? (np_uniform + s + dd->waitk_k) * dd->ratio : dd->S_cap;
+      ctl.layer = l + 1;
       if ((rc = policy_cross(h, nullptr, nullptr, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
                              dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
                              dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, dd->x, L.ln2_g,
-                             L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft))) return rc;
+                             L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft, ctlp ? &ctl : nullptr))) return rc;
       if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
       if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b))) return rc;
       if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
@@ -432,14 +489,27 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         hipLaunchKernelGGL(argmax_embed_kernel<float>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
                            (long*)out_tokens + (device_indexed ? 0 : (long)s * B), dd->n_prev, (const float*)dd->E,
                            dd->pos_table, (float*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, B,
-                           np_base);
+                           np_base, ctl);
       else
         hipLaunchKernelGGL(argmax_embed_kernel<bf16>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
                            (long*)out_tokens + (device_indexed ? 0 : (long)s * B), dd->n_prev, (const bf16*)dd->E,
                            dd->pos_table, (bf16*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, B,
-                           np_base);
+                           np_base, ctl);
       if ((rc = sl_launch_status(h, "simulst_mma_decode(argmax)")) != 0) return rc;
     }
   }
   return SIMULST_OK;
+}
+
+extern "C" int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
+                                        int64_t* tokens_io, const simulst_stream_ctl* c, int32_t n_iter) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, c); SL_CHECK_NULL(h, c->active); SL_CHECK_NULL(h, c->read_flag); SL_CHECK_NULL(h, c->online);
+  SL_CHECK_NULL(h, c->done); SL_CHECK_NULL(h, c->hyp);
+  SL_REQUIRE(h, c->cap > 0 && n_iter >= 0, SIMULST_E_SHAPE, "simulst_mma_stream_steps: cap / n_iter");
+  StreamCtl ctl;
+  ctl.active = c->active; ctl.read_flag = c->read_flag; ctl.online = c->online; ctl.done = c->done;
+  ctl.delays = c->delays_ms; ctl.hyp = (long*)c->hyp; ctl.cap = c->cap; ctl.cur_ms = c->cur_ms;
+  ctl.max_len_now = c->max_len_now;
+  return run_decode(h, dd, layers, tokens_io, nullptr, n_iter, 0, true, true, &ctl);
 }

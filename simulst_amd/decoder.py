@@ -266,6 +266,35 @@ class MMADecoder:
         st.n_prev_host += n_steps
         return out
 
+    def _decoder_desc(self, st: DecoderState, np_uniform: int):
+        cfg, dt_ = self.cfg, self.dtype
+        B, D, dev = st.B, cfg.embed_dim, self.device
+        if not hasattr(st, "ws"):
+            st.ws = {"x": torch.empty(B, D, device=dev, dtype=dt_), "qkv": torch.empty(B, 3 * D, device=dev, dtype=dt_),
+                     "ctx": torch.empty(B, D, device=dev, dtype=dt_), "q": torch.empty(B, D, device=dev, dtype=dt_),
+                     "q2": torch.empty(B, D, device=dev, dtype=dt_),
+                     "hidden": torch.empty(B, cfg.ffn_dim, device=dev, dtype=dt_),
+                     "logits": torch.empty(B, cfg.vocab, device=dev, dtype=torch.float32)}
+            st.layer_structs = self._layer_structs(st)
+        ws = st.ws
+        return _lib.DecoderDesc(B, D, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st.cap, st.S_cap,
+                                _lib.F32 if dt_ == torch.float32 else _lib.BF16, self.attn_enum, cfg.pre_decision_ratio,
+                                cfg.waitk_lagging, int(cfg.mass_preservation), int(st.online), cfg.padding_idx, cfg.eos,
+                                np_uniform, self.embed_scale, self.w.E.data_ptr(), self.w.out_proj.data_ptr(),
+                                self.w.pos.data_ptr(), self.w.ln_g.data_ptr(), self.w.ln_b.data_ptr(),
+                                st.enc_len.data_ptr(), st.n_prev.data_ptr(), ws["x"].data_ptr(), ws["qkv"].data_ptr(),
+                                ws["ctx"].data_ptr(), ws["q"].data_ptr(), ws["q2"].data_ptr(), ws["hidden"].data_ptr(),
+                                ws["logits"].data_ptr())
+
+    def stream_steps(self, st: DecoderState, tokens: torch.Tensor, ctl, n_iter: int):
+        """n_iter masked policy()/predict() rounds of a batch of streams (simulst_mma_stream_steps): rows read
+        and write independently under the device-side masks of ``ctl`` (_lib.StreamCtl)."""
+        import ctypes as C
+        d = self._decoder_desc(st, -1)
+        self.ops.h.check(self.ops.lib.simulst_mma_stream_steps(self.ops.h.ptr, C.byref(d), st.layer_structs,
+                                                               tokens.data_ptr(), C.byref(ctl), n_iter),
+                         "simulst_mma_stream_steps")
+
     # ------------------------------------------------------------------ offline greedy (generate.py semantics)
     def greedy_offline(self, enc_btd: torch.Tensor, enc_len: torch.Tensor, n_steps: int, mask_eos: bool = True,
                        fused: bool = True, s_cap: Optional[int] = None, cap: Optional[int] = None):

@@ -94,3 +94,46 @@ def test_agent_actions_tokens_al_identical_to_oracle(ops, attn, kw):
         assert got["delays_ms"] == ref["delays_ms"]
         assert got["AL"] == ref["AL"]
         assert got["n_enc"] == ref["n_enc"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("attn,kw", [("waitk_fixed_pre_decision", dict(waitk_lagging=3)),
+                                     ("hard_aligned_fixed_pre_decision", {}),
+                                     ("infinite_lookback_fixed_pre_decision", {})])
+def test_batched_streaming_rows_equal_single_streams(ops, attn, kw, dtype):
+    """B streams through one batch with per-row READ/WRITE divergence (simulst_mma_stream_steps): every row's
+    actions / tokens / delays are IDENTICAL to the B=1 agent on that utterance; the fp32 rows are also checked
+    against the CPU oracle."""
+    from simulst_amd.agent import BatchedStreamingAgent, FairseqSimulSTAgent
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, simul_attn_type=attn, max_target_positions=40, **kw)
+    w = init_model(cfg, seed=4242)
+    if "waitk" not in attn:
+        for l in range(2):
+            w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 8
+    # rows finish at different times: bias EOS up so that hypotheses end early / at different lengths
+    w["decoder.embed_tokens.weight"][cfg.eos] *= 1.5
+    model = SimulSTModel(cfg, w, dtype=dtype, ops=ops)
+    B, T = 5, 560
+    fb = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(77))
+    single = FairseqSimulSTAgent(model)
+    refs = [single.run_utterance(fb[b].cuda()) for b in range(B)]
+    for spc in (1, 4):
+        got = BatchedStreamingAgent(model, steps_per_call=spc).run_batch(fb)
+        for b in range(B):
+            assert got[b]["actions"] == refs[b]["actions"], (attn, b, spc)
+            assert got[b]["tokens"] == refs[b]["tokens"], (attn, b, spc)
+            assert got[b]["delays_ms"] == refs[b]["delays_ms"]
+            assert got[b]["AL"] == refs[b]["AL"]
+    if "waitk" not in attn:
+        assert len({r["actions"] for r in refs}) > 1, "test needs rows that diverge"
+    if dtype == torch.float32:
+        from oracle import agent as oag
+        from oracle.configs import from_model_config
+        ecfg, dcfg = from_model_config(cfg)
+        for b in (0, B - 1):
+            ref = oag.simulate_mma(w, ecfg, dcfg, fb[b])
+            assert got[b]["actions"] == ref["actions"] and got[b]["tokens"] == ref["tokens"]
+            assert got[b]["delays_ms"] == ref["delays_ms"]
