@@ -8,8 +8,13 @@
 Workload (BASELINE.json configs[1]): Emformer encoder + wait-k=5 decoder (mma_model_s,
 waitk_fixed_pre_decision ratio 8), bf16, synthetic 80x1000 fbank, batch 64 per GPU, 110 forced
 greedy steps (EOS masked) => 7040 tokens per step per GPU.  One "step" = one pass of the hot
-path (encoder forward + 110 decoder steps + argmax) over one batch already resident in HBM, the
-stopwatch placement of eval/generate.py:200-209.  Utterance batches shard across ranks with no
+path (encoder forward + 110 decoder steps + argmax) over one batch of 64 utterances already
+resident in HBM, the stopwatch placement of eval/generate.py:200-209.  Scheduling (reported in
+config.schedule): --group G independent batches ride in one launch sequence (their rows are
+stacked; every row's result is independent of its batch, tests/test_hip_properties.py) and
+--concurrency S such sequences are in flight on S HIP streams, so S*G batches of 64 are in flight
+and K timed steps are K batches whatever G and S are.  serial_one_batch_in_flight is the same
+path with one batch of 64 alone on the GPU.  Utterance batches shard across ranks with no
 data-path collective (weak scaling); the only RCCL traffic is the all_gather of hypotheses.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
@@ -92,13 +97,15 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=9)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrency", type=int, default=3,
-                    help="independent 64-utterance batches in flight (one HIP stream + host thread each)")
+                    help="independent launch sequences in flight (one HIP stream + host thread each)")
+    ap.add_argument("--group", type=int, default=4,
+                    help="independent 64-utterance batches stacked into one launch sequence")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode loop of each batch strictly one after the other")
     ap.add_argument("--graph", action="store_true",
@@ -136,16 +143,19 @@ def main():
     if args.graph:
         model.ops.h.graph_enable(True)
     B = args.batch
-    # synthetic fbank, seed 999 + global utterance id, resident in HBM before the clock starts
-    fb = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + rank * B + i))
-                      for i in range(B)]).to(device=f"cuda:{local}", dtype=dtype)
-    L = torch.full((B,), T_FRAMES, device=f"cuda:{local}")
+    G = max(1, args.group)
+    # synthetic fbank, seed 999 + global utterance id, resident in HBM before the clock starts: G batches of B
+    fb_all = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + rank * B * G + i))
+                          for i in range(B * G)]).to(device=f"cuda:{local}", dtype=dtype)
+    L_all = torch.full((B * G,), T_FRAMES, device=f"cuda:{local}")
+    fb, L = fb_all[:B], L_all[:B]              # one batch (serial reference, instrumented replay uses a group)
 
-    def one_step():
-        toks, _ = model.generate_offline(fb, L, n_steps=N_STEPS_DECODE, mask_eos=True)
-        if dist is not None:
-            toks = gather_hypotheses(toks, dist)
-        return toks
+    def groups(k):
+        """k batches -> launch sequences of G stacked batches (+ one shorter sequence for the remainder)"""
+        seq = [(fb_all, L_all)] * (k // G)
+        if k % G:
+            seq.append((fb_all[:B * (k % G)], L_all[:B * (k % G)]))
+        return seq
 
     pipe = None
     if args.concurrency > 1:
@@ -159,12 +169,14 @@ def main():
         """k passes of the hot path. Pipelined mode overlaps the encoder of batch i+1 with the greedy loop of
         batch i (two HIP streams); every batch still runs the full encoder + 110 decode steps."""
         if pipe is None:
-            for _ in range(k):
-                one_step()
+            for f_, l_ in groups(k):
+                toks, _ = model.generate_offline(f_, l_, n_steps=N_STEPS_DECODE, mask_eos=True)
+                if dist is not None:
+                    gather_hypotheses(toks.t(), dist)
             return
-        out = pipe.run([(fb, L)] * k, N_STEPS_DECODE, mask_eos=True)
+        out = pipe.run(groups(k), N_STEPS_DECODE, mask_eos=True)
         if dist is not None:       # ONE collective for the k batches, issued from the main thread in rank order
-            gather_hypotheses(torch.cat(out, dim=0), dist)
+            gather_hypotheses(torch.cat([o.t() for o in out], dim=0), dist)     # [utterances, U]
 
     log(f"model + inputs resident on cuda:{local}; host cores {os.cpu_count()}")
     with torch.no_grad():
@@ -199,12 +211,19 @@ def main():
             model.generate_offline(fb, L, n_steps=N_STEPS_DECODE, mask_eos=True)
         torch.cuda.synchronize()
         serial_s = time.perf_counter() - ts0
+        with torch.no_grad():                  # the launch sequence of G stacked batches, un-instrumented, twice
+            model.generate_offline(fb_all, L_all, n_steps=N_STEPS_DECODE, mask_eos=True)
+            torch.cuda.synchronize()
+            tg0 = time.perf_counter()
+            model.generate_offline(fb_all, L_all, n_steps=N_STEPS_DECODE, mask_eos=True)
+            torch.cuda.synchronize()
+        group_s = time.perf_counter() - tg0
         h.timer_reset()
         h.timer_enable(-1, True)
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
         with torch.no_grad():
-            model.generate_offline(fb, L, n_steps=N_STEPS_DECODE, mask_eos=True)
+            model.generate_offline(fb_all, L_all, n_steps=N_STEPS_DECODE, mask_eos=True)
         torch.cuda.synchronize()
         replay_s = time.perf_counter() - tr0
         h.timer_enable(-1, False)
@@ -212,14 +231,15 @@ def main():
         # every timed launch carries one extra event record; its cost = (instrumented pass - plain pass)
         # spread over the launches, removed from each class
         n_launch = sum(v[1] for v in raw.values())
-        plain_s = serial_s
+        plain_s = group_s
         ovh_ms = max(0.0, (replay_s - plain_s) * 1e3 / max(n_launch, 1))
         per_class = {k: (max(0.0, v[0] - ovh_ms * v[1]), v[1]) for k, v in raw.items()}
         log(f"instrumented replay done: {replay_s * 1e3:.1f} ms vs {plain_s * 1e3:.1f} ms plain, "
             f"{n_launch} launches, event record cost {ovh_ms * 1e3:.2f} us")
         dom = max(per_class, key=lambda k: per_class[k][0])
         dom_ms, dom_n = per_class[dom]
-        fl, dims = algorithmic_work(cfg, B, T_FRAMES, N_STEPS_DECODE)
+        Bs = B * G                              # rows of the instrumented launch sequence
+        fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, N_STEPS_DECODE)
         esz = 2 if args.dtype == "bf16" else 4
         D, H, F, V, Ld = cfg.embed_dim, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers
         U = N_STEPS_DECODE
@@ -236,19 +256,19 @@ def main():
                 # far left of the ridge (312 flop/B) => HBM/L2 bound. Algorithmic bytes per launch =
                 # weights N*K + activations M*K in, M*N out.
                 def gb(n, k):
-                    return (n * k + B * k + B * n) * esz
+                    return (n * k + Bs * k + Bs * n) * esz
                 per_layer = gb(3 * D, D) + 2 * gb(D, D) + gb(F, D) + gb(D, F)   # q-proj lives in the cross-attention launch
                 byts = U * (Ld * per_layer + gb(V, D))
             elif dom == "emformer_attention":
-                byts = cfg.encoder_layers * B * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
+                byts = cfg.encoder_layers * Bs * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
             elif dom == "decoder_cross_attention":
                 # wait-k: target t reads min((t + k) * ratio, Te) key and value rows of D channels
                 rows = sum(min((t + WAITK) * cfg.pre_decision_ratio, dims["Te"]) for t in range(U))
-                byts = Ld * B * (2 * rows * D + 2 * U * D) * esz
+                byts = Ld * Bs * (2 * rows * D + 2 * U * D) * esz
             elif dom == "decoder_self_attention":
-                byts = Ld * B * sum((2 * (u + 1) * D + 4 * D) for u in range(U)) * esz
+                byts = Ld * Bs * sum((2 * (u + 1) * D + 4 * D) for u in range(U)) * esz
             elif dom == "layernorm":
-                byts = (cfg.encoder_layers * 2 * B * dims["rows_x"] * 2 * D) * esz
+                byts = (cfg.encoder_layers * 2 * Bs * dims["rows_x"] * 2 * D) * esz
             else:
                 byts = 0
             ach = byts / (dom_ms * 1e-3) / 1e9
@@ -266,11 +286,12 @@ def main():
         roofline["path_hbm_model"] = {"bytes_per_token": 2.135e6, "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / 2.135e6),
                                       "frac": round(value / world / (HBM_PEAK_GBS * 1e9 / 2.135e6), 5)}
         roofline["kernel"] = dom
-        roofline["launches_per_step"] = dom_n
+        roofline["launches_per_sequence"] = dom_n
+        roofline["rows_per_sequence"] = Bs
         roofline["avg_launch_us"] = round(dom_ms * 1e3 / max(dom_n, 1), 3)
         roofline["algorithmic_bytes_per_launch" if roofline["bound"] == "hbm" else "algorithmic_flop_per_launch"] = \
             round((byts if roofline["bound"] == "hbm" else flops) / max(dom_n, 1))
-        roofline["class_ms_per_step"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
+        roofline["class_ms_per_sequence"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
         # the MFMA-bound encoder contractions, reported beside the dominant class
         lin_ms = per_class["linear"][0]
         if lin_ms > 0:
@@ -289,11 +310,15 @@ def main():
                                    "batch 64/GPU, 110 forced greedy steps",
                        "batch_per_gpu": B, "frames": T_FRAMES, "decode_steps": N_STEPS_DECODE,
                        "tokens_per_step": tokens_per_step, "sharding": f"utterance-sharded x{world}",
-                       "schedule": (f"{args.concurrency} independent batches in flight on {args.concurrency} HIP streams"
-                                    if args.concurrency > 1 else "serial" if args.no_pipeline
-                                    else "encoder(i+1) overlapped with decode(i) on 2 streams")},
+                       "co_scheduled_batches": G, "streams": args.concurrency,
+                       "schedule": (f"{G * args.concurrency} independent batches of {B} in flight: {G} stacked per launch "
+                                    f"sequence x {args.concurrency} HIP streams" if args.concurrency > 1
+                                    else f"{G} stacked per launch sequence, " +
+                                    ("serial" if args.no_pipeline else "encoder(i+1) overlapped with decode(i) on 2 streams"))},
             "serial_one_batch_in_flight": {"tokens_per_s": round(B * N_STEPS_DECODE / serial_s, 1),
                                            "ms_per_batch": round(serial_s * 1e3, 3)},
+            "serial_one_sequence_in_flight": {"tokens_per_s": round(Bs * N_STEPS_DECODE / group_s, 1),
+                                              "ms_per_sequence": round(group_s * 1e3, 3)},
             "roofline": roofline, "cpu_baseline": cpu_base,
         }
         print(json.dumps(out))

@@ -84,6 +84,9 @@ int simulst_timer_reset(simulst_handle* h);
 int simulst_graph_enable(simulst_handle* h, int on);
 /* test hook: route bf16 Emformer attention through the fp32-VALU kernel instead of the MFMA one */
 int simulst_debug_force_valu_attention(simulst_handle* h, int on);
+/* test hook: run simulst_mma_decode / simulst_mma_stream_steps with the 7-launch layer even when the head-split
+ * workspace is supplied (A/B parity of the two paths) */
+int simulst_debug_force_unfused_decode(simulst_handle* h, int on);
 
 /* ---- dense contraction ----------------------------------------------------------
  * C[r, :] = epi(A[r, :] . W^T) for logical rows r = b * rows_per_batch + i.
@@ -115,6 +118,11 @@ typedef struct {
   const float* ln_gamma;       /* optional LayerNorm PROLOGUE: A rows are normalised (eps 1e-5, fp32 stats,   */
   const float* ln_beta;        /* rounded to the operand dtype) before the contraction; NULL = none.          */
                                /* Supported when M <= 128 and rows do not overlap (decode-step shapes).       */
+  int32_t w_fragment_major;    /* W is stored in MFMA-fragment order instead of row-major [N][K] (decode-step    */
+                               /* shapes only, N % 16 == 0, K % KS == 0): element (n, k) at                      */
+                               /*   ((n/16 * K/KS + k/KS) * 64 + (k%KS)/G * 16 + n%16) * G + k%G,                */
+                               /* G = 8 (bf16) / 4 (fp32) elements, KS = 4 G: each wave load is 1 KB contiguous. */
+                               /* simulst_pack_fragment_major produces it.                                       */
 } simulst_linear_desc;
 
 int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, const void* A, const void* W,
@@ -275,6 +283,10 @@ int simulst_decoder_cross_attention(simulst_handle* h, const void* q, const void
 int simulst_greedy_argmax(simulst_handle* h, const float* logits, const float* eos_bias, int64_t* out,
                           int32_t B, int32_t V, int32_t pad_idx, int32_t eos_idx, int32_t mask_eos);
 
+/* Reorder a row-major weight matrix W [N][K] (device) into the fragment-major order described at
+ * simulst_linear_desc.w_fragment_major; out has N*K elements.  One-off, at model load. */
+int simulst_pack_fragment_major(simulst_handle* h, const void* W, void* out, int32_t N, int32_t K, int32_t dtype);
+
 /* ---- whole decode steps on the device ----------------------------------------------
  * Runs n_steps consecutive WRITE steps of the MMA / wait-k decoder for a batch in lockstep with no
  * host round trip: embed -> n_layers x { LN+QKV, self-attention, out-proj+res, LN+q-proj,
@@ -314,6 +326,17 @@ typedef struct {
   int32_t* n_prev;                               /* [B] in/out: tokens written so far */
   void *x, *qkv, *ctx, *q, *q2, *hidden;         /* workspace: [B][D], [B][3D], [B][D], [B][D], [B][D], [B][F] */
   float* logits;                                 /* workspace [B][V] */
+  /* optional workspace of the head-split self-attention block (both non-NULL, cap <= 256, head_dim % 16 == 0,
+   * D <= 512): { LN + QKV GEMM, self-attention, out-proj GEMM } become ONE launch per layer in which every
+   * (head, utterance) workgroup projects its own q/k/v rows, appends to the cache, attends, and multiplies by
+   * its head's columns of the output projection; the fp32 per-head partials are added (head order, deterministic)
+   * together with the bias and the residual by the following policy/cross-attention launch.  NULL: 7-launch layer. */
+  void* x_mid;                                   /* [B][D] */
+  float* partial_self;                           /* [B][H][D] */
+  int32_t weights_fragment_major;                /* every weight MATRIX of simulst_dec_layer and out_proj is in the
+                                                    fragment-major order of simulst_linear_desc.w_fragment_major
+                                                    (E stays row-major: it is read by row); required by the
+                                                    head-split block */
 } simulst_decoder_desc;
 
 /* tokens_io [B] int64: in = newest token of [eos]+hyp, out = last token picked.

@@ -32,7 +32,7 @@ class LinearDesc(C.Structure):
                 ("r_batch_stride", C.c_int64), ("r_row_stride", C.c_int64),
                 ("epilogue", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_float),
                 ("n_main", C.c_int32), ("aux_rows", C.c_int32), ("aux_batch_stride", C.c_int64),
-                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p)]
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("w_fragment_major", C.c_int32)]
 
 
 class EmfAttnDesc(C.Structure):
@@ -56,7 +56,8 @@ class DecoderDesc(C.Structure):
                                          "n_prev_uniform")] + \
                [("embed_scale", C.c_float)] + \
                [(n, C.c_void_p) for n in ("E", "out_proj", "pos_table", "ln_g", "ln_b", "enc_len", "n_prev", "x", "qkv",
-                                          "ctx", "q", "q2", "hidden", "logits")]
+                                          "ctx", "q", "q2", "hidden", "logits", "x_mid", "partial_self")] + \
+               [("weights_fragment_major", C.c_int32)]
 
 class StreamCtl(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("active", "read_flag", "online", "done", "delays_ms", "hyp")] + \
@@ -75,6 +76,8 @@ SIGNATURES = {
     "simulst_timer_reset": [_vp],
     "simulst_graph_enable": [_vp, C.c_int],
     "simulst_debug_force_valu_attention": [_vp, C.c_int],
+    "simulst_debug_force_unfused_decode": [_vp, C.c_int],
+    "simulst_pack_fragment_major": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_emformer_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],

@@ -29,6 +29,7 @@ struct simulst_handle {
   bool graph_on;
   bool capturing;
   bool force_valu_attention;   // test hook: route bf16 Emformer attention through the VALU kernel
+  bool force_unfused_decode;   // test hook: 7-launch decoder layer even when the head-split workspace is given
   hipGraphExec_t graph_exec;
   uint64_t graph_key;
 };
@@ -156,6 +157,16 @@ __device__ __forceinline__ void store4(bf16* p, const float (&o)[4]) {
 // device array (np_uniform < 0)
 int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev,
                       int np_uniform, void* ctx, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t dtype);
+
+// fused decoder self-attention block (decode_fused.hip): LN + q/k/v rows of the head + cache append + attention +
+// the head's columns of the output projection as an fp32 partial [B][H][D]
+static inline bool sl_self_attention_fused_ok(int H, int d, int cap) {
+  return (d == 32 || d == 64) && H * d <= 1024 && cap <= 256;
+}
+int sl_self_attention_fused(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* Wqkv,
+                            const float* bqkv, const void* Wo, void* k_cache, void* v_cache, const int32_t* n_prev,
+                            int np_uniform, float* partial, int32_t B, int32_t H, int32_t d, int32_t cap,
+                            int32_t dtype);
 
 int sl_emformer_attention_mfma(simulst_handle* h, const simulst_emf_attn_desc* d, const void* QKV,
                                const int32_t* lengths, const void* lc_k, const void* lc_v, const int32_t* lc_valid,

@@ -13,14 +13,14 @@
 
 namespace {
 
-template <typename T>
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
                                                         T* __restrict__ vc, const int* __restrict__ n_prev,
                                                         int np_uniform, T* __restrict__ ctx, int H, int d, int cap) {
   extern __shared__ float sm[];
   float* q_s = sm;                 // [64]
   float* red = sm + 64;            // [1024 + 8]
-  float* sc = red + 1032;          // [max(cap, 256)]
+  float* sc = red + attn::RED_FLOATS;   // [max(cap, 256)]
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int D = H * d;
   const int np = np_uniform >= 0 ? np_uniform : n_prev[b];
@@ -28,8 +28,18 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const T* __restrict__ qk
   T* Kh = kc + ((long)b * H + h) * cap * d;
   T* Vh = vc + ((long)b * H + h) * cap * d;
   const int n = np + 1;
-  float o;
-  if (n <= 256) {
+  float o = 0.f;
+  if (NP > 0 && n <= 256) {
+    if constexpr (NP > 0) {
+      attn::Regs2<T, NP> r;
+      attn::prefetch2<T, NP>(r, row + h * d, Kh, d, Vh, d, n, np, row + D + h * d, row + 2 * D + h * d);
+      if (tid < d) {                                      // append for the following steps
+        Kh[(long)np * d + tid] = row[D + h * d + tid];
+        Vh[(long)np * d + tid] = row[2 * D + h * d + tid];
+      }
+      o = attn::finish2<T, NP>(r, n, n, rsqrtf((float)d), sc, red, nullptr, nullptr);
+    }
+  } else if (n <= 256) {
     attn::Regs<T> r;
     attn::prefetch<T>(r, row + h * d, Kh, d, Vh, d, n, d, np, row + D + h * d, row + 2 * D + h * d);
     if (tid < d) {                                      // append for the following steps
@@ -49,7 +59,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const T* __restrict__ qk
   if (tid < d) ctx[(long)b * D + h * d + tid] = from_f32<T>(o);
 }
 
-template <typename T>
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ Kc,
                                                          const T* __restrict__ Vc, const long* __restrict__ step,
                                                          const int* __restrict__ key_len, T* __restrict__ ctx,
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const T* __restrict__ q
   extern __shared__ float sm[];
   float* q_s = sm;
   float* red = sm + 64;
-  float* sc = red + 1032;
+  float* sc = red + attn::RED_FLOATS;
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int D = H * d;
   const int len = key_len ? key_len[b] : S_cap;
@@ -84,7 +94,13 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const T* __restrict__ q
     // softmax over keys <= step, zeroed if the head has not moved (:278-293)
     const int n = (int)(st < len - 1 ? st : len - 1) + 1;
     if (st > 0 && n > 0) {
-      if (n <= 256) {
+      if (NP > 0 && n <= 256) {
+        if constexpr (NP > 0) {
+          attn::Regs2<T, NP> r;
+          attn::prefetch2<T, NP>(r, q + (long)b * D + h * d, Kh, D, Vh, D, n, -1, nullptr, nullptr);
+          o = attn::finish2<T, NP>(r, n, n, rsqrtf((float)d), sc, red, bt);
+        }
+      } else if (n <= 256) {
         attn::Regs<T> r;
         attn::prefetch<T>(r, q + (long)b * D + h * d, Kh, D, Vh, D, n, d, -1, nullptr, nullptr);
         o = attn::finish<T>(r, n, d, rsqrtf((float)d), sc, red, bt);
@@ -116,17 +132,19 @@ int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v
   SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_decoder_self_attention: dtype");
   SL_REQUIRE(h, H > 0 && d >= 8 && d <= 64 && d % 8 == 0 && cap > 0, SIMULST_E_SHAPE,
              "simulst_decoder_self_attention: head_dim must be a multiple of 8, <= 64");
-  const size_t lds = (size_t)(64 + 1032 + (cap > 256 ? cap : 256)) * sizeof(float);
+  const size_t lds = (size_t)(64 + attn::RED_FLOATS + (cap > 256 ? cap : 256)) * sizeof(float);
   SL_REQUIRE(h, lds <= 64 * 1024, SIMULST_E_SHAPE, "simulst_decoder_self_attention: cache capacity too large for LDS scores");
   if (B <= 0) return SIMULST_OK;
   KTimer t(h, SIMULST_K_DEC_SELF_ATTN);
   dim3 grid(H, B);
-  if (dtype == SIMULST_F32)
-    hipLaunchKernelGGL(self_attn_kernel<float>, grid, dim3(256), lds, h->stream, (const float*)qkv,
-                       (float*)k_cache, (float*)v_cache, n_prev, np_uniform, (float*)ctx, H, d, cap);
-  else
-    hipLaunchKernelGGL(self_attn_kernel<bf16>, grid, dim3(256), lds, h->stream, (const bf16*)qkv,
-                       (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, H, d, cap);
+#define SA_F32(NP) hipLaunchKernelGGL((self_attn_kernel<float, NP>), grid, dim3(256), lds, h->stream, (const float*)qkv, \
+                                     (float*)k_cache, (float*)v_cache, n_prev, np_uniform, (float*)ctx, H, d, cap)
+#define SA_BF16(NP) hipLaunchKernelGGL((self_attn_kernel<bf16, NP>), grid, dim3(256), lds, h->stream, (const bf16*)qkv, \
+                                      (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, H, d, cap)
+  if (dtype == SIMULST_F32) { SL_DISPATCH_NP(attn::lanes_per_row<float>(d), SA_F32) }
+  else { SL_DISPATCH_NP(attn::lanes_per_row<bf16>(d), SA_BF16) }
+#undef SA_F32
+#undef SA_BF16
   return sl_launch_status(h, "simulst_decoder_self_attention");
 }
 
@@ -142,18 +160,20 @@ extern "C" int simulst_decoder_cross_attention(simulst_handle* h, const void* q,
              "simulst_decoder_cross_attention: attn_type");
   SL_REQUIRE(h, H > 0 && d >= 8 && d <= 64 && d % 8 == 0 && S_cap > 0, SIMULST_E_SHAPE,
              "simulst_decoder_cross_attention: head_dim must be a multiple of 8, <= 64");
-  const size_t lds = (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256)) * sizeof(float);
+  const size_t lds = (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256)) * sizeof(float);
   SL_REQUIRE(h, lds <= 64 * 1024, SIMULST_E_SHAPE, "simulst_decoder_cross_attention: source too long for LDS scores");
   if (B <= 0) return SIMULST_OK;
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
   dim3 grid(H, B);
-  if (dtype == SIMULST_F32)
-    hipLaunchKernelGGL(cross_attn_kernel<float>, grid, dim3(256), lds, h->stream, (const float*)q, (const float*)Kc,
-                       (const float*)Vc, (const long*)step, key_len, (float*)ctx, beta, H, d, S_cap, attn_type,
-                       mass_preservation);
-  else
-    hipLaunchKernelGGL(cross_attn_kernel<bf16>, grid, dim3(256), lds, h->stream, (const bf16*)q, (const bf16*)Kc,
-                       (const bf16*)Vc, (const long*)step, key_len, (bf16*)ctx, beta, H, d, S_cap, attn_type,
-                       mass_preservation);
+#define CA_F32(NP) hipLaunchKernelGGL((cross_attn_kernel<float, NP>), grid, dim3(256), lds, h->stream, (const float*)q,   \
+                                     (const float*)Kc, (const float*)Vc, (const long*)step, key_len, (float*)ctx, beta, \
+                                     H, d, S_cap, attn_type, mass_preservation)
+#define CA_BF16(NP) hipLaunchKernelGGL((cross_attn_kernel<bf16, NP>), grid, dim3(256), lds, h->stream, (const bf16*)q,    \
+                                      (const bf16*)Kc, (const bf16*)Vc, (const long*)step, key_len, (bf16*)ctx, beta,  \
+                                      H, d, S_cap, attn_type, mass_preservation)
+  if (dtype == SIMULST_F32) { SL_DISPATCH_NP(attn::lanes_per_row<float>(d), CA_F32) }
+  else { SL_DISPATCH_NP(attn::lanes_per_row<bf16>(d), CA_BF16) }
+#undef CA_F32
+#undef CA_BF16
   return sl_launch_status(h, "simulst_decoder_cross_attention");
 }

@@ -7,6 +7,7 @@
 //   argmax_embed_kernel      : greedy pick + commit (n_prev += 1) + next token's embedding
 // LayerNorms ride as prologues of the following skinny GEMM (simulst_linear_desc.ln_gamma).
 #include "attn_core.h"
+#include "gemv_mfma.h"
 
 namespace {
 
@@ -31,13 +32,21 @@ struct StreamCtl {
   int layer;            // 1-based id of the launching layer: read_flag holds the id of the layer that fired
 };
 
+// head-split projections around the policy kernel (all null: separate GEMM launches do the projections)
+struct HeadSplit {
+  const float* po;     // [B][H][D] self-attention output-projection partials to add to the residual row
+  const float* bo;     // [D] bias of that projection
+  void* x_mid;         // [B][D] out: the residual row after the self-attention block
+  int w_packed;        // Wqm / Wqs in fragment-major order: the query projection runs on the matrix cores
+};
+
 // One workgroup per (head, utterance).
 //  1. pooled step probabilities pp[j] (thread per pooled key), zero-inserted into p[] in LDS
 //     (modules/fixed_pre_decision.py:85-167; wait-k one-hot utils/p_choose_strategy.py:6-53)
 //  2. wave 0: mask the past, force the stop, first index with p >= 0.5
 //     (modules/monotonic_multihead_attention.py:196-257) -> head_step, head_read
 //  3. hard gather / softmax over keys <= step (:261-297), PV
-template <typename T>
+template <typename T, int NP>
 __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
     const T* __restrict__ qm, const T* __restrict__ qs, const T* __restrict__ Km, const T* __restrict__ Ks,
     const T* __restrict__ Vc, float energy_bias, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
@@ -47,7 +56,10 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
     // separate LN2 + q-proj GEMM launch; qm / qs are then ignored
     const T* __restrict__ xres, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
     const T* __restrict__ Wqm, const float* __restrict__ bqm, const T* __restrict__ Wqs,
-    const float* __restrict__ bqs, StreamCtl ctl) {
+    const float* __restrict__ bqs, StreamCtl ctl,
+    // head-split self-attention block (decode_fused.hip): the residual row is xres + bo + sum_h po[b][h][:] (that
+    // block's per-head output-projection partials, added in head order), written once to x_mid
+    const float* __restrict__ po, const float* __restrict__ bo, T* __restrict__ x_mid, int w_packed) {
   constexpr int W = VL<T>::W;
   if (ctl.active) {   // row parked / finished, or an EARLIER layer asked for source (heads of one layer all run)
     const unsigned char rf = ctl.read_flag[blockIdx.y];
@@ -57,12 +69,13 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
   extern __shared__ float sm[];
   float* q_s = sm;                 // [64]
   float* red = sm + 64;            // [1024 + 8]
-  float* sc = red + 1032;          // [max(S_cap,256)] scores
+  float* sc = red + attn::RED_FLOATS;   // [max(S_cap,256)] scores
   float* pl = sc + (S_cap > 256 ? S_cap : 256);   // [S_cap + 1] step probabilities
   float* pp = pl + S_cap + 1;      // [S_cap] pooled probabilities
   float* xn = pp + S_cap;          // [D] normalised residual row (fused projection only)
   float* qsoft_s = xn + H * d;     // [64] scaled soft-energy query (fused projection only)
   __shared__ int s_found;
+  __shared__ __attribute__((aligned(16))) T xn_t[1024];   // normalised row in the operand dtype (MFMA projection)
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int D = H * d;
   const int len = key_len ? key_len[b] : S_cap;
@@ -74,32 +87,73 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
   const T* Vh = Vc + (long)b * S_cap * D + h * d;
   const T* Kh = Ks ? Ks + (long)b * S_cap * D + h * d : nullptr;
   const bool soft = attn_type != SIMULST_ATTN_HARD;
-  const bool fast = soft && S_cap <= 256;     // rows >= len exist (zero-filled) and are masked by n <= len
-  attn::Regs<T> rg;
+  // single-latency path: soft attention over <= 256 keys with a lanes-per-row instantiation (rows >= len exist,
+  // zero-filled, and are masked by n <= len); anything else takes the looped path
+  const bool fast = NP > 0 && soft && S_cap <= 256;
+  attn::Regs2<T, NP> rg2;
   // n_hint: upper bound on the keys this step can attend to: host-known (wait-k in lockstep), derived from
   // the device-side target index (n_hint < 0, wait-k: target t sees at most (t + k) * ratio frames), else S_cap
   const int tg = tgt_idx ? tgt_idx[b] : 0;    // scalar inputs of the policy: issued with the prefetch
   const long hs = head_step[r];
   if (n_hint < 0) n_hint = attn_type == SIMULST_ATTN_WAITK ? (tg + waitk_k) * ratio : S_cap;
   const bool fusedq = xres != nullptr;
-  if (fast) {
-    if (fusedq) attn::prefetch_kv<T>(rg, Kh, D, Vh, D, min(S_cap, n_hint), d);
-    else attn::prefetch<T>(rg, qs + (long)b * D + h * d, Kh, D, Vh, D, min(S_cap, n_hint), d, -1, nullptr, nullptr);
+  const int n_pref = min(S_cap, n_hint);
+  if constexpr (NP > 0) {
+    if (fast) attn::prefetch2<T, NP>(rg2, fusedq ? nullptr : qs + (long)b * D + h * d, Kh, D, Vh, D, n_pref, -1, nullptr, nullptr);
   }
   if (fusedq) {
     // LayerNorm of the residual row (fp32 stats, rounded to the activation dtype like the unfused path), then
     // 4 threads per output channel: 16-byte loads along K, shuffle-reduce, bias, round, scale
     float ps = 0.f;
-    for (int k = tid; k < D; k += 256) ps += to_f32(xres[(long)b * D + k]);
+    for (int k = tid; k < D; k += 256) {
+      float v = to_f32(xres[(long)b * D + k]);
+      if (po) {                                   // residual add of the self-attention block, heads in fixed order
+        float a = 0.f;
+        for (int hh = 0; hh < H; ++hh) a += po[((long)b * H + hh) * D + k];
+        const T r = from_f32<T>(a + (bo ? bo[k] : 0.f) + v);
+        if (h == 0) x_mid[(long)b * D + k] = r;
+        v = to_f32(r);
+      }
+      xn[k] = v;
+      ps += v;
+    }
     const float mean = attn::blk_sum(ps, red + 1024) / (float)D;
     float pq = 0.f;
-    for (int k = tid; k < D; k += 256) { const float dd = to_f32(xres[(long)b * D + k]) - mean; pq += dd * dd; }
+    for (int k = tid; k < D; k += 256) { const float dd = xn[k] - mean; pq += dd * dd; }
     const float rstd = 1.0f / sqrtf(attn::blk_sum(pq, red + 1024) / (float)D + 1e-5f);
+    const float scl = rsqrtf((float)d);
+    if (w_packed) {
+      // matrix-core projection from fragment-major weights: one 16-channel tile per wave (head_dim <= 64)
+      constexpr int KS = gemv::MF<T>::KS;
+      const int nks = D / KS, wave = tid >> 6, tpp = d >> 4;
+      const int tile = (h * d >> 4) + min(wave, tpp - 1);
+      gemv::Frag<T, 8> fm, fs;
+      gemv::load<T, 8>(fm, Wqm, tile, nks, 0, min(nks, 8));
+      if (Wqs) gemv::load<T, 8>(fs, Wqs, tile, nks, 0, min(nks, 8));
+      for (int k = tid; k < D; k += 256) xn_t[k] = from_f32<T>((xn[k] - mean) * rstd * ln_g[k] + ln_b[k]);
+      __syncthreads();
+      for (int pass = 0; pass < 2; ++pass) {
+        const T* Wp = pass == 0 ? Wqm : Wqs;
+        const float* bp = pass == 0 ? bqm : bqs;
+        if (!Wp) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        gemv::mac<T, 8>(acc, pass == 0 ? fm : fs, xn_t, min(nks, 8));
+        for (int s0 = 8; s0 < nks; s0 += 8) {
+          gemv::Frag<T, 8> f;
+          gemv::load<T, 8>(f, Wp, tile, nks, s0, min(nks - s0, 8));
+          gemv::mac<T, 8>(acc, f, xn_t + s0 * KS, min(nks - s0, 8));
+        }
+        if (wave < tpp && lane < 16) {
+          const int o = wave * 16 + lane;
+          const float qv = to_f32(from_f32<T>(acc[0] + (bp ? bp[h * d + o] : 0.f))) * scl;
+          if (pass == 0) q_s[o] = qv; else qsoft_s[o] = qv;
+        }
+      }
+    } else {
     for (int k = tid; k < D; k += 256)
-      xn[k] = to_f32(from_f32<T>((to_f32(xres[(long)b * D + k]) - mean) * rstd * ln_g[k] + ln_b[k]));
+      xn[k] = to_f32(from_f32<T>((xn[k] - mean) * rstd * ln_g[k] + ln_b[k]));
     __syncthreads();
     const int o = tid >> 2, part = tid & 3, kq = D >> 2;        // output channel, quarter of K
-    const float scl = rsqrtf((float)d);
     for (int pass = 0; pass < 2; ++pass) {
       const T* Wp = pass == 0 ? Wqm : Wqs;
       const float* bp = pass == 0 ? bqm : bqs;
@@ -120,6 +174,7 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
         const float qv = to_f32(from_f32<T>(acc + (bp ? bp[h * d + o] : 0.f))) * scl;
         if (pass == 0) q_s[o] = qv; else qsoft_s[o] = qv;
       }
+    }
     }
     __syncthreads();
   }
@@ -201,7 +256,7 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
     if (st > 0 && n > 0) {
       const float* qfused = fusedq ? (Wqs ? qsoft_s : q_s) : nullptr;
       if (fast) {
-        o = attn::finish<T>(rg, n, d, rsqrtf((float)d), sc, red, nullptr, qfused);
+        if constexpr (NP > 0) o = attn::finish2<T, NP>(rg2, n, n_pref, rsqrtf((float)d), sc, red, nullptr, qfused);
       } else {
         __syncthreads();
         if (!fusedq) {
@@ -299,14 +354,14 @@ __global__ void embed_first_kernel(const long* __restrict__ tokens, const T* __r
 }
 
 int lin(simulst_handle* h, int dtype, int B, int N, int K, const void* A, const void* W, const float* bias,
-        const void* R, void* C, int epi, const float* ln_g, const float* ln_b) {
+        const void* R, void* C, int epi, const float* ln_g, const float* ln_b, int w_packed = 0) {
   simulst_linear_desc d;
   d.M_batches = 1; d.rows_per_batch = B; d.N = N; d.K = K;
   d.a_batch_stride = 0; d.a_row_stride = K; d.a_lead = 0;
   d.c_batch_stride = 0; d.c_row_stride = N;
   d.r_batch_stride = 0; d.r_row_stride = N;
   d.epilogue = epi; d.dtype = dtype; d.scale = 1.f; d.n_main = 0; d.aux_rows = 0; d.aux_batch_stride = 0;
-  d.ln_gamma = ln_g; d.ln_beta = ln_b;
+  d.ln_gamma = ln_g; d.ln_beta = ln_b; d.w_fragment_major = w_packed;
   return simulst_linear(h, &d, A, W, bias, R, C, nullptr);
 }
 
@@ -316,13 +371,17 @@ int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int64_t* head_step, uint8_t* head_read, void* ctx, int B, int H, int d, int S_cap, int ratio,
                         int attn_type, int waitk_k, int online, int mass_pres, int n_hint, const void* xres,
                         const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
-                        const float* bqs, const StreamCtl& ctl) {
-  const size_t lds = (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
+                        const float* bqs, const StreamCtl& ctl, const HeadSplit& hs) {
+  const size_t lds = (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
-  hipLaunchKernelGGL(policy_cross_attn_kernel<T>, dim3(H, B), dim3(256), lds, h->stream, (const T*)qm, (const T*)qs,
-                     (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx, (long*)head_step,
-                     head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres, n_hint,
-                     (const T*)xres, ln_g, ln_b, (const T*)Wqm, bqm, (const T*)Wqs, bqs, ctl);
+#define PC_LAUNCH(NP)                                                                                                  \
+  hipLaunchKernelGGL((policy_cross_attn_kernel<T, NP>), dim3(H, B), dim3(256), lds, h->stream, (const T*)qm,           \
+                     (const T*)qs, (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx,            \
+                     (long*)head_step, head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres,   \
+                     n_hint, (const T*)xres, ln_g, ln_b, (const T*)Wqm, bqm, (const T*)Wqs, bqs, ctl, hs.po, hs.bo,     \
+                     (T*)hs.x_mid, hs.w_packed)
+  SL_DISPATCH_NP(attn::lanes_per_row<T>(d), PC_LAUNCH)
+#undef PC_LAUNCH
   return sl_launch_status(h, "simulst_policy_cross_attention");
 }
 
@@ -335,7 +394,7 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int32_t mass_preservation, int32_t dtype, int32_t n_hint, const void* xres = nullptr,
                         const float* ln_g = nullptr, const float* ln_b = nullptr, const void* Wqm = nullptr,
                         const float* bqm = nullptr, const void* Wqs = nullptr, const float* bqs = nullptr,
-                        const StreamCtl* ctl = nullptr);
+                        const StreamCtl* ctl = nullptr, const HeadSplit* hs = nullptr);
 
 extern "C" int simulst_policy_cross_attention(simulst_handle* h, const void* qm, const void* qs, const void* Kmono,
                                               const void* Ksoft, const void* Vc, float energy_bias,
@@ -353,10 +412,16 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k, int32_t online,
                         int32_t mass_preservation, int32_t dtype, int32_t n_hint, const void* xres,
                         const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
-                        const float* bqs, const StreamCtl* ctlp) {
+                        const float* bqs, const StreamCtl* ctlp, const HeadSplit* hsp) {
   if (!h) return SIMULST_E_NULL;
   StreamCtl ctl = {};
   if (ctlp) ctl = *ctlp;
+  HeadSplit hs = {};
+  if (hsp) {
+    hs = *hsp;
+    SL_REQUIRE(h, (xres || (!hs.po && !hs.w_packed)) && (!hs.po || hs.x_mid) && (!hs.w_packed || d % 16 == 0), SIMULST_E_ARG,
+               "simulst_policy_cross_attention: head-split projections need the fused query path");
+  }
   SL_CHECK_NULL(h, Vc); SL_CHECK_NULL(h, head_step); SL_CHECK_NULL(h, head_read); SL_CHECK_NULL(h, ctx);
   SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_policy_cross_attention: dtype");
   SL_REQUIRE(h, attn_type >= SIMULST_ATTN_HARD && attn_type <= SIMULST_ATTN_CHUNKWISE, SIMULST_E_ARG,
@@ -368,16 +433,16 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
               SL_REQUIRE(h, (H * d) % 32 == 0, SIMULST_E_SHAPE, "simulst_policy_cross_attention: D % 32 for the fused projection"); }
   SL_REQUIRE(h, H > 0 && d >= 8 && d <= 64 && d % 8 == 0 && S_cap > 0 && ratio >= 1, SIMULST_E_SHAPE,
              "simulst_policy_cross_attention: head_dim must be a multiple of 8, <= 64");
-  SL_REQUIRE(h, (size_t)(64 + 1032 + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE,
+  SL_REQUIRE(h, (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE,
              "simulst_policy_cross_attention: source too long for the LDS rows");
   if (B <= 0) return SIMULST_OK;
   if (dtype == SIMULST_F32)
     return launch_policy_cross<float>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
                                       ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint,
-                                      xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl);
+                                      xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl, hs);
   return launch_policy_cross<bf16>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
                                    ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint,
-                                   xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl);
+                                   xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl, hs);
 }
 
 static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
@@ -460,15 +525,33 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
                          (const bf16*)dd->E, dd->pos_table, dd->n_prev, (bf16*)dd->x, D, dd->pad_idx, dd->embed_scale);
     if ((rc = sl_launch_status(h, "simulst_mma_decode(embed)")) != 0) return rc;
   }
+  // weights of the step GEMMs / GEMVs in fragment-major order (1 KB contiguous per wave load)
+  const int pk = dd->weights_fragment_major;
+  SL_REQUIRE(h, !pk || (D % 64 == 0 && F % 64 == 0 && V % 16 == 0 && d % 16 == 0), SIMULST_E_SHAPE,
+             "simulst_mma_decode: fragment-major weights need D, F multiples of 64, V and head_dim of 16");
+  // head-split self-attention block (decode_fused.hip): 5 launches per layer instead of 7 when the host supplied the
+  // partial buffer, the weights are fragment-major and the shapes fit (cached target positions <= 256)
+  const bool split = pk && dd->x_mid && dd->partial_self && !h->force_unfused_decode &&
+                     sl_self_attention_fused_ok(H, d, dd->cap) && B <= 128 && (dt == SIMULST_BF16 ? D <= 512 : D <= 256);
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_dec_layer& L = layers[l];
-      if ((rc = lin(h, dt, B, 3 * D, D, dd->x, L.wqkv, L.bqkv, nullptr, dd->qkv, SIMULST_EPI_BIAS, L.ln1_g, L.ln1_b))) return rc;
-      if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
-                                  dd->ctx, B, H, d, dd->cap, dt))) return rc;
-      if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
-      // LN2 + query projection(s) + policy + cross-attention in ONE launch: each (head, utterance) workgroup
-      // normalises its residual row and projects its own 64 query channels (32 KB of W per workgroup)
+      const void* xin = dd->x;                   // residual row entering the cross-attention block
+      HeadSplit hs = {nullptr, nullptr, nullptr, pk};
+      if (split) {
+        if ((rc = sl_self_attention_fused(h, dd->x, L.ln1_g, L.ln1_b, L.wqkv, L.bqkv, L.wo, L.k_cache, L.v_cache,
+                                          dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s, dd->partial_self, B, H, d,
+                                          dd->cap, dt))) return rc;
+        hs.po = dd->partial_self; hs.bo = L.bo; hs.x_mid = dd->x_mid;
+        xin = dd->x_mid;
+      } else {
+        if ((rc = lin(h, dt, B, 3 * D, D, dd->x, L.wqkv, L.bqkv, nullptr, dd->qkv, SIMULST_EPI_BIAS, L.ln1_g, L.ln1_b, pk))) return rc;
+        if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
+                                    dd->ctx, B, H, d, dd->cap, dt))) return rc;
+        if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
+      }
+      // (residual add of the head-split block +) LN2 + query projection(s) + policy + cross-attention in ONE launch:
+      // each (head, utterance) workgroup normalises its residual row and projects its own 64 query channels
       const int n_hint = device_indexed ? -1
                          : (dd->attn_type == SIMULST_ATTN_WAITK && np_uniform >= 0)
                                ? (np_uniform + s + dd->waitk_k) * dd->ratio : dd->S_cap;
@@ -476,13 +559,13 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
       if ((rc = policy_cross(h, nullptr, nullptr, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
                              dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
                              dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, dd->x, L.ln2_g,
-                             L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft, ctlp ? &ctl : nullptr))) return rc;
-      if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
-      if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b))) return rc;
-      if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr))) return rc;
+                             L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft, ctlp ? &ctl : nullptr, &hs))) return rc;
+      if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, xin, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
+      if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b, pk))) return rc;
+      if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
     }
     if ((rc = lin(h, dt, B, V, D, dd->x, dd->out_proj, nullptr, nullptr, dd->logits, SIMULST_EPI_BIAS_F32OUT, dd->ln_g,
-                  dd->ln_b))) return rc;
+                  dd->ln_b, pk))) return rc;
     {
       KTimer t(h, SIMULST_K_ARGMAX);
       if (dt == SIMULST_F32)

@@ -322,10 +322,14 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
   p.r_bs = d->r_batch_stride; p.r_rs = d->r_row_stride;
   p.scale = d->scale; p.n_main = d->n_main; p.aux_rows = d->aux_rows; p.aux_bs = d->aux_batch_stride;
   p.ln_g = d->ln_gamma; p.ln_b = d->ln_beta;
+  p.w_packed = d->w_fragment_major;
   if (d->ln_gamma || d->ln_beta)
     SL_REQUIRE(h, d->ln_gamma && d->ln_beta, SIMULST_E_NULL, "simulst_linear: LN prologue needs gamma and beta");
-  const bool skinny_ok = M <= 128 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&
+  const bool skinny_ok = M <= 512 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&
                          d->epilogue != SIMULST_EPI_EMF_OUT;
+  if (p.w_packed)
+    SL_REQUIRE(h, skinny_ok && d->N % 16 == 0 && d->K % (4 * G) == 0, SIMULST_E_SHAPE,
+               "simulst_linear: fragment-major weights need a decode-step shape, N % 16 == 0 and K % (64 bytes) == 0");
   if (skinny_ok) return sl_launch_skinny(h, d->dtype, d->epilogue, A, W, bias, R, C, p);
   SL_REQUIRE(h, !p.ln_g, SIMULST_E_SHAPE, "simulst_linear: LN prologue needs a decode-step shape");
   KTimer t(h, SIMULST_K_LINEAR);

@@ -14,6 +14,7 @@ struct LinArgs {
   long aux_bs;
   const float* ln_g;
   const float* ln_b;
+  int w_packed;        // weights in fragment-major order (gemv_mfma.h); decode-step shapes only
 };
 
 

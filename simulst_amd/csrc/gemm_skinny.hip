@@ -108,13 +108,18 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
   const bool aok = ar < p.M;
   const int ab = aok ? ar / p.rpb : 0, ai = aok ? ar - ab * p.rpb : 0;
   const TA* arow = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
+  // row-major: lane -> row n0 + j*16 + lr, 16 bytes at k.  Fragment-major (p.w_packed): the 64 lanes of a k-step
+  // are contiguous: ((tile * K/KS + k/KS) * 64 + lane) * G
   const TA* wrow[NT];
   bool wok[NT];
+  const bool pk = p.w_packed != 0;
+  const long wks = pk ? 64L * G / KS : 1;        // element stride per unit of k  (packed: 64*G per KS)
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + j * 16 + lr;
     wok[j] = n < p.N;
-    wrow[j] = W + (long)(wok[j] ? n : 0) * p.K;
+    wrow[j] = pk ? W + ((long)(wok[j] ? blockIdx.x * NT + j : 0) * (p.K / KS) * 64 + lane) * G - (long)lg * G * wks
+                 : W + (long)(wok[j] ? n : 0) * p.K;
   }
   f32x4 acc[NT];
 #pragma unroll
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const uint4 v = ld16(wrow[j] + kc);
+        const uint4 v = ld16(wrow[j] + (long)kc * wks);
         const bool ok = kin && wok[j];
         fw[u][j] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
       }

@@ -14,6 +14,7 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->graph_on = false;
   h->capturing = false;
   h->force_valu_attention = false;
+  h->force_unfused_decode = false;
   h->graph_exec = nullptr;
   h->graph_key = 0;
   for (int i = 0; i < SIMULST_K_COUNT; ++i) { h->timer_on[i] = false; h->timer_ms[i] = 0.0; h->timer_n[i] = 0; }
@@ -94,5 +95,11 @@ extern "C" int simulst_graph_enable(simulst_handle* h, int on) {
 extern "C" int simulst_debug_force_valu_attention(simulst_handle* h, int on) {
   if (!h) return SIMULST_E_NULL;
   h->force_valu_attention = on != 0;
+  return SIMULST_OK;
+}
+
+extern "C" int simulst_debug_force_unfused_decode(simulst_handle* h, int on) {
+  if (!h) return SIMULST_E_NULL;
+  h->force_unfused_decode = on != 0;
   return SIMULST_OK;
 }

@@ -335,3 +335,40 @@ extern "C" int simulst_greedy_argmax(simulst_handle* h, const float* logits, con
                      eos_idx, mask_eos);
   return sl_launch_status(h, "simulst_greedy_argmax");
 }
+
+// ---- fragment-major weight order (simulst_linear_desc.w_fragment_major) ----------------------------------------------
+namespace {
+template <typename T, int G>
+__global__ void pack_fragment_major_kernel(const T* __restrict__ W, T* __restrict__ out, int N, int K) {
+  constexpr int KS = 4 * G;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;        // one 16-byte group per thread
+  const long groups = (long)N * K / G;
+  if (i >= groups) return;
+  const int lane = (int)(i & 63);
+  const long ts = i >> 6;                                            // tile * (K/KS) + kstep
+  const int nks = K / KS;
+  const int tile = (int)(ts / nks), s = (int)(ts - (long)tile * nks);
+  const int n = tile * 16 + (lane & 15), k = s * KS + (lane >> 4) * G;
+  *reinterpret_cast<uint4*>(out + i * G) = *reinterpret_cast<const uint4*>(W + (long)n * K + k);
+}
+}  // namespace
+
+extern "C" int simulst_pack_fragment_major(simulst_handle* h, const void* W, void* out, int32_t N, int32_t K,
+                                           int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, W); SL_CHECK_NULL(h, out);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_pack_fragment_major: dtype");
+  const int G = dtype == SIMULST_F32 ? 4 : 8;
+  SL_REQUIRE(h, N > 0 && K > 0 && N % 16 == 0 && K % (4 * G) == 0, SIMULST_E_SHAPE,
+             "simulst_pack_fragment_major: N % 16 and K % (64 bytes of elements)");
+  SL_REQUIRE(h, W != out, SIMULST_E_ARG, "simulst_pack_fragment_major: in place");
+  const long groups = (long)N * K / G;
+  KTimer t(h, SIMULST_K_MISC);
+  if (dtype == SIMULST_F32)
+    hipLaunchKernelGGL((pack_fragment_major_kernel<float, 4>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0,
+                       h->stream, (const float*)W, (float*)out, N, K);
+  else
+    hipLaunchKernelGGL((pack_fragment_major_kernel<bf16, 8>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0,
+                       h->stream, (const bf16*)W, (bf16*)out, N, K);
+  return sl_launch_status(h, "simulst_pack_fragment_major");
+}

@@ -12,6 +12,7 @@ and cached (the reference re-projects the whole source every decode step,
 modules/monotonic_multihead_attention.py:401); results are identical.
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -118,6 +119,15 @@ class MMADecoder:
         self.soft = cfg.attn_type != "hard_aligned"
         self.separate_soft = cfg.attn_type in ("infinite_lookback", "chunkwise")
         self.embed_scale = math.sqrt(cfg.embed_dim)
+        # head-split self-attention block (5 launches per decoder layer instead of 7) in the device decode loop.
+        # Measured on MI355X (bench.py --batch 64/128, 1-3 streams): it shortens the dependent chain of ONE
+        # 64-row sequence (211 k vs 204 k tokens/s) but every (head, row) workgroup re-streams its 128 KB of
+        # weights, so it loses as soon as independent work shares the chip (352 k vs 404 k with 3 streams,
+        # 404 k vs 527 k at 128 rows) => off by default, SIMULST_HEAD_SPLIT=1 / .head_split = True turns it on.
+        self.head_split = os.environ.get("SIMULST_HEAD_SPLIT", "0") == "1"
+        D, F, V = cfg.embed_dim, cfg.ffn_dim, cfg.vocab
+        # decode-loop weights in MFMA-fragment order (1 KB contiguous per wave load) when the shapes allow
+        self.fragment_major = D % 64 == 0 and F % 64 == 0 and V % 16 == 0 and cfg.head_dim % 16 == 0
 
     # the agent reads decoder.layers[0].encoder_attn.pre_decision_ratio (agents/default_agent.py:157-161)
     @property
@@ -216,16 +226,27 @@ class MMADecoder:
         return None
 
     # ------------------------------------------------------------------ device-resident step loop
+    def _packed(self):
+        """Fragment-major copies of the decode-loop weight matrices (made once, shared through the weights object)."""
+        w = self.w
+        if not hasattr(w, "packed"):
+            names = ["wqkv", "wo", "c_wq", "c_wo", "fc1", "fc2"] + (["c_wq_soft"] if self.separate_soft else [])
+            w.packed = [{n: self.ops.pack_fragment_major(L[n]) for n in names} for L in w.layers]
+            w.out_proj_packed = self.ops.pack_fragment_major(w.out_proj)
+        return w.packed
+
     def _layer_structs(self, st: DecoderState):
         arr = (_lib.DecLayer * self.cfg.decoder_layers)()
         st.head_read = [torch.zeros(st.B * self.cfg.num_heads, device=self.device, dtype=torch.uint8)
                         if hr is None else hr for hr in st.head_read]
         for l, L in enumerate(self.w.layers):
             a = arr[l]
-            for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b", "c_wq",
-                      "c_bq", "c_wo", "c_bo", "fc1", "b1", "fc2", "b2"):
+            P = self._packed()[l] if self.fragment_major else L
+            for n in ("bqkv", "bo", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b", "c_bq", "c_bo", "b1", "b2"):
                 setattr(a, n, L[n].data_ptr())
-            a.c_wq_soft = L["c_wq_soft"].data_ptr() if self.separate_soft else None
+            for n in ("wqkv", "wo", "c_wq", "c_wo", "fc1", "fc2"):
+                setattr(a, n, P[n].data_ptr())
+            a.c_wq_soft = P["c_wq_soft"].data_ptr() if self.separate_soft else None
             a.c_bq_soft = L["c_bq_soft"].data_ptr() if self.separate_soft else None
             a.energy_bias = L["energy_bias"]
             a.k_cache, a.v_cache = st.k_cache[l].data_ptr(), st.v_cache[l].data_ptr()
@@ -237,25 +258,11 @@ class MMADecoder:
     def decode_steps(self, st: DecoderState, last_tokens: torch.Tensor, n_steps: int, mask_eos: bool):
         """n_steps WRITE steps entirely on the device (simulst_mma_decode). last_tokens [B] int64 is
         updated in place; returns tokens [n_steps, B]."""
-        cfg, ops = self.cfg, self.ops
-        B, D = st.B, cfg.embed_dim
-        dev, dt_ = self.device, self.dtype
-        if not hasattr(st, "ws"):
-            st.ws = {"x": torch.empty(B, D, device=dev, dtype=dt_), "qkv": torch.empty(B, 3 * D, device=dev, dtype=dt_),
-                     "ctx": torch.empty(B, D, device=dev, dtype=dt_), "q": torch.empty(B, D, device=dev, dtype=dt_),
-                     "q2": torch.empty(B, D, device=dev, dtype=dt_),
-                     "hidden": torch.empty(B, cfg.ffn_dim, device=dev, dtype=dt_),
-                     "logits": torch.empty(B, cfg.vocab, device=dev, dtype=torch.float32)}
-            st.layer_structs = self._layer_structs(st)
+        ops = self.ops
+        B, dev = st.B, self.device
         assert st.n_prev_host + n_steps < st.cap, "decoder state capacity exceeded"
+        d = self._decoder_desc(st, st.n_prev_host if st.lockstep else -1)
         ws = st.ws
-        d = _lib.DecoderDesc(B, D, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st.cap, st.S_cap,
-                             _lib.F32 if dt_ == torch.float32 else _lib.BF16, self.attn_enum, cfg.pre_decision_ratio,
-                             cfg.waitk_lagging, int(cfg.mass_preservation), int(st.online), cfg.padding_idx, cfg.eos,
-                             st.n_prev_host if st.lockstep else -1, self.embed_scale, self.w.E.data_ptr(), self.w.out_proj.data_ptr(), self.w.pos.data_ptr(),
-                             self.w.ln_g.data_ptr(), self.w.ln_b.data_ptr(), st.enc_len.data_ptr(),
-                             st.n_prev.data_ptr(), ws["x"].data_ptr(), ws["qkv"].data_ptr(), ws["ctx"].data_ptr(),
-                             ws["q"].data_ptr(), ws["q2"].data_ptr(), ws["hidden"].data_ptr(), ws["logits"].data_ptr())
         okey = f"out{n_steps}"
         if okey not in ws:                     # persistent: a cached hipGraph replays into the same buffer
             ws[okey] = torch.empty(n_steps, B, device=dev, dtype=torch.int64)
@@ -274,17 +281,27 @@ class MMADecoder:
                      "ctx": torch.empty(B, D, device=dev, dtype=dt_), "q": torch.empty(B, D, device=dev, dtype=dt_),
                      "q2": torch.empty(B, D, device=dev, dtype=dt_),
                      "hidden": torch.empty(B, cfg.ffn_dim, device=dev, dtype=dt_),
-                     "logits": torch.empty(B, cfg.vocab, device=dev, dtype=torch.float32)}
+                     "logits": torch.empty(B, cfg.vocab, device=dev, dtype=torch.float32),
+                     # head-split self-attention block workspace (simulst_decoder_desc.x_mid / partial_self)
+                     "x_mid": torch.empty(B, D, device=dev, dtype=dt_),
+                     "p_self": torch.empty(B, cfg.num_heads, D, device=dev, dtype=torch.float32)}
+        if getattr(st, "structs_fragment_major", None) != self.fragment_major:   # states are cached across calls
             st.layer_structs = self._layer_structs(st)
+            st.structs_fragment_major = self.fragment_major
         ws = st.ws
+        split = self.head_split and self.fragment_major
+        if self.fragment_major:
+            self._packed()
+        out_proj = self.w.out_proj_packed if self.fragment_major else self.w.out_proj
         return _lib.DecoderDesc(B, D, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st.cap, st.S_cap,
                                 _lib.F32 if dt_ == torch.float32 else _lib.BF16, self.attn_enum, cfg.pre_decision_ratio,
                                 cfg.waitk_lagging, int(cfg.mass_preservation), int(st.online), cfg.padding_idx, cfg.eos,
-                                np_uniform, self.embed_scale, self.w.E.data_ptr(), self.w.out_proj.data_ptr(),
+                                np_uniform, self.embed_scale, self.w.E.data_ptr(), out_proj.data_ptr(),
                                 self.w.pos.data_ptr(), self.w.ln_g.data_ptr(), self.w.ln_b.data_ptr(),
                                 st.enc_len.data_ptr(), st.n_prev.data_ptr(), ws["x"].data_ptr(), ws["qkv"].data_ptr(),
                                 ws["ctx"].data_ptr(), ws["q"].data_ptr(), ws["q2"].data_ptr(), ws["hidden"].data_ptr(),
-                                ws["logits"].data_ptr())
+                                ws["logits"].data_ptr(), ws["x_mid"].data_ptr() if split else None,
+                                ws["p_self"].data_ptr() if split else None, int(self.fragment_major))
 
     def stream_steps(self, st: DecoderState, tokens: torch.Tensor, ctl, n_iter: int):
         """n_iter masked policy()/predict() rounds of a batch of streams (simulst_mma_stream_steps): rows read

@@ -47,15 +47,27 @@ class Ops:
     # ------------------------------------------------------------------ dense
     def linear_raw(self, A, W, bias, C_out, *, M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead=0,
                    c_bs, c_rs, epilogue=EPI_BIAS, R=None, r_bs=0, r_rs=0, scale=1.0, n_main=0, aux=None,
-                   aux_rows=0, aux_bs=0, ln=None):
+                   aux_rows=0, aux_bs=0, ln=None, w_fragment_major=False):
         d = LinearDesc(M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead, c_bs, c_rs, r_bs, r_rs,
                        epilogue, dt(A), scale, n_main, aux_rows, aux_bs,
-                       ln[0].data_ptr() if ln is not None else None, ln[1].data_ptr() if ln is not None else None)
+                       ln[0].data_ptr() if ln is not None else None, ln[1].data_ptr() if ln is not None else None,
+                       int(w_fragment_major))
         self.h.check(self.lib.simulst_linear(self.h.ptr, C.byref(d), _p(A), _p(W), _p(bias), _p(R), _p(C_out),
                                              _p(aux)), "simulst_linear")
         return C_out
 
-    def linear(self, x, W, bias=None, *, epilogue=EPI_BIAS, residual=None, out=None, ln=None):
+    def pack_fragment_major(self, W):
+        """Row-major weight [N, K] -> the MFMA-fragment order the decode-step kernels stream with 1 KB contiguous
+        wave loads (simulst_linear_desc.w_fragment_major).  Returned tensor keeps the [N, K] shape (storage order
+        only)."""
+        _chk_contig(W)
+        out = torch.empty_like(W)
+        self.h.check(self.lib.simulst_pack_fragment_major(self.h.ptr, _p(W), _p(out), W.shape[0], W.shape[1], dt(W)),
+                     "simulst_pack_fragment_major")
+        return out
+
+    def linear(self, x, W, bias=None, *, epilogue=EPI_BIAS, residual=None, out=None, ln=None,
+               w_fragment_major=False):
         """y[rows, N] = epi(LN?(x)[rows, K] @ W[N, K]^T + bias). x 2-D contiguous. ln = (gamma, beta) fuses a
         LayerNorm prologue (decode-step shapes only)."""
         _chk_contig(x, W, residual, out)
@@ -66,7 +78,8 @@ class Ops:
             odt = torch.float32 if epilogue == EPI_BIAS_F32OUT else x.dtype
             out = torch.empty(rows, N, device=x.device, dtype=odt)
         return self.linear_raw(x, W, bias, out, M_batches=1, rows_per_batch=rows, N=N, K=K, a_bs=0, a_rs=K,
-                               c_bs=0, c_rs=N, epilogue=epilogue, R=residual, r_bs=0, r_rs=N, ln=ln)
+                               c_bs=0, c_rs=N, epilogue=epilogue, R=residual, r_bs=0, r_rs=N, ln=ln,
+                               w_fragment_major=w_fragment_major)
 
     def causal_conv1d_glu(self, x, Wp, bp, *, ksize, stride, scale=1.0, out=None):
         """Strided causal Conv1d + GLU over channel-last frames.

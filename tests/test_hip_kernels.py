@@ -428,3 +428,29 @@ def test_emformer_attention_mfma_equals_valu(ops, streaming):
     ops.h.check(ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, 0), "force")
     torch.testing.assert_close(out[0], out[1], atol=2e-2, rtol=2e-2)
     assert float(out[1].abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fragment_major_pack_and_linear(ops, dtype):
+    """simulst_pack_fragment_major against the index formula of include/simulst_hip.h, and the decode-step GEMM on
+    fragment-major weights bit-identical to the same GEMM on row-major weights (only the storage order differs)."""
+    from simulst_amd._lib import EPI_BIAS, EPI_BIAS_GELU
+    g = torch.Generator().manual_seed(31)
+    G = 4 if dtype == torch.float32 else 8
+    KS = 4 * G
+    for N, K, M in ((256, 256, 64), (2048, 256, 64), (256, 2048, 33), (48, 64, 5)):
+        W = torch.randn(N, K, generator=g).to(dtype).cuda()
+        Wp = ops.pack_fragment_major(W)
+        ref = W.view(N // 16, 16, K // KS, 4, G).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+        assert torch.equal(Wp, ref)
+        x = torch.randn(M, K, generator=g).to(dtype).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        for epi in (EPI_BIAS, EPI_BIAS_GELU):
+            y0 = ops.linear(x, W, b, epilogue=epi)
+            y1 = ops.linear(x, Wp, b, epilogue=epi, w_fragment_major=True)
+            assert torch.equal(y0, y1)
+        if K <= (256 if dtype == torch.float32 else 512):
+            gam, bet = torch.rand(K, generator=g).cuda() + 0.5, torch.randn(K, generator=g).cuda()
+            y0 = ops.linear(x, W, b, ln=(gam, bet))
+            y1 = ops.linear(x, Wp, b, ln=(gam, bet), w_fragment_major=True)
+            assert torch.equal(y0, y1)
