@@ -29,6 +29,7 @@ struct simulst_handle {
   bool graph_on;
   bool capturing;
   bool force_valu_attention;   // test hook: route bf16 Emformer attention through the VALU kernel
+  int fuse_q_max_rows;         // decode loop: rows up to which LN2 + q-proj ride inside the policy/cross-attention launch
   bool force_unfused_decode;   // test hook: 7-launch decoder layer even when the head-split workspace is given
   hipGraphExec_t graph_exec;
   uint64_t graph_key;

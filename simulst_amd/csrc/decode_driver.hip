@@ -47,7 +47,7 @@ struct HeadSplit {
 //     (modules/monotonic_multihead_attention.py:196-257) -> head_step, head_read
 //  3. hard gather / softmax over keys <= step (:261-297), PV
 template <typename T, int NP>
-__global__ __launch_bounds__(256) void policy_cross_attn_kernel(
+__global__ __launch_bounds__(256, NP >= 16 ? 2 : 3) void policy_cross_attn_kernel(
     const T* __restrict__ qm, const T* __restrict__ qs, const T* __restrict__ Km, const T* __restrict__ Ks,
     const T* __restrict__ Vc, float energy_bias, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
     long* __restrict__ head_step, unsigned char* __restrict__ head_read, T* __restrict__ ctx, int H, int d,
@@ -127,9 +127,8 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
       constexpr int KS = gemv::MF<T>::KS;
       const int nks = D / KS, wave = tid >> 6, tpp = d >> 4;
       const int tile = (h * d >> 4) + min(wave, tpp - 1);
-      gemv::Frag<T, 8> fm, fs;
-      gemv::load<T, 8>(fm, Wqm, tile, nks, 0, min(nks, 8));
-      if (Wqs) gemv::load<T, 8>(fs, Wqs, tile, nks, 0, min(nks, 8));
+      gemv::Frag<T, 8> fm;                          // monotonic-energy projection requested before the LayerNorm;
+      gemv::load<T, 8>(fm, Wqm, tile, nks, 0, min(nks, 8));   // the soft-energy one reuses the registers afterwards
       for (int k = tid; k < D; k += 256) xn_t[k] = from_f32<T>((xn[k] - mean) * rstd * ln_g[k] + ln_b[k]);
       __syncthreads();
       for (int pass = 0; pass < 2; ++pass) {
@@ -137,7 +136,8 @@ __global__ __launch_bounds__(256) void policy_cross_attn_kernel(
         const float* bp = pass == 0 ? bqm : bqs;
         if (!Wp) continue;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        gemv::mac<T, 8>(acc, pass == 0 ? fm : fs, xn_t, min(nks, 8));
+        if (pass == 1) gemv::load<T, 8>(fm, Wqs, tile, nks, 0, min(nks, 8));
+        gemv::mac<T, 8>(acc, fm, xn_t, min(nks, 8));
         for (int s0 = 8; s0 < nks; s0 += 8) {
           gemv::Frag<T, 8> f;
           gemv::load<T, 8>(f, Wp, tile, nks, s0, min(nks - s0, 8));
@@ -533,6 +533,9 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   // partial buffer, the weights are fragment-major and the shapes fit (cached target positions <= 256)
   const bool split = pk && dd->x_mid && dd->partial_self && !h->force_unfused_decode &&
                      sl_self_attention_fused_ok(H, d, dd->cap) && B <= 128 && (dt == SIMULST_BF16 ? D <= 512 : D <= 256);
+  // LN2 + query projection inside the policy/cross-attention launch (few rows: one launch less on the dependent
+  // chain) or as its own GEMM (many rows: no per-workgroup re-read of the projection weights)
+  const bool fuse_q = split || B <= h->fuse_q_max_rows;
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_dec_layer& L = layers[l];
@@ -556,10 +559,25 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
                          : (dd->attn_type == SIMULST_ATTN_WAITK && np_uniform >= 0)
                                ? (np_uniform + s + dd->waitk_k) * dd->ratio : dd->S_cap;
       ctl.layer = l + 1;
-      if ((rc = policy_cross(h, nullptr, nullptr, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
-                             dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
-                             dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, dd->x, L.ln2_g,
-                             L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft, ctlp ? &ctl : nullptr, &hs))) return rc;
+      if (fuse_q) {
+        if ((rc = policy_cross(h, nullptr, nullptr, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
+                               dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
+                               dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, dd->x, L.ln2_g,
+                               L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft, ctlp ? &ctl : nullptr, &hs))) return rc;
+      } else {
+        // many rows: every (head, row) workgroup re-streaming its 32 KB of the query projection through L2 costs
+        // more than one LN-prologue GEMM launch that reads the weights once per row tile
+        if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq, L.c_bq, nullptr, dd->q, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b, pk))) return rc;
+        const void* qsoft = dd->q;
+        if (L.c_wq_soft) {
+          if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq_soft, L.c_bq_soft, nullptr, dd->q2, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b, pk))) return rc;
+          qsoft = dd->q2;
+        }
+        if ((rc = policy_cross(h, dd->q, qsoft, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
+                               dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
+                               dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, ctlp ? &ctl : nullptr, nullptr))) return rc;
+      }
       if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, xin, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
       if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b, pk))) return rc;
       if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;

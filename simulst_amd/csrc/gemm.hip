@@ -186,36 +186,44 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
     // bf16 output without residual (QKV, FFN1): bias / GELU in registers, tile staged through LDS (the operand
     // buffers are free now) and written with 16-byte row-contiguous stores instead of 64 two-byte ones per lane
     constexpr int CS = BN + 8;                       // bf16 elements per staged row
-    static_assert(BM * CS <= LDS_A + LDS_W, "staging tile must fit in the operand buffers");
-    __syncthreads();
+    // the whole tile when it fits in the operand buffers, else one wave-row (WM rows) at a time
+    constexpr bool WHOLE = BM * CS <= LDS_A + LDS_W;
+    constexpr int SROWS = WHOLE ? BM : WM;
+    static_assert(SROWS * CS <= LDS_A + LDS_W, "staging tile must fit in the operand buffers");
     bf16* Cs = smem;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int cl = wc * WN + j * 32 + lcol;
-      const int c = n0 + cl;
-      const float bv = (bias && c < p.N) ? bias[c] : 0.f;
+    for (int half = 0; half < (WHOLE ? 1 : 2); ++half) {
+      __syncthreads();
+      if (WHOLE || wr == half) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+          const int cl = wc * WN + j * 32 + lcol;
+          const int c = n0 + cl;
+          const float bv = (bias && c < p.N) ? bias[c] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int rl = wr * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-          float v = acc[i][j][e] + bv;
-          if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast(v);
-          Cs[rl * CS + cl] = __float2bfloat16(v);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int rl = (WHOLE ? wr * WM : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+              float v = acc[i][j][e] + bv;
+              if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast(v);
+              Cs[rl * CS + cl] = __float2bfloat16(v);
+            }
         }
-    }
-    __syncthreads();
-    constexpr int CHUNKS = BM * BN / 8;              // 16-byte chunks in the tile
-    for (int ch = tid; ch < CHUNKS; ch += 256) {
-      const int rl = ch / (BN / 8), c8 = (ch % (BN / 8)) * 8;
-      const int r = m0 + rl, c = n0 + c8;
-      if (r >= p.M || c >= p.N) continue;
-      const int b = r / p.rpb, ii = r - b * p.rpb;
-      TC* dst = C + (long)b * p.c_bs + (long)ii * p.c_rs + c;
-      if (c + 8 <= p.N && ((p.c_rs | p.c_bs) & 7) == 0) {
-        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&Cs[rl * CS + c8]);
-      } else {
-        for (int q = 0; q < 8 && c + q < p.N; ++q) dst[q] = Cs[rl * CS + c8 + q];
+      }
+      __syncthreads();
+      constexpr int CHUNKS = SROWS * BN / 8;         // 16-byte chunks staged
+      for (int ch = tid; ch < CHUNKS; ch += 256) {
+        const int rl = ch / (BN / 8), c8 = (ch % (BN / 8)) * 8;
+        const int r = m0 + (WHOLE ? 0 : half * WM) + rl, c = n0 + c8;
+        if (r >= p.M || c >= p.N) continue;
+        const int b = r / p.rpb, ii = r - b * p.rpb;
+        TC* dst = C + (long)b * p.c_bs + (long)ii * p.c_rs + c;
+        if (c + 8 <= p.N && ((p.c_rs | p.c_bs) & 7) == 0) {
+          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&Cs[rl * CS + c8]);
+        } else {
+          for (int q = 0; q < 8 && c + q < p.N; ++q) dst[q] = Cs[rl * CS + c8 + q];
+        }
       }
     }
   } else {
@@ -265,6 +273,8 @@ void launch_tiles(simulst_handle* h, const void* A, const void* W, const float* 
                   void* C, void* aux, const LinArgs& p) {
   // tall problems get the 128x128 tile, mid-size the 64x64 one (decode-step shapes are routed to
   // gemm_skinny.hip before this point)
+  // (a 256 x 128 tile was measured 2x SLOWER on MI355X for the encoder shapes: 272+ VGPRs and 55 KB of LDS leave
+  // one workgroup per CU)
   if (EPI == SIMULST_EPI_GLU || p.M > 512)
     launch<TA, TC, 128, 128, EPI>(h, A, W, bias, R, C, aux, p);
   else {
@@ -325,7 +335,7 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
   p.w_packed = d->w_fragment_major;
   if (d->ln_gamma || d->ln_beta)
     SL_REQUIRE(h, d->ln_gamma && d->ln_beta, SIMULST_E_NULL, "simulst_linear: LN prologue needs gamma and beta");
-  const bool skinny_ok = M <= 512 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&
+  const bool skinny_ok = M <= 1024 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&
                          d->epilogue != SIMULST_EPI_EMF_OUT;
   if (p.w_packed)
     SL_REQUIRE(h, skinny_ok && d->N % 16 == 0 && d->K % (4 * G) == 0, SIMULST_E_SHAPE,

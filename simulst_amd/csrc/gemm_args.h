@@ -24,3 +24,8 @@ __device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<con
 // decode-step (M <= 128) contraction, defined in gemm_skinny.hip
 int sl_launch_skinny(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                      const void* R, void* C, const LinArgs& p);
+
+// 64 x 64 tile for co-scheduled batches (M >= 256) with wide outputs, defined in gemm_mid.hip
+bool sl_mid_wanted(int dtype, const LinArgs& p);
+int sl_launch_mid(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
+                  const void* R, void* C, const LinArgs& p);

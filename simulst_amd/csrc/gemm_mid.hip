@@ -1,0 +1,280 @@
+// Decode-step contraction for CO-SCHEDULED batches (256 .. 1024 rows) and wide outputs (N >= 512): QKV, fc1 and
+// the vocabulary projection of several stacked 64-utterance batches (gfx950).
+//
+// The 16 x BN kernel of gemm_skinny.hip splits K over the 4 waves and adds the partial tiles through LDS -- right
+// for 64 rows (it puts a 16-row problem on every CU), wasteful here: at 1024 x 2048 x 256 the LDS reduction moves
+// more data than the operands.  This kernel gives every wave its own 32 x 32 output block of a 64 x 64 tile and
+// the whole K range: operand fragments come straight from global memory into registers (weights fragment-major:
+// 1 KB contiguous per wave load; activations row-major), 8 k-steps (256 bf16 elements) in flight per wave, no
+// operand staging and no cross-wave reduction.  The LayerNorm prologue needs no barrier either: a wave holds
+// complete rows (K <= 8 k-steps), so the row moments are two shuffles away.  The epilogue goes through LDS once to
+// turn the MFMA accumulator layout into 32-byte row segments.
+#include "gemm_args.h"
+
+namespace {
+
+#ifdef SL_PROBE
+__device__ long sl_probe_mid[16];
+#define PROBE(i) do { if (blockIdx.x == 3 && blockIdx.y == 2 && threadIdx.x == 0) sl_probe_mid[i] = wall_clock64(); } while (0)
+#else
+#define PROBE(i)
+#endif
+
+__device__ __forceinline__ uint4 ln_frag_mid(uint4 v, float mean, float rstd, const float* gs, const float* bs, int k,
+                                             float) {
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = (f[e] - mean) * rstd * gs[k + e] + bs[k + e];
+  return v;
+}
+__device__ __forceinline__ uint4 ln_frag_mid(uint4 v, float mean, float rstd, const float* gs, const float* bs, int k,
+                                             bf16) {
+  unsigned int* u = reinterpret_cast<unsigned int*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+    lo = (lo - mean) * rstd * gs[k + 2 * i] + bs[k + 2 * i];
+    hi = (hi - mean) * rstd * gs[k + 2 * i + 1] + bs[k + 2 * i + 1];
+    bf16 l2 = __float2bfloat16(lo), h2 = __float2bfloat16(hi);
+    u[i] = (unsigned int)(*reinterpret_cast<unsigned short*>(&l2)) |
+           ((unsigned int)(*reinterpret_cast<unsigned short*>(&h2)) << 16);
+  }
+  return v;
+}
+__device__ __forceinline__ void moments_mid(uint4 v, float& s1, float& s2, float) {
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s1 += f[e]; s2 = fmaf(f[e], f[e], s2); }
+}
+__device__ __forceinline__ void moments_mid(uint4 v, float& s1, float& s2, bf16) {
+  const unsigned int* u = reinterpret_cast<const unsigned int*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+    s1 += lo + hi;
+    s2 = fmaf(lo, lo, fmaf(hi, hi, s2));
+  }
+}
+
+template <typename TA, typename TC, int EPI, bool PRO_LN>
+__global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, const TA* __restrict__ W,
+                                                  const float* __restrict__ bias, const TA* __restrict__ R,
+                                                  TC* __restrict__ C, LinArgs p) {
+  constexpr bool F32 = std::is_same<TA, float>::value;
+  constexpr int KS = F32 ? 16 : 32, G = F32 ? 4 : 8, CH = 8;      // CH k-steps per chunk
+  __shared__ float tile[64][65];
+  __shared__ float lng[PRO_LN ? 512 : 1], lnb[PRO_LN ? 512 : 1];
+  PROBE(0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  // ---- epilogue ownership: row tid/4, 16 consecutive columns; the residual segment is requested now
+  const int er = tid >> 2, ec = (tid & 3) * 16;
+  const int erow = m0 + er;
+  const bool e_ok = erow < p.M;
+  const int eb = e_ok ? erow / p.rpb : 0, ei = e_ok ? erow - eb * p.rpb : 0;
+  float resv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) resv[e] = 0.f;
+  if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) {
+    if (e_ok) {
+      const TA* rp = R + (long)eb * p.r_bs + (long)ei * p.r_rs + n0 + ec;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (n0 + ec + e < p.N) resv[e] = to_f32(rp[e]);
+    }
+  }
+  // ---- fragment sources: 2 row tiles (A) and 2 column tiles (W) per wave
+  const TA* arow[2];
+  bool aok[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int ar = m0 + wm * 32 + m * 16 + lr;
+    aok[m] = ar < p.M;
+    const int ab = aok[m] ? ar / p.rpb : 0, ai = aok[m] ? ar - ab * p.rpb : 0;
+    arow[m] = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
+#ifdef SL_EXP_APACKED   // timing experiment only (wrong results): activations read as if fragment-major
+    arow[m] = A + ((long)((m0 + wm * 32 + m * 16) >> 4) * (p.K / KS) * 64 + lane) * G - (long)lg * G * (64L * G / KS);
+#endif
+  }
+  const bool pk = p.w_packed != 0;
+  const long wks = pk ? 64L * G / KS : 1;
+  const TA* wrow[2];
+  bool wok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 32 + j * 16 + lr;
+    wok[j] = n < p.N;
+    wrow[j] = pk ? W + ((long)(wok[j] ? n >> 4 : 0) * (p.K / KS) * 64 + lane) * G - (long)lg * G * wks
+                 : W + (long)(wok[j] ? n : 0) * p.K;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nks = (p.K + KS - 1) / KS;
+  for (int s0 = 0; s0 < nks; s0 += CH) {
+    uint4 fa[2][CH], fw[2][CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int k = (s0 + u) * KS + lg * G;
+      const bool kin = s0 + u < nks && k < p.K;
+      const int kc = kin ? k : 0;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#ifdef SL_EXP_APACKED
+        const uint4 v = ld16(arow[m] + (long)kc * (64L * G / KS));
+#else
+        const uint4 v = ld16(arow[m] + kc);
+#endif
+        const bool ok = kin && aok[m];
+        fa[m][u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint4 v = ld16(wrow[j] + (long)kc * wks);
+        const bool ok = kin && wok[j];
+        fw[j][u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      }
+    }
+    PROBE(1);
+    if constexpr (PRO_LN) {
+      // LayerNorm affine staged AFTER the operand loads were issued (single trip: K <= CH k-steps)
+      for (int k = tid; k < p.K; k += 256) { lng[k] = p.ln_g[k]; lnb[k] = p.ln_b[k]; }
+      __syncthreads();
+      // the wave holds whole rows; moments over this lane's chunks, then the 4 k-groups
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) moments_mid(fa[m][u], s1, s2, TA());
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        const float mean = s1 / (float)p.K;
+        const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int k = (s0 + u) * KS + lg * G;
+          if (s0 + u < nks && k < p.K && aok[m]) fa[m][u] = ln_frag_mid(fa[m][u], mean, rstd, lng, lnb, k, TA());
+        }
+      }
+    }
+    PROBE(2);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if constexpr (F32) {
+          const float* af = reinterpret_cast<const float*>(&fa[m][u]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float* wf = reinterpret_cast<const float*>(&fw[j][u]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wf[e], acc[m][j], 0, 0, 0);
+          }
+        } else {
+          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(&fa[m][u]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, *reinterpret_cast<const bf16x8_t*>(&fw[j][u]),
+                                                               acc[m][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  PROBE(3);
+  // ---- accumulators -> LDS tile: acc[m][j][e] = C[wm*32 + m*16 + lg*4 + e][wn*32 + j*16 + lr]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[wm * 32 + m * 16 + lg * 4 + e][wn * 32 + j * 16 + lr] = acc[m][j][e];
+  __syncthreads();
+  PROBE(4);
+  if (!e_ok) return;
+  TC* cp = C + (long)eb * p.c_bs + (long)ei * p.c_rs + n0 + ec;
+  float y[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int c = n0 + ec + e;
+    float v = tile[er][ec + e] + ((bias && c < p.N) ? bias[c] : 0.f);
+    if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) v += resv[e];
+    if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) {
+      if constexpr (std::is_same<TC, bf16>::value) v = gelu_fast(v); else v = gelu_erf(v);
+    }
+    y[e] = v;
+  }
+  if (n0 + ec + 16 <= p.N && (p.c_rs % 8) == 0 && (p.c_bs % 8) == 0) {
+    if constexpr (std::is_same<TC, float>::value) {
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(cp + e) = float4{y[e], y[e + 1], y[e + 2], y[e + 3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) store4(cp + e, reinterpret_cast<const float(&)[4]>(y[e]));
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (n0 + ec + e < p.N) cp[e] = from_f32<TC>(y[e]);
+  }
+  PROBE(5);
+}
+
+template <typename TA, typename TC, int EPI>
+int launch_mid(simulst_handle* h, const void* A, const void* W, const float* bias, const void* R, void* C,
+               const LinArgs& p) {
+  dim3 grid((p.N + 63) / 64, (p.M + 63) / 64);
+  KTimer t(h, SIMULST_K_LINEAR_SKINNY);
+  if (p.ln_g)
+    hipLaunchKernelGGL((mid_kernel<TA, TC, EPI, true>), grid, dim3(256), 0, h->stream, (const TA*)A, (const TA*)W,
+                       bias, (const TA*)R, (TC*)C, p);
+  else
+    hipLaunchKernelGGL((mid_kernel<TA, TC, EPI, false>), grid, dim3(256), 0, h->stream, (const TA*)A, (const TA*)W,
+                       bias, (const TA*)R, (TC*)C, p);
+#ifdef SL_PROBE
+  {
+    static int calls = 0;
+    if ((++calls % 1499) == 0) {
+      (void)hipStreamSynchronize(h->stream);
+      long t[16];
+      (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(sl_probe_mid), sizeof t);
+      fprintf(stderr, "[probe 64x64 tile] M=%d N=%d K=%d ln=%d: issue %.2f  wait+LN %.2f  mfma %.2f  tile %.2f  epilogue %.2f  total %.2f us\n",
+              p.M, p.N, p.K, p.ln_g != nullptr, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01,
+              (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[5] - t[0]) * 0.01);
+    }
+  }
+#endif
+  return sl_launch_status(h, "simulst_linear(64x64 decode tile)");
+}
+
+template <typename TA>
+int mid_by_epilogue(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
+                    const LinArgs& p) {
+  switch (epi) {
+    case SIMULST_EPI_BIAS: return launch_mid<TA, TA, SIMULST_EPI_BIAS>(h, A, W, bias, R, C, p);
+    case SIMULST_EPI_BIAS_GELU: return launch_mid<TA, TA, SIMULST_EPI_BIAS_GELU>(h, A, W, bias, R, C, p);
+    case SIMULST_EPI_BIAS_RES: return launch_mid<TA, TA, SIMULST_EPI_BIAS_RES>(h, A, W, bias, R, C, p);
+    case SIMULST_EPI_BIAS_F32OUT: return launch_mid<TA, float, SIMULST_EPI_BIAS>(h, A, W, bias, R, C, p);
+    case SIMULST_EPI_BIAS_RES_GELU: return launch_mid<TA, TA, SIMULST_EPI_BIAS_RES_GELU>(h, A, W, bias, R, C, p);
+    default: h->err = "simulst_linear: epilogue not available for decode-step shapes"; return SIMULST_E_ARG;
+  }
+}
+
+}  // namespace
+
+// shapes this kernel takes over from the 16 x BN kernel: co-scheduled batches with a wide output
+bool sl_mid_wanted(int dtype, const LinArgs& p) {
+  const int KS = dtype == SIMULST_F32 ? 16 : 32;
+  const long blocks = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);     // one 64 x 64 tile per workgroup: fill the chip
+  return p.M >= 256 && p.N >= 512 && blocks >= 256 && p.K <= 1024 && (!p.ln_g || p.K <= 8 * KS);
+}
+
+int sl_launch_mid(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
+                  const void* R, void* C, const LinArgs& p) {
+  return dtype == SIMULST_F32 ? mid_by_epilogue<float>(h, epilogue, A, W, bias, R, C, p)
+                              : mid_by_epilogue<bf16>(h, epilogue, A, W, bias, R, C, p);
+}

@@ -64,8 +64,9 @@ __device__ __forceinline__ void epilogue_store(float v, int r, int c, const floa
   C[(long)b * p.c_bs + (long)ii * p.c_rs + c] = from_f32<TC>(v);
 }
 
-// NT = 16-column MFMA tiles per workgroup (BN = 16 * NT). UNR = k-steps per wave kept in flight.
-template <typename TA, typename TC, int EPI, bool PRO_LN, int NT, bool SPLIT>
+// NT = 16-column MFMA tiles per workgroup (BN = 16 * NT), MT = 16-row tiles (BM = 16 * MT): a weight fragment
+// loaded once is used against MT activation fragments.  UNR = k-steps per wave kept in flight.
+template <typename TA, typename TC, int EPI, bool PRO_LN, int NT, bool SPLIT, int MT = 1>
 __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, const TA* __restrict__ W,
                                                      const float* __restrict__ bias, const TA* __restrict__ R,
                                                      TC* __restrict__ C, float* __restrict__ partial, LinArgs p,
@@ -73,41 +74,52 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
   constexpr bool F32 = std::is_same<TA, float>::value;
   constexpr int KS = F32 ? 16 : 32;            // k consumed per k-step (one 16-byte fragment per lane)
   constexpr int G = F32 ? 4 : 8;               // elements per 16-byte fragment
-  constexpr int UNR = 4;
-  constexpr int BN = 16 * NT;
-  __shared__ float part[4][16 * (BN + 1)];
-  __shared__ float st1[4][16], st2[4][16];
+  constexpr int UNR = MT > 2 ? 2 : 4;
+  constexpr int BN = 16 * NT, BM = 16 * MT;
+  __shared__ float part[4][BM * (BN + 1)];
+  __shared__ float st1[4][BM], st2[4][BM];
   __shared__ float lng[PRO_LN ? 512 : 1], lnb[PRO_LN ? 512 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;    // fragment row / k-group of this lane
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * 16;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int ks0 = blockIdx.z * k_per_split;    // this split's K range [ks0, ks1)
   const int ks1 = min(p.K, ks0 + k_per_split);
-  // ---- epilogue ownership + early residual load: thread -> (row tid / BN', col), BN' = BN
-  constexpr int EL = 16 * BN / 256;            // outputs per thread (1 for BN=16, 2 for BN=32)
-  const int er = tid / (BN / EL) % 16, ec = (tid % (BN / EL)) * EL;
-  const int erow = m0 + er;
-  const bool e_ok = erow < p.M;
-  float resv[EL];
+  // ---- epilogue ownership + early residual load: EL consecutive columns of one row per thread and pass
+  constexpr int EL = BN / 16;                  // 1 (BN=16) or 2 (BN=32) outputs per thread and row pass
+  constexpr int RPP = 256 / 16;                // rows covered per pass (16 threads per row)
+  constexpr int NPASS = BM / RPP;              // MT passes
+  const int er = tid >> 4, ec = (tid & 15) * EL;
+  float resv[NPASS][EL];
 #pragma unroll
-  for (int e = 0; e < EL; ++e) resv[e] = 0.f;
+  for (int q = 0; q < NPASS; ++q)
+#pragma unroll
+    for (int e = 0; e < EL; ++e) resv[q][e] = 0.f;
   if constexpr (!SPLIT && (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU)) {
-    if (e_ok) {
-      const int b = erow / p.rpb, ii = erow - b * p.rpb;
-      const TA* rp = R + (long)b * p.r_bs + (long)ii * p.r_rs + n0 + ec;
 #pragma unroll
-      for (int e = 0; e < EL; ++e)
-        if (n0 + ec + e < p.N) resv[e] = to_f32(rp[e]);
+    for (int q = 0; q < NPASS; ++q) {
+      const int erow = m0 + q * RPP + er;
+      if (erow < p.M) {
+        const int b = erow / p.rpb, ii = erow - b * p.rpb;
+        const TA* rp = R + (long)b * p.r_bs + (long)ii * p.r_rs + n0 + ec;
+#pragma unroll
+        for (int e = 0; e < EL; ++e)
+          if (n0 + ec + e < p.N) resv[q][e] = to_f32(rp[e]);
+      }
     }
   }
   if constexpr (PRO_LN) {
     for (int k = tid; k < p.K; k += 256) { lng[k] = p.ln_g[k]; lnb[k] = p.ln_b[k]; }
   }
   // ---- fragment sources
-  const int ar = m0 + lr;
-  const bool aok = ar < p.M;
-  const int ab = aok ? ar / p.rpb : 0, ai = aok ? ar - ab * p.rpb : 0;
-  const TA* arow = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
+  const TA* arow[MT];
+  bool aok[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int ar = m0 + m * 16 + lr;
+    aok[m] = ar < p.M;
+    const int ab = aok[m] ? ar / p.rpb : 0, ai = aok[m] ? ar - ab * p.rpb : 0;
+    arow[m] = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
+  }
   // row-major: lane -> row n0 + j*16 + lr, 16 bytes at k.  Fragment-major (p.w_packed): the 64 lanes of a k-step
   // are contiguous: ((tile * K/KS + k/KS) * 64 + lane) * G
   const TA* wrow[NT];
@@ -121,26 +133,29 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
     wrow[j] = pk ? W + ((long)(wok[j] ? blockIdx.x * NT + j : 0) * (p.K / KS) * 64 + lane) * G - (long)lg * G * wks
                  : W + (long)(wok[j] ? n : 0) * p.K;
   }
-  f32x4 acc[NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nks = (ks1 - ks0 + KS - 1) / KS;
   // uniform trip count for all 4 waves (the LN prologue has a workgroup barrier inside the body)
   const int n_iter = max(1, (nks + 4 * UNR - 1) / (4 * UNR));
   for (int it = 0; it < n_iter; ++it) {
     const int s0 = wave + it * 4 * UNR;
-    uint4 fa[UNR], fw[UNR][NT];
+    uint4 fa[UNR][MT], fw[UNR][NT];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int s = s0 + 4 * u;
       const int k = ks0 + s * KS + lg * G;
       const bool kin = s < nks && k < ks1;
       const int kc = kin ? k : 0;              // clamped: loads stay unconditional, zeroed by select
-      {
-        const uint4 v = ld16(arow + kc);
-        const bool ok = kin && aok;
-        fa[u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint4 v = ld16(arow[m] + kc);
+        const bool ok = kin && aok[m];
+        fa[u][m] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -150,66 +165,83 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
       }
     }
     if constexpr (PRO_LN) {
-      // host guarantees one chunk (K <= 4 waves * UNR * KS): moments of row lr from this lane's
+      // host guarantees one chunk (K <= 4 waves * UNR * KS): moments of row lr (+16 per row tile) from this lane's
       // fragments -> the 4 k-groups of the wave -> the 4 waves
-      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) frag_moments(fa[u], s1, s2, TA());
-      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (lg == 0) { st1[wave][lr] = s1; st2[wave][lr] = s2; }
+      for (int m = 0; m < MT; ++m) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) frag_moments(fa[u][m], s1, s2, TA());
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (lg == 0) { st1[wave][m * 16 + lr] = s1; st2[wave][m * 16 + lr] = s2; }
+      }
       __syncthreads();
-      const float t1 = (st1[0][lr] + st1[1][lr]) + (st1[2][lr] + st1[3][lr]);
-      const float t2 = (st2[0][lr] + st2[1][lr]) + (st2[2][lr] + st2[3][lr]);
-      const float mean = t1 / (float)p.K;
-      const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int s = s0 + 4 * u;
-        const int k = ks0 + s * KS + lg * G;
-        if (s < nks && k < ks1 && aok) fa[u] = ln_frag(fa[u], mean, rstd, lng, lnb, k, TA());
+      for (int m = 0; m < MT; ++m) {
+        const int rr = m * 16 + lr;
+        const float t1 = (st1[0][rr] + st1[1][rr]) + (st1[2][rr] + st1[3][rr]);
+        const float t2 = (st2[0][rr] + st2[1][rr]) + (st2[2][rr] + st2[3][rr]);
+        const float mean = t1 / (float)p.K;
+        const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int s = s0 + 4 * u;
+          const int k = ks0 + s * KS + lg * G;
+          if (s < nks && k < ks1 && aok[m]) fa[u][m] = ln_frag(fa[u][m], mean, rstd, lng, lnb, k, TA());
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      if constexpr (F32) {
-        const float* af = reinterpret_cast<const float*>(&fa[u]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float* wf = reinterpret_cast<const float*>(&fw[u][j]);
+      for (int m = 0; m < MT; ++m) {
+        if constexpr (F32) {
+          const float* af = reinterpret_cast<const float*>(&fa[u][m]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wf[e], acc[j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) {
+            const float* wf = reinterpret_cast<const float*>(&fw[u][j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wf[e], acc[m][j], 0, 0, 0);
+          }
+        } else {
+          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(&fa[u][m]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, *reinterpret_cast<const bf16x8_t*>(&fw[u][j]),
+                                                               acc[m][j], 0, 0, 0);
         }
-      } else {
-        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(&fa[u]);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, *reinterpret_cast<const bf16x8_t*>(&fw[u][j]), acc[j],
-                                                          0, 0, 0);
       }
     }
   }
-  // ---- wave partials -> LDS: acc[j][e] = C[row lg*4 + e][col j*16 + lr]
+  // ---- wave partials -> LDS: acc[m][j][e] = C[row m*16 + lg*4 + e][col j*16 + lr]
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) part[wave][(lg * 4 + e) * (BN + 1) + j * 16 + lr] = acc[j][e];
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[wave][(m * 16 + lg * 4 + e) * (BN + 1) + j * 16 + lr] = acc[m][j][e];
   __syncthreads();
-  if (!e_ok) return;
 #pragma unroll
-  for (int e = 0; e < EL; ++e) {
-    const int c = n0 + ec + e;
-    if (c >= p.N) continue;
-    const int o = er * (BN + 1) + ec + e;
-    const float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
-    if constexpr (SPLIT) {
-      partial[((long)blockIdx.z * p.M + erow) * p.N + c] = v;
-    } else {
-      const int b = erow / p.rpb, ii = erow - b * p.rpb;
-      float y = v + (bias ? bias[c] : 0.f);
-      if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) y += resv[e];
-      if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) y = gelu_erf(y);
-      C[(long)b * p.c_bs + (long)ii * p.c_rs + c] = from_f32<TC>(y);
+  for (int q = 0; q < NPASS; ++q) {
+    const int prow = q * RPP + er, erow = m0 + prow;
+    if (erow >= p.M) continue;
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      const int c = n0 + ec + e;
+      if (c >= p.N) continue;
+      const int o = prow * (BN + 1) + ec + e;
+      const float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+      if constexpr (SPLIT) {
+        partial[((long)blockIdx.z * p.M + erow) * p.N + c] = v;
+      } else {
+        const int b = erow / p.rpb, ii = erow - b * p.rpb;
+        float y = v + (bias ? bias[c] : 0.f);
+        if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) y += resv[q][e];
+        if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) y = gelu_erf(y);
+        C[(long)b * p.c_bs + (long)ii * p.c_rs + c] = from_f32<TC>(y);
+      }
     }
   }
 }
@@ -232,10 +264,17 @@ int launch_all(simulst_handle* h, const void* A, const void* W, const float* bia
                const LinArgs& p) {
   constexpr bool F32 = std::is_same<TA, float>::value;
   constexpr int KS = F32 ? 16 : 32;
-  const int mt = (p.M + 15) / 16;
-  // spread over the chip: 16-column tiles while that gives <= 512 workgroups, else 32-column tiles
-  const bool wide = (long)mt * ((p.N + 15) / 16) > 512;
-  const int bn = wide ? 32 : 16;
+  // spread over the chip: start from 64 x 32 tiles (a weight fragment reused by 4 row tiles) and shrink -- columns
+  // first, then rows -- until the grid has >= 512 workgroups (two per CU) or the tile is the 16 x 16 minimum
+  int MTs = 4, NTs = 2;
+  auto blocks = [&](int m_, int n_) { return (long)((p.M + 16 * m_ - 1) / (16 * m_)) * ((p.N + 16 * n_ - 1) / (16 * n_)); };
+  while (blocks(MTs, NTs) < 512 && (MTs > 1 || NTs > 1)) {
+    if (NTs > 1) NTs = 1; else MTs >>= 1;
+  }
+  if (MTs == 1 && NTs == 1 && blocks(1, 1) > 512) NTs = 2;      // the M <= 64 policy of the 16 x BN kernel
+  const bool wide = NTs == 2;
+  const int mt = (p.M + 16 * MTs - 1) / (16 * MTs);
+  const int bn = 16 * NTs;
   const int nt = (p.N + bn - 1) / bn;
   int splits = 1;
   // measured on MI355X (bench.py, K = 2048 fc2): one 16x16-tile launch streaming 128 KB per workgroup is as
@@ -243,6 +282,7 @@ int launch_all(simulst_handle* h, const void* A, const void* W, const float* bia
   if (!p.ln_g && p.K >= 4096) {
     splits = p.K / 1024;
     while (splits > 1 && (long)mt * nt * splits > 1024) splits >>= 1;
+    if (splits > 1) { MTs = 1; }
   }
   int kps = (p.K + splits - 1) / splits;
   kps = (kps + KS - 1) / KS * KS;
@@ -251,6 +291,7 @@ int launch_all(simulst_handle* h, const void* A, const void* W, const float* bia
     h->err = "simulst_linear: LN prologue needs K <= 512 (bf16) / 256 (fp32)";
     return SIMULST_E_SHAPE;
   }
+  if (p.ln_g && MTs > 2 && p.K > 4 * 2 * KS) MTs = 2;           // 64-row tiles keep 2 k-steps per wave in flight
   float* partial = nullptr;
   if (splits > 1) {
     const size_t need = (size_t)splits * p.M * p.N * sizeof(float);
@@ -264,16 +305,24 @@ int launch_all(simulst_handle* h, const void* A, const void* W, const float* bia
     }
     partial = (float*)h->ws;
   }
-  dim3 grid(nt, mt, splits);
-#define SK_LAUNCH(LN, NTT, SP)                                                                                     \
-  hipLaunchKernelGGL((skinny_kernel<TA, TC, EPI, LN, NTT, SP>), grid, dim3(256), 0, h->stream, (const TA*)A,      \
+  const int mt2 = (p.M + 16 * MTs - 1) / (16 * MTs);
+  dim3 grid(nt, mt2, splits);
+#define SK_LAUNCH(LN, NTT, SP, MTT)                                                                                \
+  hipLaunchKernelGGL((skinny_kernel<TA, TC, EPI, LN, NTT, SP, MTT>), grid, dim3(256), 0, h->stream, (const TA*)A, \
                      (const TA*)W, bias, (const TA*)R, (TC*)C, partial, p, kps)
+#define SK_BY_MT(LN, NTT, SP)                                                          \
+  do {                                                                                 \
+    if (MTs == 4) SK_LAUNCH(LN, NTT, SP, 4);                                           \
+    else if (MTs == 2) SK_LAUNCH(LN, NTT, SP, 2);                                      \
+    else SK_LAUNCH(LN, NTT, SP, 1);                                                    \
+  } while (0)
   {
     KTimer t(h, SIMULST_K_LINEAR_SKINNY);
-    if (splits > 1) { if (wide) SK_LAUNCH(false, 2, true); else SK_LAUNCH(false, 1, true); }
-    else if (p.ln_g) { if (wide) SK_LAUNCH(true, 2, false); else SK_LAUNCH(true, 1, false); }
-    else { if (wide) SK_LAUNCH(false, 2, false); else SK_LAUNCH(false, 1, false); }
+    if (splits > 1) { if (wide) SK_LAUNCH(false, 2, true, 1); else SK_LAUNCH(false, 1, true, 1); }
+    else if (p.ln_g) { if (wide) SK_BY_MT(true, 2, false); else SK_BY_MT(true, 1, false); }
+    else { if (wide) SK_BY_MT(false, 2, false); else SK_BY_MT(false, 1, false); }
   }
+#undef SK_BY_MT
 #undef SK_LAUNCH
   int rc = sl_launch_status(h, "simulst_linear(skinny)");
   if (rc) return rc;
@@ -304,6 +353,7 @@ int by_epilogue(simulst_handle* h, int epi, const void* A, const void* W, const 
 
 int sl_launch_skinny(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                      const void* R, void* C, const LinArgs& p) {
+  if (sl_mid_wanted(dtype, p)) return sl_launch_mid(h, dtype, epilogue, A, W, bias, R, C, p);
   return dtype == SIMULST_F32 ? by_epilogue<float>(h, epilogue, A, W, bias, R, C, p)
                               : by_epilogue<bf16>(h, epilogue, A, W, bias, R, C, p);
 }

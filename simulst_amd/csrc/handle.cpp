@@ -1,5 +1,6 @@
 // Handle lifecycle + timers of libsimulst_hip.so.
 #include "common.h"
+#include <cstdlib>
 
 extern "C" int simulst_version(void) { return 100; }
 
@@ -15,6 +16,8 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->capturing = false;
   h->force_valu_attention = false;
   h->force_unfused_decode = false;
+  h->fuse_q_max_rows = 128;
+  if (const char* e = getenv("SIMULST_FUSE_Q_MAX_ROWS")) h->fuse_q_max_rows = atoi(e);
   h->graph_exec = nullptr;
   h->graph_key = 0;
   for (int i = 0; i < SIMULST_K_COUNT; ++i) { h->timer_on[i] = false; h->timer_ms[i] = 0.0; h->timer_n[i] = 0; }

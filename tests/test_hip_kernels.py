@@ -454,3 +454,30 @@ def test_fragment_major_pack_and_linear(ops, dtype):
             y0 = ops.linear(x, W, b, ln=(gam, bet))
             y1 = ops.linear(x, Wp, b, ln=(gam, bet), w_fragment_major=True)
             assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_gemm_row_tiles(ops, dtype):
+    """Decode-step GEMM at the row counts of co-scheduled batches (64 .. 1024 rows, ragged): the 32- and 64-row
+    tiles against torch fp32, every epilogue the decode loop uses, LayerNorm prologue, fragment-major weights."""
+    from simulst_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_F32OUT
+    g = torch.Generator().manual_seed(77)
+    tol = dict(atol=2e-4, rtol=2e-4) if dtype == torch.float32 else dict(atol=6e-2, rtol=3e-2)
+    for M, N, K in ((200, 256, 256), (512, 768, 256), (1000, 2048, 256), (1024, 256, 2048), (130, 4096, 256)):
+        x = torch.randn(M, K, generator=g).to(dtype).cuda()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        r = torch.randn(M, N, generator=g).to(dtype).cuda()
+        Wp = ops.pack_fragment_major(W)
+        ref = x.float() @ W.float().t() + b
+        for Wx, fm in ((W, False), (Wp, True)):
+            torch.testing.assert_close(ops.linear(x, Wx, b, epilogue=EPI_BIAS, w_fragment_major=fm).float(), ref, **tol)
+            torch.testing.assert_close(ops.linear(x, Wx, b, epilogue=EPI_BIAS_RES, residual=r, w_fragment_major=fm).float(),
+                                       ref + r.float(), **tol)
+            torch.testing.assert_close(ops.linear(x, Wx, b, epilogue=EPI_BIAS_GELU, w_fragment_major=fm).float(),
+                                       torch.nn.functional.gelu(ref), **tol)
+            if K <= 256:
+                gam, bet = torch.rand(K, generator=g).cuda() + 0.5, torch.randn(K, generator=g).cuda() * 0.1
+                xn = torch.nn.functional.layer_norm(x.float(), (K,), gam, bet).to(dtype).float()
+                y = ops.linear(x, Wx, b, epilogue=EPI_BIAS_F32OUT, ln=(gam, bet), w_fragment_major=fm)
+                torch.testing.assert_close(y, xn @ W.float().t() + b, **tol)
