@@ -138,6 +138,14 @@ int simulst_conv_pos(simulst_handle* h, const void* x, const void* hist, const v
                      const float* bias, const int32_t* lengths, void* y,
                      int32_t B, int32_t T, int32_t D, int32_t groups, int32_t k, int32_t dtype);
 
+/* The same operator on the matrix cores: bf16, 16 channels per group, kernel width 16 / 32 / 64.  Wp is the weight
+ * prepacked ONCE into MFMA-fragment order (two taps x 16 input channels per k-step, 1 KB contiguous per wave load):
+ *   Wp[((g * k/2 + s) * 64 + lane) * 8 + j] = W[g*16 + (lane & 15)][((lane >> 4) & 1) * 8 + j][2*s + (lane >> 5)]
+ * for group g, k-step s < k/2, lane < 64, j < 8.  Same x / hist / lengths / y contract as simulst_conv_pos. */
+int simulst_conv_pos_mfma(simulst_handle* h, const void* x, const void* hist, const void* Wp, const float* bias,
+                          const int32_t* lengths, void* y, int32_t B, int32_t T, int32_t D, int32_t groups,
+                          int32_t k);
+
 /* ---- Emformer layer pieces ------------------------------------------------------
  * Per-utterance row blocks of a layer buffer Z [B][n_mem + n_rc + T + n_sum][D]:
  *   [memory rows | right-context block rows | utterance rows | summary rows].

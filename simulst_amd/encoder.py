@@ -101,6 +101,8 @@ class S2TEmformerEncoder:
         self.left_context, self.right_context, self.segment_length = cfg.Lc, cfg.R, cfg.S
         self.max_memory_size = cfg.M
 
+    use_mfma_conv_pos = True
+
     def conv_layer_stride(self):
         return self.stride
 
@@ -132,6 +134,18 @@ class S2TEmformerEncoder:
         return x
 
     # ---------------------------------------------------------------- Emformer
+    def _conv_pos(self, x, hist, lengths_i32):
+        """Causal grouped conv-pos + residual + padding mask: matrix-core kernel for bf16 / 16 channels per group /
+        kernel width 16, 32 or 64 (the reference configuration), else the VALU kernel."""
+        cfg, w = self.cfg, self.w
+        if getattr(w, "pos_w_packed", None) is None:
+            k = w.pos_w.shape[2]
+            ok = w.pos_w.dtype == torch.bfloat16 and w.pos_w.shape[1] == 16 and k in (16, 32, 64)
+            w.pos_w_packed = self.ops.pack_conv_pos_weight(w.pos_w) if ok else False
+        if w.pos_w_packed is not False and self.use_mfma_conv_pos:
+            return self.ops.conv_pos_mfma(x, hist, w.pos_w_packed, w.pos_b, lengths_i32, cfg.conv_pos_groups)
+        return self.ops.conv_pos(x, hist, w.pos_w, w.pos_b, lengths_i32, cfg.conv_pos_groups)
+
     def _rc_index(self, T: int, device):
         """Row gather for the right-context blocks (Emformer._gen_right_context,
         torchaudio_models/emformer.py:700-709) over an input extended by one all-zero row T."""
@@ -193,7 +207,7 @@ class S2TEmformerEncoder:
         enc_len = self.out_lengths(src_lengths.to(x.device), len(self.w.conv))
         Te = x.size(1)
         len_i32 = enc_len.to(torch.int32)
-        x = ops.conv_pos(x, None, self.w.pos_w, self.w.pos_b, len_i32, cfg.conv_pos_groups)
+        x = self._conv_pos(x, None, len_i32)
         D, R, S = cfg.embed_dim, cfg.R, cfg.S
         idx, N = self._rc_index(Te, x.device)
         xz = torch.cat([x, x.new_zeros(B, 1, D)], dim=1)
@@ -333,7 +347,7 @@ class S2TEmformerEncoder:
             st["prev_len"] = src_tokens.size(1)
             x = self._subsample_stream(new, st)
             if x.size(1) > 0:
-                y = ops.conv_pos(x, st["pos_hist"], self.w.pos_w, self.w.pos_b, None, cfg.conv_pos_groups)
+                y = self._conv_pos(x, st["pos_hist"], None)
                 kp1 = st["pos_hist"].size(1)
                 st["pos_hist"] = torch.cat([st["pos_hist"], x], dim=1)[:, -kp1:].contiguous()
                 x = y

@@ -134,6 +134,23 @@ class Ops:
                                                B, T, D, groups, k, dt(x)), "simulst_conv_pos")
         return out
 
+    @staticmethod
+    def pack_conv_pos_weight(W):
+        """W [D, 16, k] (weight norm folded) -> the fragment order of simulst_conv_pos_mfma."""
+        D, cpg, k = W.shape
+        assert cpg == 16 and k % 2 == 0
+        return W.view(D // 16, 16, 2, 8, k // 2, 2).permute(0, 4, 5, 2, 1, 3).contiguous().view(D, cpg, k)
+
+    def conv_pos_mfma(self, x, hist, Wp, bias, lengths, groups, out=None):
+        _chk_contig(x, hist, Wp, out)
+        B, T, D = x.shape
+        k = Wp.shape[2]
+        if out is None:
+            out = torch.empty_like(x)
+        self.h.check(self.lib.simulst_conv_pos_mfma(self.h.ptr, _p(x), _p(hist), _p(Wp), _p(bias), _p(lengths), _p(out),
+                                                    B, T, D, groups, k), "simulst_conv_pos_mfma")
+        return out
+
     def emformer_attention(self, QKV, lengths, CTX, *, B, T, D, H, S, R, Lc, M, n_mem, n_seg, use_summary,
                            lc_k=None, lc_v=None, lc_valid=None, n_mem_valid=None):
         d = EmfAttnDesc(B, T, D, H, S, R, Lc, M, n_mem, n_seg, int(use_summary), dt(QKV))

@@ -481,3 +481,27 @@ def test_decode_gemm_row_tiles(ops, dtype):
                 xn = torch.nn.functional.layer_norm(x.float(), (K,), gam, bet).to(dtype).float()
                 y = ops.linear(x, Wx, b, epilogue=EPI_BIAS_F32OUT, ln=(gam, bet), w_fragment_major=fm)
                 torch.testing.assert_close(y, xn @ W.float().t() + b, **tol)
+
+
+def test_conv_pos_mfma_equals_valu_kernel(ops):
+    """simulst_conv_pos_mfma (prepacked weight, matrix cores) against simulst_conv_pos on the same bf16 inputs and a
+    torch fp32 reference: offline (ragged lengths), streaming (hist), T not a multiple of the tile."""
+    g = torch.Generator().manual_seed(5)
+    D, groups = 256, 16
+    for k in (64, 32):
+        W = (torch.randn(D, D // groups, k, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        b = (torch.randn(D, generator=g) * 0.1).cuda()
+        Wp = ops.pack_conv_pos_weight(W)
+        for B, T, with_hist in ((3, 250, False), (2, 37, True), (1, 300, False), (5, 16, True)):
+            x = torch.randn(B, T, D, generator=g).to(torch.bfloat16).cuda()
+            hist = torch.randn(B, k - 1, D, generator=g).to(torch.bfloat16).cuda() if with_hist else None
+            L = None if with_hist else torch.randint(1, T + 1, (B,), generator=g).to(torch.int32).cuda()
+            y0 = ops.conv_pos(x, hist, W, b, L, groups)
+            y1 = ops.conv_pos_mfma(x, hist, Wp, b, L, groups)
+            xin = torch.cat([hist if with_hist else x.new_zeros(B, k - 1, D), x], 1).float().transpose(1, 2)
+            ref = torch.nn.functional.conv1d(xin, W.float(), b, groups=groups).transpose(1, 2)
+            ref = x.float() + torch.nn.functional.gelu(ref)
+            if L is not None:
+                ref = ref * (torch.arange(T, device="cuda")[None, :, None] < L[:, None, None])
+            torch.testing.assert_close(y1.float(), ref, atol=3e-2, rtol=2e-2)
+            torch.testing.assert_close(y1.float(), y0.float(), atol=3e-2, rtol=2e-2)
