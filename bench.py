@@ -97,15 +97,16 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="independent launch sequences in flight (one HIP stream + host thread each)")
-    ap.add_argument("--group", type=int, default=4,
-                    help="independent 64-utterance batches stacked into one launch sequence")
+    ap.add_argument("--group", type=int, default=16,
+                    help="independent 64-utterance batches stacked into one launch sequence (fewer when --steps "
+                         "does not fill group x concurrency sequences)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode loop of each batch strictly one after the other")
     ap.add_argument("--graph", action="store_true",
@@ -151,10 +152,12 @@ def main():
     fb, L = fb_all[:B], L_all[:B]              # one batch (serial reference, instrumented replay uses a group)
 
     def groups(k):
-        """k batches -> launch sequences of G stacked batches (+ one shorter sequence for the remainder)"""
-        seq = [(fb_all, L_all)] * (k // G)
-        if k % G:
-            seq.append((fb_all[:B * (k % G)], L_all[:B * (k % G)]))
+        """k batches -> launch sequences of up to G stacked batches, sized so that every stream gets work when k is
+        small (+ one shorter sequence for the remainder)"""
+        g = max(1, min(G, -(-k // max(1, args.concurrency))))
+        seq = [(fb_all[:B * g], L_all[:B * g])] * (k // g)
+        if k % g:
+            seq.append((fb_all[:B * (k % g)], L_all[:B * (k % g)]))
         return seq
 
     pipe = None
@@ -251,14 +254,16 @@ def main():
             roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 5), "traffic": None}
         else:
-            if dom == "linear_skinny":
+            if dom in ("linear_skinny", "linear_tile64"):
                 # decode-step contractions at M = 64 rows: arithmetic intensity = M flop/byte of weight,
                 # far left of the ridge (312 flop/B) => HBM/L2 bound. Algorithmic bytes per launch =
                 # weights N*K + activations M*K in, M*N out.
                 def gb(n, k):
                     return (n * k + Bs * k + Bs * n) * esz
-                per_layer = gb(3 * D, D) + 2 * gb(D, D) + gb(F, D) + gb(D, F)   # q-proj lives in the cross-attention launch
-                byts = U * (Ld * per_layer + gb(V, D))
+                wide = Ld * (gb(3 * D, D) + gb(F, D)) + gb(V, D)          # N >= 512: QKV, fc1, vocabulary projection
+                narrow = Ld * (3 * gb(D, D) + gb(D, F))                    # out-proj x2, q-proj, fc2
+                tile64 = Bs >= 256
+                byts = U * ((wide if tile64 else 0) if dom == "linear_tile64" else (narrow if tile64 else wide + narrow))
             elif dom == "emformer_attention":
                 byts = cfg.encoder_layers * Bs * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
             elif dom == "decoder_cross_attention":
@@ -277,7 +282,7 @@ def main():
         # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate runs of this same command; profiles/*_pmc_traffic.json says how it was corrected)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")))
             if dom in pmc:
                 roofline["traffic"] = pmc[dom]["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):

@@ -65,7 +65,8 @@ enum { SIMULST_ATTN_HARD = 0, SIMULST_ATTN_INFINITE_LOOKBACK = 1, SIMULST_ATTN_W
 /* kernel classes for simulst_timer_* (roofline accounting in bench.py) */
 enum { SIMULST_K_LINEAR = 0, SIMULST_K_LAYERNORM = 1, SIMULST_K_EMF_ATTN = 2, SIMULST_K_CONV_POS = 3,
        SIMULST_K_DEC_SELF_ATTN = 4, SIMULST_K_DEC_CROSS_ATTN = 5, SIMULST_K_SCAN = 6,
-       SIMULST_K_ARGMAX = 7, SIMULST_K_MISC = 8, SIMULST_K_LINEAR_SKINNY = 9, SIMULST_K_COUNT = 10 };
+       SIMULST_K_ARGMAX = 7, SIMULST_K_MISC = 8, SIMULST_K_LINEAR_SKINNY = 9, SIMULST_K_LINEAR_TILE64 = 10,
+       SIMULST_K_COUNT = 11 };
 
 /* ---- handle ------------------------------------------------------------------ */
 int simulst_create(simulst_handle** out, void* hip_stream);

@@ -17,9 +17,9 @@ F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_GLU, EPI_EMF_OUT, EPI_BIAS_F32OUT, EPI_BIAS_RES_GELU = range(7)
 ATTN_HARD, ATTN_INFINITE_LOOKBACK, ATTN_WAITK, ATTN_CHUNKWISE = range(4)
 (K_LINEAR, K_LAYERNORM, K_EMF_ATTN, K_CONV_POS, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_SCAN, K_ARGMAX,
- K_MISC, K_LINEAR_SKINNY, K_COUNT) = range(11)
+ K_MISC, K_LINEAR_SKINNY, K_LINEAR_TILE64, K_COUNT) = range(12)
 KERNEL_CLASS_NAMES = ["linear", "layernorm", "emformer_attention", "conv_pos", "decoder_self_attention",
-                      "decoder_cross_attention", "scan", "argmax", "misc", "linear_skinny"]
+                      "decoder_cross_attention", "scan", "argmax", "misc", "linear_skinny", "linear_tile64"]
 
 ATTN_ENUM = {"hard_aligned": ATTN_HARD, "infinite_lookback": ATTN_INFINITE_LOOKBACK,
              "waitk": ATTN_WAITK, "chunkwise": ATTN_CHUNKWISE}

@@ -56,97 +56,83 @@ __device__ __forceinline__ void moments_mid(uint4 v, float& s1, float& s2, bf16)
   }
 }
 
-template <typename TA, typename TC, int EPI, bool PRO_LN>
+// RW = 16-row tiles per wave: the workgroup tile is (64 * RW) x 64, wave w owns rows [16*RW*w, 16*RW*(w+1)) of it and
+// all 64 columns.  The 64 x K weight block is the only operand the 4 waves share: it is staged in LDS in
+// fragment-major order (from fragment-major global memory a straight 16-byte copy; from row-major a scatter), so a
+// B fragment is one conflict-free 1 KB ds_read; the A fragments of a wave's own rows go global -> registers.
+template <typename TA, typename TC, int EPI, bool PRO_LN, int RW>
 __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, const TA* __restrict__ W,
                                                   const float* __restrict__ bias, const TA* __restrict__ R,
                                                   TC* __restrict__ C, LinArgs p) {
   constexpr bool F32 = std::is_same<TA, float>::value;
   constexpr int KS = F32 ? 16 : 32, G = F32 ? 4 : 8, CH = 8;      // CH k-steps per chunk
-  __shared__ float tile[64][65];
+  constexpr int BM = 64 * RW, WR = 16 * RW;
+  constexpr int W_BYTES = 4 * CH * 64 * 16;                       // 4 column tiles x CH k-steps x 1 KB
+  constexpr int T_BYTES = BM * 65 * 4;                            // epilogue tile (fp32, padded rows)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[W_BYTES > T_BYTES ? W_BYTES : T_BYTES];
   __shared__ float lng[PRO_LN ? 512 : 1], lnb[PRO_LN ? 512 : 1];
+  uint4* wl = reinterpret_cast<uint4*>(smem);                     // [j][s][lane]
+  float (*tile)[65] = reinterpret_cast<float (*)[65]>(smem);
   PROBE(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  // ---- epilogue ownership: row tid/4, 16 consecutive columns; the residual segment is requested now
-  const int er = tid >> 2, ec = (tid & 3) * 16;
-  const int erow = m0 + er;
-  const bool e_ok = erow < p.M;
-  const int eb = e_ok ? erow / p.rpb : 0, ei = e_ok ? erow - eb * p.rpb : 0;
-  float resv[16];
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 64;
+  const int nksT = p.K / KS;                                      // host: K % KS == 0
+  // ---- A sources: RW row tiles of this wave
+  const TA* arow[RW];
+  bool aok[RW];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) resv[e] = 0.f;
-  if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) {
-    if (e_ok) {
-      const TA* rp = R + (long)eb * p.r_bs + (long)ei * p.r_rs + n0 + ec;
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (n0 + ec + e < p.N) resv[e] = to_f32(rp[e]);
-    }
-  }
-  // ---- fragment sources: 2 row tiles (A) and 2 column tiles (W) per wave
-  const TA* arow[2];
-  bool aok[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const int ar = m0 + wm * 32 + m * 16 + lr;
+  for (int m = 0; m < RW; ++m) {
+    const int ar = m0 + wave * WR + m * 16 + lr;
     aok[m] = ar < p.M;
     const int ab = aok[m] ? ar / p.rpb : 0, ai = aok[m] ? ar - ab * p.rpb : 0;
     arow[m] = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
-#ifdef SL_EXP_APACKED   // timing experiment only (wrong results): activations read as if fragment-major
-    arow[m] = A + ((long)((m0 + wm * 32 + m * 16) >> 4) * (p.K / KS) * 64 + lane) * G - (long)lg * G * (64L * G / KS);
-#endif
   }
   const bool pk = p.w_packed != 0;
-  const long wks = pk ? 64L * G / KS : 1;
-  const TA* wrow[2];
-  bool wok[2];
+  f32x4 acc[RW][4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 32 + j * 16 + lr;
-    wok[j] = n < p.N;
-    wrow[j] = pk ? W + ((long)(wok[j] ? n >> 4 : 0) * (p.K / KS) * 64 + lane) * G - (long)lg * G * wks
-                 : W + (long)(wok[j] ? n : 0) * p.K;
-  }
-  f32x4 acc[2][2];
+  for (int m = 0; m < RW; ++m)
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nks = (p.K + KS - 1) / KS;
+    for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nks = nksT;
   for (int s0 = 0; s0 < nks; s0 += CH) {
-    uint4 fa[2][CH], fw[2][CH];
+    // ---- operand loads of this chunk: A fragments to registers, the weight block to registers then LDS
+    uint4 fa[RW][CH];
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-      const int k = (s0 + u) * KS + lg * G;
-      const bool kin = s0 + u < nks && k < p.K;
-      const int kc = kin ? k : 0;
+      const bool kin = s0 + u < nks;
+      const int kc = kin ? (s0 + u) * KS + lg * G : 0;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-#ifdef SL_EXP_APACKED
-        const uint4 v = ld16(arow[m] + (long)kc * (64L * G / KS));
-#else
+      for (int m = 0; m < RW; ++m) {
         const uint4 v = ld16(arow[m] + kc);
-#endif
         const bool ok = kin && aok[m];
         fa[m][u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint4 v = ld16(wrow[j] + (long)kc * wks);
-        const bool ok = kin && wok[j];
-        fw[j][u] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
-      }
     }
+    uint4 wv[CH];                                                  // slot q = pass * 256 + tid -> (j, s, lane)
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int slot = q * 256 + tid;
+      const int ln = slot & 63, su = (slot >> 6) % CH, j = slot / (64 * CH);
+      const int n = n0 + j * 16 + (ln & 15);
+      const bool ok = s0 + su < nks && n < p.N;
+      const TA* src = pk ? W + ((long)((ok ? n : 0) >> 4) * nksT * 64 + (long)(ok ? s0 + su : 0) * 64 + ln) * G
+                         : W + (long)(ok ? n : 0) * p.K + (ok ? (s0 + su) * KS + (ln >> 4) * G : 0);
+      const uint4 v = ld16(src);
+      wv[q] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+    if (s0 > 0) __syncthreads();                                   // previous chunk's readers are done
+    if constexpr (PRO_LN) {
+      if (s0 == 0) for (int k = tid; k < p.K; k += 256) { lng[k] = p.ln_g[k]; lnb[k] = p.ln_b[k]; }
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q) wl[q * 256 + tid] = wv[q];
+    __syncthreads();
     PROBE(1);
     if constexpr (PRO_LN) {
-      // LayerNorm affine staged AFTER the operand loads were issued (single trip: K <= CH k-steps)
-      for (int k = tid; k < p.K; k += 256) { lng[k] = p.ln_g[k]; lnb[k] = p.ln_b[k]; }
-      __syncthreads();
-      // the wave holds whole rows; moments over this lane's chunks, then the 4 k-groups
+      // single chunk (host: K <= CH k-steps): the wave holds whole rows; moments over this lane's chunks + 4 k-groups
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < RW; ++m) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int u = 0; u < CH; ++u) moments_mid(fa[m][u], s1, s2, TA());
@@ -157,7 +143,7 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
           const int k = (s0 + u) * KS + lg * G;
-          if (s0 + u < nks && k < p.K && aok[m]) fa[m][u] = ln_frag_mid(fa[m][u], mean, rstd, lng, lnb, k, TA());
+          if (s0 + u < nks && aok[m]) fa[m][u] = ln_frag_mid(fa[m][u], mean, rstd, lng, lnb, k, TA());
         }
       }
     }
@@ -165,61 +151,72 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if constexpr (F32) {
-          const float* af = reinterpret_cast<const float*>(&fa[m][u]);
+      for (int j = 0; j < 4; ++j) {
+        const uint4 wf4 = wl[(j * CH + u) * 64 + lane];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float* wf = reinterpret_cast<const float*>(&fw[j][u]);
+        for (int m = 0; m < RW; ++m) {
+          if constexpr (F32) {
+            const float* af = reinterpret_cast<const float*>(&fa[m][u]);
+            const float* wf = reinterpret_cast<const float*>(&wf4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wf[e], acc[m][j], 0, 0, 0);
+          } else {
+            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&fa[m][u]),
+                                                               *reinterpret_cast<const bf16x8_t*>(&wf4), acc[m][j],
+                                                               0, 0, 0);
           }
-        } else {
-          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(&fa[m][u]);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, *reinterpret_cast<const bf16x8_t*>(&fw[j][u]),
-                                                               acc[m][j], 0, 0, 0);
         }
       }
     }
   }
   PROBE(3);
-  // ---- accumulators -> LDS tile: acc[m][j][e] = C[wm*32 + m*16 + lg*4 + e][wn*32 + j*16 + lr]
+  // ---- accumulators -> LDS tile (the weight buffer is free once every wave is past its last fragment read):
+  //      acc[m][j][e] = C[wave*WR + m*16 + lg*4 + e][j*16 + lr]
+  __syncthreads();
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < RW; ++m)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tile[wm * 32 + m * 16 + lg * 4 + e][wn * 32 + j * 16 + lr] = acc[m][j][e];
+      for (int e = 0; e < 4; ++e) tile[wave * WR + m * 16 + lg * 4 + e][j * 16 + lr] = acc[m][j][e];
   __syncthreads();
   PROBE(4);
-  if (!e_ok) return;
-  TC* cp = C + (long)eb * p.c_bs + (long)ei * p.c_rs + n0 + ec;
-  float y[16];
+  // ---- epilogue: row (pass * 64 + tid / 4), 16 consecutive columns per thread
+  const int ec = (tid & 3) * 16;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int c = n0 + ec + e;
-    float v = tile[er][ec + e] + ((bias && c < p.N) ? bias[c] : 0.f);
-    if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) v += resv[e];
-    if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) {
-      if constexpr (std::is_same<TC, bf16>::value) v = gelu_fast(v); else v = gelu_erf(v);
+  for (int q = 0; q < RW; ++q) {
+    const int er = q * 64 + (tid >> 2);
+    const int erow = m0 + er;
+    if (erow >= p.M) continue;
+    const int eb = erow / p.rpb, ei = erow - eb * p.rpb;
+    TC* cp = C + (long)eb * p.c_bs + (long)ei * p.c_rs + n0 + ec;
+    float y[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c = n0 + ec + e;
+      float v = tile[er][ec + e] + ((bias && c < p.N) ? bias[c] : 0.f);
+      if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) {
+        if (c < p.N) v += to_f32(R[(long)eb * p.r_bs + (long)ei * p.r_rs + c]);
+      }
+      if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) {
+        if constexpr (std::is_same<TC, bf16>::value) v = gelu_fast(v); else v = gelu_erf(v);
+      }
+      y[e] = v;
     }
-    y[e] = v;
-  }
-  if (n0 + ec + 16 <= p.N && (p.c_rs % 8) == 0 && (p.c_bs % 8) == 0) {
-    if constexpr (std::is_same<TC, float>::value) {
+    if (n0 + ec + 16 <= p.N && (p.c_rs % 8) == 0 && (p.c_bs % 8) == 0) {
+      if constexpr (std::is_same<TC, float>::value) {
 #pragma unroll
-      for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(cp + e) = float4{y[e], y[e + 1], y[e + 2], y[e + 3]};
+        for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(cp + e) = float4{y[e], y[e + 1], y[e + 2], y[e + 3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) store4(cp + e, reinterpret_cast<const float(&)[4]>(y[e]));
+      }
     } else {
 #pragma unroll
-      for (int e = 0; e < 16; e += 4) store4(cp + e, reinterpret_cast<const float(&)[4]>(y[e]));
+      for (int e = 0; e < 16; ++e)
+        if (n0 + ec + e < p.N) cp[e] = from_f32<TC>(y[e]);
     }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-      if (n0 + ec + e < p.N) cp[e] = from_f32<TC>(y[e]);
   }
   PROBE(5);
 }
@@ -227,14 +224,18 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
 template <typename TA, typename TC, int EPI>
 int launch_mid(simulst_handle* h, const void* A, const void* W, const float* bias, const void* R, void* C,
                const LinArgs& p) {
-  dim3 grid((p.N + 63) / 64, (p.M + 63) / 64);
-  KTimer t(h, SIMULST_K_LINEAR_SKINNY);
-  if (p.ln_g)
-    hipLaunchKernelGGL((mid_kernel<TA, TC, EPI, true>), grid, dim3(256), 0, h->stream, (const TA*)A, (const TA*)W,
-                       bias, (const TA*)R, (TC*)C, p);
-  else
-    hipLaunchKernelGGL((mid_kernel<TA, TC, EPI, false>), grid, dim3(256), 0, h->stream, (const TA*)A, (const TA*)W,
-                       bias, (const TA*)R, (TC*)C, p);
+  // 128-row tiles only when they still give every CU two workgroups (measured at 1024 rows: fc1 with 256 tall
+  // workgroups 14.0 us, with 512 of 64 rows 11.5 us; the vocabulary projection 20.7 vs 21.2 us)
+  const int nt = (p.N + 63) / 64;
+  const bool tall = (long)((p.M + 127) / 128) * nt >= 512;
+  dim3 grid(nt, tall ? (p.M + 127) / 128 : (p.M + 63) / 64);
+  KTimer t(h, SIMULST_K_LINEAR_TILE64);
+#define MID(LN, RWW)                                                                                                  \
+  hipLaunchKernelGGL((mid_kernel<TA, TC, EPI, LN, RWW>), grid, dim3(256), 0, h->stream, (const TA*)A, (const TA*)W,   \
+                     bias, (const TA*)R, (TC*)C, p)
+  if (p.ln_g) { if (tall) MID(true, 2); else MID(true, 1); }
+  else { if (tall) MID(false, 2); else MID(false, 1); }
+#undef MID
 #ifdef SL_PROBE
   {
     static int calls = 0;
@@ -269,8 +270,8 @@ int mid_by_epilogue(simulst_handle* h, int epi, const void* A, const void* W, co
 // shapes this kernel takes over from the 16 x BN kernel: co-scheduled batches with a wide output
 bool sl_mid_wanted(int dtype, const LinArgs& p) {
   const int KS = dtype == SIMULST_F32 ? 16 : 32;
-  const long blocks = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);     // one 64 x 64 tile per workgroup: fill the chip
-  return p.M >= 256 && p.N >= 512 && blocks >= 256 && p.K <= 1024 && (!p.ln_g || p.K <= 8 * KS);
+  const long blocks = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);     // 64 x 64 tiles: most of the chip gets one
+  return p.M >= 256 && p.N >= 512 && blocks >= 192 && p.K % KS == 0 && (!p.ln_g || p.K <= 8 * KS);
 }
 
 int sl_launch_mid(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
