@@ -113,6 +113,8 @@ def main():
                     help="replay the decode step as a hipGraph (measured neutral on MI355X: the step is bound by "
                          "kernel bodies, not by launch cost)")
     ap.add_argument("--cpu-sample", type=int, default=64)
+    ap.add_argument("--timed-only", action="store_true",
+                    help="warm-up + timed region only, no JSON line (rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -205,6 +207,8 @@ def main():
     log(f"timed region: {elapsed:.3f} s for {args.steps} steps -> {value:.0f} tokens/s")
 
     roofline, cpu_base = None, None
+    if args.timed_only:
+        return
     if rank == 0:
         # ---- instrumented replay of ONE step: HIP events around every launch, per kernel class
         h = model.ops.h
