@@ -129,6 +129,20 @@ typedef struct {
 int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, const void* A, const void* W,
                    const float* bias, const void* R, void* C, void* aux);
 
+/* ---- feature front-end -----------------------------------------
+ * Kaldi-compatible log-mel filterbank of B waveforms: frame f of row b covers samples [160 f, 160 f + 400) of
+ * wave[b * wave_stride ...] (16 kHz, 25 ms window, 10 ms shift, snip_edges), DC removal, pre-emphasis, Povey window,
+ * 512-point power spectrum, n_mel triangular mel filters, log(max(e, FLT_EPSILON)).  Replaces the
+ * _get_kaldi_fbank / _get_torchaudio_fbank call of OnlineFeatureExtractor.__call__ (agents/default_agent.py:66-71)
+ * and DATA/data_utils.py:73-98.  Tables are caller-made, once (simulst_amd/fbank.py shows how):
+ *   window [400] fp32; tw_cos / tw_sin [256] = cos / sin(2 pi k / 512);
+ *   mel_lo [n_mel] first FFT bin of each filter, mel_w [n_mel][24] its weights (zero padded).
+ * out [B][n_frames][n_mel] in out_dtype.  The residual-sample carry between READs stays on the host
+ * (fbank.OnlineFeatureExtractor), as in the reference. */
+int simulst_fbank(simulst_handle* h, const float* wave, int64_t wave_stride, const float* window, const float* tw_cos,
+                  const float* tw_sin, const int32_t* mel_lo, const float* mel_w, void* out, int32_t B,
+                  int32_t n_frames, int32_t n_mel, float preemphasis, int32_t out_dtype);
+
 /* ---- causal conv front-end ------------------------------------------------------
  * conv-pos: y = x + gelu(causal grouped Conv1d(x)) then rows t >= lengths[b] zeroed.
  * x, y [B][T][D] (+ optional `hist` [B][k-1][D] = the k-1 frames before x for streaming,

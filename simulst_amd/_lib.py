@@ -80,6 +80,7 @@ SIGNATURES = {
     "simulst_pack_fragment_major": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
+    "simulst_fbank": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _i32],
     "simulst_conv_pos_mfma": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
     "simulst_emformer_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_layernorm": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i32],
