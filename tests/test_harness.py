@@ -1,0 +1,94 @@
+"""word merging (units_to_segment) pinned to the fixture recorded from the reference method, the
+oracle and product copies against it, latency scorers incl. computation-aware variants, instance log on the GPU."""
+import json
+import os
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _fixture():
+    return json.load(open(os.path.join(HERE, "golden", "g15_units_to_segment.json")))
+
+
+def _replay(push_fn):
+    g = _fixture()
+    for case in g["cases"]:
+        push_fn(g, case)
+
+
+def test_oracle_units_to_segment_matches_reference_fixture():
+    from oracle import harness as oh
+
+    def run(g, case):
+        symbols = ["<s>", "<pad>", "</s>", "<unk>"] + g["pieces"]
+        q, target = oh.Queue(), []
+        for ev in case["events"]:
+            q.append(ev["pushed"]); target.append(ev["pushed"])
+            out = oh.units_to_segment(q, symbols, g["eos"], len(target), case["max_len"])
+            assert out == ev["returned"], (case["tokens"], ev)
+            assert q.value == ev["queue_after"]
+    _replay(run)
+
+
+def test_product_units_to_segment_matches_reference_fixture():
+    from simulst_amd import harness as ph
+
+    def run(g, case):
+        d = ph.Dictionary(["<s>", "<pad>", "</s>", "<unk>"] + g["pieces"], g["eos"])
+        q, target = ph.ListEntry(), []
+        for ev in case["events"]:
+            q.append(ev["pushed"]); target.append(ev["pushed"])
+            out = ph.units_to_segment(q, d, len(target), case["max_len"])
+            assert out == ev["returned"], (case["tokens"], ev)
+            assert q.value == ev["queue_after"]
+    _replay(run)
+
+
+def test_latency_scores_and_schema():
+    from oracle import harness as oh
+    from simulst_amd import harness as ph
+    delays = [975.0, 975.0, 1615.0, 2255.0, 2895.0, 3000.0]
+    elapsed = [d + 3.0 * (i + 1) for i, d in enumerate(delays)]
+    a, b = oh.latency_scores(delays, elapsed, 3000.0), ph.latency_scores(delays, elapsed, 3000.0)
+    assert a == b and set(a) == {"AL", "AL_CA", "AP", "AP_CA", "DAL", "DAL_CA"}
+    assert a["AL_CA"] > a["AL"] and a["AP_CA"] > a["AP"] and a["DAL_CA"] >= a["DAL"]
+    # known answer: wait-until-end (every delay = source length) => AL = source length, AP = 1
+    w = ph.latency_scores([3000.0] * 4, [3000.0] * 4, 3000.0)
+    assert w["AL"] == 3000.0 and w["AP"] == 1.0
+    inst = [{"prediction": "a b c d", "metric": {"latency": a}}, {"prediction": "a b x d e", "metric": {"latency": a}}]
+    s = ph.corpus_scores(inst, ["a b c d", "a b c d e"])
+    assert set(s) == {"Quality", "Latency"} and set(s["Latency"]) == set(a) and 0.0 < s["Quality"]["BLEU"] < 100.0
+    assert ph.corpus_bleu(["a b c d e"], ["a b c d e"]) == pytest.approx(100.0)
+
+
+@pytest.mark.gpu
+def test_run_instance_words_and_delays():
+    """Word-level instance log on the GPU agent: the words are the merge of the committed units, each word's delay is
+    the source time at which its LAST unit was followed by the next word start (monotone, <= source length), and the
+    unit-level run of the same agent commits the same tokens."""
+    from simulst_amd import harness as ph
+    from simulst_amd.agent import FairseqSimulSTAgent
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, waitk_lagging=3, max_target_positions=40)
+    w = init_model(cfg, seed=999)
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0          # tied output row: EOS never wins, the run ends on max_len
+    model = SimulSTModel(cfg, w, dtype=torch.float32)
+    agent = FairseqSimulSTAgent(model)
+    # synthetic vocabulary: every third id starts a word
+    symbols = [("▁" if i % 3 == 0 else "") + f"t{i}" for i in range(cfg.vocab)]
+    symbols[cfg.eos] = "</s>"
+    d = ph.Dictionary(symbols, cfg.eos)
+    fb = torch.randn(520, 80, generator=torch.Generator().manual_seed(5)).cuda()
+    units = agent.run_utterance(fb)
+    inst = ph.run_instance(agent, fb, d, index=7)
+    hyp = d.string(units["tokens"], "sentencepiece")
+    assert inst["prediction"].replace(" ", "") == hyp.replace(" ", "")
+    assert inst["prediction_length"] == len(inst["delays"]) == len(inst["elapsed"]) > 0
+    assert all(a <= b for a, b in zip(inst["delays"], inst["delays"][1:]))
+    assert all(e >= dl for e, dl in zip(inst["elapsed"], inst["delays"])) and inst["delays"][-1] <= inst["source_length"]
+    assert set(inst["metric"]["latency"]) == {"AL", "AL_CA", "AP", "AP_CA", "DAL", "DAL_CA"}
