@@ -310,6 +310,24 @@ int simulst_greedy_argmax(simulst_handle* h, const float* logits, const float* e
  * simulst_linear_desc.w_fragment_major; out has N*K elements.  One-off, at model load. */
 int simulst_pack_fragment_major(simulst_handle* h, const void* W, void* out, int32_t N, int32_t K, int32_t dtype);
 
+/* ---- CTC best alignment ----------------------------------------
+ * Maximum-probability CTC state sequence of each utterance given log-probabilities and its target labels: the
+ * reference's CUDA kernel (criterion/best_alignment/best_alignment.cu:58-187) together with the final-state choice,
+ * back-tracking and optional label translation its Python wrapper does (criterion/best_alignment/__init__.py:56-111).
+ *   log_probs  fp32, element (t, b, v) at t*lp_stride_t + b*lp_stride_b + v*lp_stride_v (after log_softmax)
+ *   targets    int64 [N][>= max_target_length], row stride tg_stride_b;  input_lengths / target_lengths int64 [N]
+ *   out        int64 [N][S]: CTC state in [0, 2T+1) per frame (as_labels: the label, blank for even states);
+ *              frames >= input_lengths[b] get state 0 / blank, as the reference returns
+ *   scratch    simulst_ctc_best_alignment_scratch_bytes(N, S, max_target_length) bytes (1-byte back-pointers)
+ *   neg_log_likelihood  optional fp32 [N]: -log of the two final Viterbi scores' sum (the kernel's first output)
+ * Tie rules are the reference's: predecessor preference s, s-1, s-2 under strict '>', first maximum at the end. */
+int64_t simulst_ctc_best_alignment_scratch_bytes(int32_t N, int32_t S, int32_t max_target_length);
+int simulst_ctc_best_alignment(simulst_handle* h, const float* log_probs, int64_t lp_stride_t, int64_t lp_stride_b,
+                               int64_t lp_stride_v, const int64_t* targets, int64_t tg_stride_b,
+                               const int64_t* input_lengths, const int64_t* target_lengths, int32_t S, int32_t N,
+                               int32_t max_target_length, int32_t blank, int32_t as_labels, void* scratch,
+                               int64_t* out, float* neg_log_likelihood);
+
 /* ---- whole decode steps on the device ----------------------------------------------
  * Runs n_steps consecutive WRITE steps of the MMA / wait-k decoder for a batch in lockstep with no
  * host round trip: embed -> n_layers x { LN+QKV, self-attention, out-proj+res, LN+q-proj,

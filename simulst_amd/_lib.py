@@ -80,6 +80,9 @@ SIGNATURES = {
     "simulst_pack_fragment_major": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
+    "simulst_ctc_best_alignment_scratch_bytes": [_i32, _i32, _i32],
+    "simulst_ctc_best_alignment": [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp,
+                                   _vp, _vp],
     "simulst_fbank": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _i32],
     "simulst_conv_pos_mfma": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
     "simulst_emformer_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
@@ -122,7 +125,8 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "simulst_last_error" else C.c_int
+        fn.restype = (C.c_char_p if name == "simulst_last_error"
+                      else C.c_int64 if name == "simulst_ctc_best_alignment_scratch_bytes" else C.c_int)
     _lib = lib
     return lib
 
