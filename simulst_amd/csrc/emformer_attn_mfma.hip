@@ -36,7 +36,13 @@ __global__ __launch_bounds__(256) void emformer_attn_mfma_kernel(
     bf16* __restrict__ CTX, EmfArgsM a) {
   __shared__ __attribute__((aligned(16))) unsigned short vt_all[4][64 * VT_STRIDE];
   __shared__ float inv_all[4][32];
-  const int i = blockIdx.x, b = blockIdx.y;
+  // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; permuting them makes every XCD walk through
+  // consecutive (utterance, segment) pairs, so the left-context / memory rows a segment shares with its two
+  // predecessors are still in that XCD's L2 (each key row is used by ~3 segments)
+  const int nb_full = (int)gridDim.x & ~7;
+  const int bid = (int)blockIdx.x < nb_full ? ((int)blockIdx.x & 7) * (nb_full >> 3) + ((int)blockIdx.x >> 3)
+                                            : (int)blockIdx.x;
+  const int i = bid % a.n_seg, b = bid / a.n_seg;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int D3 = 3 * a.D;
@@ -227,7 +233,7 @@ int sl_emformer_attention_mfma(simulst_handle* h, const simulst_emf_attn_desc* d
   a.rows_z = d->n_mem + d->n_seg * d->R + d->T + n_sum;
   a.rows_c = d->n_seg * d->R + d->T + n_sum;
   KTimer t(h, SIMULST_K_EMF_ATTN);
-  hipLaunchKernelGGL(emformer_attn_mfma_kernel, dim3(d->n_seg, d->B), dim3(256), 0, h->stream, (const bf16*)QKV,
+  hipLaunchKernelGGL(emformer_attn_mfma_kernel, dim3(d->n_seg * d->B), dim3(256), 0, h->stream, (const bf16*)QKV,
                      lengths, (const bf16*)lc_k, (const bf16*)lc_v, lc_valid, n_mem_valid, (bf16*)CTX, a);
   return sl_launch_status(h, "simulst_emformer_attention(mfma)");
 }

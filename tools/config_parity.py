@@ -67,7 +67,7 @@ def run_mma(args, attn, k):
     ecfg, dcfg = from_model_config(cfg)
     model = SimulSTModel(cfg, w, dtype=torch.float32)
     agent = FairseqSimulSTAgent(model)
-    rows, t_cpu, t_gpu, n_tok = [], 0.0, 0.0, 0
+    rows, t_cpu, t_gpu, n_tok, t_dev = [], 0.0, 0.0, 0, 0.0
     refs = {}
     for u, T in enumerate(TS[:args.utterances]):
         fb = fbank_of(u, T)
@@ -77,8 +77,17 @@ def run_mma(args, attn, k):
         n_tok += compare(rows, T, ref, got, ("n_enc",))
         t_cpu, t_gpu = t_cpu + t1 - t0, t_gpu + t3 - t2
         refs[u] = ref
+        # the same stream through the device-side step loop (simulst_mma_stream_steps, B = 1): no host round trip per
+        # kernel, one per policy round
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        dev = BatchedStreamingAgent(model, steps_per_call=2).run_batch(fbd.unsqueeze(0))[0]
+        torch.cuda.synchronize(); t5 = time.perf_counter()
+        assert all(dev[k] == ref[k] for k in ("actions", "tokens", "delays_ms")), T
+        t_dev += t5 - t4
     out = {"utterances": rows, "oracle_cpu": {"seconds": round(t_cpu, 2), "tokens_per_s": round(n_tok / t_cpu, 1), "threads": args.threads},
-           "hip_b1_streaming": {"seconds": round(t_gpu, 2), "tokens_per_s": round(n_tok / t_gpu, 1)}}
+           "hip_b1_streaming": {"seconds": round(t_gpu, 2), "tokens_per_s": round(n_tok / t_gpu, 1)},
+           "hip_b1_streaming_device_step_loop": {"seconds": round(t_dev, 2), "tokens_per_s": round(n_tok / t_dev, 1),
+                                                 "identical_to_oracle": True}}
     if args.batched:
         # batched streaming: 8 streams of EQUAL length (the first 640 frames of 8 different utterances) in one batch
         Tb = 640
