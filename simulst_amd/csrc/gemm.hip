@@ -231,6 +231,67 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
         }
       }
     }
+  } else if constexpr ((EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_EMF_OUT) && std::is_same<TC, bf16>::value &&
+                       std::is_same<TA, bf16>::value && (WM * (BN + 4) * 4 <= (LDS_A + LDS_W) * 2)) {
+    // bf16 output WITH residual (fc2, Emformer out-proj): fp32 (acc + bias) staged through LDS one wave-row (WM rows)
+    // at a time, then every thread owns 8 consecutive columns of a row: one 16-byte residual load, add, round once,
+    // one 16-byte store -- instead of 64 two-byte loads and stores per lane in the accumulator layout
+    constexpr int FS = BN + 4;                        // fp32 elements per staged row
+    float* Fs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if (wr == half) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int cl = wc * WN + j * 32 + lcol;
+          const int c = n0 + cl;
+          const float bv = (bias && c < p.N) ? bias[c] : 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              Fs[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi) * FS + cl] = acc[i][j][e] + bv;
+        }
+      }
+      __syncthreads();
+      constexpr int CHUNKS = WM * BN / 8;
+      for (int ch = tid; ch < CHUNKS; ch += 256) {
+        const int rl = ch / (BN / 8), c8 = (ch % (BN / 8)) * 8;
+        const int r = m0 + half * WM + rl, c = n0 + c8;
+        if (r >= p.M || c >= p.N) continue;
+        const int b = r / p.rpb, ii = r - b * p.rpb;
+        const float* fs = &Fs[rl * FS + c8];
+        const bool vec = c + 8 <= p.N && ((p.c_rs | p.c_bs | p.r_rs | p.r_bs) & 7) == 0;
+        if constexpr (EPI == SIMULST_EPI_EMF_OUT) {
+          if (ii >= p.n_main) {                       // summary rows: tanh into the next layer's memory bank
+            const int srow = ii - p.n_main;
+            if (srow < p.aux_rows)
+              for (int q = 0; q < 8 && c + q < p.N; ++q)
+                aux[(long)b * p.aux_bs + (long)srow * p.N + c + q] = from_f32<TA>(tanhf(fs[q]));
+            continue;
+          }
+        }
+        const TA* rp = R + (long)b * p.r_bs + (long)ii * p.r_rs + c;
+        TC* dst = C + (long)b * p.c_bs + (long)ii * p.c_rs + c;
+        if (vec) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(rp);
+          const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
+          unsigned int ou[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = fs[2 * q] + __uint_as_float(ru[q] << 16);
+            const float hi = fs[2 * q + 1] + __uint_as_float(ru[q] & 0xffff0000u);
+            bf16 l2 = __float2bfloat16(lo), h2 = __float2bfloat16(hi);
+            ou[q] = (unsigned int)(*reinterpret_cast<unsigned short*>(&l2)) |
+                    ((unsigned int)(*reinterpret_cast<unsigned short*>(&h2)) << 16);
+          }
+          *reinterpret_cast<uint4*>(dst) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+        } else {
+          for (int q = 0; q < 8 && c + q < p.N; ++q) dst[q] = from_f32<TC>(fs[q] + to_f32(rp[q]));
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
