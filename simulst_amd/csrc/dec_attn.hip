@@ -59,6 +59,100 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const T* __restrict__ qk
   if (tid < d) ctx[(long)b * D + h * d + tid] = from_f32<T>(o);
 }
 
+// Wave-per-(head, utterance) variant for bf16, head_dim 64 and <= 128 cached positions: everything -- scores, max,
+// sum, PV -- is reduced with lane shuffles inside ONE wavefront, so the kernel has no workgroup barrier at all (the
+// block version above spends most of its time in ~8 of them for 14 KB of K/V).  8 lanes share a key row, 8 rows per
+// pass, <= 16 passes; a workgroup is just 4 independent waves.
+__global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc,
+                                                             bf16* __restrict__ vc, const int* __restrict__ n_prev,
+                                                             int np_uniform, bf16* __restrict__ ctx, int BH, int H,
+                                                             int cap) {
+  constexpr int d = 64, NPL = 8, RPP = 8, MAXP = 16;       // lanes per row, rows per pass, passes
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= BH) return;
+  const int b = pair / H, h = pair - b * H;
+  const int D = H * d;
+  const int np = np_uniform >= 0 ? np_uniform : n_prev[b];
+  const int n = np + 1;
+  const bf16* row = qkv + (long)b * 3 * D;
+  bf16* Kh = kc + ((long)b * H + h) * cap * d;
+  bf16* Vh = vc + ((long)b * H + h) * cap * d;
+  const int c = lane & (NPL - 1), rg = lane >> 3;
+  const bf16* k_new = row + D + h * d;
+  const bf16* v_new = row + 2 * D + h * d;
+  const uint4 qv = *reinterpret_cast<const uint4*>(row + h * d + c * 8);
+  uint4 kk[MAXP], vv[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    if (i * RPP < n) {
+      int j = rg + RPP * i;
+      if (j >= n) j = 0;
+      const bf16* kr = (j == np) ? k_new : Kh + (long)j * d;
+      const bf16* vr = (j == np) ? v_new : Vh + (long)j * d;
+      kk[i] = *reinterpret_cast<const uint4*>(kr + c * 8);
+      vv[i] = *reinterpret_cast<const uint4*>(vr + c * 8);
+    }
+  }
+  // append the new position for the following steps (the 8 lanes of row group 0 hold chunk c)
+  if (rg == 0) {
+    *reinterpret_cast<uint4*>(Kh + (long)np * d + c * 8) = *reinterpret_cast<const uint4*>(k_new + c * 8);
+    *reinterpret_cast<uint4*>(Vh + (long)np * d + c * 8) = *reinterpret_cast<const uint4*>(v_new + c * 8);
+  }
+  float qf[8];
+  attn::VL<bf16>::cvt(qv, qf);
+  const float qscale = rsqrtf((float)d);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qf[e] *= qscale;
+  float sc[MAXP];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    sc[i] = -INFINITY;
+    if (i * RPP < n) {
+      float ka[8];
+      attn::VL<bf16>::cvt(kk[i], ka);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(qf[e], ka[e], s);
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (rg + RPP * i < n) { sc[i] = s; mx = fmaxf(mx, s); }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float den = 0.f, a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    if (i * RPP < n && rg + RPP * i < n) {
+      const float p = expf(sc[i] - mx);
+      den += p;
+      float va[8];
+      attn::VL<bf16>::cvt(vv[i], va);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = fmaf(p, va[e], a[e]);
+    }
+  }
+  // across the 8 row groups (lanes 8, 16, 32 apart); den is identical on the 8 lanes of a row
+  den += __shfl_xor(den, 8, 64); den += __shfl_xor(den, 16, 64); den += __shfl_xor(den, 32, 64);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] += __shfl_xor(a[e], 8, 64); a[e] += __shfl_xor(a[e], 16, 64); a[e] += __shfl_xor(a[e], 32, 64);
+  }
+  if (rg == 0) {
+    const float inv = 1.0f / den;
+    float o[4];
+    bf16* dst = ctx + (long)b * D + h * d + c * 8;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = a[half * 4 + e] * inv;
+      store4(dst + half * 4, o);
+    }
+  }
+}
+
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ Kc,
                                                          const T* __restrict__ Vc, const long* __restrict__ step,
@@ -137,6 +231,12 @@ int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v
   if (B <= 0) return SIMULST_OK;
   KTimer t(h, SIMULST_K_DEC_SELF_ATTN);
   dim3 grid(H, B);
+  if (dtype == SIMULST_BF16 && d == 64 && cap <= 128 && !h->force_valu_attention) {
+    // barrier-free wave-per-(head, utterance) kernel: every cached position fits 16 passes of 8 rows
+    hipLaunchKernelGGL(self_attn_wave_kernel, dim3((B * H + 3) / 4), dim3(256), 0, h->stream, (const bf16*)qkv,
+                       (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, B * H, H, cap);
+    return sl_launch_status(h, "simulst_decoder_self_attention(wave)");
+  }
 #define SA_F32(NP) hipLaunchKernelGGL((self_attn_kernel<float, NP>), grid, dim3(256), lds, h->stream, (const float*)qkv, \
                                      (float*)k_cache, (float*)v_cache, n_prev, np_uniform, (float*)ctx, H, d, cap)
 #define SA_BF16(NP) hipLaunchKernelGGL((self_attn_kernel<bf16, NP>), grid, dim3(256), lds, h->stream, (const bf16*)qkv, \

@@ -505,3 +505,41 @@ def test_conv_pos_mfma_equals_valu_kernel(ops):
                 ref = ref * (torch.arange(T, device="cuda")[None, :, None] < L[:, None, None])
             torch.testing.assert_close(y1.float(), ref, atol=3e-2, rtol=2e-2)
             torch.testing.assert_close(y1.float(), y0.float(), atol=3e-2, rtol=2e-2)
+
+
+def test_decoder_self_attention_wave_kernel(ops):
+    """bf16, head_dim 64, cache capacity <= 128: the barrier-free wave-per-(head, utterance) kernel, rows at DIFFERENT
+    target positions (device-side n_prev), every position up to the capacity, against torch fp32 and against the
+    workgroup kernel (test hook simulst_debug_force_valu_attention)."""
+    g = torch.Generator().manual_seed(18)
+    B, H, d, cap = 7, 4, 64, 128
+    D = H * d
+    kc = torch.zeros(B, H, cap, d, device="cuda", dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    kc2, vc2 = kc.clone(), vc.clone()
+    start = torch.tensor([0, 1, 5, 8, 63, 64, 100])
+    hist_k = torch.randn(B, H, cap, d, generator=g).to(torch.bfloat16)
+    hist_v = torch.randn(B, H, cap, d, generator=g).to(torch.bfloat16)
+    for b in range(B):
+        kc[b, :, :start[b]] = hist_k[b, :, :start[b]].cuda(); vc[b, :, :start[b]] = hist_v[b, :, :start[b]].cuda()
+    kc2.copy_(kc); vc2.copy_(vc)
+    n_prev = start.to(torch.int32).clone()
+    for step in range(27):
+        qkv = dev(torch.randn(B, 3 * D, generator=g), torch.bfloat16)
+        ctx = ops.decoder_self_attention(qkv, kc, vc, dev(n_prev))
+        ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, 1)
+        try:
+            ctx_blk = ops.decoder_self_attention(qkv, kc2, vc2, dev(n_prev))
+        finally:
+            ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, 0)
+        f = qkv.float().cpu()
+        for b in range(B):
+            n = int(n_prev[b]) + 1
+            K = kc[b, :, :n].float().cpu(); V = vc[b, :, :n].float().cpu()
+            assert torch.equal(K[:, -1], f[b, D:2 * D].view(H, d)) and torch.equal(V[:, -1], f[b, 2 * D:].view(H, d))
+            q = f[b, :D].view(H, 1, d) * d ** -0.5
+            ref = (torch.softmax(q @ K.transpose(-1, -2), -1) @ V).view(D)
+            close(ctx[b], ref, atol=3e-2, rtol=3e-2)
+        close(ctx, ctx_blk.float().cpu(), atol=2e-2, rtol=2e-2)
+        assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
+        n_prev += 1
