@@ -46,8 +46,10 @@ struct HeadSplit {
 //  2. wave 0: mask the past, force the stop, first index with p >= 0.5
 //     (modules/monotonic_multihead_attention.py:196-257) -> head_step, head_read
 //  3. hard gather / softmax over keys <= step (:261-297), PV
-template <typename T, int NP>
-__global__ __launch_bounds__(256, NP >= 16 ? 2 : 3) void policy_cross_attn_kernel(
+// FQ = the fused-query instantiation (LN2 + q-projection inside the launch, <= 128 rows); the plain one drops that code
+// and its registers and runs 4 workgroups per CU
+template <typename T, int NP, bool FQ>
+__global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross_attn_kernel(
     const T* __restrict__ qm, const T* __restrict__ qs, const T* __restrict__ Km, const T* __restrict__ Ks,
     const T* __restrict__ Vc, float energy_bias, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
     long* __restrict__ head_step, unsigned char* __restrict__ head_read, T* __restrict__ ctx, int H, int d,
@@ -96,12 +98,12 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : 3) void policy_cross_attn_kerne
   const int tg = tgt_idx ? tgt_idx[b] : 0;    // scalar inputs of the policy: issued with the prefetch
   const long hs = head_step[r];
   if (n_hint < 0) n_hint = attn_type == SIMULST_ATTN_WAITK ? (tg + waitk_k) * ratio : S_cap;
-  const bool fusedq = xres != nullptr;
+  const bool fusedq = FQ && xres != nullptr;
   const int n_pref = min(S_cap, n_hint);
   if constexpr (NP > 0) {
     if (fast) attn::prefetch2<T, NP>(rg2, fusedq ? nullptr : qs + (long)b * D + h * d, Kh, D, Vh, D, n_pref, -1, nullptr, nullptr);
   }
-  if (fusedq) {
+  if constexpr (FQ) if (fusedq) {
     // LayerNorm of the residual row (fp32 stats, rounded to the activation dtype like the unfused path), then
     // 4 threads per output channel: 16-byte loads along K, shuffle-reduce, bias, round, scale
     float ps = 0.f;
@@ -374,14 +376,16 @@ int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         const float* bqs, const StreamCtl& ctl, const HeadSplit& hs) {
   const size_t lds = (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
-#define PC_LAUNCH(NP)                                                                                                  \
-  hipLaunchKernelGGL((policy_cross_attn_kernel<T, NP>), dim3(H, B), dim3(256), lds, h->stream, (const T*)qm,           \
+#define PC_LAUNCH_Q(NP, FQ)                                                                                            \
+  hipLaunchKernelGGL((policy_cross_attn_kernel<T, NP, FQ>), dim3(H, B), dim3(256), lds, h->stream, (const T*)qm,       \
                      (const T*)qs, (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx,            \
                      (long*)head_step, head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres,   \
                      n_hint, (const T*)xres, ln_g, ln_b, (const T*)Wqm, bqm, (const T*)Wqs, bqs, ctl, hs.po, hs.bo,     \
                      (T*)hs.x_mid, hs.w_packed)
+#define PC_LAUNCH(NP) do { if (xres) PC_LAUNCH_Q(NP, true); else PC_LAUNCH_Q(NP, false); } while (0)
   SL_DISPATCH_NP(attn::lanes_per_row<T>(d), PC_LAUNCH)
 #undef PC_LAUNCH
+#undef PC_LAUNCH_Q
   return sl_launch_status(h, "simulst_policy_cross_attention");
 }
 
