@@ -227,16 +227,19 @@ def main():
                 torch.cuda.synchronize()
                 if rep >= 2:
                     group_s = min(group_s, time.perf_counter() - tg0)
-        h.timer_reset()
-        h.timer_enable(-1, True)
-        torch.cuda.synchronize()
-        tr0 = time.perf_counter()
-        with torch.no_grad():
-            model.generate_offline(fb_all, L_all, n_steps=N_STEPS_DECODE, mask_eos=True)
-        torch.cuda.synchronize()
-        replay_s = time.perf_counter() - tr0
-        h.timer_enable(-1, False)
-        raw = {_lib.KERNEL_CLASS_NAMES[c]: h.timer_read(c) for c in range(_lib.K_COUNT)}
+        raw, replay_s = None, float("inf")
+        for rep in range(2):                   # two instrumented replays, per class the faster one (a replay that hits
+            h.timer_reset()                    # allocator growth or a clock ramp would otherwise name the wrong class)
+            h.timer_enable(-1, True)
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            with torch.no_grad():
+                model.generate_offline(fb_all, L_all, n_steps=N_STEPS_DECODE, mask_eos=True)
+            torch.cuda.synchronize()
+            replay_s = min(replay_s, time.perf_counter() - tr0)
+            h.timer_enable(-1, False)
+            cur = {_lib.KERNEL_CLASS_NAMES[c]: h.timer_read(c) for c in range(_lib.K_COUNT)}
+            raw = cur if raw is None else {k: (min(raw[k][0], cur[k][0]), cur[k][1]) for k in cur}
         # every timed launch carries one extra event record; its cost = (instrumented pass - plain pass)
         # spread over the launches, removed from each class
         n_launch = sum(v[1] for v in raw.values())

@@ -401,7 +401,7 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
   p.w_packed = d->w_fragment_major;
   if (d->ln_gamma || d->ln_beta)
     SL_REQUIRE(h, d->ln_gamma && d->ln_beta, SIMULST_E_NULL, "simulst_linear: LN prologue needs gamma and beta");
-  const bool skinny_ok = M <= 1024 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&
+  const bool skinny_ok = M <= 2048 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&
                          d->epilogue != SIMULST_EPI_EMF_OUT;
   if (p.w_packed)
     SL_REQUIRE(h, skinny_ok && d->N % 16 == 0 && d->K % (4 * G) == 0, SIMULST_E_SHAPE,
