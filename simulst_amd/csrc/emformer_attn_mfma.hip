@@ -125,15 +125,27 @@ __global__ __launch_bounds__(256) void emformer_attn_mfma_kernel(
         qf[kk] = q_ok ? v : zero4;
       }
     }
-    // ---- V transposed into LDS: vt[channel][key], zero beyond nk (P is 0 there, but 0 * garbage != 0)
-    for (int j = 0; j < 64; ++j) {
-      unsigned short v = 0;
-      if (j < nk) {
-        const bf16 *kp, *vp;
-        key_rows(j, kp, vp);
-        v = *reinterpret_cast<const unsigned short*>(vp + hc + lane);
+    // ---- V transposed into LDS: vt[channel][key], zero beyond nk (P is 0 there, but 0 * garbage != 0).  Rows are
+    //      fetched as 16-byte chunks (8 lanes per key row, 8 rows per wave load) and scattered from registers
+    {
+      uint4 vrows[8];
+      const int vc8 = (lane & 7) * 8;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int j = 8 * it + (lane >> 3);
+        const bool ok = j < nk;
+        const bf16 *kp, *vp = Zb + 2 * a.D;
+        if (ok) key_rows(j, kp, vp);
+        const uint4 v = *reinterpret_cast<const uint4*>(vp + hc + vc8);
+        vrows[it] = ok ? v : zero4;
       }
-      vt[lane * VT_STRIDE + j] = v;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int j = 8 * it + (lane >> 3);
+        const unsigned short* e = reinterpret_cast<const unsigned short*>(&vrows[it]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vt[(vc8 + q) * VT_STRIDE + j] = e[q];
+      }
     }
     // ---- S^T tiles: st[t][e] = score(key 32t + (e&3) + 8(e>>2) + 4lh, query lr)
     f32x16 st[2];
@@ -199,19 +211,28 @@ __global__ __launch_bounds__(256) void emformer_attn_mfma_kernel(
                                                           *reinterpret_cast<const bf16x8_t*>(&vb), o[nt], 0, 0, 0);
         }
       }
-    // ---- o[nt][e] = ctx(query (e&3) + 8(e>>2) + 4lh, channel 32nt + lr) / sum(query)
+    // ---- o[nt][e] = ctx(query (e&3) + 8(e>>2) + 4lh, channel 32nt + lr) / sum(query): through LDS (the V image is
+    //      consumed) as [query][64 channels], then 16-byte row-contiguous stores
+    constexpr int OT_STRIDE = 72;
+    unsigned short* ot = vt;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int qi = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const float inv = invs[qi];
+      bf16 v0 = __float2bfloat16(o[0][e] * inv), v1 = __float2bfloat16(o[1][e] * inv);
+      ot[qi * OT_STRIDE + lr] = *reinterpret_cast<unsigned short*>(&v0);
+      ot[qi * OT_STRIDE + 32 + lr] = *reinterpret_cast<unsigned short*>(&v1);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int qi = 8 * it + (lane >> 3);
       if (qi < nq) {
         int cr;
         if (qi < a.R) cr = i * a.R + qi;
         else if (qi < a.R + (t1 - t0)) cr = n_rc + t0 + qi - a.R;
         else cr = n_rc + a.T + i;
-        const float inv = invs[qi];
-        bf16* dst = CTX + ((long)b * a.rows_c + cr) * a.D + hc + lr;
-        dst[0] = __float2bfloat16(o[0][e] * inv);
-        dst[32] = __float2bfloat16(o[1][e] * inv);
+        *reinterpret_cast<uint4*>(CTX + ((long)b * a.rows_c + cr) * a.D + hc + (lane & 7) * 8) =
+            *reinterpret_cast<const uint4*>(&ot[qi * OT_STRIDE + (lane & 7) * 8]);
       }
     }
     __builtin_amdgcn_wave_barrier();
