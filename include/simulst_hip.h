@@ -124,6 +124,9 @@ typedef struct {
                                /*   ((n/16 * K/KS + k/KS) * 64 + (k%KS)/G * 16 + n%16) * G + k%G,                */
                                /* G = 8 (bf16) / 4 (fp32) elements, KS = 4 G: each wave load is 1 KB contiguous. */
                                /* simulst_pack_fragment_major produces it.                                       */
+  int32_t c_head_dim;          /* > 0 (bias epilogue only): HEAD-MAJOR output, column c of row (b, i) is stored at */
+  int64_t c_head_stride;       /*   b*c_batch_stride + (c / c_head_dim)*c_head_stride + i*c_row_stride + c % c_head_dim */
+                               /* -- how the cross-attention K / V projections land in [B][H][S_cap][head_dim].   */
 } simulst_linear_desc;
 
 int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, const void* A, const void* W,
@@ -240,7 +243,8 @@ int simulst_expected_soft_attention(simulst_handle* h, const float* alpha, const
 /* Step probabilities for ONE decode step of every utterance, with fixed pre-decision:
  * p [B*H][S_cap] fp32 (zero beyond key_len[b]).
  *   q     [B][D]  monotonic-energy query = q_proj(x) (1/sqrt(d) scaling applied inside)
- *   Kmono [B][S_cap][D] = k_proj(encoder states), cached by the caller as the source grows.
+ *   Kmono [B][H][S_cap][head_dim] (HEAD-MAJOR) = k_proj(encoder states), cached by the caller as the source grows
+ *         (simulst_linear with c_head_dim writes it in this order).
  *   Pooled key j = mean of Kmono frames [j*ratio, min((j+1)*ratio, len)): AvgPool1d(ceil_mode)
  *   commutes with the affine k_proj, so pool -> k_proj of the reference
  *   (modules/fixed_pre_decision.py:97-121) equals k_proj -> pool up to fp32 rounding; the pooled
@@ -288,7 +292,7 @@ int simulst_decoder_self_attention(simulst_handle* h, const void* qkv, void* k_c
                                    int32_t cap, int32_t dtype);
 
 /* Monotonic cross-attention value aggregation for one decode step.
- * q [B][D] (soft-energy query = q_proj(x), the 1/sqrt(d) scaling is applied inside), Kc/Vc [B][S_cap][D] cached
+ * q [B][D] (soft-energy query = q_proj(x), the 1/sqrt(d) scaling is applied inside), Kc/Vc [B][H][S_cap][head_dim] (head-major) cached
  * projections of the encoder states, step [B*H] int64 = head_step after the search.
  *   HARD : ctx = Vc[clamp(step)] (zero if !mass_preservation && step == len)
  *   soft : ctx = softmax_{s <= step}(q.Kc[s]) Vc, zero if step == 0  (CHUNKWISE == INFINITE_LOOKBACK at
@@ -349,7 +353,8 @@ typedef struct {
   void *k_cache, *v_cache;                       /* [B][H][cap][d] */
   int64_t* head_step;                            /* [B*H] in/out */
   uint8_t* head_read;                            /* [B*H] out */
-  const void *Kmono, *Ksoft, *V;                 /* [B][S_cap][D] cached projections of the encoder states */
+  const void *Kmono, *Ksoft, *V;                 /* [B][H][S_cap][head_dim] (head-major) cached projections of the
+                                                    encoder states: a head's key rows are contiguous 128-byte lines */
 } simulst_dec_layer;
 
 typedef struct {

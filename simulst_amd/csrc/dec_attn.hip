@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const T* __restrict__ q
   const int D = H * d;
   const int len = key_len ? key_len[b] : S_cap;
   const long st = step[(long)b * H + h];
-  const T* Kh = Kc + (long)b * S_cap * D + h * d;
-  const T* Vh = Vc + (long)b * S_cap * D + h * d;
+  const T* Kh = Kc + ((long)b * H + h) * S_cap * d;     // head-major [B][H][S_cap][d]
+  const T* Vh = Vc + ((long)b * H + h) * S_cap * d;
   float* bt = beta ? beta + ((long)b * H + h) * S_cap : nullptr;
   if (bt) {
     for (int j = tid; j < S_cap; j += 256) bt[j] = 0.f;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const T* __restrict__ q
     const long scl = st < 0 ? 0 : (st > len - 1 ? len - 1 : st);
     const bool dead = (!mass_pres) && st == len;
     if (!dead) {
-      if (tid < d) o = to_f32(Vh[scl * D + tid]);
+      if (tid < d) o = to_f32(Vh[scl * d + tid]);
       if (bt && tid == 0) bt[scl] = 1.f;
     }
   } else {
@@ -191,17 +191,17 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const T* __restrict__ q
       if (NP > 0 && n <= 256) {
         if constexpr (NP > 0) {
           attn::Regs2<T, NP> r;
-          attn::prefetch2<T, NP>(r, q + (long)b * D + h * d, Kh, D, Vh, D, n, -1, nullptr, nullptr);
+          attn::prefetch2<T, NP>(r, q + (long)b * D + h * d, Kh, d, Vh, d, n, -1, nullptr, nullptr);
           o = attn::finish2<T, NP>(r, n, n, rsqrtf((float)d), sc, red, bt);
         }
       } else if (n <= 256) {
         attn::Regs<T> r;
-        attn::prefetch<T>(r, q + (long)b * D + h * d, Kh, D, Vh, D, n, d, -1, nullptr, nullptr);
+        attn::prefetch<T>(r, q + (long)b * D + h * d, Kh, d, Vh, d, n, d, -1, nullptr, nullptr);
         o = attn::finish<T>(r, n, d, rsqrtf((float)d), sc, red, bt);
       } else {
         if (tid < d) q_s[tid] = to_f32(q[(long)b * D + h * d + tid]) * rsqrtf((float)d);
         __syncthreads();
-        o = attn::looped<T>(q_s, Kh, D, Vh, D, n, d, -1, nullptr, nullptr, sc, red, bt);
+        o = attn::looped<T>(q_s, Kh, d, Vh, d, n, d, -1, nullptr, nullptr, sc, red, bt);
       }
     }
   }

@@ -86,8 +86,11 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
   P = min(P, max(1, len / ratio));           // inference: floor-trimmed, at least one (:123-131)
   // ---- 0. every load of the value-aggregation phase goes out first (soft attention over <= 256 keys):
   //         the policy below then runs under their latency
-  const T* Vh = Vc + (long)b * S_cap * D + h * d;
-  const T* Kh = Ks ? Ks + (long)b * S_cap * D + h * d : nullptr;
+  // cached projections are HEAD-MAJOR [B][H][S_cap][d]: a head's key rows are contiguous 128-byte lines (measured
+  // 7.0 vs 5.6 TB/s for the interleaved [B][S_cap][D] layout, tools/microbench_kv_layout.hip)
+  const long hb = ((long)b * H + h) * S_cap * d;
+  const T* Vh = Vc + hb;
+  const T* Kh = Ks ? Ks + hb : nullptr;
   const bool soft = attn_type != SIMULST_ATTN_HARD;
   // single-latency path: soft attention over <= 256 keys with a lanes-per-row instantiation (rows >= len exist,
   // zero-filled, and are masked by n <= len); anything else takes the looped path
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
   const bool fusedq = FQ && xres != nullptr;
   const int n_pref = min(S_cap, n_hint);
   if constexpr (NP > 0) {
-    if (fast) attn::prefetch2<T, NP>(rg2, fusedq ? nullptr : qs + (long)b * D + h * d, Kh, D, Vh, D, n_pref, -1, nullptr, nullptr);
+    if (fast) attn::prefetch2<T, NP>(rg2, fusedq ? nullptr : qs + (long)b * D + h * d, Kh, d, Vh, d, n_pref, -1, nullptr, nullptr);
   }
   if constexpr (FQ) if (fusedq) {
     // LayerNorm of the residual row (fp32 stats, rounded to the activation dtype like the unfused path), then
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
         for (int i = 0; i < W; ++i) accv[i] = 0.f;
         for (int f = f0; f < f1; ++f) {
           float kv[W];
-          VL<T>::cvt(*reinterpret_cast<const uint4*>(Km + ((long)b * S_cap + f) * D + h * d + c), kv);
+          VL<T>::cvt(*reinterpret_cast<const uint4*>(Km + hb + (long)f * d + c), kv);
 #pragma unroll
           for (int i = 0; i < W; ++i) accv[i] += kv[i];
         }
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
   if (!soft) {
     const long scl = st < 0 ? 0 : (st > len - 1 ? len - 1 : st);
     const bool dead = (!mass_pres) && st == len;
-    if (!dead && tid < d) o = to_f32(Vh[scl * D + tid]);
+    if (!dead && tid < d) o = to_f32(Vh[scl * d + tid]);
   } else {
     const int n = (int)(st < len - 1 ? st : len - 1) + 1;
     if (st > 0 && n > 0) {
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
           if (tid < d) q_s[tid] = to_f32(qs[(long)b * D + h * d + tid]) * rsqrtf((float)d);
           __syncthreads();
         }
-        o = attn::looped<T>(fusedq ? qfused : q_s, Kh, D, Vh, D, n, d, -1, nullptr, nullptr, sc, red, nullptr);
+        o = attn::looped<T>(fusedq ? qfused : q_s, Kh, d, Vh, d, n, d, -1, nullptr, nullptr, sc, red, nullptr);
       }
     }
   }
@@ -363,7 +366,7 @@ int lin(simulst_handle* h, int dtype, int B, int N, int K, const void* A, const 
   d.c_batch_stride = 0; d.c_row_stride = N;
   d.r_batch_stride = 0; d.r_row_stride = N;
   d.epilogue = epi; d.dtype = dtype; d.scale = 1.f; d.n_main = 0; d.aux_rows = 0; d.aux_batch_stride = 0;
-  d.ln_gamma = ln_g; d.ln_beta = ln_b; d.w_fragment_major = w_packed;
+  d.ln_gamma = ln_g; d.ln_beta = ln_b; d.w_fragment_major = w_packed; d.c_head_dim = 0; d.c_head_stride = 0;
   return simulst_linear(h, &d, A, W, bias, R, C, nullptr);
 }
 

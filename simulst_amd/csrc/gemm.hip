@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
         const int r = m0 + (WHOLE ? 0 : half * WM) + rl, c = n0 + c8;
         if (r >= p.M || c >= p.N) continue;
         const int b = r / p.rpb, ii = r - b * p.rpb;
-        TC* dst = C + (long)b * p.c_bs + (long)ii * p.c_rs + c;
-        if (c + 8 <= p.N && ((p.c_rs | p.c_bs) & 7) == 0) {
+        TC* dst = C + c_index(p, b, ii, c);
+        if (c + 8 <= p.N && ((p.c_rs | p.c_bs | p.c_hs) & 7) == 0) {
           *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&Cs[rl * CS + c8]);
         } else {
           for (int q = 0; q < 8 && c + q < p.N; ++q) dst[q] = Cs[rl * CS + c8 + q];
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
               if (s < p.aux_rows) aux[(long)b * p.aux_bs + (long)s * p.N + c] = from_f32<TA>(tanhf(v));
             }
           } else {
-            C[(long)b * p.c_bs + (long)ii * p.c_rs + c] = from_f32<TC>(v);
+            C[c_index(p, b, ii, c)] = from_f32<TC>(v);
           }
         }
       }
@@ -399,6 +399,9 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
   p.scale = d->scale; p.n_main = d->n_main; p.aux_rows = d->aux_rows; p.aux_bs = d->aux_batch_stride;
   p.ln_g = d->ln_gamma; p.ln_b = d->ln_beta;
   p.w_packed = d->w_fragment_major;
+  p.c_hd = d->c_head_dim; p.c_hs = d->c_head_stride;
+  SL_REQUIRE(h, p.c_hd == 0 || (p.c_hd > 0 && p.c_hd % 8 == 0 && d->N % p.c_hd == 0 && d->epilogue == SIMULST_EPI_BIAS),
+             SIMULST_E_ARG, "simulst_linear: head-major output needs the bias epilogue and head_dim % 8 == 0");
   if (d->ln_gamma || d->ln_beta)
     SL_REQUIRE(h, d->ln_gamma && d->ln_beta, SIMULST_E_NULL, "simulst_linear: LN prologue needs gamma and beta");
   const bool skinny_ok = M <= 2048 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&

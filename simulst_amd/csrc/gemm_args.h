@@ -15,7 +15,14 @@ struct LinArgs {
   const float* ln_g;
   const float* ln_b;
   int w_packed;        // weights in fragment-major order (gemv_mfma.h); decode-step shapes only
+  int c_hd;            // > 0: head-major output -- column c of row (b, ii) goes to b*c_bs + (c/c_hd)*c_hs + ii*c_rs + c%c_hd
+  long c_hs;           //      (cross-attention K/V projections stored [B][H][S_cap][head_dim]); 0: plain [.., N] rows
 };
+
+__device__ __forceinline__ long c_index(const LinArgs& p, int b, int ii, int c) {
+  const long base = (long)b * p.c_bs + (long)ii * p.c_rs;
+  return p.c_hd > 0 ? base + (long)(c / p.c_hd) * p.c_hs + (c % p.c_hd) : base + c;
+}
 
 
 template <typename T>

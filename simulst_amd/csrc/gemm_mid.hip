@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
     const int erow = m0 + er;
     if (erow >= p.M) continue;
     const int eb = erow / p.rpb, ei = erow - eb * p.rpb;
-    TC* cp = C + (long)eb * p.c_bs + (long)ei * p.c_rs + n0 + ec;
+    TC* cp = C + c_index(p, eb, ei, n0 + ec);        // 16 consecutive columns stay inside one head (head_dim % 16 == 0)
     float y[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
       }
       y[e] = v;
     }
-    if (n0 + ec + 16 <= p.N && (p.c_rs % 8) == 0 && (p.c_bs % 8) == 0) {
+    if (n0 + ec + 16 <= p.N && (p.c_rs % 8) == 0 && (p.c_bs % 8) == 0 && (p.c_hd == 0 || (p.c_hd % 16 == 0 && p.c_hs % 8 == 0))) {
       if constexpr (std::is_same<TC, float>::value) {
 #pragma unroll
         for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(cp + e) = float4{y[e], y[e + 1], y[e + 2], y[e + 3]};
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
     } else {
 #pragma unroll
       for (int e = 0; e < 16; ++e)
-        if (n0 + ec + e < p.N) cp[e] = from_f32<TC>(y[e]);
+        if (n0 + ec + e < p.N) C[c_index(p, eb, ei, n0 + ec + e)] = from_f32<TC>(y[e]);
     }
   }
   PROBE(5);

@@ -61,7 +61,7 @@ __device__ __forceinline__ void epilogue_store(float v, int r, int c, const floa
   if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU)
     v += to_f32(R[(long)b * p.r_bs + (long)ii * p.r_rs + c]);
   if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) v = gelu_erf(v);
-  C[(long)b * p.c_bs + (long)ii * p.c_rs + c] = from_f32<TC>(v);
+  C[c_index(p, b, ii, c)] = from_f32<TC>(v);
 }
 
 // NT = 16-column MFMA tiles per workgroup (BN = 16 * NT), MT = 16-row tiles (BM = 16 * MT): a weight fragment
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
         float y = v + (bias ? bias[c] : 0.f);
         if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) y += resv[q][e];
         if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) y = gelu_erf(y);
-        C[(long)b * p.c_bs + (long)ii * p.c_rs + c] = from_f32<TC>(y);
+        C[c_index(p, b, ii, c)] = from_f32<TC>(y);
       }
     }
   }

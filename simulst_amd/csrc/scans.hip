@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void step_p_choose_kernel(const T* __restrict_
         const int f0 = j * ratio, f1 = min(f0 + ratio, len);
         float acc = 0.f;
         if (lane < d)
-          for (int f = f0; f < f1; ++f) acc += to_f32(Km[((long)b * S_cap + f) * D + h * d + lane]);
+          for (int f = f0; f < f1; ++f) acc += to_f32(Km[(((long)b * H + h) * S_cap + f) * d + lane]);
         acc = acc / (float)(f1 - f0) * qv;
         const float en = wave_sum(acc) + energy_bias;
         if (lane == 0) pp[j] = 1.0f / (1.0f + expf(-en));

@@ -96,9 +96,10 @@ class DecoderState:
         self.n_prev = torch.zeros(B, device=device, dtype=torch.int32)
         self.n_prev_host = 0                 # lockstep batches: every row has written this many tokens
         # cached cross-attention projections of the encoder states, per layer
-        self.Kmono = [torch.zeros(B, S_cap, D, device=device, dtype=dtype) for _ in range(Ld)]
+        # cached cross-attention projections, HEAD-MAJOR [B, H, S_cap, d]: a head's key rows are contiguous lines
+        self.Kmono = [torch.zeros(B, H, S_cap, d, device=device, dtype=dtype) for _ in range(Ld)]
         self.Ksoft = None
-        self.V = [torch.zeros(B, S_cap, D, device=device, dtype=dtype) for _ in range(Ld)]
+        self.V = [torch.zeros(B, H, S_cap, d, device=device, dtype=dtype) for _ in range(Ld)]
         self.enc_len = torch.zeros(B, device=device, dtype=torch.int32)
         self.enc_len_bh = torch.zeros(B * H, device=device, dtype=torch.int32)
         self.enc_rows = 0                    # rows of the source already projected (lockstep)
@@ -140,7 +141,7 @@ class MMADecoder:
     def new_state(self, B: int, cap: int = 128, S_cap: int = 256) -> DecoderState:
         st = DecoderState(self.cfg, B, cap, S_cap, self.device, self.dtype)
         if self.separate_soft:
-            st.Ksoft = [torch.zeros(B, S_cap, self.cfg.embed_dim, device=self.device, dtype=self.dtype)
+            st.Ksoft = [torch.zeros(B, self.cfg.num_heads, S_cap, self.cfg.head_dim, device=self.device, dtype=self.dtype)
                         for _ in range(self.cfg.decoder_layers)]
         return st
 
@@ -160,8 +161,10 @@ class MMADecoder:
                 if self.separate_soft:
                     jobs.append((L["c_wk_soft"], L["c_bk_soft"], st.Ksoft[l]))
                 for Wt, bt, dst in jobs:
-                    ops.linear_raw(enc_new, Wt, bt, dst[:, r0:], M_batches=B, rows_per_batch=n, N=D, K=D,
-                                   a_bs=a_bs, a_rs=D, c_bs=st.S_cap * D, c_rs=D, epilogue=EPI_BIAS)
+                    hd = cfg.head_dim                # head-major store: [b][h][r0 + i][c % hd]
+                    ops.linear_raw(enc_new, Wt, bt, dst[:, :, r0:], M_batches=B, rows_per_batch=n, N=D, K=D,
+                                   a_bs=a_bs, a_rs=D, c_bs=cfg.num_heads * st.S_cap * hd, c_rs=hd, epilogue=EPI_BIAS,
+                                   c_head_dim=hd, c_head_stride=st.S_cap * hd)
         st.enc_rows = r0 + n
         st.enc_len = enc_len.to(device=self.device, dtype=torch.int32)
         st.enc_len_bh = st.enc_len.repeat_interleave(cfg.num_heads).contiguous()

@@ -47,11 +47,11 @@ class Ops:
     # ------------------------------------------------------------------ dense
     def linear_raw(self, A, W, bias, C_out, *, M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead=0,
                    c_bs, c_rs, epilogue=EPI_BIAS, R=None, r_bs=0, r_rs=0, scale=1.0, n_main=0, aux=None,
-                   aux_rows=0, aux_bs=0, ln=None, w_fragment_major=False):
+                   aux_rows=0, aux_bs=0, ln=None, w_fragment_major=False, c_head_dim=0, c_head_stride=0):
         d = LinearDesc(M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead, c_bs, c_rs, r_bs, r_rs,
                        epilogue, dt(A), scale, n_main, aux_rows, aux_bs,
                        ln[0].data_ptr() if ln is not None else None, ln[1].data_ptr() if ln is not None else None,
-                       int(w_fragment_major))
+                       int(w_fragment_major), c_head_dim, c_head_stride)
         self.h.check(self.lib.simulst_linear(self.h.ptr, C.byref(d), _p(A), _p(W), _p(bias), _p(R), _p(C_out),
                                              _p(aux)), "simulst_linear")
         return C_out
@@ -256,8 +256,9 @@ class Ops:
 
     def decoder_cross_attention(self, q, Kc, Vc, step, *, H, attn_type, mass_preservation, key_len=None,
                                 want_beta=False, out=None):
-        B, S_cap, D = Vc.shape
-        d = D // H
+        B, H_, S_cap, d = Vc.shape              # head-major [B, H, S_cap, head_dim]
+        assert H_ == H
+        D = H * d
         if out is None:
             out = torch.empty(B, D, device=Vc.device, dtype=Vc.dtype)
         beta = torch.empty(B * H, S_cap, device=Vc.device, dtype=torch.float32) if want_beta else None
@@ -270,8 +271,9 @@ class Ops:
     def policy_cross_attention(self, qm, qs, Kmono, Ksoft, V, head_step, *, H, ratio, attn_type, key_len,
                                tgt_idx=None, energy_bias=0.0, waitk_k=0, online=False, mass_preservation=True,
                                out=None):
-        B, S_cap, D = V.shape
-        d = D // H
+        B, H_, S_cap, d = V.shape               # head-major [B, H, S_cap, head_dim]
+        assert H_ == H
+        D = H * d
         if out is None:
             out = torch.empty(B, D, device=V.device, dtype=V.dtype)
         head_read = torch.empty(B * H, device=V.device, dtype=torch.uint8)

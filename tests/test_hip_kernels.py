@@ -280,6 +280,7 @@ def test_g7_step_p_choose_vs_golden(ops, name):
         else:
             kmp = torch.zeros(2, S_cap, D)
             kmp[:, :21] = km
+            kmp = kmp.view(2, S_cap, H, d).permute(0, 2, 1, 3).contiguous()      # head-major [B, H, S_cap, d]
             ops.step_p_choose(dev(qp), dev(kmp), p, B=2, S_cap=S_cap, H=H, d=d, ratio=ratio, incremental=True,
                               attn_type=_lib.ATTN_ENUM[base], key_len=dev(kl))
         if name.endswith("fixed_pre_decision"):
@@ -377,7 +378,8 @@ def test_decoder_cross_attention(ops, attn):
     step = torch.stack([torch.randint(0, int(l) + 1, (H,), generator=g) for l in lens]).view(-1)
     step[0] = 0
     for mp in (True, False):
-        ctx, beta = ops.decoder_cross_attention(dev(q), dev(Kc), dev(Vc), dev(step), H=H,
+        hm = lambda t: t.view(B, S, H, d).permute(0, 2, 1, 3).contiguous()      # head-major [B, H, S, d]
+        ctx, beta = ops.decoder_cross_attention(dev(q), dev(hm(Kc)), dev(hm(Vc)), dev(step), H=H,
                                                 attn_type=_lib.ATTN_ENUM[attn], mass_preservation=mp,
                                                 key_len=dev(lens), want_beta=True)
         for b in range(B):

@@ -19,7 +19,7 @@ for cap, npv in ((112, 5), (112, 100), (260, 250)):
     print(f"self_attn cap {cap} n_prev {npv}: {timeit(lambda: ops.decoder_self_attention(qkv, kc, vc, n_prev, out=out)):.2f} us")
 for S_cap, ln in ((250, 40), (250, 250)):
     q = torch.randn(B, D, device="cuda").to(dt)
-    K = torch.randn(B, S_cap, D, device="cuda").to(dt); V = torch.randn_like(K)
+    K = torch.randn(B, H, S_cap, d, device="cuda").to(dt); V = torch.randn_like(K)   # head-major
     key_len = torch.full((B,), ln, device="cuda", dtype=torch.int32)
     tgt = torch.full((B,), 100, device="cuda", dtype=torch.int32)
     hs = torch.zeros(B * H, device="cuda", dtype=torch.int64)
