@@ -262,6 +262,99 @@ __device__ __forceinline__ float finish2(const Regs2<T, NP>& r, int n, int n_max
   return o;
 }
 
+// Split-softmax finish (flash-decoding style): the thread -> row map of prefetch2 already gives every WAVE its own
+// quarter of the key rows (row groups 8w .. 8w+7 of each pass), so each wave reduces its rows to (max, sum,
+// 64 partial output channels) with lane shuffles only, the four partials meet in LDS and ONE workgroup barrier
+// replaces the six of finish2.  Same contract as finish2; beta (normalised probabilities per key) costs a second
+// barrier-free pass over the scores kept in registers.
+template <typename T, int NP>
+__device__ __forceinline__ float finish3(const Regs2<T, NP>& r, int n, int n_max, float qscale, float* red,
+                                         float* beta, const float* q_lds = nullptr) {
+  constexpr int W = VL<T>::W, RP = 256 / (NP > 0 ? NP : 1), d = NP * W;
+  constexpr int GW = 64 / (NP > 0 ? NP : 1);     // row groups per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = tid % NP, rg = tid / NP;
+  float qf[W];
+  if (q_lds) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) qf[i] = q_lds[c * W + i];
+  } else {
+    VL<T>::cvt(r.q, qf);
+#pragma unroll
+    for (int i = 0; i < W; ++i) qf[i] *= qscale;
+  }
+  float sc[NP > 0 ? NP : 1];
+  float mw = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    sc[i] = -INFINITY;
+    if (i * RP < n_max) {
+      float ka[W];
+      VL<T>::cvt(r.k[i], ka);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < W; ++e) s = fmaf(qf[e], ka[e], s);
+#pragma unroll
+      for (int o = 1; o < NP; o <<= 1) s += __shfl_xor(s, o, 64);
+      if (rg + RP * i < n) { sc[i] = s; mw = fmaxf(mw, s); }
+    }
+  }
+#pragma unroll
+  for (int o = NP; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));      // across the wave's row groups
+  float lw = 0.f, a[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) a[w] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (i * RP < n_max && rg + RP * i < n) {
+      const float p = expf(sc[i] - mw);
+      lw += p;
+      float va[W];
+      VL<T>::cvt(r.v[i], va);
+#pragma unroll
+      for (int w = 0; w < W; ++w) a[w] = fmaf(p, va[w], a[w]);
+    }
+  }
+#pragma unroll
+  for (int o = NP; o < 64; o <<= 1) {
+    lw += __shfl_xor(lw, o, 64);
+#pragma unroll
+    for (int w = 0; w < W; ++w) a[w] += __shfl_xor(a[w], o, 64);
+  }
+  // partial of this wave: red[wave*(d+2)] = max, +1 = sum, +2.. = channels
+  float* pw = red + wave * (d + 2);
+  if (lane < NP) {
+    if (lane == 0) { pw[0] = mw; pw[1] = lw; }
+#pragma unroll
+    for (int w = 0; w < W; ++w) pw[2 + c * W + w] = a[w];
+  }
+  (void)GW;
+  __syncthreads();
+  float m = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) m = fmaxf(m, red[w * (d + 2)]);
+  float l = 0.f, sw[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float mv = red[w * (d + 2)];
+    sw[w] = mv == -INFINITY ? 0.f : expf(mv - m);
+    l += red[w * (d + 2) + 1] * sw[w];
+  }
+  const float inv = 1.0f / l;
+  float o = 0.f;
+  if (tid < d) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) o += red[w * (d + 2) + 2 + tid] * sw[w];
+    o *= inv;
+  }
+  if (beta) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (i * RP < n_max && rg + RP * i < n && c == 0) beta[rg + RP * i] = expf(sc[i] - m) * inv;
+  }
+  return o;
+}
+
 // host-side dispatch over the instantiated NP values: CALL(NP) is a statement using the constant
 #define SL_DISPATCH_NP(np, CALL)                                    \
   switch (np) {                                                     \

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const T* __restrict__ qk
         Kh[(long)np * d + tid] = row[D + h * d + tid];
         Vh[(long)np * d + tid] = row[2 * D + h * d + tid];
       }
-      o = attn::finish2<T, NP>(r, n, n, rsqrtf((float)d), sc, red, nullptr, nullptr);
+      o = attn::finish3<T, NP>(r, n, n, rsqrtf((float)d), red, nullptr, nullptr);
     }
   } else if (n <= 256) {
     attn::Regs<T> r;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const T* __restrict__ q
         if constexpr (NP > 0) {
           attn::Regs2<T, NP> r;
           attn::prefetch2<T, NP>(r, q + (long)b * D + h * d, Kh, d, Vh, d, n, -1, nullptr, nullptr);
-          o = attn::finish2<T, NP>(r, n, n, rsqrtf((float)d), sc, red, bt);
+          o = attn::finish3<T, NP>(r, n, n, rsqrtf((float)d), red, bt);
         }
       } else if (n <= 256) {
         attn::Regs<T> r;

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
     if (st > 0 && n > 0) {
       const float* qfused = fusedq ? (Wqs ? qsoft_s : q_s) : nullptr;
       if (fast) {
-        if constexpr (NP > 0) o = attn::finish2<T, NP>(rg2, n, n_pref, rsqrtf((float)d), sc, red, nullptr, qfused);
+        if constexpr (NP > 0) o = attn::finish3<T, NP>(rg2, n, n_pref, rsqrtf((float)d), red, nullptr, qfused);
       } else {
         __syncthreads();
         if (!fusedq) {

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void self_attn_fused_kernel(
       }
   }
   PROBE(4);
-  const float o = attn::finish2<T, NP>(rg, n, n, qscale, sc, red, nullptr, q_s);
+  const float o = attn::finish3<T, NP>(rg, n, n, qscale, red, nullptr, q_s);
   PROBE(5);
   if (tid < d) ctx_s[tid] = from_f32<T>(o);
   __syncthreads();
