@@ -294,7 +294,7 @@ def main():
         # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate runs of this same command; profiles/*_pmc_traffic.json says how it was corrected)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")))
             if dom in pmc:
                 roofline["traffic"] = pmc[dom]["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
