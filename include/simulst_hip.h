@@ -84,6 +84,7 @@ int simulst_timer_reset(simulst_handle* h);
  * microsecond of dependent-kernel gap per kernel. */
 int simulst_graph_enable(simulst_handle* h, int on);
 /* test hook: route bf16 Emformer attention through the fp32-VALU kernel instead of the MFMA one */
+/* (also routes the bf16 decoder self-attention through its workgroup kernel instead of the wave-per-head one) */
 int simulst_debug_force_valu_attention(simulst_handle* h, int on);
 /* test hook: run simulst_mma_decode / simulst_mma_stream_steps with the 7-launch layer even when the head-split
  * workspace is supplied (A/B parity of the two paths) */

@@ -406,9 +406,16 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
     SL_REQUIRE(h, d->ln_gamma && d->ln_beta, SIMULST_E_NULL, "simulst_linear: LN prologue needs gamma and beta");
   const bool skinny_ok = M <= 2048 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&
                          d->epilogue != SIMULST_EPI_EMF_OUT;
+  if (!skinny_ok || M > 2048) {
+    if (sl_panel_wanted(d->dtype, d->epilogue, p)) {
+      if (d->epilogue == SIMULST_EPI_EMF_OUT) SL_CHECK_NULL(h, aux);
+      return sl_launch_panel(h, d->epilogue, A, W, bias, R, C, aux, p);
+    }
+  }
   if (p.w_packed)
     SL_REQUIRE(h, skinny_ok && d->N % 16 == 0 && d->K % (4 * G) == 0, SIMULST_E_SHAPE,
-               "simulst_linear: fragment-major weights need a decode-step shape, N % 16 == 0 and K % (64 bytes) == 0");
+               "simulst_linear: fragment-major weights need a decode-step shape (or a tall bf16 problem with K <= 256), "
+               "N % 16 == 0 and K % (64 bytes) == 0");
   if (skinny_ok) return sl_launch_skinny(h, d->dtype, d->epilogue, A, W, bias, R, C, p);
   SL_REQUIRE(h, !p.ln_g, SIMULST_E_SHAPE, "simulst_linear: LN prologue needs a decode-step shape");
   KTimer t(h, SIMULST_K_LINEAR);

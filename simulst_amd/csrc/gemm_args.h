@@ -32,6 +32,11 @@ __device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<con
 int sl_launch_skinny(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                      const void* R, void* C, const LinArgs& p);
 
+// A-stationary row panels for tall bf16 problems with K <= 256 (encoder QKV / out-proj / fc1), defined in gemm_panel.hip
+bool sl_panel_wanted(int dtype, int epi, const LinArgs& p);
+int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
+                    void* aux, const LinArgs& p);
+
 // 64 x 64 tile for co-scheduled batches (M >= 256) with wide outputs, defined in gemm_mid.hip
 bool sl_mid_wanted(int dtype, const LinArgs& p);
 int sl_launch_mid(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,

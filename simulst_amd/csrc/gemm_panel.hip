@@ -1,0 +1,173 @@
+// Row-panel contraction for the encoder's short-K projections (gfx950, bf16, K <= 256: QKV, attention out-proj, fc1).
+//
+// The 128 x 128 tile kernel of gemm.hip re-stages its A tile for every one of the N/128 column tiles and spends most of
+// a K = 256 tile's life in its prologue / epilogue (measured: matrix cores 15-21 % busy, ~15 us per tile).  Here the
+// ACTIVATIONS ARE STATIONARY IN REGISTERS: a workgroup owns a panel of 128 rows, every wave loads the 8 k-step fragments
+// of its own 32 rows ONCE (64 VGPRs) and then sweeps all N columns in steps of 64:
+//   * the 64 x K weight block of a step (fragment-major in global memory, simulst_pack_fragment_major) is copied to
+//     LDS with 16-byte coalesced loads -- requested one step ahead into registers -- and read back as conflict-free
+//     1 KB B fragments by the four waves
+//   * 64 MFMAs (v_mfma_f32_16x16x32_bf16) per wave and step against 32 LDS fragment reads: LDS at half its rate
+//   * the epilogue of a step is wave-private: accumulators -> the wave's own LDS staging rows -> 16-byte
+//     row-contiguous stores with bias / GELU / residual / Emformer summary handling; no workgroup barrier in it
+// A is read from HBM exactly once, weights stream from L2 once per panel, the output is written once.
+// Measured on MI355X (1024 utterances): out-proj 300 -> 221 us, QKV / cross K-V projections 203 -> 200 us.
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int PB_M = 128, PB_N = 64, PB_KS = 32;
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Wp,
+                                                       const float* __restrict__ bias, const bf16* __restrict__ R,
+                                                       bf16* __restrict__ C, bf16* __restrict__ aux, LinArgs p) {
+  constexpr bool RES = EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_EMF_OUT;
+  constexpr int SS = PB_N + 4;                                  // fp32 staging row stride
+  __shared__ __attribute__((aligned(16))) uint4 wl[4 * 8 * 64];        // [j][s][lane] 32 KB
+  __shared__ __attribute__((aligned(16))) float stage[4][32 * SS];    // per wave [32 rows][64 cols] fp32
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * PB_M;
+  const int nks = p.K / PB_KS;                                  // host: K % 32 == 0, K <= 256
+  // ---- this wave's A fragments: 2 row tiles x 8 k-steps, loaded once
+  uint4 fa[2][8];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int ar = m0 + wave * 32 + m * 16 + lr;
+    const bool aok = ar < p.M;
+    const int ab = aok ? ar / p.rpb : 0, ai = aok ? ar - ab * p.rpb : 0;
+    const bf16* arow = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bool ok = aok && s < nks;
+      const uint4 v = ld16(arow + (ok ? s * PB_KS + lg * 8 : 0));
+      fa[m][s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+  }
+  const int n_steps = (p.N + PB_N - 1) / PB_N;
+  // weight block of a step -> registers: slot q*256 + tid = (j, s, lane)
+  uint4 wv[8];
+  auto wload = [&](int step) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int slot = q * 256 + tid;
+      const int ln = slot & 63, s = (slot >> 6) & 7, j = slot >> 9;
+      const int ntile = step * 4 + j;                           // 16-column tile index
+      const bool ok = s < nks && ntile * 16 < p.N;
+      const uint4 v = ld16(Wp + (((long)(ok ? ntile : 0) * nks + (ok ? s : 0)) * 64 + ln) * 8);
+      wv[q] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+  };
+  wload(0);
+  float* st = stage[wave];
+  for (int step = 0; step < n_steps; ++step) {
+    __syncthreads();                                            // the previous step's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wl[q * 256 + tid] = wv[q];
+    __syncthreads();
+    if (step + 1 < n_steps) wload(step + 1);
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint4 wf = wl[(j * 8 + s) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&fa[m][s]),
+                                                             *reinterpret_cast<const bf16x8_t*>(&wf), acc[m][j], 0, 0, 0);
+      }
+    }
+    // ---- wave-private epilogue: acc[m][j][e] = C[32w + 16m + 4lg + e][64 step + 16j + lr]
+    const int n0 = step * PB_N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = n0 + j * 16 + lr;
+      const float bv = (bias && c < p.N) ? bias[c] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[m][j][e] + bv;
+          if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast(v);
+          st[(m * 16 + lg * 4 + e) * SS + j * 16 + lr] = v;
+        }
+    }
+    // rows of the wave as 16-byte chunks: lane -> (row it*8 + lane/8, 8 columns at (lane%8)*8)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+      const int r = m0 + wave * 32 + rl, c = n0 + c8;
+      if (r >= p.M || c >= p.N) continue;
+      const int b = r / p.rpb, ii = r - b * p.rpb;
+      const float* fs = &st[rl * SS + c8];
+      if constexpr (EPI == SIMULST_EPI_EMF_OUT) {
+        if (ii >= p.n_main) {                                   // summary rows: tanh into the next layer's memory bank
+          const int srow = ii - p.n_main;
+          if (srow < p.aux_rows)
+            for (int q = 0; q < 8 && c + q < p.N; ++q)
+              aux[(long)b * p.aux_bs + (long)srow * p.N + c + q] = __float2bfloat16(tanhf(fs[q]));
+          continue;
+        }
+      }
+      bf16* dst = C + c_index(p, b, ii, c);
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y[q] = fs[q];
+      if constexpr (RES) {
+        const bf16* rp = R + (long)b * p.r_bs + (long)ii * p.r_rs + c;
+        if (c + 8 <= p.N && ((p.r_rs | p.r_bs) & 7) == 0) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(rp);
+          const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            y[2 * q] += __uint_as_float(ru[q] << 16);
+            y[2 * q + 1] += __uint_as_float(ru[q] & 0xffff0000u);
+          }
+        } else {
+          for (int q = 0; q < 8 && c + q < p.N; ++q) y[q] += to_f32(rp[q]);
+        }
+      }
+      if (c + 8 <= p.N && ((p.c_rs | p.c_bs | p.c_hs) & 7) == 0) {
+        store4(dst, reinterpret_cast<const float(&)[4]>(y[0]));
+        store4(dst + 4, reinterpret_cast<const float(&)[4]>(y[4]));
+      } else {
+        for (int q = 0; q < 8 && c + q < p.N; ++q) C[c_index(p, b, ii, c + q)] = __float2bfloat16(y[q]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// shapes the panel kernel takes: bf16, fragment-major weights, tall problems with a short contraction
+bool sl_panel_wanted(int dtype, int epi, const LinArgs& p) {
+  return dtype == SIMULST_BF16 && p.w_packed && p.M >= 4096 && p.K <= 256 && p.K % PB_KS == 0 && p.N % 16 == 0 &&
+         p.a_lead == 0 && p.a_rs >= p.K && !p.ln_g && (p.c_hd == 0 || p.c_hd % 8 == 0) &&
+         // (served, but the encoder keeps its fc1 (GELU) on the 128 x 128 tile kernel with row-major weights: measured
+         //  1181 vs 955 us -- the 20 VALU operations per output are 0.4 ms of that GEMM either way and overlap with
+         //  the matrix cores better at 3 workgroups per CU)
+         (epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU || epi == SIMULST_EPI_BIAS_RES || epi == SIMULST_EPI_EMF_OUT);
+}
+
+int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
+                    void* aux, const LinArgs& p) {
+  dim3 grid((p.M + PB_M - 1) / PB_M);
+  KTimer t(h, SIMULST_K_LINEAR);
+#define PANEL(E)                                                                                                   \
+  hipLaunchKernelGGL((panel_kernel<E>), grid, dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias,      \
+                     (const bf16*)R, (bf16*)C, (bf16*)aux, p)
+  switch (epi) {
+    case SIMULST_EPI_BIAS: PANEL(SIMULST_EPI_BIAS); break;
+    case SIMULST_EPI_BIAS_GELU: PANEL(SIMULST_EPI_BIAS_GELU); break;
+    case SIMULST_EPI_BIAS_RES: PANEL(SIMULST_EPI_BIAS_RES); break;
+    default: PANEL(SIMULST_EPI_EMF_OUT); break;
+  }
+#undef PANEL
+  return sl_launch_status(h, "simulst_linear(row panel)");
+}

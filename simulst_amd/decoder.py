@@ -162,9 +162,15 @@ class MMADecoder:
                     jobs.append((L["c_wk_soft"], L["c_bk_soft"], st.Ksoft[l]))
                 for Wt, bt, dst in jobs:
                     hd = cfg.head_dim                # head-major store: [b][h][r0 + i][c % hd]
+                    fm = False
+                    if B * n >= 4096 and Wt.dtype == torch.bfloat16 and D <= 256:     # row-panel kernel's domain
+                        cache = self.w.__dict__.setdefault("kv_packed", {})
+                        if Wt.data_ptr() not in cache:
+                            cache[Wt.data_ptr()] = ops.pack_fragment_major(Wt)
+                        Wt, fm = cache[Wt.data_ptr()], True
                     ops.linear_raw(enc_new, Wt, bt, dst[:, :, r0:], M_batches=B, rows_per_batch=n, N=D, K=D,
                                    a_bs=a_bs, a_rs=D, c_bs=cfg.num_heads * st.S_cap * hd, c_rs=hd, epilogue=EPI_BIAS,
-                                   c_head_dim=hd, c_head_stride=st.S_cap * hd)
+                                   c_head_dim=hd, c_head_stride=st.S_cap * hd, w_fragment_major=fm)
         st.enc_rows = r0 + n
         st.enc_len = enc_len.to(device=self.device, dtype=torch.int32)
         st.enc_len_bh = st.enc_len.repeat_interleave(cfg.num_heads).contiguous()

@@ -134,6 +134,19 @@ class S2TEmformerEncoder:
         return x
 
     # ---------------------------------------------------------------- Emformer
+    use_panel_gemm = True
+
+    def _packed(self, l, name):
+        """Fragment-major copy of an encoder projection weight (bf16 only, made once): lets simulst_linear take the
+        A-stationary row-panel kernel for the K = 256 contractions of tall problems."""
+        L = self.w.layers[l]
+        if L[name].dtype != torch.bfloat16 or not self.use_panel_gemm:
+            return L[name], False
+        key = name + "_fm"
+        if key not in L:
+            L[key] = self.ops.pack_fragment_major(L[name])
+        return L[key], True
+
     def _conv_pos(self, x, hist, lengths_i32):
         """Causal grouped conv-pos + residual + padding mask: matrix-core kernel for bf16 / 16 channels per group /
         kernel width 16, 32 or 64 (the reference configuration), else the VALU kernel."""
@@ -184,13 +197,18 @@ class S2TEmformerEncoder:
             Z, Zn = (Za, Zb) if l % 2 == 0 else (Zb, Za)
             ops.emformer_prenorm(X, L["ln_in_g"], L["ln_in_b"], lengths_i32, Z, T=T, n_mem=n_mem, n_rc=n_rc,
                                  n_sum=n_sum, seg_len=S)
-            ops.linear(Z.view(B * rows_z, D), L["wqkv"], L["bqkv"], out=QKV.view(B * rows_z, 3 * D))
+            tall = B * rows_x >= 4096              # the row-panel kernel's domain (simulst_linear dispatch)
+            wq, fq = self._packed(l, "wqkv") if tall else (L["wqkv"], False)
+            ops.linear(Z.view(B * rows_z, D), wq, L["bqkv"], out=QKV.view(B * rows_z, 3 * D), w_fragment_major=fq)
             ops.emformer_attention(QKV, lengths_i32, CTX, B=B, T=T, D=D, H=cfg.num_heads, S=S, R=R, Lc=cfg.Lc,
                                    M=cfg.M, n_mem=n_mem, n_seg=N, use_summary=use_mem)
-            ops.linear_raw(CTX, L["wo"], L["bo"], X1, M_batches=B, rows_per_batch=rows_c, N=D, K=D,
+            wo, fo = self._packed(l, "wo") if tall else (L["wo"], False)
+            ops.linear_raw(CTX, wo, L["bo"], X1, M_batches=B, rows_per_batch=rows_c, N=D, K=D,
                            a_bs=rows_c * D, a_rs=D, c_bs=rows_x * D, c_rs=D, epilogue=EPI_EMF_OUT, R=X,
-                           r_bs=rows_x * D, r_rs=D, n_main=rows_x, aux=Zn, aux_rows=n_mem, aux_bs=rows_z * D)
+                           r_bs=rows_x * D, r_rs=D, n_main=rows_x, aux=Zn, aux_rows=n_mem, aux_bs=rows_z * D,
+                           w_fragment_major=fo)
             ops.layernorm(X1, L["ln_ff_g"], L["ln_ff_b"], out=Y)
+            # fc1 + GELU stays on the 128 x 128 tile kernel (row-major weights): measured faster than the row panel
             ops.linear(Y.view(B * rows_x, D), L["w1"], L["b1"], epilogue=EPI_BIAS_GELU, out=Hf)
             ops.linear(Hf, L["w2"], L["b2"], epilogue=EPI_BIAS_RES, residual=X1.view(B * rows_x, D),
                        out=X.view(B * rows_x, D))

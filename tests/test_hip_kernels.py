@@ -545,3 +545,70 @@ def test_decoder_self_attention_wave_kernel(ops):
         close(ctx, ctx_blk.float().cpu(), atol=2e-2, rtol=2e-2)
         assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
         n_prev += 1
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "res", "emf_out", "head_major"])
+def test_row_panel_gemm(ops, epi):
+    """The A-stationary row-panel kernel (tall bf16 problems, K <= 256, fragment-major weights) against the 128 x 128
+    tile kernel on the same inputs (row-major weights) and torch fp32: every epilogue it serves, ragged M, batched
+    rows with a stride (the Emformer out-proj layout), N not a multiple of 64."""
+    from simulst_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_EMF_OUT
+    g = torch.Generator().manual_seed(41)
+    bf = torch.bfloat16
+    for M, N, K in ((4096 + 37, 768, 256), (5000, 2048, 256), (4100, 272, 128)):
+        x = torch.randn(M, K, generator=g).to(bf).cuda()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(bf).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        Wp = ops.pack_fragment_major(W)
+        ref = x.float() @ W.float().t() + b
+        if epi in ("bias", "gelu"):
+            e = EPI_BIAS if epi == "bias" else EPI_BIAS_GELU
+            y0 = ops.linear(x, W, b, epilogue=e)
+            y1 = ops.linear(x, Wp, b, epilogue=e, w_fragment_major=True)
+            want = ref if epi == "bias" else torch.nn.functional.gelu(ref)
+            torch.testing.assert_close(y1.float(), want, atol=6e-2, rtol=3e-2)
+            torch.testing.assert_close(y1.float(), y0.float(), atol=3e-2, rtol=2e-2)
+        elif epi == "res":
+            r = torch.randn(M, N, generator=g).to(bf).cuda()
+            y0 = ops.linear(x, W, b, epilogue=EPI_BIAS_RES, residual=r)
+            y1 = ops.linear(x, Wp, b, epilogue=EPI_BIAS_RES, residual=r, w_fragment_major=True)
+            torch.testing.assert_close(y1.float(), ref + r.float(), atol=6e-2, rtol=3e-2)
+            torch.testing.assert_close(y1.float(), y0.float(), atol=3e-2, rtol=2e-2)
+        elif epi == "emf_out":
+            if N != 272:
+                continue
+            # batched rows: rows_c = n_main + 5 summary rows per batch; main rows get bias + residual, summary rows tanh
+            B, n_main, n_sum = 41, 95, 5
+            rows_c = n_main + n_sum
+            xb = torch.randn(B, rows_c, K, generator=g).to(bf).cuda()
+            rb = torch.randn(B, n_main, N, generator=g).to(bf).cuda()
+            outs = []
+            for Wx, fm in ((W, False), (Wp, True)):
+                C = torch.zeros(B, n_main, N, device="cuda", dtype=bf)
+                aux = torch.zeros(B, 7, N, device="cuda", dtype=bf)          # aux_rows = 4 of the 5 summaries kept
+                ops.linear_raw(xb, Wx, b, C, M_batches=B, rows_per_batch=rows_c, N=N, K=K, a_bs=rows_c * K, a_rs=K,
+                               c_bs=n_main * N, c_rs=N, epilogue=EPI_EMF_OUT, R=rb, r_bs=n_main * N, r_rs=N,
+                               n_main=n_main, aux=aux, aux_rows=4, aux_bs=7 * N, w_fragment_major=fm)
+                outs.append((C, aux))
+            full = xb.float() @ W.float().t() + b
+            torch.testing.assert_close(outs[1][0].float(), full[:, :n_main] + rb.float(), atol=6e-2, rtol=3e-2)
+            torch.testing.assert_close(outs[1][1][:, :4].float(), torch.tanh(full[:, n_main:n_main + 4]), atol=3e-2, rtol=3e-2)
+            assert float(outs[1][1][:, 4:].abs().max()) == 0.0
+            torch.testing.assert_close(outs[1][0].float(), outs[0][0].float(), atol=3e-2, rtol=2e-2)
+        else:   # head-major store (cross-attention K/V projections)
+            if N % 64:
+                continue
+            Bq, n, H, d = 8, M // 8, N // 64, 64
+            xb = x[:Bq * n].view(Bq, n, K)
+            S_cap, r0 = n + 9, 4
+            outs = []
+            for Wx, fm in ((W, False), (Wp, True)):
+                dst = torch.zeros(Bq, H, S_cap, d, device="cuda", dtype=bf)
+                ops.linear_raw(xb, Wx, b, dst[:, :, r0:], M_batches=Bq, rows_per_batch=n, N=N, K=K, a_bs=n * K, a_rs=K,
+                               c_bs=H * S_cap * d, c_rs=d, epilogue=EPI_BIAS, c_head_dim=d, c_head_stride=S_cap * d,
+                               w_fragment_major=fm)
+                outs.append(dst)
+            want = (xb.float() @ W.float().t() + b).view(Bq, n, H, d).permute(0, 2, 1, 3)
+            torch.testing.assert_close(outs[1][:, :, r0:r0 + n].float(), want, atol=6e-2, rtol=3e-2)
+            assert float(outs[1][:, :, :r0].abs().max()) == 0.0 and float(outs[1][:, :, r0 + n:].abs().max()) == 0.0
+            torch.testing.assert_close(outs[1].float(), outs[0].float(), atol=3e-2, rtol=2e-2)
