@@ -612,3 +612,49 @@ def test_row_panel_gemm(ops, epi):
             torch.testing.assert_close(outs[1][:, :, r0:r0 + n].float(), want, atol=6e-2, rtol=3e-2)
             assert float(outs[1][:, :, :r0].abs().max()) == 0.0 and float(outs[1][:, :, r0 + n:].abs().max()) == 0.0
             torch.testing.assert_close(outs[1].float(), outs[0].float(), atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_long_range_attention_chunks(ops, dtype):
+    """Key ranges beyond 256 rows (sources over ~10 s, long target prefixes): the chunked online-softmax path against
+    torch fp32 -- cross-attention context + normalised probabilities over 700 source rows, and incremental
+    self-attention at positions 255 .. 330 of a 400-slot cache."""
+    from simulst_amd import _lib
+    g = torch.Generator().manual_seed(23)
+    B, H, d, S = 3, 4, 64, 700
+    D = H * d
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
+    q = torch.randn(B, D, generator=g).to(dtype)
+    Kc, Vc = torch.randn(B, H, S, d, generator=g).to(dtype), torch.randn(B, H, S, d, generator=g).to(dtype)
+    lens = torch.tensor([700, 513, 257], dtype=torch.int32)
+    step = torch.tensor([699, 300, 256, 10, 512, 511, 400, 1, 256, 255, 100, 0])
+    ctx, beta = ops.decoder_cross_attention(dev(q), dev(Kc), dev(Vc), dev(step), H=H, attn_type=_lib.ATTN_INFINITE_LOOKBACK,
+                                            mass_preservation=True, key_len=dev(lens), want_beta=True)
+    for b in range(B):
+        for h in range(H):
+            st = int(step[b * H + h])
+            if st == 0:
+                ref = torch.zeros(d)
+            else:
+                n = min(st, int(lens[b]) - 1) + 1
+                e = (q[b, h * d:(h + 1) * d].float() * d ** -0.5) @ Kc[b, h, :n].float().t()
+                pr = torch.softmax(e, -1)
+                ref = pr @ Vc[b, h, :n].float()
+                close(beta[b * H + h, :n], pr, atol=1e-5 if dtype == torch.float32 else 2e-3, rtol=1e-3 if dtype == torch.float32 else 5e-2)
+            close(ctx[b, h * d:(h + 1) * d], ref, **tol)
+    # self-attention past 256 cached positions
+    cap = 400
+    kc = torch.randn(B, H, cap, d, generator=g).to(dtype).cuda()
+    vc = torch.randn(B, H, cap, d, generator=g).to(dtype).cuda()
+    n_prev = torch.tensor([255, 256, 329], dtype=torch.int32)
+    for step_i in range(3):
+        qkv = dev(torch.randn(B, 3 * D, generator=g), dtype)
+        out = ops.decoder_self_attention(qkv, kc, vc, dev(n_prev))
+        f = qkv.float().cpu()
+        for b in range(B):
+            n = int(n_prev[b]) + 1
+            K, V = kc[b, :, :n].float().cpu(), vc[b, :, :n].float().cpu()
+            assert torch.equal(K[:, -1], f[b, D:2 * D].view(H, d))
+            qh = f[b, :D].view(H, 1, d) * d ** -0.5
+            close(out[b], (torch.softmax(qh @ K.transpose(-1, -2), -1) @ V).view(D), **tol)
+        n_prev += 1
