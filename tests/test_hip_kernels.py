@@ -615,10 +615,10 @@ def test_row_panel_gemm(ops, epi):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_long_range_attention_chunks(ops, dtype):
-    """Key ranges beyond 256 rows (sources over ~10 s, long target prefixes): the chunked online-softmax path against
-    torch fp32 -- cross-attention context + normalised probabilities over 700 source rows, and incremental
-    self-attention at positions 255 .. 330 of a 400-slot cache."""
+def test_long_range_attention(ops, dtype):
+    """Key ranges beyond 256 rows (sources over ~10 s, long target prefixes) take the looped path of attn_core.h:
+    cross-attention context + normalised probabilities over 700 source rows, and incremental self-attention at
+    positions 255 .. 330 of a 400-slot cache, against torch fp32."""
     from simulst_amd import _lib
     g = torch.Generator().manual_seed(23)
     B, H, d, S = 3, 4, 64, 700
