@@ -156,11 +156,8 @@ def main():
     def groups(k):
         """k batches -> launch sequences of up to G stacked batches, sized so that every stream gets work when k is
         small (+ one shorter sequence for the remainder)"""
-        g = max(1, min(G, -(-k // max(1, args.concurrency))))
-        seq = [(fb_all[:B * g], L_all[:B * g])] * (k // g)
-        if k % g:
-            seq.append((fb_all[:B * (k % g)], L_all[:B * (k % g)]))
-        return seq
+        from simulst_amd.sharding import plan_launch_sequences
+        return [(fb_all[:B * g], L_all[:B * g]) for g in plan_launch_sequences(k, G, args.concurrency)]
 
     pipe = None
     if args.concurrency > 1:

@@ -64,3 +64,17 @@ def gather_records(utt_ids: torch.Tensor, n_tok: torch.Tensor, tokens: torch.Ten
             out[uid] = {"tokens": r[2:2 + min(k, width)].tolist(),
                         "delays_ms": r[2 + width:2 + width + min(k, width)].tolist()}
     return out
+
+
+def plan_launch_sequences(n_batches: int, group: int, streams: int):
+    """How `n_batches` independent batches are packed into launch sequences: up to `group` batches are stacked per
+    sequence, fewer when that would leave streams idle (n_batches < group * streams), plus one shorter sequence for
+    the remainder.  Returns the list of batches-per-sequence; it always sums to n_batches (bench.py times EXACTLY the
+    number of steps it was asked for)."""
+    if n_batches <= 0:
+        return []
+    g = max(1, min(group, -(-n_batches // max(1, streams))))
+    plan = [g] * (n_batches // g)
+    if n_batches % g:
+        plan.append(n_batches % g)
+    return plan

@@ -58,3 +58,22 @@ def test_gather_records_two_ranks_gloo():
         assert r["tokens"] == [100 * u + j for j in range(k)]
         assert r["delays_ms"] == [10 * (100 * u + j) for j in range(k)]
     assert same == [[0, 0, 0], [0, 0, 0], [1, 1, 1], [1, 1, 1]]
+
+
+def test_plan_launch_sequences():
+    """bench.py packs K timed batches into launch sequences of up to G stacked batches over S streams: the plan always
+    covers exactly K batches, never exceeds G, and shrinks the group when K cannot fill G x S sequences."""
+    from simulst_amd.sharding import plan_launch_sequences as plan
+    assert plan(96, 16, 3) == [16] * 6
+    assert plan(48, 16, 3) == [16, 16, 16]
+    assert plan(10, 16, 3) == [4, 4, 2]
+    assert plan(5, 16, 3) == [2, 2, 1]
+    assert plan(1, 16, 3) == [1]
+    assert plan(0, 16, 3) == []
+    assert plan(50, 16, 3) == [16, 16, 16, 2]
+    assert plan(7, 4, 1) == [4, 3]
+    for k in range(1, 120):
+        for g in (1, 4, 16):
+            for s in (1, 2, 3):
+                p = plan(k, g, s)
+                assert sum(p) == k and max(p) <= g and min(p) >= 1
