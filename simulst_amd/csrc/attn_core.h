@@ -1,12 +1,14 @@
 // Single-latency attention core shared by the decoder step kernels (gfx950).
 //
-// One 256-thread workgroup per (head, utterance).  Every dependent memory round trip costs ~1 us
-// at decode-step sizes, so ALL global loads are issued before anything is consumed:
-//   attn_prefetch : q (broadcast), one K row per thread, this thread's share of V rows -> registers
-//   attn_finish   : q.K per thread -> fp32 scores in LDS -> block max / exp / sum -> PV from the
-//                   preloaded V registers (4 channels per lane, 256/(d/4) rows per pass) -> LDS reduce
-// Fast path covers n <= 256 keys (cross-attention over <= 256 encoder frames, self-attention over
-// <= 256 target positions); longer rows take the looped path attn_looped.
+// One 256-thread workgroup per (head, utterance).  Every dependent memory round trip costs ~1 us at decode-step
+// sizes, so ALL global loads are issued before anything is consumed.  Two generations live here:
+//   prefetch2 / finish3  (head dims whose 16-byte chunks map onto 2/4/8/16 lanes -- every configuration of the
+//                        reference): d/8 lanes share a key row, so a wave load reads whole 128-byte rows; every wave
+//                        reduces its quarter of the rows to (max, sum, partial channels) with shuffles, the four
+//                        partials meet in LDS behind ONE workgroup barrier (split softmax)
+//   prefetch / finish    (any other head dim): one K row per thread, scores through LDS, block max / exp / sum
+// Both cover n <= 256 keys (cross-attention over <= 256 encoder frames, self-attention over <= 256 target
+// positions); longer key ranges take `looped`.
 #pragma once
 #include "common.h"
 
@@ -81,27 +83,6 @@ __device__ __forceinline__ void prefetch(Regs<T>& r, const T* qp, const T* Kb, l
   }
 }
 
-// K/V-only prefetch (the query is produced inside the kernel and read from LDS later)
-template <typename T>
-__device__ __forceinline__ void prefetch_kv(Regs<T>& r, const T* Kb, long ks, const T* Vb, long vs, int n_max, int d) {
-  constexpr int W = VL<T>::W;
-  const int tid = threadIdx.x;
-  const int jk = tid < n_max ? tid : 0;
-  const T* kr = Kb + (long)jk * ks;
-#pragma unroll
-  for (int c = 0; c < Regs<T>::NQ; ++c) {
-    const int cc = c * W < d ? c * W : 0;
-    r.k[c] = *reinterpret_cast<const uint4*>(kr + cc);
-  }
-  const int lpr = d >> 2, c4 = tid % lpr, rw = tid / lpr, RR = 256 / lpr;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int j = rw + RR * i;
-    if (i >= lpr || j >= n_max) j = 0;
-    load4(Vb + (long)j * vs + c4 * 4, r.v[i]);
-  }
-}
-
 // softmax(q.K[0..n)) V from the prefetched registers. n <= n_max <= 256. Threads tid < d return ctx[tid].
 // q_lds != nullptr: the (already scaled) query is read from LDS instead of the prefetched registers.
 template <typename T>
@@ -158,7 +139,7 @@ __device__ __forceinline__ float finish(const Regs<T>& r, int n, int d, float qs
 // for bf16, d = 64) instead of 16 bytes from each of 64 rows; the same thread -> (row group, 16-byte chunk) map serves
 // K (scores: partial dot + shuffle reduce over the row's lanes) and V (W channels per lane, row groups reduced
 // through LDS).  Measured on MI355X at 256 rows x 4 heads: the row-per-lane version above moved 2.1 TB/s of K/V.
-constexpr int RED2 = 2048;                       // floats of LDS for the PV partials (row groups x d), + 8 scratch
+constexpr int RED2 = 2048;                       // floats of LDS scratch shared with the row-per-lane path, + 8
 constexpr int RED_FLOATS = RED2 + 8;             // size of the `red` LDS region every caller reserves
 
 
@@ -197,75 +178,12 @@ __device__ __forceinline__ void prefetch2(Regs2<T, NP>& r, const T* qp, const T*
   }
 }
 
-// softmax(q.K[0..n)) V from the prefetched registers, n <= n_max <= 256, d = NP * W; threads tid < d return ctx[tid].
-// q_lds != nullptr: already scaled query in LDS, else the register chunk r.q scaled by qscale.
-// sc: LDS [256], red: LDS [RED_FLOATS].
-template <typename T, int NP>
-__device__ __forceinline__ float finish2(const Regs2<T, NP>& r, int n, int n_max, float qscale, float* sc,
-                                         float* red, float* beta, const float* q_lds = nullptr) {
-  constexpr int W = VL<T>::W, RP = 256 / (NP > 0 ? NP : 1), d = NP * W;
-  const int tid = threadIdx.x;
-  const int c = tid % NP, rg = tid / NP;
-  float qf[W];
-  if (q_lds) {
-#pragma unroll
-    for (int i = 0; i < W; ++i) qf[i] = q_lds[c * W + i];
-  } else {
-    VL<T>::cvt(r.q, qf);
-#pragma unroll
-    for (int i = 0; i < W; ++i) qf[i] *= qscale;
-  }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    if (i * RP < n_max) {
-      float ka[W];
-      VL<T>::cvt(r.k[i], ka);
-      float s = 0.f;
-#pragma unroll
-      for (int e = 0; e < W; ++e) s = fmaf(qf[e], ka[e], s);
-#pragma unroll
-      for (int o = 1; o < NP; o <<= 1) s += __shfl_xor(s, o, 64);
-      if (c == 0) sc[rg + RP * i] = s;
-    }
-  }
-  __syncthreads();
-  const bool live = tid < n;
-  const float s = live ? sc[tid] : 0.f;
-  const float mx = blk_max(live ? s : -INFINITY, red + RED2);
-  const float e = live ? expf(s - mx) : 0.f;
-  sc[tid] = e;
-  const float inv = 1.0f / blk_sum(e, red + RED2);            // barrier inside also publishes sc[]
-  float a[W];
-#pragma unroll
-  for (int w = 0; w < W; ++w) a[w] = 0.f;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int j = rg + RP * i;
-    if (i * RP < n_max && j < n) {
-      float va[W];
-      VL<T>::cvt(r.v[i], va);
-      const float pj = sc[j];
-#pragma unroll
-      for (int w = 0; w < W; ++w) a[w] = fmaf(pj, va[w], a[w]);
-    }
-  }
-  float* rr = red + rg * d + c * W;
-#pragma unroll
-  for (int w = 0; w < W; ++w) rr[w] = a[w];
-  __syncthreads();
-  float o = 0.f;
-  if (tid < d) {
-    for (int k = 0; k < RP; ++k) o += red[k * d + tid];
-    o *= inv;
-  }
-  if (beta && tid < n) beta[tid] = e * inv;
-  return o;
-}
-
 // Split-softmax finish (flash-decoding style): the thread -> row map of prefetch2 already gives every WAVE its own
 // quarter of the key rows (row groups 8w .. 8w+7 of each pass), so each wave reduces its rows to (max, sum,
 // 64 partial output channels) with lane shuffles only, the four partials meet in LDS and ONE workgroup barrier
-// replaces the six of finish2.  Same contract as finish2; beta (normalised probabilities per key) costs a second
+// replaces the six of the row-per-lane `finish`.  softmax(q.K[0..n)) V from the prefetched registers, n <= n_max <= 256,
+// d = NP * W; threads tid < d return ctx[tid]; q_lds != nullptr: already scaled query in LDS, else the register chunk
+// r.q scaled by qscale; red: LDS [RED_FLOATS]; beta (normalised probabilities per key) costs a second
 // barrier-free pass over the scores kept in registers.
 template <typename T, int NP>
 __device__ __forceinline__ float finish3(const Regs2<T, NP>& r, int n, int n_max, float qscale, float* red,
