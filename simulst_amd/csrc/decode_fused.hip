@@ -34,7 +34,6 @@ __global__ __launch_bounds__(256) void self_attn_fused_kernel(
   constexpr int W = VL<T>::W;
   __shared__ float q_s[64];
   __shared__ float red[attn::RED_FLOATS];
-  __shared__ float sc[256];
   __shared__ __attribute__((aligned(16))) T xn[1024];
   __shared__ __attribute__((aligned(16))) T knew[64];
   __shared__ __attribute__((aligned(16))) T vnew[64];

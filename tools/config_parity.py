@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--utterances", type=int, default=8)
     ap.add_argument("--batched", action="store_true", default=None)
+    ap.add_argument("--attn", default=None,
+                    help="with --config 3: another monotonic attention type, e.g. infinite_lookback_fixed_pre_decision")
     args = ap.parse_args()
     if args.batched is None:
         args.batched = args.config == 3
@@ -152,8 +154,9 @@ def main():
             res = run_mma(args, "waitk_fixed_pre_decision", 3)
             name = "configs[0]: wait-k=3, ratio 8"
         elif args.config == 3:
-            res = run_mma(args, "hard_aligned_fixed_pre_decision", 0)
-            name = "configs[2]: MMA-hard (hard_aligned_fixed_pre_decision, ratio 8, mass preservation)"
+            attn = args.attn or "hard_aligned_fixed_pre_decision"
+            res = run_mma(args, attn, 0)
+            name = f"configs[2]: MMA ({attn}, ratio 8, mass preservation)"
         else:
             res = run_cif(args)
             name = "configs[3]: CIF adaptive policy (cif_transformer_s), beta 1.0 and 0.926"
