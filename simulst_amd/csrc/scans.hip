@@ -233,94 +233,131 @@ __global__ __launch_bounds__(256) void step_p_choose_kernel(const T* __restrict_
 // (left slot, fire count, left weight, right weight) in LDS; phase 2 lane = channel walks the
 // source once, emitting a slot each time it fires.
 template <typename T>
-__global__ __launch_bounds__(64) void cif_kernel(const T* __restrict__ x, const float* __restrict__ alpha,
-                                                 const int* __restrict__ src_len, T* __restrict__ out,
-                                                 int* __restrict__ cif_len, float* __restrict__ delays,
-                                                 float* __restrict__ tail_w, float* __restrict__ alpha_sum, int S,
-                                                 int C, int T_cap, float beta, float tail_thres) {
+__global__ __launch_bounds__(256) void cif_kernel(const T* __restrict__ x, const float* __restrict__ alpha,
+                                                  const int* __restrict__ src_len, T* __restrict__ out,
+                                                  int* __restrict__ cif_len, float* __restrict__ delays,
+                                                  float* __restrict__ tail_w, float* __restrict__ alpha_sum, int S,
+                                                  int C, int T_cap, float beta, float tail_thres, int spw) {
+  // Slot-parallel integrate-and-fire (spw = slots per wave, a multiple of 2; 4 * spw slots per workgroup).  Phase 1 (wave 0): wavefront prefix sum of alpha -> per frame the left / right
+  // weights, the slot its left part lands in and how many slots it fires; per fired slot the frame that closes it.
+  // Phase 2: a workgroup owns 64 consecutive output slots of an utterance (16 per wave); a slot is a weighted sum over
+  // the few CONTIGUOUS frames between the frame that closed the previous slot and the frame that closes this one,
+  // rows loaded whole (4 channels per lane, 64 lanes = 256 channels per pass) and added in frame order with the same
+  // operation sequence as a sequential sweep -- the frame loop of the first version is gone.
   extern __shared__ float sm[];
   float* lw = sm;                    // [S] left weight
   float* rw = sm + S;                // [S] right weight
   int* li = (int*)(sm + 2 * S);      // [S] left slot index
   int* fn = li + S;                  // [S] fires
-  const int b = blockIdx.y, lane = threadIdx.x;
+  int* send = fn + S;                // [T_cap + 1] frame that closes slot t
+  __shared__ float s_total, s_twsum;
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = src_len ? src_len[b] : S;
   const float* al = alpha + (long)b * S;
-  float carry = 0.f;
-  int prev_right = 0;
-  for (int s0 = 0; s0 < S; s0 += 64) {
-    const int s = s0 + lane;
-    const float a = (s < S && s < len) ? al[s] : 0.f;
-    const float cs = carry + wave_scan_incl(a, lane);
-    const int ri = (int)floorf(cs / beta);
-    int left = __shfl_up(ri, 1, 64);
-    if (lane == 0) left = prev_right;
-    const int fires = ri - left;
-    const float r_w = fires > 0 ? cs - (float)ri * beta : 0.f;
-    const float l_w = a - r_w - (float)max(fires - 1, 0) * beta;
-    if (s < S) { lw[s] = l_w; rw[s] = r_w; li[s] = left; fn[s] = fires; }
-    carry = __shfl(cs, 63, 64);
-    prev_right = __shfl(ri, 63, 64);
+  if (wave == 0) {
+    float carry = 0.f;
+    int prev_right = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      const float a = (s < S && s < len) ? al[s] : 0.f;
+      const float cs = carry + wave_scan_incl(a, lane);
+      const int ri = (int)floorf(cs / beta);
+      int left = __shfl_up(ri, 1, 64);
+      if (lane == 0) left = prev_right;
+      const int fires = ri - left;
+      const float r_w = fires > 0 ? cs - (float)ri * beta : 0.f;
+      const float l_w = a - r_w - (float)max(fires - 1, 0) * beta;
+      if (s < S) {
+        lw[s] = l_w; rw[s] = r_w; li[s] = left; fn[s] = fires;
+        for (int f = 0; f < fires; ++f)
+          if (left + f <= T_cap) send[left + f] = s;
+      }
+      carry = __shfl(cs, 63, 64);
+      prev_right = __shfl(ri, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int n_full0 = (int)floorf(carry / beta);
+    // tail weight = what landed in slot n_full (summed from the per-frame weights, like the reference's scatter)
+    float twsum = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      float v = 0.f;
+      if (fn[s] > 0 && li[s] + fn[s] == n_full0) v += rw[s];
+      if (li[s] == n_full0) v += lw[s];
+      twsum += v;
+    }
+    twsum = wave_sum(twsum);
+    if (lane == 0) { s_total = carry; s_twsum = twsum; }
   }
-  __builtin_amdgcn_wave_barrier();
-  const float total = carry;
-  int n_full = (int)floorf(total / beta);      // feat_lengths before the tail decision
-  // phase 2
-  const int c = blockIdx.x * 64 + lane;
-  const bool cin = c < C;
+  __syncthreads();
+  const float total = s_total, twsum = s_twsum;
+  const int n_full = (int)floorf(total / beta);      // feat_lengths before the tail decision
+  const bool extend = twsum >= tail_thres;
+  const int n_out = extend ? n_full + 1 : n_full;
   const T* xb = x + (long)b * S * C;
   T* ob = out + (long)b * T_cap * C;
-  float acc = 0.f, dacc = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const float xv = cin ? to_f32(xb[(long)s * C + c]) : 0.f;
-    const float pos = (float)(s + 1);
-    acc = fmaf(lw[s], xv, acc);
-    dacc += lw[s] * pos / beta;
-    const int f = fn[s];
-    if (f > 0) {
-      int slot = li[s];
-      if (slot < T_cap) {
-        if (cin) ob[(long)slot * C + c] = from_f32<T>(acc);
-        if (blockIdx.x == 0 && lane == 0) delays[(long)b * T_cap + slot] = dacc;
-      }
-      for (int e = 1; e < f; ++e) {            // whole-beta slots (alpha > beta)
-        ++slot;
-        if (slot < T_cap) {
-          if (cin) ob[(long)slot * C + c] = from_f32<T>(xv * beta);
-          if (blockIdx.x == 0 && lane == 0) delays[(long)b * T_cap + slot] = pos;
+  // two slots per wave at a time (one per half-wave), 8 channels per lane: 32 lanes x 8 = 256 channels per pass
+  const int half = lane >> 5, l32 = lane & 31;
+  for (int i = 0; i < spw / 2; ++i) {
+    const int t = (blockIdx.x * 4 + wave) * spw + 2 * i + half;
+    if (t >= T_cap) continue;
+    const bool tail = t == n_full;
+    if (t > n_full || (tail && !extend)) {           // beyond the fired positions: zeros
+      const float z[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c = l32 * 8; c < C; c += 256) { store4(ob + (long)t * C + c, z); if (c + 4 < C) store4(ob + (long)t * C + c + 4, z); }
+      if (l32 == 0) delays[(long)b * T_cap + t] = 0.f;
+      continue;
+    }
+    const int first = t > 0 ? send[t - 1] : 0;       // the frame that closed slot t-1 carries its remainder into t
+    const int last = tail ? S - 1 : send[t];
+    const bool whole = !tail && fn[last] > 1 && li[last] < t;     // a frame with alpha > beta fills whole slots
+    for (int c = l32 * 8; c < C; c += 256) {
+      const bool hi = c + 4 < C;                      // second group of 4 channels present (C % 8 may be 4)
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float xa[4], xb4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (whole) {
+        load4(xb + (long)last * C + c, xa);
+        if (hi) load4(xb + (long)last * C + c + 4, xb4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] = xa[e] * beta; acc[4 + e] = xb4[e] * beta; }
+      } else {
+        int s = first;
+        if (t > 0) {                                  // remainder of the closing frame: a product, not an fma
+          load4(xb + (long)s * C + c, xa);
+          if (hi) load4(xb + (long)s * C + c + 4, xb4);
+          const float w = rw[s];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[e] = w * xa[e]; acc[4 + e] = w * xb4[e]; }
+          ++s;
+        }
+        for (; s <= last; ++s) {
+          load4(xb + (long)s * C + c, xa);
+          if (hi) load4(xb + (long)s * C + c + 4, xb4);
+          const float w = lw[s];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[e] = fmaf(w, xa[e], acc[e]); acc[4 + e] = fmaf(w, xb4[e], acc[4 + e]); }
+        }
+        if (tail) {
+          const float sc = beta / twsum;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] *= sc;
         }
       }
-      acc = rw[s] * xv;
-      dacc = rw[s] * pos / beta;
+      store4(ob + (long)t * C + c, reinterpret_cast<const float(&)[4]>(acc[0]));
+      if (hi) store4(ob + (long)t * C + c + 4, reinterpret_cast<const float(&)[4]>(acc[4]));
+    }
+    if (l32 == 0) {
+      float dacc;
+      if (whole) dacc = (float)(last + 1);
+      else {
+        int s = first;
+        dacc = 0.f;
+        if (t > 0) { dacc = rw[s] * (float)(s + 1) / beta; ++s; }
+        for (; s <= last; ++s) dacc += lw[s] * (float)(s + 1) / beta;
+      }
+      delays[(long)b * T_cap + t] = dacc;
     }
   }
-  // tail: leftover weight in slot n_full
-  const float tw = total - (float)n_full * beta;
-  // the reference sums the contributions that landed in slot n_full; that is acc's weight.
-  // Recompute it from the per-frame weights for bit-for-bit agreement of the threshold test.
-  float twsum = 0.f;
-  for (int s = lane; s < S; s += 64) {
-    float v = 0.f;
-    if (fn[s] > 0 && li[s] + fn[s] == n_full) v += rw[s];
-    if (li[s] == n_full) v += lw[s];
-    twsum += v;
-  }
-  twsum = wave_sum(twsum);
-  (void)tw;
-  const bool extend = twsum >= tail_thres;
-  int n_out = n_full;
-  if (extend) {
-    if (n_full < T_cap) {
-      if (cin) ob[(long)n_full * C + c] = from_f32<T>(acc * (beta / twsum));
-      if (blockIdx.x == 0 && lane == 0) delays[(long)b * T_cap + n_full] = dacc;
-    }
-    n_out = n_full + 1;
-  }
-  for (int t = min(n_out, T_cap); t < T_cap; ++t) {
-    if (cin) ob[(long)t * C + c] = from_f32<T>(0.f);
-    if (blockIdx.x == 0 && lane == 0) delays[(long)b * T_cap + t] = 0.f;
-  }
-  if (blockIdx.x == 0 && lane == 0) {
+  if (blockIdx.x == 0 && tid == 0) {
     cif_len[b] = n_out;
     tail_w[b] = twsum;
     alpha_sum[b] = total;
@@ -456,17 +493,23 @@ extern "C" int simulst_cif_integrate(simulst_handle* h, const void* x, const flo
   SL_CHECK_NULL(h, delays); SL_CHECK_NULL(h, tail_w); SL_CHECK_NULL(h, alpha_sum);
   SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_cif_integrate: dtype");
   SL_REQUIRE(h, S > 0 && C > 0 && T_cap > 0 && beta > 0.f, SIMULST_E_SHAPE, "simulst_cif_integrate: shape");
-  SL_REQUIRE(h, (size_t)4 * S * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE, "simulst_cif_integrate: S <= 4096");
+  const size_t lds = (size_t)(4 * S + T_cap + 1) * sizeof(float);
+  SL_REQUIRE(h, lds <= 64 * 1024, SIMULST_E_SHAPE, "simulst_cif_integrate: 4 S + T_cap floats of LDS (S up to ~3000)");
+  SL_REQUIRE(h, C % 4 == 0, SIMULST_E_SHAPE, "simulst_cif_integrate: C % 4");
   if (B <= 0) return SIMULST_OK;
   KTimer t(h, SIMULST_K_SCAN);
-  dim3 grid((C + 63) / 64, B);
-  const size_t lds = (size_t)4 * S * sizeof(float);
+  // every workgroup repeats the (cheap, single-wave) scan of its utterance: at most ~8 slot ranges per utterance,
+  // shrunk again while the grid would leave CUs idle (measured [1024,1500]: 850 us at 16 slots per wave, 607 at 64;
+  // [1024,250]: 91 us at 16, 111 at 64)
+  int spw = T_cap <= 512 ? 16 : (T_cap <= 1024 ? 32 : 64);
+  while (spw > 16 && (long)B * ((T_cap + 4 * spw - 1) / (4 * spw)) < 512) spw >>= 1;
+  dim3 grid((T_cap + 4 * spw - 1) / (4 * spw), B);
   if (dtype == SIMULST_F32)
-    hipLaunchKernelGGL(cif_kernel<float>, grid, dim3(64), lds, h->stream, (const float*)x, alpha, src_len, (float*)out,
-                       cif_len, delays, tail_w, alpha_sum, S, C, T_cap, beta, tail_thres);
+    hipLaunchKernelGGL(cif_kernel<float>, grid, dim3(256), lds, h->stream, (const float*)x, alpha, src_len, (float*)out,
+                       cif_len, delays, tail_w, alpha_sum, S, C, T_cap, beta, tail_thres, spw);
   else
-    hipLaunchKernelGGL(cif_kernel<bf16>, grid, dim3(64), lds, h->stream, (const bf16*)x, alpha, src_len, (bf16*)out,
-                       cif_len, delays, tail_w, alpha_sum, S, C, T_cap, beta, tail_thres);
+    hipLaunchKernelGGL(cif_kernel<bf16>, grid, dim3(256), lds, h->stream, (const bf16*)x, alpha, src_len, (bf16*)out,
+                       cif_len, delays, tail_w, alpha_sum, S, C, T_cap, beta, tail_thres, spw);
   return sl_launch_status(h, "simulst_cif_integrate");
 }
 
