@@ -183,12 +183,36 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
     }
     __syncthreads();
   }
-  // ---- 1. pooled probabilities
+  // ---- 1+2. policy.  wait-k in closed form (no LDS rows, no barrier): the one-hot pooled probability sits at pooled
+  //           index wk, i.e. at frame (wk+1)*ratio - 1, and/or at the last frame when the final window is the
+  //           pooled position wk (fixed_pre_decision.py:133-167); the search then is a minimum over <= 3 candidates.
+  //           Every thread computes it; thread 0 publishes.  Other attention types: pooled energies + search below.
+  long st;
   if (attn_type == SIMULST_ATTN_WAITK) {
     int wk = tg + waitk_k - 1;
     if (!online) wk = min(wk, P - 1);
-    for (int j = tid; j < P; j += 256) pp[j] = (j == wk) ? 1.f : 0.f;
+    int s1 = -1, s2 = -1;                               // frames with p = 1
+    if (wk < P) {
+      const int c1 = (wk + 1) * ratio - 1;
+      if (c1 < len) s1 = c1;
+      if (wk == P - 1 && P * ratio >= len) s2 = len - 1;
+    }
+    const int max_steps = mass_pres ? len - 1 : len;
+    int found = max_steps;                              // the forced stop, valid even below head_step
+    if (s1 >= 0 && (long)s1 >= hs) found = min(found, s1);
+    if (s2 >= 0 && (long)s2 >= hs) found = min(found, s2);
+    if (found < 0) found = 0;
+    if (tid == 0) {
+      const int clampi = min(max(found, 0), len - 1);
+      const bool one = clampi >= 0 && (clampi == s1 || clampi == s2);
+      const bool hr = found == max_steps && !one;
+      head_step[r] = found;
+      head_read[r] = hr ? 1 : 0;
+      if (ctl.read_flag && hr && online) ctl.read_flag[b] = (unsigned char)ctl.layer;
+    }
+    st = found;
   } else {
+  {
     if (!fusedq) {
       if (tid < d) q_s[tid] = to_f32(qm[(long)b * D + h * d + tid]) * rsqrtf((float)d);
       __syncthreads();
@@ -249,7 +273,8 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
     }
   }
   __syncthreads();
-  const long st = s_found;
+    st = s_found;
+  }
   // ---- 3. value aggregation
   float o = 0.f;
   if (!soft) {
