@@ -41,3 +41,8 @@ int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, co
 bool sl_mid_wanted(int dtype, const LinArgs& p);
 int sl_launch_mid(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                   const void* R, void* C, const LinArgs& p);
+
+// one wave per 16 x 16 tile for narrow outputs (N < 512) of co-scheduled batches with K <= 8 k-steps, gemm_mid.hip
+bool sl_wave_tile_wanted(int dtype, const LinArgs& p);
+int sl_launch_wave_tile(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
+                        const void* R, void* C, const LinArgs& p);

@@ -221,6 +221,113 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
   PROBE(5);
 }
 
+// One WAVE per 16 x 16 output tile, whole K (<= 8 k-steps) in one trip: the narrow projections of co-scheduled batches
+// (out-proj, q-proj: N = 256, K = 256 at 256 .. 2048 rows).  No k-split, no LDS reduction, no workgroup barrier -- a
+// workgroup is four independent waves; 16 operand loads in flight per lane, 8 MFMAs, epilogue straight from the
+// accumulators (32-byte row segments).  The LayerNorm prologue needs only the wave's own shuffles.
+template <typename TA, typename TC, int EPI, bool PRO_LN>
+__global__ __launch_bounds__(256) void wave_tile_kernel(const TA* __restrict__ A, const TA* __restrict__ W,
+                                                        const float* __restrict__ bias, const TA* __restrict__ R,
+                                                        TC* __restrict__ C, LinArgs p, int tiles_n) {
+  constexpr bool F32 = std::is_same<TA, float>::value;
+  constexpr int KS = F32 ? 16 : 32, G = F32 ? 4 : 8, CH = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const long tile = (long)blockIdx.x * 4 + wave;                 // column tiles fastest: neighbours share A rows
+  const int tm = (int)(tile / tiles_n), tn = (int)(tile % tiles_n);
+  const int m0 = tm * 16, n0 = tn * 16;
+  if (m0 >= p.M) return;
+  const int nks = p.K / KS;                                       // host: K % KS == 0, nks <= CH
+  const int ar = m0 + lr;
+  const bool aok = ar < p.M;
+  const int ab = aok ? ar / p.rpb : 0, ai = aok ? ar - ab * p.rpb : 0;
+  const TA* arow = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
+  const int wn = n0 + lr;
+  const bool wok = wn < p.N;
+  const bool pk = p.w_packed != 0;
+  uint4 fa[CH], fw[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const bool kin = u < nks;
+    const int kc = kin ? u * KS + lg * G : 0;
+    const uint4 va = ld16(arow + kc);
+    const bool oka = kin && aok;
+    fa[u] = make_uint4(oka ? va.x : 0u, oka ? va.y : 0u, oka ? va.z : 0u, oka ? va.w : 0u);
+    const TA* wsrc = pk ? W + (((long)(wok ? tn : 0) * nks + (kin ? u : 0)) * 64 + lane) * G
+                        : W + (long)(wok ? wn : 0) * p.K + kc;
+    const uint4 vw = ld16(wsrc);
+    const bool okw = kin && wok;
+    fw[u] = make_uint4(okw ? vw.x : 0u, okw ? vw.y : 0u, okw ? vw.z : 0u, okw ? vw.w : 0u);
+  }
+  // epilogue operands requested with the tiles: acc[e] = C[m0 + lg*4 + e][n0 + lr]
+  const int c = n0 + lr;
+  const float bv = (bias && c < p.N) ? bias[c] : 0.f;
+  float resv[4] = {0.f, 0.f, 0.f, 0.f};
+  int eb[4], ei[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = m0 + lg * 4 + e;
+    eb[e] = r < p.M ? r / p.rpb : 0;
+    ei[e] = r < p.M ? r - eb[e] * p.rpb : 0;
+    if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) {
+      if (r < p.M && c < p.N) resv[e] = to_f32(R[(long)eb[e] * p.r_bs + (long)ei[e] * p.r_rs + c]);
+    }
+  }
+  if constexpr (PRO_LN) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) moments_mid(fa[u], s1, s2, TA());
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    const float mean = s1 / (float)p.K;
+    const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int k = u * KS + lg * G;
+      if (u < nks && aok) fa[u] = ln_frag_mid(fa[u], mean, rstd, p.ln_g, p.ln_b, k, TA());
+    }
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    if constexpr (F32) {
+      const float* af = reinterpret_cast<const float*>(&fa[u]);
+      const float* wf = reinterpret_cast<const float*>(&fw[u]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], wf[e], acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&fa[u]),
+                                                    *reinterpret_cast<const bf16x8_t*>(&fw[u]), acc, 0, 0, 0);
+    }
+  }
+  if (c >= p.N) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = m0 + lg * 4 + e;
+    if (r >= p.M) continue;
+    float y = acc[e] + bv;
+    if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) y += resv[e];
+    if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) y = gelu_erf(y);
+    C[c_index(p, eb[e], ei[e], c)] = from_f32<TC>(y);
+  }
+}
+
+template <typename TA, typename TC, int EPI>
+int launch_wave_tile(simulst_handle* h, const void* A, const void* W, const float* bias, const void* R, void* C,
+                     const LinArgs& p) {
+  const int tiles_n = (p.N + 15) / 16;
+  const long tiles = (long)((p.M + 15) / 16) * tiles_n;
+  dim3 grid((unsigned)((tiles + 3) / 4));
+  KTimer t(h, SIMULST_K_LINEAR_SKINNY);
+  if (p.ln_g)
+    hipLaunchKernelGGL((wave_tile_kernel<TA, TC, EPI, true>), grid, dim3(256), 0, h->stream, (const TA*)A, (const TA*)W,
+                       bias, (const TA*)R, (TC*)C, p, tiles_n);
+  else
+    hipLaunchKernelGGL((wave_tile_kernel<TA, TC, EPI, false>), grid, dim3(256), 0, h->stream, (const TA*)A,
+                       (const TA*)W, bias, (const TA*)R, (TC*)C, p, tiles_n);
+  return sl_launch_status(h, "simulst_linear(wave per 16x16 tile)");
+}
+
 template <typename TA, typename TC, int EPI>
 int launch_mid(simulst_handle* h, const void* A, const void* W, const float* bias, const void* R, void* C,
                const LinArgs& p) {
@@ -272,6 +379,33 @@ bool sl_mid_wanted(int dtype, const LinArgs& p) {
   const int KS = dtype == SIMULST_F32 ? 16 : 32;
   const long blocks = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);     // 64 x 64 tiles: most of the chip gets one
   return p.M >= 256 && p.N >= 512 && blocks >= 192 && p.K % KS == 0 && (!p.ln_g || p.K <= 8 * KS);
+}
+
+// narrow outputs of co-scheduled batches with a short contraction: one wave per tile
+bool sl_wave_tile_wanted(int dtype, const LinArgs& p) {
+  const int KS = dtype == SIMULST_F32 ? 16 : 32;
+  return p.M >= 256 && p.N < 512 && p.K % KS == 0 && p.K <= 8 * KS;
+}
+
+namespace {
+template <typename TA>
+int wave_tile_by_epilogue(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R,
+                          void* C, const LinArgs& p) {
+  switch (epi) {
+    case SIMULST_EPI_BIAS: return launch_wave_tile<TA, TA, SIMULST_EPI_BIAS>(h, A, W, bias, R, C, p);
+    case SIMULST_EPI_BIAS_GELU: return launch_wave_tile<TA, TA, SIMULST_EPI_BIAS_GELU>(h, A, W, bias, R, C, p);
+    case SIMULST_EPI_BIAS_RES: return launch_wave_tile<TA, TA, SIMULST_EPI_BIAS_RES>(h, A, W, bias, R, C, p);
+    case SIMULST_EPI_BIAS_F32OUT: return launch_wave_tile<TA, float, SIMULST_EPI_BIAS>(h, A, W, bias, R, C, p);
+    case SIMULST_EPI_BIAS_RES_GELU: return launch_wave_tile<TA, TA, SIMULST_EPI_BIAS_RES_GELU>(h, A, W, bias, R, C, p);
+    default: h->err = "simulst_linear: epilogue not available for decode-step shapes"; return SIMULST_E_ARG;
+  }
+}
+}  // namespace
+
+int sl_launch_wave_tile(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
+                        const void* R, void* C, const LinArgs& p) {
+  return dtype == SIMULST_F32 ? wave_tile_by_epilogue<float>(h, epilogue, A, W, bias, R, C, p)
+                              : wave_tile_by_epilogue<bf16>(h, epilogue, A, W, bias, R, C, p);
 }
 
 int sl_launch_mid(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,

@@ -465,7 +465,8 @@ def test_decode_gemm_row_tiles(ops, dtype):
     from simulst_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_BIAS_F32OUT
     g = torch.Generator().manual_seed(77)
     tol = dict(atol=2e-4, rtol=2e-4) if dtype == torch.float32 else dict(atol=6e-2, rtol=3e-2)
-    for M, N, K in ((200, 256, 256), (512, 768, 256), (1000, 2048, 256), (1024, 256, 2048), (130, 4096, 256)):
+    for M, N, K in ((200, 256, 256), (512, 768, 256), (1000, 2048, 256), (1024, 256, 2048), (130, 4096, 256),
+                    (1024, 256, 256), (300, 272, 128)):       # the last two: one wave per 16 x 16 tile
         x = torch.randn(M, K, generator=g).to(dtype).cuda()
         W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).cuda()
         b = torch.randn(N, generator=g).cuda()
