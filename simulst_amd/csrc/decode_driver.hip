@@ -599,12 +599,10 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
       } else {
         // many rows: every (head, row) workgroup re-streaming its 32 KB of the query projection through L2 costs
         // more than one LN-prologue GEMM launch that reads the weights once per row tile
+        const void* qsoft = L.c_wq_soft ? dd->q2 : dd->q;
         if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq, L.c_bq, nullptr, dd->q, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b, pk))) return rc;
-        const void* qsoft = dd->q;
-        if (L.c_wq_soft) {
+        if (L.c_wq_soft)
           if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq_soft, L.c_bq_soft, nullptr, dd->q2, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b, pk))) return rc;
-          qsoft = dd->q2;
-        }
         if ((rc = policy_cross(h, dd->q, qsoft, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
                                dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
                                dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, nullptr, nullptr,

@@ -185,3 +185,4 @@ int sl_self_attention_fused(simulst_handle* h, const void* x, const float* ln_g,
 #endif
   return sl_launch_status(h, "simulst_mma_decode(self-attention block)");
 }
+

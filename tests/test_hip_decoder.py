@@ -278,3 +278,4 @@ def test_force_unfused_hook(ops):
     finally:
         ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
     assert torch.equal(t_split, t_seven)
+
