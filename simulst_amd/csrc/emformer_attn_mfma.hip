@@ -30,7 +30,7 @@ __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
          ((unsigned int)(*reinterpret_cast<unsigned short*>(&h)) << 16);
 }
 
-__global__ __launch_bounds__(256) void emformer_attn_mfma_kernel(
+__global__ __launch_bounds__(256, 3) void emformer_attn_mfma_kernel(
     const bf16* __restrict__ QKV, const int* __restrict__ lengths, const bf16* __restrict__ lc_k,
     const bf16* __restrict__ lc_v, const int* __restrict__ lc_valid, const int* __restrict__ n_mem_valid,
     bf16* __restrict__ CTX, EmfArgsM a) {
@@ -125,28 +125,6 @@ __global__ __launch_bounds__(256) void emformer_attn_mfma_kernel(
         qf[kk] = q_ok ? v : zero4;
       }
     }
-    // ---- V transposed into LDS: vt[channel][key], zero beyond nk (P is 0 there, but 0 * garbage != 0).  Rows are
-    //      fetched as 16-byte chunks (8 lanes per key row, 8 rows per wave load) and scattered from registers
-    {
-      uint4 vrows[8];
-      const int vc8 = (lane & 7) * 8;
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int j = 8 * it + (lane >> 3);
-        const bool ok = j < nk;
-        const bf16 *kp, *vp = Zb + 2 * a.D;
-        if (ok) key_rows(j, kp, vp);
-        const uint4 v = *reinterpret_cast<const uint4*>(vp + hc + vc8);
-        vrows[it] = ok ? v : zero4;
-      }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int j = 8 * it + (lane >> 3);
-        const unsigned short* e = reinterpret_cast<const unsigned short*>(&vrows[it]);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) vt[(vc8 + q) * VT_STRIDE + j] = e[q];
-      }
-    }
     // ---- S^T tiles: st[t][e] = score(key 32t + (e&3) + 8(e>>2) + 4lh, query lr)
     f32x16 st[2];
 #pragma unroll
@@ -157,6 +135,20 @@ __global__ __launch_bounds__(256) void emformer_attn_mfma_kernel(
       for (int kk = 0; kk < 4; ++kk)
         st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&kf[t][kk]),
                                                         *reinterpret_cast<const bf16x8_t*>(&qf[kk]), st[t], 0, 0, 0);
+    }
+    // ---- V rows requested now (the K / Q fragments are consumed, their registers are free): 16-byte chunks, 8 lanes
+    //      per key row, 8 rows per wave load; they land while the softmax below runs
+    uint4 vrows[8];
+    const int vc8 = (lane & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int j = 8 * it + (lane >> 3);
+      const bool ok = j < nk;
+      const bf16 *kp, *vp = Zb + 2 * a.D;
+      if (ok) key_rows(j, kp, vp);
+      const uint4 v = *reinterpret_cast<const uint4*>(vp + hc + vc8);
+      vrows[it] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);   // per-component select:
+                                                      // `ok ? v : zero4` on the struct went through scratch memory
     }
     // ---- fp32 softmax over the keys of query lr (half in this lane, half in lane ^ 32)
     const float scaling = 0.125f;     // 64^-0.5
@@ -184,6 +176,15 @@ __global__ __launch_bounds__(256) void emformer_attn_mfma_kernel(
       }
     sum += __shfl_xor(sum, 32, 64);
     if (lh == 0) invs[lr] = 1.0f / sum;
+    // ---- V transposed into LDS: vt[channel][key], zero beyond nk (P is 0 there, but 0 * garbage != 0)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int j = 8 * it + (lane >> 3);
+      const unsigned int u[4] = {vrows[it].x, vrows[it].y, vrows[it].z, vrows[it].w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        vt[(vc8 + q) * VT_STRIDE + j] = (unsigned short)((q & 1) ? (u[q >> 1] >> 16) : (u[q >> 1] & 0xffffu));
+    }
     // ---- O = P . V: A = P^T fragments from the accumulators (registers 8s..8s+7 of tile t = keys
     //      32t + 16s + 8(j>>2) + 4lh + (j&3)), B = V from vt in the same key order
     f32x16 o[2];
@@ -219,9 +220,9 @@ __global__ __launch_bounds__(256) void emformer_attn_mfma_kernel(
     for (int e = 0; e < 16; ++e) {
       const int qi = (e & 3) + 8 * (e >> 2) + 4 * lh;
       const float inv = invs[qi];
-      bf16 v0 = __float2bfloat16(o[0][e] * inv), v1 = __float2bfloat16(o[1][e] * inv);
-      ot[qi * OT_STRIDE + lr] = *reinterpret_cast<unsigned short*>(&v0);
-      ot[qi * OT_STRIDE + 32 + lr] = *reinterpret_cast<unsigned short*>(&v1);
+      const unsigned int pr = pack2(o[0][e] * inv, o[1][e] * inv);
+      ot[qi * OT_STRIDE + lr] = (unsigned short)(pr & 0xffffu);
+      ot[qi * OT_STRIDE + 32 + lr] = (unsigned short)(pr >> 16);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
