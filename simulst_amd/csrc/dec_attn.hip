@@ -63,11 +63,12 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const T* __restrict__ qk
 // sum, PV -- is reduced with lane shuffles inside ONE wavefront, so the kernel has no workgroup barrier at all (the
 // block version above spends most of its time in ~8 of them for 14 KB of K/V).  8 lanes share a key row, 8 rows per
 // pass, <= 16 passes; a workgroup is just 4 independent waves.
+template <int MAXP>      // passes of 8 rows: 8 covers 64 cached positions (host-known, lockstep batches), 16 covers 128
 __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc,
                                                              bf16* __restrict__ vc, const int* __restrict__ n_prev,
                                                              int np_uniform, bf16* __restrict__ ctx, int BH, int H,
                                                              int cap) {
-  constexpr int d = 64, NPL = 8, RPP = 8, MAXP = 16;       // lanes per row, rows per pass, passes
+  constexpr int d = 64, NPL = 8, RPP = 8;                  // lanes per row, rows per pass
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= BH) return;
@@ -233,8 +234,12 @@ int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v
   dim3 grid(H, B);
   if (dtype == SIMULST_BF16 && d == 64 && cap <= 128 && !h->force_valu_attention) {
     // barrier-free wave-per-(head, utterance) kernel: every cached position fits 16 passes of 8 rows
-    hipLaunchKernelGGL(self_attn_wave_kernel, dim3((B * H + 3) / 4), dim3(256), 0, h->stream, (const bf16*)qkv,
-                       (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, B * H, H, cap);
+    if (np_uniform >= 0 && np_uniform < 64)      // every row holds < 64 positions: half the registers, twice the waves
+      hipLaunchKernelGGL(self_attn_wave_kernel<8>, dim3((B * H + 3) / 4), dim3(256), 0, h->stream, (const bf16*)qkv,
+                         (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, B * H, H, cap);
+    else
+      hipLaunchKernelGGL(self_attn_wave_kernel<16>, dim3((B * H + 3) / 4), dim3(256), 0, h->stream, (const bf16*)qkv,
+                         (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, B * H, H, cap);
     return sl_launch_status(h, "simulst_decoder_self_attention(wave)");
   }
 #define SA_F32(NP) hipLaunchKernelGGL((self_attn_kernel<float, NP>), grid, dim3(256), lds, h->stream, (const float*)qkv, \
