@@ -10,7 +10,7 @@ waitk_fixed_pre_decision ratio 8), bf16, synthetic 80x1000 fbank, batch 64 per G
 greedy steps (EOS masked) => 7040 tokens per step per GPU.  One "step" = one pass of the hot
 path (encoder forward + 110 decoder steps + argmax) over one batch of 64 utterances already
 resident in HBM, the stopwatch placement of eval/generate.py:200-209.  Scheduling (reported in
-config.schedule): --group G independent batches ride in one launch sequence (their rows are
+config.schedule): --group G (default 24) independent batches ride in one launch sequence (their rows are
 stacked; every row's result is independent of its batch, tests/test_hip_properties.py) and
 --concurrency S such sequences are in flight on S HIP streams, so S*G batches of 64 are in flight
 and K timed steps are K batches whatever G and S are.  serial_one_batch_in_flight is the same
@@ -97,14 +97,14 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=144)
+    ap.add_argument("--warmup", type=int, default=72)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="independent launch sequences in flight (one HIP stream + host thread each)")
-    ap.add_argument("--group", type=int, default=16,
+    ap.add_argument("--group", type=int, default=24,
                     help="independent 64-utterance batches stacked into one launch sequence (fewer when --steps "
                          "does not fill group x concurrency sequences)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -291,7 +291,7 @@ def main():
         # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate runs of this same command; profiles/*_pmc_traffic.json says how it was corrected)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_m_pmc_traffic.json")))
             if dom in pmc:
                 roofline["traffic"] = pmc[dom]["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
