@@ -84,7 +84,7 @@ def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps):
         dt = time.perf_counter() - t0
     return {"value": round(toks.numel() / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"{sample_B} utterances x {T_FRAMES} frames, {n_steps} forced greedy steps "
-                      f"({toks.numel()} tokens) in {dt:.1f} s, torch fp32, {cores} threads"}
+                      f"({toks.numel()} tokens) in {dt:.1f} s, torch fp32, {cores} threads"}, toks, fb
 
 
 _T0 = time.perf_counter()
@@ -312,8 +312,21 @@ def main():
             enc_fl = fl["conv"] + fl["enc_linear"] + fl["dec_cross_kv"]
             roofline["encoder_gemm_tflops"] = round(enc_fl / (lin_ms * 1e-3) / 1e12, 2)
         if world == 1 and not args.no_cpu_baseline:
-            cpu_base = run_cpu_baseline(cfg, weights, args.cpu_sample, N_STEPS_DECODE)
+            cpu_base, ref_toks, ref_fb = run_cpu_baseline(cfg, weights, args.cpu_sample, N_STEPS_DECODE)
             log("cpu baseline done")
+            # the checker's other job: the HIP path on the SAME sample against the oracle's tokens -- fp32 must be
+            # identical (the bit-exact claim of the wait-k path), the bf16 run of the bench reports its agreement
+            with torch.no_grad():
+                m32 = SimulSTModel(cfg, weights, device=f"cuda:{local}", dtype=torch.float32)
+                n_s = ref_fb.size(0)
+                t32, _ = m32.generate_offline(ref_fb.to(f"cuda:{local}"), torch.full((n_s,), T_FRAMES), n_steps=N_STEPS_DECODE,
+                                              mask_eos=True)
+                t16, _ = model.generate_offline(ref_fb.to(device=f"cuda:{local}", dtype=dtype), torch.full((n_s,), T_FRAMES),
+                                                n_steps=N_STEPS_DECODE, mask_eos=True)
+            cpu_base["parity_on_sample"] = {
+                "fp32_tokens_identical_to_oracle": bool(torch.equal(t32.cpu(), ref_toks)),
+                f"{args.dtype}_token_agreement_with_fp32_oracle": round(float((t16.cpu() == ref_toks).float().mean()), 4)}
+            log(f"parity on the cpu sample: {cpu_base['parity_on_sample']}")
         out = {
             "metric": "decoded tgt tokens/sec (Emformer encoder + wait-k=5 greedy decode, MuST-C en-de shape)",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
