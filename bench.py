@@ -124,7 +124,9 @@ def main():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # SIMULST_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1: the RCCL path (barriers, MAX over ranks, hypothesis
+    # gather) on a one-GPU box
+    if world > 1 or os.environ.get("SIMULST_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

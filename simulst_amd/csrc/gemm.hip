@@ -208,11 +208,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int rl = (WHOLE ? wr * WM : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
-              float v = acc[i][j][e] + bv;
-              if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast(v);
-              Cs[rl * CS + cl] = __float2bfloat16(v);
+            for (int e = 0; e < 16; e += 2) {
+              const int rl = (WHOLE ? wr * WM : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;   // rows rl, rl + 1
+              f32x2 v = f32x2{acc[i][j][e] + bv, acc[i][j][e + 1] + bv};
+              if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast2(v);
+              Cs[rl * CS + cl] = __float2bfloat16(v.x);
+              Cs[(rl + 1) * CS + cl] = __float2bfloat16(v.y);
             }
         }
       }

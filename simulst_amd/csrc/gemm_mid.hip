@@ -199,10 +199,17 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
       if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) {
         if (c < p.N) v += to_f32(R[(long)eb * p.r_bs + (long)ei * p.r_rs + c]);
       }
-      if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) {
-        if constexpr (std::is_same<TC, bf16>::value) v = gelu_fast(v); else v = gelu_erf(v);
-      }
+      if constexpr ((EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) && !std::is_same<TC, bf16>::value)
+        v = gelu_erf(v);
       y[e] = v;
+    }
+    if constexpr ((EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) && std::is_same<TC, bf16>::value) {
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const f32x2 g = gelu_fast2(f32x2{y[e], y[e + 1]});
+        y[e] = g.x;
+        y[e + 1] = g.y;
+      }
     }
     if (n0 + ec + 16 <= p.N && (p.c_rs % 8) == 0 && (p.c_bs % 8) == 0 && (p.c_hd == 0 || (p.c_hd % 16 == 0 && p.c_hs % 8 == 0))) {
       if constexpr (std::is_same<TC, float>::value) {

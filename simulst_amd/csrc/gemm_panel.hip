@@ -92,10 +92,11 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[m][j][e] + bv;
-          if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast(v);
-          st[(m * 16 + lg * 4 + e) * SS + j * 16 + lr] = v;
+        for (int e = 0; e < 4; e += 2) {
+          f32x2 v = f32x2{acc[m][j][e] + bv, acc[m][j][e + 1] + bv};
+          if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast2(v);
+          st[(m * 16 + lg * 4 + e) * SS + j * 16 + lr] = v.x;
+          st[(m * 16 + lg * 4 + e + 1) * SS + j * 16 + lr] = v.y;
         }
     }
     // rows of the wave as 16-byte chunks: lane -> (row it*8 + lane/8, 8 columns at (lane%8)*8)
