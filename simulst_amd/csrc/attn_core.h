@@ -172,8 +172,8 @@ __device__ __forceinline__ void prefetch2(Regs2<T, NP>& r, const T* qp, const T*
       if (j >= n_max) j = 0;
       const T* kr = (j == j_new) ? k_new : Kb + (long)j * ks;
       const T* vr = (j == j_new) ? v_new : Vb + (long)j * vs;
-      r.k[i] = *reinterpret_cast<const uint4*>(kr + c * W);
-      r.v[i] = *reinterpret_cast<const uint4*>(vr + c * W);
+      r.k[i] = ld_stream16(kr + c * W);
+      r.v[i] = ld_stream16(vr + c * W);
     }
   }
 }

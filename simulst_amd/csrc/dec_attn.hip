@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restr
       if (j >= n) j = 0;
       const bf16* kr = (j == np) ? k_new : Kh + (long)j * d;
       const bf16* vr = (j == np) ? v_new : Vh + (long)j * d;
-      kk[i] = *reinterpret_cast<const uint4*>(kr + c * 8);
-      vv[i] = *reinterpret_cast<const uint4*>(vr + c * 8);
+      kk[i] = ld_stream16(kr + c * 8);
+      vv[i] = ld_stream16(vr + c * 8);
     }
   }
   // append the new position for the following steps (the 8 lanes of row group 0 hold chunk c)

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
         const int b = r / p.rpb, ii = r - b * p.rpb;
         TC* dst = C + c_index(p, b, ii, c);
         if (c + 8 <= p.N && ((p.c_rs | p.c_bs | p.c_hs) & 7) == 0) {
-          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&Cs[rl * CS + c8]);
+          st_stream16(dst, *reinterpret_cast<const uint4*>(&Cs[rl * CS + c8]));
         } else {
           for (int q = 0; q < 8 && c + q < p.N; ++q) dst[q] = Cs[rl * CS + c8 + q];
         }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
             ou[q] = (unsigned int)(*reinterpret_cast<unsigned short*>(&l2)) |
                     ((unsigned int)(*reinterpret_cast<unsigned short*>(&h2)) << 16);
           }
-          *reinterpret_cast<uint4*>(dst) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+          st_stream16(dst, make_uint4(ou[0], ou[1], ou[2], ou[3]));
         } else {
           for (int q = 0; q < 8 && c + q < p.N; ++q) dst[q] = from_f32<TC>(fs[q] + to_f32(rp[q]));
         }
@@ -405,9 +405,10 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
              SIMULST_E_ARG, "simulst_linear: head-major output needs the bias epilogue and head_dim % 8 == 0");
   if (d->ln_gamma || d->ln_beta)
     SL_REQUIRE(h, d->ln_gamma && d->ln_beta, SIMULST_E_NULL, "simulst_linear: LN prologue needs gamma and beta");
-  const bool skinny_ok = M <= 2048 && d->a_lead == 0 && d->a_row_stride >= d->K && d->epilogue != SIMULST_EPI_GLU &&
-                         d->epilogue != SIMULST_EPI_EMF_OUT;
-  if (!skinny_ok || M > 2048) {
+  // decode-step shapes: up to 2048 rows, up to 8192 when the caller packed the weights for them (co-scheduled batches)
+  const bool skinny_ok = M <= (p.w_packed ? 8192 : 2048) && d->a_lead == 0 && d->a_row_stride >= d->K &&
+                         d->epilogue != SIMULST_EPI_GLU && d->epilogue != SIMULST_EPI_EMF_OUT;
+  if (!skinny_ok) {
     if (sl_panel_wanted(d->dtype, d->epilogue, p)) {
       if (d->epilogue == SIMULST_EPI_EMF_OUT) SL_CHECK_NULL(h, aux);
       return sl_launch_panel(h, d->epilogue, A, W, bias, R, C, aux, p);

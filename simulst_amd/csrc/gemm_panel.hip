@@ -135,8 +135,14 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
         }
       }
       if (c + 8 <= p.N && ((p.c_rs | p.c_bs | p.c_hs) & 7) == 0) {
-        store4(dst, reinterpret_cast<const float(&)[4]>(y[0]));
-        store4(dst + 4, reinterpret_cast<const float(&)[4]>(y[4]));
+        unsigned int ou[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bf16 lo = __float2bfloat16(y[2 * q]), hi = __float2bfloat16(y[2 * q + 1]);
+          ou[q] = (unsigned int)(*reinterpret_cast<const unsigned short*>(&lo)) |
+                  ((unsigned int)(*reinterpret_cast<const unsigned short*>(&hi)) << 16);
+        }
+        st_stream16(dst, make_uint4(ou[0], ou[1], ou[2], ou[3]));
       } else {
         for (int q = 0; q < 8 && c + q < p.N; ++q) C[c_index(p, b, ii, c + q)] = __float2bfloat16(y[q]);
       }
@@ -150,9 +156,8 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
 bool sl_panel_wanted(int dtype, int epi, const LinArgs& p) {
   return dtype == SIMULST_BF16 && p.w_packed && p.M >= 4096 && p.K <= 256 && p.K % PB_KS == 0 && p.N % 16 == 0 &&
          p.a_lead == 0 && p.a_rs >= p.K && !p.ln_g && (p.c_hd == 0 || p.c_hd % 8 == 0) &&
-         // (served, but the encoder keeps its fc1 (GELU) on the 128 x 128 tile kernel with row-major weights: measured
-         //  1181 vs 955 us -- the 20 VALU operations per output are 0.4 ms of that GEMM either way and overlap with
-         //  the matrix cores better at 3 workgroups per CU)
+         // (fc1 + GELU: 1568 us here vs 1795 us on the 128 x 128 tile kernel at 605 k rows, N = 2048, now that the
+         //  GELU issues on the packed fp32 pipe; with the exp-based form the tile kernel had been the faster one)
          (epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU || epi == SIMULST_EPI_BIAS_RES || epi == SIMULST_EPI_EMF_OUT);
 }
 

@@ -217,8 +217,9 @@ class S2TEmformerEncoder:
                            r_bs=rows_x * D, r_rs=D, n_main=rows_x, aux=Zn, aux_rows=n_mem, aux_bs=rows_z * D,
                            w_fragment_major=fo)
             ops.layernorm(X1, L["ln_ff_g"], L["ln_ff_b"], out=Y)
-            # fc1 + GELU stays on the 128 x 128 tile kernel (row-major weights): measured faster than the row panel
-            ops.linear(Y.view(B * rows_x, D), L["w1"], L["b1"], epilogue=EPI_BIAS_GELU, out=Hf)
+            # fc1 + GELU on the row panel too since its GELU went to the packed fp32 pipe (1568 vs 1795 us at 605 k rows)
+            w1, f1 = self._packed(l, "w1") if tall else (L["w1"], False)
+            ops.linear(Y.view(B * rows_x, D), w1, L["b1"], epilogue=EPI_BIAS_GELU, out=Hf, w_fragment_major=f1)
             ops.linear(Hf, L["w2"], L["b2"], epilogue=EPI_BIAS_RES, residual=X1.view(B * rows_x, D),
                        out=X.view(B * rows_x, D))
             states.append(None)
