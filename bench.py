@@ -10,7 +10,7 @@ waitk_fixed_pre_decision ratio 8), bf16, synthetic 80x1000 fbank, batch 64 per G
 greedy steps (EOS masked) => 7040 tokens per step per GPU.  One "step" = one pass of the hot
 path (encoder forward + 110 decoder steps + argmax) over one batch of 64 utterances already
 resident in HBM, the stopwatch placement of eval/generate.py:200-209.  Scheduling (reported in
-config.schedule): --group G (default 24) independent batches ride in one launch sequence (their rows are
+config.schedule): --group G (default 64) independent batches ride in one launch sequence (their rows are
 stacked; every row's result is independent of its batch, tests/test_hip_properties.py) and
 --concurrency S such sequences are in flight on S HIP streams, so S*G batches of 64 are in flight
 and K timed steps are K batches whatever G and S are.  serial_one_batch_in_flight is the same
@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 # execute concurrently on this stack (tools/microbench_streams.hip); 8 lets 3-4 independent decode chains overlap.
 # Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+PMC_TRAFFIC_FILE = "r01_m_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py
 
 import torch  # noqa: E402
 
@@ -97,14 +98,14 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=144)
-    ap.add_argument("--warmup", type=int, default=72)
+    ap.add_argument("--steps", type=int, default=384)
+    ap.add_argument("--warmup", type=int, default=192)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="independent launch sequences in flight (one HIP stream + host thread each)")
-    ap.add_argument("--group", type=int, default=24,
+    ap.add_argument("--group", type=int, default=64,
                     help="independent 64-utterance batches stacked into one launch sequence (fewer when --steps "
                          "does not fill group x concurrency sequences)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -293,9 +294,10 @@ def main():
         # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate runs of this same command; profiles/*_pmc_traffic.json says how it was corrected)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_m_pmc_traffic.json")))
-            if dom in pmc:
-                roofline["traffic"] = pmc[dom]["traffic_bytes_per_launch"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+            if dom in pmc:                      # per-launch bytes of these kernels are linear in the rows of a sequence
+                roofline["traffic"] = round(pmc[dom]["traffic_bytes_per_launch"] * Bs / pmc.get("rows_per_sequence", 1536))
+                roofline["traffic_source"] = f"profiles/{PMC_TRAFFIC_FILE} ({pmc.get('rows_per_sequence', 1536)} rows per sequence)"
         except (OSError, ValueError, KeyError):
             pass
         # whole-path HBM model of SURVEY.md 8(d): 2.135 MB of algorithmic traffic per token at batch 64 x 110 steps

@@ -28,6 +28,44 @@ __device__ __forceinline__ long c_index(const LinArgs& p, int b, int ii, int c) 
 template <typename T>
 __device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
 
+// LayerNorm prologue on MFMA A fragments held in registers (a wave holds whole rows): moments of a 16-byte chunk,
+// normalisation of a chunk with gamma / beta from LDS (gemm_mid.hip, gemm_panel.hip)
+__device__ __forceinline__ uint4 ln_frag_mid(uint4 v, float mean, float rstd, const float* gs, const float* bs, int k,
+                                             float) {
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) f[e] = (f[e] - mean) * rstd * gs[k + e] + bs[k + e];
+  return v;
+}
+__device__ __forceinline__ uint4 ln_frag_mid(uint4 v, float mean, float rstd, const float* gs, const float* bs, int k,
+                                             bf16) {
+  unsigned int* u = reinterpret_cast<unsigned int*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+    lo = (lo - mean) * rstd * gs[k + 2 * i] + bs[k + 2 * i];
+    hi = (hi - mean) * rstd * gs[k + 2 * i + 1] + bs[k + 2 * i + 1];
+    bf16 l2 = __float2bfloat16(lo), h2 = __float2bfloat16(hi);
+    u[i] = (unsigned int)(*reinterpret_cast<unsigned short*>(&l2)) |
+           ((unsigned int)(*reinterpret_cast<unsigned short*>(&h2)) << 16);
+  }
+  return v;
+}
+__device__ __forceinline__ void moments_mid(uint4 v, float& s1, float& s2, float) {
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { s1 += f[e]; s2 = fmaf(f[e], f[e], s2); }
+}
+__device__ __forceinline__ void moments_mid(uint4 v, float& s1, float& s2, bf16) {
+  const unsigned int* u = reinterpret_cast<const unsigned int*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+    s1 += lo + hi;
+    s2 = fmaf(lo, lo, fmaf(hi, hi, s2));
+  }
+}
+
 // decode-step (M <= 128) contraction, defined in gemm_skinny.hip
 int sl_launch_skinny(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                      const void* R, void* C, const LinArgs& p);
@@ -36,9 +74,14 @@ int sl_launch_skinny(simulst_handle* h, int dtype, int epilogue, const void* A, 
 bool sl_panel_wanted(int dtype, int epi, const LinArgs& p);
 int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
                     void* aux, const LinArgs& p);
+// the same kernel for co-scheduled decode batches (thousands of rows): column range split over blockIdx.y so that the
+// chip is filled, optional LayerNorm prologue on the stationary A fragments
+bool sl_panel_split_wanted(const simulst_handle* h, int dtype, int epi, const LinArgs& p);
+int sl_launch_panel_split(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R,
+                          void* C, const LinArgs& p);
 
 // 64 x 64 tile for co-scheduled batches (M >= 256) with wide outputs, defined in gemm_mid.hip
-bool sl_mid_wanted(int dtype, const LinArgs& p);
+bool sl_mid_wanted(const simulst_handle* h, int dtype, const LinArgs& p);
 int sl_launch_mid(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                   const void* R, void* C, const LinArgs& p);
 

@@ -20,42 +20,6 @@ __device__ long sl_probe_mid[16];
 #define PROBE(i)
 #endif
 
-__device__ __forceinline__ uint4 ln_frag_mid(uint4 v, float mean, float rstd, const float* gs, const float* bs, int k,
-                                             float) {
-  float* f = reinterpret_cast<float*>(&v);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) f[e] = (f[e] - mean) * rstd * gs[k + e] + bs[k + e];
-  return v;
-}
-__device__ __forceinline__ uint4 ln_frag_mid(uint4 v, float mean, float rstd, const float* gs, const float* bs, int k,
-                                             bf16) {
-  unsigned int* u = reinterpret_cast<unsigned int*>(&v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
-    lo = (lo - mean) * rstd * gs[k + 2 * i] + bs[k + 2 * i];
-    hi = (hi - mean) * rstd * gs[k + 2 * i + 1] + bs[k + 2 * i + 1];
-    bf16 l2 = __float2bfloat16(lo), h2 = __float2bfloat16(hi);
-    u[i] = (unsigned int)(*reinterpret_cast<unsigned short*>(&l2)) |
-           ((unsigned int)(*reinterpret_cast<unsigned short*>(&h2)) << 16);
-  }
-  return v;
-}
-__device__ __forceinline__ void moments_mid(uint4 v, float& s1, float& s2, float) {
-  const float* f = reinterpret_cast<const float*>(&v);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { s1 += f[e]; s2 = fmaf(f[e], f[e], s2); }
-}
-__device__ __forceinline__ void moments_mid(uint4 v, float& s1, float& s2, bf16) {
-  const unsigned int* u = reinterpret_cast<const unsigned int*>(&v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
-    s1 += lo + hi;
-    s2 = fmaf(lo, lo, fmaf(hi, hi, s2));
-  }
-}
-
 // RW = 16-row tiles per wave: the workgroup tile is (64 * RW) x 64, wave w owns rows [16*RW*w, 16*RW*(w+1)) of it and
 // all 64 columns.  The 64 x K weight block is the only operand the 4 waves share: it is staged in LDS in
 // fragment-major order (from fragment-major global memory a straight 16-byte copy; from row-major a scatter), so a
@@ -382,10 +346,14 @@ int mid_by_epilogue(simulst_handle* h, int epi, const void* A, const void* W, co
 }  // namespace
 
 // shapes this kernel takes over from the 16 x BN kernel: co-scheduled batches with a wide output
-bool sl_mid_wanted(int dtype, const LinArgs& p) {
+bool sl_mid_wanted(const simulst_handle* h, int dtype, const LinArgs& p) {
   const int KS = dtype == SIMULST_F32 ? 16 : 32;
   const long blocks = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);     // 64 x 64 tiles: most of the chip gets one
-  return p.M >= 256 && p.N >= 512 && blocks >= 192 && p.K % KS == 0 && (!p.ln_g || p.K <= 8 * KS);
+  // narrow outputs with a short contraction (out-proj, q-proj: N = 256, K = 256) from mid_narrow_min_rows rows on:
+  // one wave per 16 x 16 tile re-reads 16 KB of operands per 131 kflop and is L2-bound there (4096 rows: 9.3 -> 7.9 us
+  // out-proj, 12.8 -> 7.6 us LN + q-proj).  fc2 (K = 2048) measured the same on both kernels and keeps the k-split one.
+  const bool narrow = p.N >= 64 && p.N < 512 && p.K <= 8 * KS && p.M >= h->mid_narrow_min_rows;
+  return p.M >= 256 && (p.N >= 512 || narrow) && blocks >= 192 && p.K % KS == 0 && (!p.ln_g || p.K <= 8 * KS);
 }
 
 // narrow outputs of co-scheduled batches with a short contraction: one wave per tile

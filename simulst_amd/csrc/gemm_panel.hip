@@ -18,14 +18,17 @@ namespace {
 
 constexpr int PB_M = 128, PB_N = 64, PB_KS = 32;
 
-template <int EPI>
+// spb: column steps (of 64) per workgroup; blockIdx.y selects the range (1 range = the whole width for the encoder)
+template <int EPI, bool PRO_LN>
 __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Wp,
                                                        const float* __restrict__ bias, const bf16* __restrict__ R,
-                                                       bf16* __restrict__ C, bf16* __restrict__ aux, LinArgs p) {
+                                                       bf16* __restrict__ C, bf16* __restrict__ aux, LinArgs p,
+                                                       int spb) {
   constexpr bool RES = EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_EMF_OUT;
   constexpr int SS = PB_N + 4;                                  // fp32 staging row stride
   __shared__ __attribute__((aligned(16))) uint4 wl[4 * 8 * 64];        // [j][s][lane] 32 KB
   __shared__ __attribute__((aligned(16))) float stage[4][32 * SS];    // per wave [32 rows][64 cols] fp32
+  __shared__ float lng[PRO_LN ? 256 : 1], lnb[PRO_LN ? 256 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * PB_M;
@@ -45,7 +48,26 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
       fa[m][s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
     }
   }
-  const int n_steps = (p.N + PB_N - 1) / PB_N;
+  if constexpr (PRO_LN) {
+    // the wave holds whole rows (K <= 8 k-steps): row moments are this lane's chunks + the 4 k-groups (2 shuffles)
+    for (int k = tid; k < p.K; k += 256) { lng[k] = p.ln_g[k]; lnb[k] = p.ln_b[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) moments_mid(fa[m][s], s1, s2, bf16());
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      const float mean = s1 / (float)p.K;
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < nks) fa[m][s] = ln_frag_mid(fa[m][s], mean, rstd, lng, lnb, s * PB_KS + lg * 8, bf16());
+    }
+  }
+  const int n_all = (p.N + PB_N - 1) / PB_N;
+  const int step0 = blockIdx.y * spb, n_steps = min(n_all, step0 + spb);
   // weight block of a step -> registers: slot q*256 + tid = (j, s, lane)
   uint4 wv[8];
   auto wload = [&](int step) {
@@ -59,9 +81,9 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
       wv[q] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
     }
   };
-  wload(0);
+  wload(step0);
   float* st = stage[wave];
-  for (int step = 0; step < n_steps; ++step) {
+  for (int step = step0; step < n_steps; ++step) {
     __syncthreads();                                            // the previous step's fragment reads are done
 #pragma unroll
     for (int q = 0; q < 8; ++q) wl[q * 256 + tid] = wv[q];
@@ -164,10 +186,11 @@ bool sl_panel_wanted(int dtype, int epi, const LinArgs& p) {
 int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
                     void* aux, const LinArgs& p) {
   dim3 grid((p.M + PB_M - 1) / PB_M);
+  const int spb = (p.N + PB_N - 1) / PB_N;
   KTimer t(h, SIMULST_K_LINEAR);
-#define PANEL(E)                                                                                                   \
-  hipLaunchKernelGGL((panel_kernel<E>), grid, dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias,      \
-                     (const bf16*)R, (bf16*)C, (bf16*)aux, p)
+#define PANEL(E)                                                                                                     \
+  hipLaunchKernelGGL((panel_kernel<E, false>), grid, dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias, \
+                     (const bf16*)R, (bf16*)C, (bf16*)aux, p, spb)
   switch (epi) {
     case SIMULST_EPI_BIAS: PANEL(SIMULST_EPI_BIAS); break;
     case SIMULST_EPI_BIAS_GELU: PANEL(SIMULST_EPI_BIAS_GELU); break;
@@ -176,4 +199,47 @@ int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, co
   }
 #undef PANEL
   return sl_launch_status(h, "simulst_linear(row panel)");
+}
+
+// ---- co-scheduled decode batches -----------------------------------------------------------------------------------
+// Thousands of rows are too few panels to fill 256 CUs, so the column range is split: ~panel_split_blocks workgroups,
+// each keeping its (LayerNorm-ed) A fragments for >= 2 column steps.  With one step per workgroup this would be the
+// 64 x 64 kernel of gemm_mid.hip, which keeps those shapes.
+static int split_steps(const simulst_handle* h, const LinArgs& p) {
+  const int panels = (p.M + PB_M - 1) / PB_M, n_all = (p.N + PB_N - 1) / PB_N;
+  int nsplit = (h->panel_split_blocks + panels - 1) / panels;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > n_all) nsplit = n_all;
+  return (n_all + nsplit - 1) / nsplit;
+}
+
+bool sl_panel_split_wanted(const simulst_handle* h, int dtype, int epi, const LinArgs& p) {
+  if (!(dtype == SIMULST_BF16 && p.w_packed && p.M >= h->panel_split_min_rows && p.K <= 256 && p.K % PB_KS == 0 &&
+        p.N % 16 == 0 && p.N >= 512 && p.a_lead == 0 && p.a_rs >= p.K && (p.c_hd == 0 || p.c_hd % 8 == 0)))
+    return false;
+  if (p.ln_g ? !(epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU)
+             : !(epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU || epi == SIMULST_EPI_BIAS_RES))
+    return false;
+  return split_steps(h, p) >= 2;
+}
+
+int sl_launch_panel_split(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R,
+                          void* C, const LinArgs& p) {
+  const int spb = split_steps(h, p), n_all = (p.N + PB_N - 1) / PB_N;
+  dim3 grid((p.M + PB_M - 1) / PB_M, (n_all + spb - 1) / spb);
+  KTimer t(h, SIMULST_K_LINEAR_TILE64);
+#define PANEL(E, LN)                                                                                              \
+  hipLaunchKernelGGL((panel_kernel<E, LN>), grid, dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias, \
+                     (const bf16*)R, (bf16*)C, (bf16*)nullptr, p, spb)
+  if (p.ln_g) {
+    if (epi == SIMULST_EPI_BIAS) PANEL(SIMULST_EPI_BIAS, true); else PANEL(SIMULST_EPI_BIAS_GELU, true);
+  } else {
+    switch (epi) {
+      case SIMULST_EPI_BIAS: PANEL(SIMULST_EPI_BIAS, false); break;
+      case SIMULST_EPI_BIAS_GELU: PANEL(SIMULST_EPI_BIAS_GELU, false); break;
+      default: PANEL(SIMULST_EPI_BIAS_RES, false); break;
+    }
+  }
+#undef PANEL
+  return sl_launch_status(h, "simulst_linear(row panel, split columns)");
 }

@@ -353,7 +353,8 @@ int by_epilogue(simulst_handle* h, int epi, const void* A, const void* W, const 
 
 int sl_launch_skinny(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                      const void* R, void* C, const LinArgs& p) {
-  if (sl_mid_wanted(dtype, p)) return sl_launch_mid(h, dtype, epilogue, A, W, bias, R, C, p);
+  if (sl_panel_split_wanted(h, dtype, epilogue, p)) return sl_launch_panel_split(h, epilogue, A, W, bias, R, C, p);
+  if (sl_mid_wanted(h, dtype, p)) return sl_launch_mid(h, dtype, epilogue, A, W, bias, R, C, p);
   if (sl_wave_tile_wanted(dtype, p)) return sl_launch_wave_tile(h, dtype, epilogue, A, W, bias, R, C, p);
   return dtype == SIMULST_F32 ? by_epilogue<float>(h, epilogue, A, W, bias, R, C, p)
                               : by_epilogue<bf16>(h, epilogue, A, W, bias, R, C, p);

@@ -16,6 +16,12 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->capturing = false;
   h->force_valu_attention = false;
   h->force_unfused_decode = false;
+  h->panel_split_min_rows = 2560;
+  if (const char* e = getenv("SIMULST_PANEL_SPLIT_MIN_ROWS")) h->panel_split_min_rows = atoi(e);
+  h->panel_split_blocks = 256;
+  if (const char* e = getenv("SIMULST_PANEL_SPLIT_BLOCKS")) h->panel_split_blocks = atoi(e);
+  h->mid_narrow_min_rows = 3072;
+  if (const char* e = getenv("SIMULST_MID_NARROW_MIN_ROWS")) h->mid_narrow_min_rows = atoi(e);
   h->fuse_q_max_rows = 128;
   if (const char* e = getenv("SIMULST_FUSE_Q_MAX_ROWS")) h->fuse_q_max_rows = atoi(e);
   h->graph_exec = nullptr;

@@ -466,7 +466,8 @@ def test_decode_gemm_row_tiles(ops, dtype):
     g = torch.Generator().manual_seed(77)
     tol = dict(atol=2e-4, rtol=2e-4) if dtype == torch.float32 else dict(atol=6e-2, rtol=3e-2)
     for M, N, K in ((200, 256, 256), (512, 768, 256), (1000, 2048, 256), (1024, 256, 2048), (130, 4096, 256),
-                    (1024, 256, 256), (300, 272, 128)):       # the last two: one wave per 16 x 16 tile
+                    (1024, 256, 256), (300, 272, 128),        # these two: one wave per 16 x 16 tile
+                    (3100, 256, 256)):                        # narrow output on the 64 x 64 tile kernel (>= 3072 rows)
         x = torch.randn(M, K, generator=g).to(dtype).cuda()
         W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).cuda()
         b = torch.randn(N, generator=g).cuda()
@@ -479,11 +480,47 @@ def test_decode_gemm_row_tiles(ops, dtype):
                                        ref + r.float(), **tol)
             torch.testing.assert_close(ops.linear(x, Wx, b, epilogue=EPI_BIAS_GELU, w_fragment_major=fm).float(),
                                        torch.nn.functional.gelu(ref), **tol)
-            if K <= 256:
+            if K <= 256 and (fm or M <= 2048):     # LN prologue: decode-step shapes (row-major weights: <= 2048 rows)
                 gam, bet = torch.rand(K, generator=g).cuda() + 0.5, torch.randn(K, generator=g).cuda() * 0.1
                 xn = torch.nn.functional.layer_norm(x.float(), (K,), gam, bet).to(dtype).float()
                 y = ops.linear(x, Wx, b, epilogue=EPI_BIAS_F32OUT, ln=(gam, bet), w_fragment_major=fm)
                 torch.testing.assert_close(y, xn @ W.float().t() + b, **tol)
+
+
+def test_decode_gemm_split_panel(ops):
+    """Co-scheduled decode batches of thousands of rows (bf16, fragment-major weights, K = 256, N >= 512): the
+    row-panel kernel with split column ranges and its LayerNorm prologue against torch fp32 and against the 64 x 64
+    tile kernel it replaces there (a handle created with the switch-over row count out of reach)."""
+    import os
+    from simulst_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES
+    from simulst_amd.ops import Ops
+    os.environ["SIMULST_PANEL_SPLIT_MIN_ROWS"] = "100000000"
+    try:
+        ops_tile = Ops()
+    finally:
+        del os.environ["SIMULST_PANEL_SPLIT_MIN_ROWS"]
+    g = torch.Generator().manual_seed(78)
+    tol = dict(atol=6e-2, rtol=3e-2)
+    K = 256
+    for M, N in ((2600, 768), (4099, 2048), (3072, 528), (8192, 768)):
+        x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).to(torch.bfloat16).cuda()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        r = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+        gam, bet = torch.rand(K, generator=g).cuda() + 0.5, torch.randn(K, generator=g).cuda() * 0.1
+        Wp = ops.pack_fragment_major(W)
+        ref = x.float() @ W.float().t() + b
+        xn = torch.nn.functional.layer_norm(x.float(), (K,), gam, bet).to(torch.bfloat16).float()
+        refn = xn @ W.float().t() + b
+        for epi, res, ln, want in ((EPI_BIAS, None, None, ref), (EPI_BIAS_RES, r, None, ref + r.float()),
+                                   (EPI_BIAS_GELU, None, None, torch.nn.functional.gelu(ref)),
+                                   (EPI_BIAS, None, (gam, bet), refn),
+                                   (EPI_BIAS_GELU, None, (gam, bet), torch.nn.functional.gelu(refn))):
+            y = ops.linear(x, Wp, b, epilogue=epi, residual=res, ln=ln, w_fragment_major=True)
+            y0 = ops_tile.linear(x, Wp, b, epilogue=epi, residual=res, ln=ln, w_fragment_major=True)
+            torch.testing.assert_close(y.float(), want, **tol)
+            # same products, same fp32 accumulation order per output: only the LN prologue's rounding may differ
+            torch.testing.assert_close(y.float(), y0.float(), atol=3.2e-2, rtol=1.6e-2)
 
 
 def test_conv_pos_mfma_equals_valu_kernel(ops):
