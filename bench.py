@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 # execute concurrently on this stack (tools/microbench_streams.hip); 8 lets 3-4 independent decode chains overlap.
 # Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-PMC_TRAFFIC_FILE = "r01_m_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py
+PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py
 
 import torch  # noqa: E402
 
