@@ -67,14 +67,16 @@ def gather_records(utt_ids: torch.Tensor, n_tok: torch.Tensor, tokens: torch.Ten
 
 
 def plan_launch_sequences(n_batches: int, group: int, streams: int):
-    """How `n_batches` independent batches are packed into launch sequences: up to `group` batches are stacked per
-    sequence, fewer when that would leave streams idle (n_batches < group * streams), plus one shorter sequence for
-    the remainder.  Returns the list of batches-per-sequence; it always sums to n_batches (bench.py times EXACTLY the
+    """How `n_batches` independent batches are packed into launch sequences: at most `group` batches are stacked per
+    sequence, the number of sequences is a multiple of `streams` whenever there are enough batches (every stream gets
+    the same number of sequences: no stream idles at the end of the timed region) and sequence sizes differ by at
+    most one.  Returns the list of batches-per-sequence; it always sums to n_batches (bench.py times EXACTLY the
     number of steps it was asked for)."""
     if n_batches <= 0:
         return []
-    g = max(1, min(group, -(-n_batches // max(1, streams))))
-    plan = [g] * (n_batches // g)
-    if n_batches % g:
-        plan.append(n_batches % g)
-    return plan
+    streams = max(1, streams)
+    n_seq = -(-n_batches // max(1, group))
+    n_seq = -(-n_seq // streams) * streams           # next multiple of the streams ...
+    n_seq = max(1, min(n_seq, n_batches))            # ... but never an empty sequence
+    base, extra = divmod(n_batches, n_seq)
+    return [base + 1] * extra + [base] * (n_seq - extra)

@@ -66,14 +66,17 @@ def test_plan_launch_sequences():
     from simulst_amd.sharding import plan_launch_sequences as plan
     assert plan(96, 16, 3) == [16] * 6
     assert plan(48, 16, 3) == [16, 16, 16]
-    assert plan(10, 16, 3) == [4, 4, 2]
+    assert plan(10, 16, 3) == [4, 3, 3]
     assert plan(5, 16, 3) == [2, 2, 1]
+    assert plan(2, 16, 3) == [1, 1]
     assert plan(1, 16, 3) == [1]
     assert plan(0, 16, 3) == []
-    assert plan(50, 16, 3) == [16, 16, 16, 2]
+    assert plan(50, 16, 3) == [9, 9, 8, 8, 8, 8]        # 6 balanced sequences, not 3 x 16 + a tail of 2
+    assert plan(400, 64, 3) == [45] * 4 + [44] * 5
     assert plan(7, 4, 1) == [4, 3]
     for k in range(1, 120):
         for g in (1, 4, 16):
             for s in (1, 2, 3):
                 p = plan(k, g, s)
-                assert sum(p) == k and max(p) <= g and min(p) >= 1
+                assert sum(p) == k and max(p) <= g and min(p) >= 1 and max(p) - min(p) <= 1
+                assert len(p) % s == 0 or len(p) == k or len(p) < s
