@@ -235,6 +235,20 @@ int simulst_expected_alignment(simulst_handle* h, const float* p, float* alpha, 
 int simulst_mass_preservation(simulst_handle* h, float* alpha, const int32_t* key_len,
                               int32_t BH, int32_t U, int32_t S);
 
+/* Expected delays of an expected alignment: out[r] = sum_j (j + 1) * alpha[r][j], alpha [rows][S] fp32
+ * (rows = batch * layers * heads * target steps).  Replaces the `steps * alpha_all` reduction of
+ * criterion/mma_criterion.py:147-156 (MMACriterion.compute_latency_loss). */
+int simulst_expected_delays(simulst_handle* h, const float* alpha, float* out, int64_t rows, int32_t S);
+
+/* Latency metric of every row of delays [B][T] (fp32, source steps): metric = SIMULST_LATENCY_AL (Average Lagging),
+ * _AP (Average Proportion) or _DAL (Differentiable Average Lagging); src_len / tgt_len [B] fp32;
+ * target_padding_mask [B][T] bytes or NULL (then tgt_len must hold T).  Replaces the
+ * simuleval.metrics.latency.{AverageLagging, AverageProportion, DifferentiableAverageLagging} calls at
+ * criterion/mma_criterion.py:171-176 and criterion/cif_criterion.py:210-215 (SimulEval itself is external). */
+enum { SIMULST_LATENCY_AL = 0, SIMULST_LATENCY_AP = 1, SIMULST_LATENCY_DAL = 2 };
+int simulst_latency_metric(simulst_handle* h, const float* delays, const float* src_len, const float* tgt_len,
+                           const uint8_t* target_padding_mask, float* out, int32_t B, int32_t T, int32_t metric);
+
 /* Expected soft attention beta from alpha and soft energy; chunk_size <= 0 = infinite lookback.
  * utils/monotonic_attention.py:79-152 (+ moving_sum utils/functions.py:69-125). */
 int simulst_expected_soft_attention(simulst_handle* h, const float* alpha, const float* energy,

@@ -1,0 +1,146 @@
+"""Forward values of the reference's latency / quantity losses on the GPU.
+
+Mirrors, with the reference's argument meaning:
+  * MMACriterion.compute_latency_loss   criterion/mma_criterion.py:138-207   -> mma_latency_loss
+  * CIFCriterion.compute_latency_loss   criterion/cif_criterion.py:203-220   -> cif_latency_loss
+  * CIFCriterion.compute_quantity_loss  criterion/cif_criterion.py:222-287   -> cif_quantity_loss
+  * clipped_l2_loss                     criterion/cif_criterion.py:59-69
+The reductions over the expected alignments (`simulst_expected_delays`), the latency metrics
+(`simulst_latency_metric`: AL / AP / DAL, SimulEval's tensor metrics) and the CTC Viterbi alignment behind the "align"
+quantity targets (`simulst_ctc_best_alignment`) are HIP kernels behind the C ABI; what is left here is the criterion's
+scalar bookkeeping on a handful of [B]-sized tensors.  Forward only: these are the values the reference logs as
+`latency`, `delays_var`, `latency_loss`, `quantity`, `q_acc` (validation / evaluation); there is no autograd through
+the kernels.  No CPU fallback: CPU tensors raise.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from .ctc_align import best_alignment
+from .ops import Ops, _p
+
+_METRIC = {"average_lagging": 0, "average_proportion": 1, "differentiable_average_lagging": 2}
+_ops: Optional[Ops] = None
+
+
+def _get_ops() -> Ops:
+    global _ops
+    if _ops is None:
+        _ops = Ops()
+    return _ops
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("simulst_amd.losses: tensors must live on the GPU (no CPU fallback)")
+
+
+def expected_delays(alpha: torch.Tensor, ops: Optional[Ops] = None) -> torch.Tensor:
+    """alpha [..., S] (fp32, expected alignment) -> [...]: sum_j (j + 1) * alpha[..., j]  (mma_criterion.py:147-156)"""
+    _need_cuda(alpha)
+    ops = ops or _get_ops()
+    a = alpha.float().contiguous()
+    S = a.size(-1)
+    out = torch.empty(a.shape[:-1], device=a.device, dtype=torch.float32)
+    if a.numel() == 0:
+        return out
+    ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
+    ops.h.check(ops.lib.simulst_expected_delays(ops.h.ptr, _p(a), _p(out), a.numel() // S, S), "simulst_expected_delays")
+    return out
+
+
+def latency_metric(name: str, delays, src_lens, tgt_lens, target_padding_mask=None, ops: Optional[Ops] = None):
+    """SimulEval's tensor latency metrics on delays [B, T] (source steps): returns [B] fp32."""
+    _need_cuda(delays, src_lens, tgt_lens, target_padding_mask)
+    if name not in _METRIC:
+        raise KeyError(f"unknown latency metric {name!r} (have {sorted(_METRIC)})")
+    ops = ops or _get_ops()
+    d = delays.float().contiguous()
+    B, T = d.shape
+    src = src_lens.float().contiguous()
+    tgt = tgt_lens.float().contiguous()
+    pm = None if target_padding_mask is None else target_padding_mask.to(torch.uint8).contiguous()
+    out = torch.empty(B, device=d.device, dtype=torch.float32)
+    if B == 0:
+        return out
+    ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
+    ops.h.check(ops.lib.simulst_latency_metric(ops.h.ptr, _p(d), _p(src), _p(tgt), _p(pm), _p(out), B, T, _METRIC[name]),
+                "simulst_latency_metric")
+    return out
+
+
+def mma_latency_loss(alpha_list: List[torch.Tensor], target_padding_mask, encoder_padding_mask, src_lengths, *,
+                     latency_avg_type="differentiable_average_lagging", latency_gather_method="weighted_average",
+                     latency_avg_weight=0.0, latency_var_weight=0.0, ms_per_frame_shift=10.0):
+    """MMACriterion.compute_latency_loss: alpha_list = per decoder layer [B, H, T, S] expected alignments
+    (net_output[1]["attn_list"][l]["alpha"]); returns (latency_loss, expected latency in ms summed over the batch,
+    variance of the expected delays over heads) as 0-d GPU tensors."""
+    num_layers = len(alpha_list)
+    bsz, num_heads, tgt_len, src_len = alpha_list[0].shape
+    alpha_all = torch.cat(alpha_list, dim=1).view(-1, tgt_len, src_len)
+    delays = expected_delays(alpha_all)                                              # [B * L * H, T]
+    target_lengths = (~target_padding_mask).sum(1)
+    assert not bool(encoder_padding_mask[:, 0].any()), "Only right padding is supported."
+    encoder_lengths = (~encoder_padding_mask).sum(-1)
+    rep = num_layers * num_heads
+    if latency_gather_method == "average":
+        raise NotImplementedError("the reference's `average` gather cannot run (mma_criterion.py:184-186 produces a "
+                                  "[B*L*H] vector that it then multiplies with [B] lengths); use weighted_average or max")
+    lat = latency_metric(latency_avg_type, delays, torch.repeat_interleave(encoder_lengths, rep, 0),
+                         torch.repeat_interleave(target_lengths, rep, 0),
+                         torch.repeat_interleave(target_padding_mask, rep, 0)).view(bsz, -1)
+    if latency_gather_method == "weighted_average":
+        lat = torch.sum(lat * torch.softmax(lat, dim=1), dim=1)
+    elif latency_gather_method == "max":
+        lat = lat.max(dim=1)[0]
+    else:
+        raise NotImplementedError(latency_gather_method)
+    avg_loss = latency_avg_weight * lat.clip(min=0).sum()
+    delays_var = delays.view(bsz, -1, tgt_len).var(dim=1).mean(dim=1).sum()
+    latency_loss = avg_loss + latency_var_weight * delays_var
+    lat_ms = lat * (src_lengths / encoder_lengths * ms_per_frame_shift)
+    return latency_loss, lat_ms.sum(), delays_var
+
+
+def clipped_l2_loss(x, y, reduce=True, clip=None):
+    """cif_criterion.py:59-69"""
+    y = y.type_as(x)
+    if clip is not None:
+        c = clip ** 0.5
+        y = torch.minimum(torch.maximum(y, x - c), x + c)
+    l = (x - y) ** 2
+    return l.sum() if reduce else l
+
+
+def cif_latency_loss(delays, encoder_lengths, target_lengths, target_padding_mask, src_lengths, ms_per_frame_shift=10.0):
+    """CIFCriterion.compute_latency_loss -> (latency_loss, expected latency in ms summed over the batch)"""
+    lat = latency_metric("differentiable_average_lagging", delays, encoder_lengths, target_lengths, target_padding_mask)
+    return lat.clip(min=0).sum(), (lat * (src_lengths / encoder_lengths * ms_per_frame_shift)).sum()
+
+
+def cif_quantity_loss(alpha, ctc_lprobs, encoder_lengths, encoder_padding_mask, target, target_lengths, *,
+                      quant_type="align", quant_clip=10.0, beta=1.0, blank=0):
+    """CIFCriterion.compute_quantity_loss -> (l_quant, quant_acc).  alpha [B, S]; ctc_lprobs [S, B, V] ("align")."""
+    _need_cuda(alpha, target, target_lengths)
+    if quant_type == "sum":
+        quant_targets = target_lengths.unsqueeze(1)
+        boundary = torch.ones_like(quant_targets)     # LONG ones: the reference's x[boundary] below is integer indexing
+        quant_outputs = alpha.sum(1, keepdim=True) / beta
+    elif quant_type == "align":
+        states = best_alignment(ctc_lprobs.float().contiguous(), target, encoder_lengths, target_lengths, blank=blank,
+                                ops=_get_ops())
+        seg_ids = states.div(2, rounding_mode="floor")
+        boundary = (seg_ids != seg_ids.roll(-1, dims=1)) & (states % 2 != 0)
+        if encoder_padding_mask is not None:
+            boundary[encoder_padding_mask] = 0
+        quant_targets = boundary.cumsum(1)
+        quant_outputs = alpha.cumsum(1) / beta
+    else:
+        raise NotImplementedError(quant_type)
+    l = clipped_l2_loss(quant_outputs[boundary], quant_targets[boundary], reduce=False, clip=quant_clip)
+    norm = boundary / boundary.sum(1, keepdim=True)
+    l_quant = (l * norm[boundary]).sum()
+    quant_acc = (((quant_outputs[:, -1] - target_lengths).abs() / target_lengths) <= 0.1).long().sum()
+    return l_quant, quant_acc

@@ -1,0 +1,153 @@
+"""Forward values of the reference's latency / quantity losses (second half).
+CPU: oracle/losses.py against g17_losses.npz (recorded from the reference's criterion methods).
+GPU: simulst_amd.losses (HIP reductions / scans through the C ABI) against the oracle and the same fixture."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses as ol
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "g17_losses.npz"))
+MMA_CASES = [(a, g) for a in ("differentiable_average_lagging", "average_lagging", "average_proportion")
+             for g in ("weighted_average", "max")]
+QUANT_CASES = [(q, c, b) for q in ("sum", "align") for c in (None, 10.0, 0.25) for b in (1.0, 0.926)]
+
+
+def _mma_inputs(device="cpu"):
+    alpha = [torch.from_numpy(G[f"mma.alpha{l}"]).to(device) for l in range(3)]
+    target = torch.from_numpy(G["mma.target"]).to(device)
+    return alpha, target == 1, torch.from_numpy(G["mma.enc_pad"]).to(device), torch.from_numpy(G["mma.src_lengths"]).to(device)
+
+
+def _cif_inputs(device="cpu"):
+    t = {k: torch.from_numpy(G["cif." + k]).to(device) for k in ("alpha", "lprobs", "enc_len", "enc_pad", "delays", "tpad",
+                                                                  "target", "tgt_len", "src_lengths")}
+    return t
+
+
+@pytest.mark.parametrize("avg_type,gather", MMA_CASES)
+def test_oracle_mma_latency_loss_golden(avg_type, gather):
+    alpha, tpad, epad, src = _mma_inputs()
+    got = ol.mma_latency_loss(alpha, tpad, epad, src, latency_avg_type=avg_type, latency_gather_method=gather,
+                              latency_avg_weight=0.7, latency_var_weight=0.3, ms_per_frame_shift=10)
+    np.testing.assert_allclose([float(v) for v in got], G[f"mma.{avg_type}.{gather}"], rtol=1e-5, atol=1e-5)
+
+
+def test_reference_average_gather_branch_cannot_run():
+    """the reference's `average` gather turns the per-batch latency into a [B*L*H, T]-derived vector and multiplies it
+    with [B] lengths: it raises for every real shape; recorded so nobody 'fixes' the restatement silently"""
+    assert bool(G["mma.average_branch_raises"])
+
+
+def test_oracle_cif_losses_golden():
+    t = _cif_inputs()
+    l, lat = ol.cif_latency_loss(t["delays"], t["enc_len"], t["tgt_len"], t["tpad"], t["src_lengths"], 10)
+    np.testing.assert_allclose([float(l), float(lat)], G["cif.latency"], rtol=1e-5)
+    for qt, clip, beta in QUANT_CASES:
+        lq, acc = ol.cif_quantity_loss(t["alpha"], t["lprobs"], t["enc_len"], t["enc_pad"], t["target"], t["tgt_len"],
+                                       quant_type=qt, quant_clip=clip, beta=beta, blank=0)
+        np.testing.assert_allclose([float(lq), float(acc)], G[f"cif.quant.{qt}.{clip}.{beta}"], rtol=1e-5)
+    x, y = torch.from_numpy(G["l2.x"]), torch.from_numpy(G["l2.y"])
+    np.testing.assert_allclose(ol.clipped_l2_loss(x, y, reduce=False).numpy(), G["l2.none"], rtol=1e-6)
+    np.testing.assert_allclose(ol.clipped_l2_loss(x, y, reduce=False, clip=2.0).numpy(), G["l2.clip"], rtol=1e-6)
+
+
+def test_latency_metrics_known_answers():
+    """wait-k style delays d_i = min(k + i, S) on a source of S steps, T = S targets: AL = k (definition of lagging
+    behind the diagonal), AP = area under the staircase / (S*T), DAL >= AL and equals it when no write bursts occur"""
+    S = T = 10
+    for k in (1, 3):
+        d = torch.tensor([[float(min(k + i, S)) for i in range(T)]])
+        src, tgt = torch.tensor([S]), torch.tensor([T])
+        assert abs(float(ol.average_lagging(d, src, tgt)) - k) < 1e-6
+        assert abs(float(ol.average_proportion(d, src, tgt)) - float(d.sum()) / (S * T)) < 1e-6
+        assert float(ol.differentiable_average_lagging(d, src, tgt)) >= float(ol.average_lagging(d, src, tgt)) - 1e-6
+    # a burst of writes at the same delay is spread by DAL: 3 targets all written after the whole source of 6
+    d = torch.tensor([[6.0, 6.0, 6.0]])
+    assert abs(float(ol.differentiable_average_lagging(d, torch.tensor([6]), torch.tensor([3]))) - 6.0) < 1e-6
+    assert abs(float(ol.average_lagging(d, torch.tensor([6]), torch.tensor([3]))) - 6.0) < 1e-6
+
+
+def test_tensor_metrics_equal_the_list_scorers():
+    """the batched (criterion-side) restatement and the per-instance scorers of the evaluation harness
+    (oracle/latency.py, the ones pinned by the full-size AL parity runs) are the same functions of the delays"""
+    from oracle import latency as lat
+    g = torch.Generator().manual_seed(5)
+    for _ in range(20):
+        T = int(torch.randint(1, 15, (1,), generator=g))
+        S = float(torch.randint(5, 40, (1,), generator=g))
+        d = torch.sort(torch.rand(T, generator=g) * S * 1.2)[0]
+        dl = [float(v) for v in d]
+        src, tgt = torch.tensor([S]), torch.tensor([T])
+        assert abs(float(ol.average_lagging(d[None], src, tgt)) - lat.average_lagging(dl, S)) < 1e-4
+        assert abs(float(ol.average_proportion(d[None], src, tgt)) - lat.average_proportion(dl, S)) < 1e-5
+        assert abs(float(ol.differentiable_average_lagging(d[None], src, tgt)) - lat.differentiable_average_lagging(dl, S)) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_expected_delays_and_metrics_match_oracle():
+    from simulst_amd import losses as hl
+    g = torch.Generator().manual_seed(3)
+    for rows, T, S in ((5, 7, 11), (130, 33, 250), (1, 1, 1)):
+        alpha = torch.rand(rows, T, S, generator=g)
+        got = hl.expected_delays(alpha.cuda()).cpu()
+        torch.testing.assert_close(got, ol.expected_delays(alpha), rtol=1e-5, atol=1e-4)
+        delays = torch.sort(torch.rand(rows, T, generator=g) * S, dim=1)[0]
+        src = torch.randint(max(1, S // 2), S + 1, (rows,), generator=g)
+        tgt = torch.randint(1, T + 1, (rows,), generator=g)
+        tpad = torch.arange(T).unsqueeze(0) >= tgt.unsqueeze(1)
+        for name in ("average_lagging", "average_proportion", "differentiable_average_lagging"):
+            for mask in (None, tpad):
+                tl = tgt if mask is not None else torch.full((rows,), T)
+                want = ol.LATENCY_METRICS[name](delays, src, tl, target_padding_mask=mask)
+                have = hl.latency_metric(name, delays.cuda(), src.cuda(), tl.cuda(),
+                                         target_padding_mask=None if mask is None else mask.cuda()).cpu()
+                torch.testing.assert_close(have, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("avg_type,gather", MMA_CASES)
+def test_hip_mma_latency_loss_golden(avg_type, gather):
+    from simulst_amd import losses as hl
+    alpha, tpad, epad, src = _mma_inputs("cuda")
+    got = hl.mma_latency_loss(alpha, tpad, epad, src, latency_avg_type=avg_type, latency_gather_method=gather,
+                              latency_avg_weight=0.7, latency_var_weight=0.3, ms_per_frame_shift=10)
+    np.testing.assert_allclose([float(v) for v in got], G[f"mma.{avg_type}.{gather}"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_cif_losses_golden():
+    from simulst_amd import losses as hl
+    t = _cif_inputs("cuda")
+    l, lat = hl.cif_latency_loss(t["delays"], t["enc_len"], t["tgt_len"], t["tpad"], t["src_lengths"], 10)
+    np.testing.assert_allclose([float(l), float(lat)], G["cif.latency"], rtol=2e-5)
+    for qt, clip, beta in QUANT_CASES:
+        lq, acc = hl.cif_quantity_loss(t["alpha"], t["lprobs"], t["enc_len"], t["enc_pad"], t["target"], t["tgt_len"],
+                                       quant_type=qt, quant_clip=clip, beta=beta, blank=0)
+        np.testing.assert_allclose([float(lq), float(acc)], G[f"cif.quant.{qt}.{clip}.{beta}"], rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_train_mode_chain_p_choose_to_latency():
+    """training-mode forward chain on the device: p_choose -> expected alignment (wavefront scans, scans.hip) ->
+    expected delays -> DAL, against the oracle's restatement of the same chain (utils/monotonic_attention.py:12-76 +
+    mma_criterion.py:147-176)"""
+    from oracle import monotonic as oscans
+    from simulst_amd import losses as hl
+    from simulst_amd.ops import Ops
+    ops = Ops()
+    g = torch.Generator().manual_seed(11)
+    BH, U, S = 12, 9, 40
+    p = torch.rand(BH, U, S, generator=g) * 0.6 + 0.05
+    alpha_ref = oscans.expected_alignment_from_p_choose(p, eps=1e-6)
+    alpha = ops.expected_alignment(p.cuda())
+    torch.testing.assert_close(alpha.cpu(), alpha_ref, rtol=1e-4, atol=1e-5)
+    d = hl.expected_delays(alpha)
+    torch.testing.assert_close(d.cpu(), ol.expected_delays(alpha_ref), rtol=1e-4, atol=1e-4)
+    src, tgt = torch.full((BH,), S), torch.full((BH,), U)
+    dal = hl.latency_metric("differentiable_average_lagging", d, src.cuda(), tgt.cuda())
+    torch.testing.assert_close(dal.cpu(), ol.differentiable_average_lagging(ol.expected_delays(alpha_ref), src, tgt),
+                               rtol=1e-4, atol=1e-4)
