@@ -32,6 +32,8 @@ struct simulst_handle {
   int panel_split_min_rows;    // co-scheduled decode GEMMs (K <= 256, N >= 512): rows from which the row-panel kernel with
   int panel_split_blocks;      //   split column ranges replaces the 64 x 64 tile kernel, and its target workgroup count
   int mid_narrow_min_rows;     // rows from which N < 512, K <= 256 decode GEMMs (out-proj, q-proj) take the 64 x 64 tile kernel
+  int skinny_min_blocks_tall;  // k-split decode GEMM with more rows than columns (fc2 of co-scheduled batches): workgroups
+                               //   down to which the tile chooser keeps the 64 x 32 tile
   int fuse_q_max_rows;         // decode loop: rows up to which LN2 + q-proj ride inside the policy/cross-attention launch
   bool force_unfused_decode;   // test hook: 7-launch decoder layer even when the head-split workspace is given
   hipGraphExec_t graph_exec;

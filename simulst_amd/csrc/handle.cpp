@@ -22,6 +22,8 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_PANEL_SPLIT_BLOCKS")) h->panel_split_blocks = atoi(e);
   h->mid_narrow_min_rows = 3072;
   if (const char* e = getenv("SIMULST_MID_NARROW_MIN_ROWS")) h->mid_narrow_min_rows = atoi(e);
+  h->skinny_min_blocks_tall = 192;
+  if (const char* e = getenv("SIMULST_SKINNY_MIN_BLOCKS_TALL")) h->skinny_min_blocks_tall = atoi(e);
   h->fuse_q_max_rows = 128;
   if (const char* e = getenv("SIMULST_FUSE_Q_MAX_ROWS")) h->fuse_q_max_rows = atoi(e);
   h->graph_exec = nullptr;
