@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
 // shapes the panel kernel takes: bf16, fragment-major weights, tall problems with a short contraction
 bool sl_panel_wanted(int dtype, int epi, const LinArgs& p) {
   return dtype == SIMULST_BF16 && p.w_packed && p.M >= 4096 && p.K <= 256 && p.K % PB_KS == 0 && p.N % 16 == 0 &&
-         p.a_lead == 0 && p.a_rs >= p.K && !p.ln_g && (p.c_hd == 0 || p.c_hd % 8 == 0) &&
+         p.a_lead == 0 && p.a_rs >= p.K && (p.c_hd == 0 || p.c_hd % 8 == 0) &&
+         // LayerNorm prologue (the encoder's pre-FFN LayerNorm rides in fc1: applied ONCE to the stationary A
+         // fragments of a panel, one launch and 0.8 MB of HBM traffic per utterance and layer less)
+         (!p.ln_g || epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU) &&
          // (fc1 + GELU: 1568 us here vs 1795 us on the 128 x 128 tile kernel at 605 k rows, N = 2048, now that the
          //  GELU issues on the packed fp32 pipe; with the exp-based form the tile kernel had been the faster one)
          (epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU || epi == SIMULST_EPI_BIAS_RES || epi == SIMULST_EPI_EMF_OUT);
@@ -191,6 +194,13 @@ int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, co
 #define PANEL(E)                                                                                                     \
   hipLaunchKernelGGL((panel_kernel<E, false>), grid, dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias, \
                      (const bf16*)R, (bf16*)C, (bf16*)aux, p, spb)
+#define PANEL_LN(E)                                                                                                 \
+  hipLaunchKernelGGL((panel_kernel<E, true>), grid, dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias, \
+                     (const bf16*)R, (bf16*)C, (bf16*)aux, p, spb)
+  if (p.ln_g) {
+    if (epi == SIMULST_EPI_BIAS) PANEL_LN(SIMULST_EPI_BIAS); else PANEL_LN(SIMULST_EPI_BIAS_GELU);
+    return sl_launch_status(h, "simulst_linear(row panel, LayerNorm prologue)");
+  }
   switch (epi) {
     case SIMULST_EPI_BIAS: PANEL(SIMULST_EPI_BIAS); break;
     case SIMULST_EPI_BIAS_GELU: PANEL(SIMULST_EPI_BIAS_GELU); break;
@@ -198,6 +208,7 @@ int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, co
     default: PANEL(SIMULST_EPI_EMF_OUT); break;
   }
 #undef PANEL
+#undef PANEL_LN
   return sl_launch_status(h, "simulst_linear(row panel)");
 }
 

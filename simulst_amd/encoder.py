@@ -135,6 +135,7 @@ class S2TEmformerEncoder:
 
     # ---------------------------------------------------------------- Emformer
     use_panel_gemm = True
+    fuse_ffn_layernorm = True      # bf16 row-panel path: LayerNorm as fc1's prologue instead of its own launch
 
     def _packed(self, l, name):
         """Fragment-major copy of an encoder projection weight (bf16 only, made once): lets simulst_linear take the
@@ -216,10 +217,15 @@ class S2TEmformerEncoder:
                            a_bs=rows_c * D, a_rs=D, c_bs=rows_x * D, c_rs=D, epilogue=EPI_EMF_OUT, R=X,
                            r_bs=rows_x * D, r_rs=D, n_main=rows_x, aux=Zn, aux_rows=n_mem, aux_bs=rows_z * D,
                            w_fragment_major=fo)
-            ops.layernorm(X1, L["ln_ff_g"], L["ln_ff_b"], out=Y)
-            # fc1 + GELU on the row panel too since its GELU went to the packed fp32 pipe (1568 vs 1795 us at 605 k rows)
+            # fc1 + GELU on the row panel too since its GELU went to the packed fp32 pipe (1568 vs 1795 us at 605 k rows);
+            # there the pre-FFN LayerNorm is the kernel's prologue (once per 128-row panel, on the stationary fragments)
             w1, f1 = self._packed(l, "w1") if tall else (L["w1"], False)
-            ops.linear(Y.view(B * rows_x, D), w1, L["b1"], epilogue=EPI_BIAS_GELU, out=Hf, w_fragment_major=f1)
+            if f1 and self.fuse_ffn_layernorm:
+                ops.linear(X1.view(B * rows_x, D), w1, L["b1"], epilogue=EPI_BIAS_GELU, out=Hf, w_fragment_major=True,
+                           ln=(L["ln_ff_g"], L["ln_ff_b"]))
+            else:
+                ops.layernorm(X1, L["ln_ff_g"], L["ln_ff_b"], out=Y)
+                ops.linear(Y.view(B * rows_x, D), w1, L["b1"], epilogue=EPI_BIAS_GELU, out=Hf, w_fragment_major=f1)
             ops.linear(Hf, L["w2"], L["b2"], epilogue=EPI_BIAS_RES, residual=X1.view(B * rows_x, D),
                        out=X.view(B * rows_x, D))
             states.append(None)

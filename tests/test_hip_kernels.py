@@ -606,6 +606,16 @@ def test_row_panel_gemm(ops, epi):
             want = ref if epi == "bias" else torch.nn.functional.gelu(ref)
             torch.testing.assert_close(y1.float(), want, atol=6e-2, rtol=3e-2)
             torch.testing.assert_close(y1.float(), y0.float(), atol=3e-2, rtol=2e-2)
+            # LayerNorm prologue on the stationary fragments (the encoder's pre-FFN LayerNorm inside fc1) against the
+            # LayerNorm kernel followed by the same GEMM
+            gam, bet = torch.rand(K, generator=g).cuda() + 0.5, torch.randn(K, generator=g).cuda() * 0.1
+            xs = (x.float() * 1.7 + 0.4).to(bf)
+            y2 = ops.linear(xs, Wp, b, epilogue=e, w_fragment_major=True, ln=(gam, bet))
+            y3 = ops.linear(ops.layernorm(xs, gam, bet), Wp, b, epilogue=e, w_fragment_major=True)
+            xn = torch.nn.functional.layer_norm(xs.float(), (K,), gam, bet).to(bf).float()
+            refn = xn @ W.float().t() + b
+            torch.testing.assert_close(y2.float(), refn if epi == "bias" else torch.nn.functional.gelu(refn), atol=6e-2, rtol=3e-2)
+            torch.testing.assert_close(y2.float(), y3.float(), atol=3.2e-2, rtol=1.6e-2)
         elif epi == "res":
             r = torch.randn(M, N, generator=g).to(bf).cuda()
             y0 = ops.linear(x, W, b, epilogue=EPI_BIAS_RES, residual=r)
