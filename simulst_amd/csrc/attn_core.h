@@ -33,6 +33,16 @@ template <> struct VL<bf16> {
   }
 };
 
+// q . k over one 16-byte chunk of 8 bf16 pairs on the packed dot unit (v_dot2c_f32_bf16: two products and the fp32
+// accumulate per instruction) -- 4 instructions instead of 8 unpack + 8 fma
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
+  float s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.x), __builtin_bit_cast(bf16x2_t, b.x), 0.f, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.y), __builtin_bit_cast(bf16x2_t, b.y), s, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.z), __builtin_bit_cast(bf16x2_t, b.z), s, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.w), __builtin_bit_cast(bf16x2_t, b.w), s, false);
+}
+
 __device__ __forceinline__ float blk_max(float v, float* scratch) {
   v = wave_max(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,11 +217,15 @@ __device__ __forceinline__ float finish3(const Regs2<T, NP>& r, int n, int n_max
   for (int i = 0; i < NP; ++i) {
     sc[i] = -INFINITY;
     if (i * RP < n_max) {
-      float ka[W];
-      VL<T>::cvt(r.k[i], ka);
       float s = 0.f;
+      if (std::is_same<T, bf16>::value && !q_lds) {
+        s = dot8_bf16(r.q, r.k[i]) * qscale;       // raw bf16 query chunk straight from the registers
+      } else {
+        float ka[W];
+        VL<T>::cvt(r.k[i], ka);
 #pragma unroll
-      for (int e = 0; e < W; ++e) s = fmaf(qf[e], ka[e], s);
+        for (int e = 0; e < W; ++e) s = fmaf(qf[e], ka[e], s);
+      }
 #pragma unroll
       for (int o = 1; o < NP; o <<= 1) s += __shfl_xor(s, o, 64);
       if (rg + RP * i < n) { sc[i] = s; mw = fmaxf(mw, s); }

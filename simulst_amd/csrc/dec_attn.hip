@@ -100,22 +100,14 @@ __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restr
     *reinterpret_cast<uint4*>(Kh + (long)np * d + c * 8) = *reinterpret_cast<const uint4*>(k_new + c * 8);
     *reinterpret_cast<uint4*>(Vh + (long)np * d + c * 8) = *reinterpret_cast<const uint4*>(v_new + c * 8);
   }
-  float qf[8];
-  attn::VL<bf16>::cvt(qv, qf);
   const float qscale = rsqrtf((float)d);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) qf[e] *= qscale;
   float sc[MAXP];
   float mx = -INFINITY;
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     sc[i] = -INFINITY;
     if (i * RPP < n) {
-      float ka[8];
-      attn::VL<bf16>::cvt(kk[i], ka);
-      float s = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(qf[e], ka[e], s);
+      float s = attn::dot8_bf16(qv, kk[i]) * qscale;
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
       if (rg + RPP * i < n) { sc[i] = s; mx = fmaxf(mx, s); }
     }
