@@ -129,12 +129,16 @@ def cif_quantity_loss(alpha, ctc_lprobs, encoder_lengths, encoder_padding_mask, 
     elif quant_type == "align":
         states = torch.as_tensor(best_alignment(ctc_lprobs.detach().cpu().numpy(), target.cpu().numpy(), encoder_lengths.cpu().numpy(),
                                                 target_lengths.cpu().numpy(), blank=blank))
-        seg_ids = states.div(2, rounding_mode="floor")          # blanks (even states) count towards the NEXT segment
-        boundary = (seg_ids != seg_ids.roll(-1, dims=1)) & (states % 2 != 0)
+        # Viterbi state 2i+1 = i-th target label, 2i = the blank before it (counted with the NEXT label).  A source
+        # position closes a label when it sits on a label state and its successor (cyclically: the reference rolls
+        # the row, so the last position looks at the first) belongs to another label
+        label_of = torch.div(states, 2, rounding_mode="floor")
+        successor = torch.cat([label_of[:, 1:], label_of[:, :1]], dim=1)
+        boundary = (states % 2 == 1) & (successor != label_of)
         if encoder_padding_mask is not None:
-            boundary[encoder_padding_mask] = 0
-        quant_targets = boundary.cumsum(1)
-        quant_outputs = alpha.cumsum(1) / beta
+            boundary = boundary & ~encoder_padding_mask
+        quant_targets = boundary.cumsum(1)                      # running count of closed labels
+        quant_outputs = alpha.cumsum(1) / beta                  # running integral of the CIF weights
     else:
         raise NotImplementedError(quant_type)
     # NOTE "sum": `boundary` is a LONG tensor of ones there, so the reference's `x[boundary]` is integer indexing (every

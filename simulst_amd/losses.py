@@ -131,12 +131,16 @@ def cif_quantity_loss(alpha, ctc_lprobs, encoder_lengths, encoder_padding_mask, 
     elif quant_type == "align":
         states = best_alignment(ctc_lprobs.float().contiguous(), target, encoder_lengths, target_lengths, blank=blank,
                                 ops=_get_ops())
-        seg_ids = states.div(2, rounding_mode="floor")
-        boundary = (seg_ids != seg_ids.roll(-1, dims=1)) & (states % 2 != 0)
+        # Viterbi state 2i+1 = i-th target label, 2i = the blank before it (counted with the NEXT label); a source
+        # position closes a label when it sits on a label state and its successor (cyclic, as the reference's roll)
+        # belongs to another label
+        label_of = torch.div(states, 2, rounding_mode="floor")
+        successor = torch.cat([label_of[:, 1:], label_of[:, :1]], dim=1)
+        boundary = (states % 2 == 1) & (successor != label_of)
         if encoder_padding_mask is not None:
-            boundary[encoder_padding_mask] = 0
-        quant_targets = boundary.cumsum(1)
-        quant_outputs = alpha.cumsum(1) / beta
+            boundary = boundary & ~encoder_padding_mask
+        quant_targets = boundary.cumsum(1)                      # running count of closed labels
+        quant_outputs = alpha.cumsum(1) / beta                  # running integral of the CIF weights
     else:
         raise NotImplementedError(quant_type)
     l = clipped_l2_loss(quant_outputs[boundary], quant_targets[boundary], reduce=False, clip=quant_clip)
