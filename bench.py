@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 # execute concurrently on this stack (tools/microbench_streams.hip); 8 lets 3-4 independent decode chains overlap.
 # Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+PMC_COUNTERS_FILE = "r01_n_counters.json"      # per kernel: HBM GB/s + MFMA utilisation from the same passes
 PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py
 
 import torch  # noqa: E402
@@ -303,6 +304,11 @@ def main():
                 roofline["traffic"] = round(pmc[dom]["traffic_bytes_per_launch"] * Bs / pmc.get("rows_per_sequence", 1536))
                 roofline["traffic_source"] = f"profiles/{PMC_TRAFFIC_FILE} ({pmc.get('rows_per_sequence', 1536)} rows per sequence)"
         except (OSError, ValueError, KeyError):
+            pass
+        # per-kernel HBM GB/s and MFMA utilisation against the gfx950 peaks, from the committed rocprofv3 --pmc passes
+        try:
+            roofline["counters"] = json.load(open(os.path.join(ROOT, "profiles", PMC_COUNTERS_FILE)))
+        except (OSError, ValueError):
             pass
         # whole-path HBM model of SURVEY.md 8(d): 2.135 MB of algorithmic traffic per token at batch 64 x 110 steps
         roofline["path_hbm_model"] = {"bytes_per_token": 2.135e6, "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / 2.135e6),
