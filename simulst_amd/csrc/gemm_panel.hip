@@ -138,10 +138,20 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
           continue;
         }
       }
-      bf16* dst = C + c_index(p, b, ii, c);
       float y[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) y[q] = fs[q];
+      if constexpr (EPI == SIMULST_EPI_BIAS_F32OUT) {           // fp32 logits: C is a float buffer
+        float* dstf = reinterpret_cast<float*>(C) + c_index(p, b, ii, c);
+        if (c + 8 <= p.N && ((p.c_rs | p.c_bs) & 3) == 0) {
+          *reinterpret_cast<float4*>(dstf) = float4{y[0], y[1], y[2], y[3]};
+          *reinterpret_cast<float4*>(dstf + 4) = float4{y[4], y[5], y[6], y[7]};
+        } else {
+          for (int q = 0; q < 8 && c + q < p.N; ++q) dstf[q] = y[q];
+        }
+        continue;
+      }
+      bf16* dst = C + c_index(p, b, ii, c);
       if constexpr (RES) {
         const bf16* rp = R + (long)b * p.r_bs + (long)ii * p.r_rs + c;
         if (c + 8 <= p.N && ((p.r_rs | p.r_bs) & 7) == 0) {
@@ -228,9 +238,10 @@ bool sl_panel_split_wanted(const simulst_handle* h, int dtype, int epi, const Li
   if (!(dtype == SIMULST_BF16 && p.w_packed && p.M >= h->panel_split_min_rows && p.K <= 256 && p.K % PB_KS == 0 &&
         p.N % 16 == 0 && p.N >= 512 && p.a_lead == 0 && p.a_rs >= p.K && (p.c_hd == 0 || p.c_hd % 8 == 0)))
     return false;
-  if (p.ln_g ? !(epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU)
+  if (p.ln_g ? !(epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU || epi == SIMULST_EPI_BIAS_F32OUT)
              : !(epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU || epi == SIMULST_EPI_BIAS_RES))
     return false;
+  if (epi == SIMULST_EPI_BIAS_F32OUT && p.c_hd != 0) return false;
   return split_steps(h, p) >= 2;
 }
 
@@ -243,7 +254,9 @@ int sl_launch_panel_split(simulst_handle* h, int epi, const void* A, const void*
   hipLaunchKernelGGL((panel_kernel<E, LN>), grid, dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias, \
                      (const bf16*)R, (bf16*)C, (bf16*)nullptr, p, spb)
   if (p.ln_g) {
-    if (epi == SIMULST_EPI_BIAS) PANEL(SIMULST_EPI_BIAS, true); else PANEL(SIMULST_EPI_BIAS_GELU, true);
+    if (epi == SIMULST_EPI_BIAS) PANEL(SIMULST_EPI_BIAS, true);
+    else if (epi == SIMULST_EPI_BIAS_F32OUT) PANEL(SIMULST_EPI_BIAS_F32OUT, true);     // final LayerNorm + vocabulary projection
+    else PANEL(SIMULST_EPI_BIAS_GELU, true);
   } else {
     switch (epi) {
       case SIMULST_EPI_BIAS: PANEL(SIMULST_EPI_BIAS, false); break;

@@ -492,7 +492,7 @@ def test_decode_gemm_split_panel(ops):
     row-panel kernel with split column ranges and its LayerNorm prologue against torch fp32 and against the 64 x 64
     tile kernel it replaces there (a handle created with the switch-over row count out of reach)."""
     import os
-    from simulst_amd._lib import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES
+    from simulst_amd._lib import EPI_BIAS, EPI_BIAS_F32OUT, EPI_BIAS_GELU, EPI_BIAS_RES
     from simulst_amd.ops import Ops
     os.environ["SIMULST_PANEL_SPLIT_MIN_ROWS"] = "100000000"
     try:
@@ -502,7 +502,7 @@ def test_decode_gemm_split_panel(ops):
     g = torch.Generator().manual_seed(78)
     tol = dict(atol=6e-2, rtol=3e-2)
     K = 256
-    for M, N in ((2600, 768), (4099, 2048), (3072, 528), (8192, 768)):
+    for M, N in ((2600, 768), (4099, 2048), (3072, 528), (8192, 768), (2700, 4096)):
         x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).to(torch.bfloat16).cuda()
         W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
         b = torch.randn(N, generator=g).cuda()
@@ -515,7 +515,8 @@ def test_decode_gemm_split_panel(ops):
         for epi, res, ln, want in ((EPI_BIAS, None, None, ref), (EPI_BIAS_RES, r, None, ref + r.float()),
                                    (EPI_BIAS_GELU, None, None, torch.nn.functional.gelu(ref)),
                                    (EPI_BIAS, None, (gam, bet), refn),
-                                   (EPI_BIAS_GELU, None, (gam, bet), torch.nn.functional.gelu(refn))):
+                                   (EPI_BIAS_GELU, None, (gam, bet), torch.nn.functional.gelu(refn)),
+                                   (EPI_BIAS_F32OUT, None, (gam, bet), refn)):     # final LayerNorm + vocabulary projection
             y = ops.linear(x, Wp, b, epilogue=epi, residual=res, ln=ln, w_fragment_major=True)
             y0 = ops_tile.linear(x, Wp, b, epilogue=epi, residual=res, ln=ln, w_fragment_major=True)
             torch.testing.assert_close(y.float(), want, **tol)
