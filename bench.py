@@ -337,9 +337,14 @@ def main():
                                               mask_eos=True)
                 t16, _ = model.generate_offline(ref_fb.to(device=f"cuda:{local}", dtype=dtype), torch.full((n_s,), T_FRAMES),
                                                 n_steps=N_STEPS_DECODE, mask_eos=True)
+                # the same utterances as rows 0..n_s-1 of a full launch sequence (B*G rows: the kernels chosen for
+                # thousands of co-scheduled rows), again against the oracle's tokens
+                tbig, _ = model.generate_offline(fb_all, L_all, n_steps=N_STEPS_DECODE, mask_eos=True)
             cpu_base["parity_on_sample"] = {
                 "fp32_tokens_identical_to_oracle": bool(torch.equal(t32.cpu(), ref_toks)),
-                f"{args.dtype}_token_agreement_with_fp32_oracle": round(float((t16.cpu() == ref_toks).float().mean()), 4)}
+                f"{args.dtype}_token_agreement_with_fp32_oracle": round(float((t16.cpu() == ref_toks).float().mean()), 4),
+                f"{args.dtype}_token_agreement_inside_a_{B * G}_row_launch_sequence":
+                    round(float((tbig[:n_s].cpu() == ref_toks).float().mean()), 4) if rank == 0 and B * G >= n_s else None}
             log(f"parity on the cpu sample: {cpu_base['parity_on_sample']}")
         out = {
             "metric": "decoded tgt tokens/sec (Emformer encoder + wait-k=5 greedy decode, MuST-C en-de shape)",
