@@ -18,6 +18,13 @@ namespace {
 
 constexpr int PB_M = 128, PB_N = 64, PB_KS = 32;
 
+#ifdef SL_PROBE
+__device__ long sl_probe_panel[16];
+#define PROBE(i) do { if (blockIdx.x == 3 && blockIdx.y == 1 && threadIdx.x == 0) sl_probe_panel[i] = wall_clock64(); } while (0)
+#else
+#define PROBE(i)
+#endif
+
 // spb: column steps (of 64) per workgroup; blockIdx.y selects the range (1 range = the whole width for the encoder)
 template <int EPI, bool PRO_LN>
 __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Wp,
@@ -28,11 +35,12 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
   constexpr int SS = PB_N + 4;                                  // fp32 staging row stride
   __shared__ __attribute__((aligned(16))) uint4 wl[4 * 8 * 64];        // [j][s][lane] 32 KB
   __shared__ __attribute__((aligned(16))) float stage[4][32 * SS];    // per wave [32 rows][64 cols] fp32
-  __shared__ float lng[PRO_LN ? 256 : 1], lnb[PRO_LN ? 256 : 1];
+  __shared__ __attribute__((aligned(16))) float lng[PRO_LN ? 256 : 2], lnb[PRO_LN ? 256 : 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * PB_M;
   const int nks = p.K / PB_KS;                                  // host: K % 32 == 0, K <= 256
+  PROBE(0);
   // ---- this wave's A fragments: 2 row tiles x 8 k-steps, loaded once
   uint4 fa[2][8];
 #pragma unroll
@@ -66,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
         if (s < nks) fa[m][s] = ln_frag_mid(fa[m][s], mean, rstd, lng, lnb, s * PB_KS + lg * 8, bf16());
     }
   }
+  PROBE(1);                                                     // A fragments arrived (+ LayerNorm)
   const int n_all = (p.N + PB_N - 1) / PB_N;
   const int step0 = blockIdx.y * spb, n_steps = min(n_all, step0 + spb);
   // weight block of a step -> registers: slot q*256 + tid = (j, s, lane)
@@ -88,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 8; ++q) wl[q * 256 + tid] = wv[q];
     __syncthreads();
+    if (step == step0) PROBE(2);                                // first weight block in LDS
     if (step + 1 < n_steps) wload(step + 1);
     f32x4 acc[2][4];
 #pragma unroll
@@ -105,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
                                                              *reinterpret_cast<const bf16x8_t*>(&wf), acc[m][j], 0, 0, 0);
       }
     }
+    if (step == step0) PROBE(3);                                // MFMAs of the first step issued
     // ---- wave-private epilogue: acc[m][j][e] = C[32w + 16m + 4lg + e][64 step + 16j + lr]
     const int n0 = step * PB_N;
 #pragma unroll
@@ -179,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
         for (int q = 0; q < 8 && c + q < p.N; ++q) C[c_index(p, b, ii, c + q)] = __float2bfloat16(y[q]);
       }
     }
+    if (step == step0) PROBE(4);                                // epilogue of the first step done
   }
+  PROBE(5);
 }
 
 }  // namespace
@@ -265,5 +278,18 @@ int sl_launch_panel_split(simulst_handle* h, int epi, const void* A, const void*
     }
   }
 #undef PANEL
+#ifdef SL_PROBE
+  {
+    static int calls = 0;
+    if ((++calls % 97) == 0) {
+      (void)hipStreamSynchronize(h->stream);
+      long t[16];
+      (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(sl_probe_panel), sizeof t);
+      fprintf(stderr, "[probe split panel] M=%d N=%d ln=%d epi=%d spb=%d: A+LN %.2f  W0 %.2f  mfma0 %.2f  epi0 %.2f  rest %.2f  total %.2f us\n",
+              p.M, p.N, p.ln_g != nullptr, epi, spb, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01,
+              (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[5] - t[0]) * 0.01);
+    }
+  }
+#endif
   return sl_launch_status(h, "simulst_linear(row panel, split columns)");
 }
