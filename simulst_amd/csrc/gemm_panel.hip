@@ -90,7 +90,18 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
       wv[q] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
     }
   };
+  // bias of a step's 4 column tiles, requested one step ahead like the weights (a load inside the epilogue would
+  // expose its L2 latency once per step: probe, 1.0 of the 1.9 us of a GELU epilogue)
+  float bnext[4];
+  auto bload = [&](int step) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = step * PB_N + j * 16 + lr;
+      bnext[j] = (bias && c < p.N) ? bias[c] : 0.f;
+    }
+  };
   wload(step0);
+  bload(step0);
   float* st = stage[wave];
   for (int step = step0; step < n_steps; ++step) {
     __syncthreads();                                            // the previous step's fragment reads are done
@@ -98,7 +109,10 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
     for (int q = 0; q < 8; ++q) wl[q * 256 + tid] = wv[q];
     __syncthreads();
     if (step == step0) PROBE(2);                                // first weight block in LDS
-    if (step + 1 < n_steps) wload(step + 1);
+    float bcur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bcur[j] = bnext[j];
+    if (step + 1 < n_steps) { wload(step + 1); bload(step + 1); }
     f32x4 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -120,8 +134,7 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
     const int n0 = step * PB_N;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = n0 + j * 16 + lr;
-      const float bv = (bias && c < p.N) ? bias[c] : 0.f;
+      const float bv = bcur[j];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
