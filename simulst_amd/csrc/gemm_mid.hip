@@ -53,6 +53,28 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
     arow[m] = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
   }
   const bool pk = p.w_packed != 0;
+  // ---- epilogue operands requested up front (inside the epilogue their L2 round trip would be exposed once per
+  //      workgroup: the epilogue owns row (pass * 64 + tid / 4), 16 consecutive columns per thread): the tile's 64
+  //      bias values go through LDS, a bf16 residual row segment is two 16-byte loads kept in registers
+  constexpr bool RES = EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU;
+  constexpr bool RPRE = RES && std::is_same<TA, bf16>::value;
+  __shared__ __attribute__((aligned(16))) float lbias[64];
+  const float bpre = (tid < 64 && bias && n0 + tid < p.N) ? bias[n0 + tid] : 0.f;
+  const int ec = (tid & 3) * 16;
+  uint4 rpre[RPRE ? RW : 1][2];
+  bool rfast = false;
+  if constexpr (RPRE) {
+    rfast = n0 + ec + 16 <= p.N && ((p.r_rs | p.r_bs) & 7) == 0;
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+      const int erow = m0 + q * 64 + (tid >> 2);
+      const bool ok = rfast && erow < p.M;
+      const int eb = ok ? erow / p.rpb : 0, ei = ok ? erow - eb * p.rpb : 0;
+      const TA* rp = R + (long)eb * p.r_bs + (long)ei * p.r_rs + (ok ? n0 + ec : 0);
+      rpre[q][0] = ld16(rp);
+      rpre[q][1] = ld16(rp + 8);
+    }
+  }
   f32x4 acc[RW][4];
 #pragma unroll
   for (int m = 0; m < RW; ++m)
@@ -89,6 +111,7 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
     if constexpr (PRO_LN) {
       if (s0 == 0) for (int k = tid; k < p.K; k += 256) { lng[k] = p.ln_g[k]; lnb[k] = p.ln_b[k]; }
     }
+    if (s0 == 0 && tid < 64) lbias[tid] = bpre;
 #pragma unroll
     for (int q = 0; q < CH; ++q) wl[q * 256 + tid] = wv[q];
     __syncthreads();
@@ -147,7 +170,6 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
   __syncthreads();
   PROBE(4);
   // ---- epilogue: row (pass * 64 + tid / 4), 16 consecutive columns per thread
-  const int ec = (tid & 3) * 16;
 #pragma unroll
   for (int q = 0; q < RW; ++q) {
     const int er = q * 64 + (tid >> 2);
@@ -159,9 +181,17 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = n0 + ec + e;
-      float v = tile[er][ec + e] + ((bias && c < p.N) ? bias[c] : 0.f);
-      if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) {
-        if (c < p.N) v += to_f32(R[(long)eb * p.r_bs + (long)ei * p.r_rs + c]);
+      float v = tile[er][ec + e] + lbias[ec + e];
+      if constexpr (RES) {
+        bool done = false;
+        if constexpr (RPRE) {
+          if (rfast) {
+            const unsigned int w = reinterpret_cast<const unsigned int*>(&rpre[q][e >> 3])[(e & 7) >> 1];
+            v += __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+            done = true;
+          }
+        }
+        if (!done && c < p.N) v += to_f32(R[(long)eb * p.r_bs + (long)ei * p.r_rs + c]);
       }
       if constexpr ((EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) && !std::is_same<TC, bf16>::value)
         v = gelu_erf(v);
