@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
   for (int q = 0; q < NPASS; ++q)
 #pragma unroll
     for (int e = 0; e < EL; ++e) resv[q][e] = 0.f;
+  float bpre[EL];                              // bias of this thread's columns, requested with the residual
+#pragma unroll
+  for (int e = 0; e < EL; ++e) bpre[e] = (!SPLIT && bias && n0 + ec + e < p.N) ? bias[n0 + ec + e] : 0.f;
   if constexpr (!SPLIT && (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU)) {
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const TA* __restrict__ A, c
         partial[((long)blockIdx.z * p.M + erow) * p.N + c] = v;
       } else {
         const int b = erow / p.rpb, ii = erow - b * p.rpb;
-        float y = v + (bias ? bias[c] : 0.f);
+        float y = v + bpre[e];
         if constexpr (EPI == SIMULST_EPI_BIAS_RES || EPI == SIMULST_EPI_BIAS_RES_GELU) y += resv[q][e];
         if constexpr (EPI == SIMULST_EPI_BIAS_GELU || EPI == SIMULST_EPI_BIAS_RES_GELU) y = gelu_erf(y);
         C[c_index(p, b, ii, c)] = from_f32<TC>(y);
