@@ -56,25 +56,8 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
       fa[m][s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
     }
   }
-  if constexpr (PRO_LN) {
-    // the wave holds whole rows (K <= 8 k-steps): row moments are this lane's chunks + the 4 k-groups (2 shuffles)
-    for (int k = tid; k < p.K; k += 256) { lng[k] = p.ln_g[k]; lnb[k] = p.ln_b[k]; }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) moments_mid(fa[m][s], s1, s2, bf16());
-      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-      const float mean = s1 / (float)p.K;
-      const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-        if (s < nks) fa[m][s] = ln_frag_mid(fa[m][s], mean, rstd, lng, lnb, s * PB_KS + lg * 8, bf16());
-    }
-  }
-  PROBE(1);                                                     // A fragments arrived (+ LayerNorm)
+  // the first weight block and its bias are requested BEFORE the LayerNorm prologue: they arrive while the wave waits
+  // for its rows and normalises them (probe: 1.1 us of exposed weight latency per workgroup otherwise)
   const int n_all = (p.N + PB_N - 1) / PB_N;
   const int step0 = blockIdx.y * spb, n_steps = min(n_all, step0 + spb);
   // weight block of a step -> registers: slot q*256 + tid = (j, s, lane)
@@ -102,6 +85,25 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
   };
   wload(step0);
   bload(step0);
+  if constexpr (PRO_LN) {
+    // the wave holds whole rows (K <= 8 k-steps): row moments are this lane's chunks + the 4 k-groups (2 shuffles)
+    for (int k = tid; k < p.K; k += 256) { lng[k] = p.ln_g[k]; lnb[k] = p.ln_b[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) moments_mid(fa[m][s], s1, s2, bf16());
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      const float mean = s1 / (float)p.K;
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)p.K - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < nks) fa[m][s] = ln_frag_mid(fa[m][s], mean, rstd, lng, lnb, s * PB_KS + lg * 8, bf16());
+    }
+  }
+  PROBE(1);                                                     // A fragments arrived (+ LayerNorm)
   float* st = stage[wave];
   for (int step = step0; step < n_steps; ++step) {
     __syncthreads();                                            // the previous step's fragment reads are done
