@@ -161,7 +161,7 @@ def main():
         """k batches -> launch sequences of up to G stacked batches, sized so that every stream gets work when k is
         small (+ one shorter sequence for the remainder)"""
         from simulst_amd.sharding import plan_launch_sequences
-        return [(fb_all[:B * g], L_all[:B * g]) for g in plan_launch_sequences(k, G, args.concurrency)]
+        return [(fb_all[:B * g], L_all[:B * g]) for g in plan_launch_sequences(k, G, args.concurrency, min_per_sequence=24)]
 
     pipe = None
     if args.concurrency > 1:

@@ -66,17 +66,22 @@ def gather_records(utt_ids: torch.Tensor, n_tok: torch.Tensor, tokens: torch.Ten
     return out
 
 
-def plan_launch_sequences(n_batches: int, group: int, streams: int):
+def plan_launch_sequences(n_batches: int, group: int, streams: int, min_per_sequence: int = 1):
     """How `n_batches` independent batches are packed into launch sequences: at most `group` batches are stacked per
     sequence, the number of sequences is a multiple of `streams` whenever there are enough batches (every stream gets
     the same number of sequences: no stream idles at the end of the timed region) and sequence sizes differ by at
-    most one.  Returns the list of batches-per-sequence; it always sums to n_batches (bench.py times EXACTLY the
-    number of steps it was asked for)."""
+    most one.  `min_per_sequence`: with few batches, sequences are not split below this size just to occupy more
+    streams (a launch sequence of a few hundred rows leaves the decode GEMMs at their latency floor; one bigger
+    sequence is faster than three small ones).  Returns the list of batches-per-sequence; it always sums to n_batches
+    (bench.py times EXACTLY the number of steps it was asked for)."""
     if n_batches <= 0:
         return []
     streams = max(1, streams)
     n_seq = -(-n_batches // max(1, group))
-    n_seq = -(-n_seq // streams) * streams           # next multiple of the streams ...
-    n_seq = max(1, min(n_seq, n_batches))            # ... but never an empty sequence
+    n_up = -(-n_seq // streams) * streams            # next multiple of the streams ...
+    n_up = max(1, min(n_up, n_batches))              # ... but never an empty sequence
+    if n_up > n_seq and n_batches // n_up < min_per_sequence:
+        n_up = max(n_seq, min(n_up, n_batches // max(1, min_per_sequence)))   # ... nor sequences too small to pay
+    n_seq = max(1, n_up)
     base, extra = divmod(n_batches, n_seq)
     return [base + 1] * extra + [base] * (n_seq - extra)

@@ -74,6 +74,13 @@ def test_plan_launch_sequences():
     assert plan(50, 16, 3) == [9, 9, 8, 8, 8, 8]        # 6 balanced sequences, not 3 x 16 + a tail of 2
     assert plan(400, 64, 3) == [45] * 4 + [44] * 5
     assert plan(7, 4, 1) == [4, 3]
+    # few batches: no splitting below min_per_sequence just to occupy the streams
+    assert plan(20, 64, 3, 24) == [20]
+    assert plan(50, 64, 3, 24) == [25, 25]
+    assert plan(72, 64, 3, 24) == [24, 24, 24]
+    assert plan(384, 64, 3, 24) == [64] * 6
+    assert plan(130, 64, 3, 24) == [44, 43, 43]
+    assert plan(5, 64, 3, 24) == [5]
     for k in range(1, 120):
         for g in (1, 4, 16):
             for s in (1, 2, 3):
