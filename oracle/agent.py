@@ -175,13 +175,15 @@ def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot
 
 
 def greedy_offline(w, ecfg, dcfg, src_tokens, src_lengths, n_steps=None, mask_eos=False,
-                   max_len_a=0.1, max_len_b=10):
+                   max_len_a=0.1, max_len_b=10, margins=None):
     """Offline batched greedy decode: eval/generate.py:187-209 ->
     task.inference_step -> SequenceGenerator(beam=1) semantics restated:
     encoder._forward once, then decoder steps with 'online' unset (never READs,
     mma_model.py:191-193); step cap int(0.1*T + 10) (exp/infer_st.yaml:3-5).
     With ``mask_eos`` EOS is never chosen, so exactly n_steps tokens/utterance
-    (bench config 2: 110). Returns tokens [B, n] (eos-padded after finish), lengths [B]."""
+    (bench config 2: 110). Returns tokens [B, n] (eos-padded after finish), lengths [B], encoder dict.
+    ``margins``: a list that receives, per step, the gap between the best and the second-best admissible
+    log-probability of every row [B] (how close each greedy decision is to flipping under bf16 rounding)."""
     B = src_tokens.size(0)
     enc = em.encoder_forward(w, "encoder", ecfg, src_tokens, src_lengths)
     pad = enc["encoder_padding_mask"][0]
@@ -203,6 +205,9 @@ def greedy_offline(w, ecfg, dcfg, src_tokens, src_lengths, n_steps=None, mask_eo
             lp[:, :dcfg.eos] = -float("inf")
             lp[:, dcfg.eos + 1:] = -float("inf")
         nxt = lp.argmax(dim=-1)
+        if margins is not None:
+            top2 = lp.topk(2, dim=-1).values
+            margins.append(top2[:, 0] - top2[:, 1])
         nxt = torch.where(done, torch.full_like(nxt, dcfg.eos), nxt)
         lengths += (~done).long()
         done = done | (nxt == dcfg.eos)

@@ -129,6 +129,11 @@ class MMADecoder:
         D, F, V = cfg.embed_dim, cfg.ffn_dim, cfg.vocab
         # decode-loop weights in MFMA-fragment order (1 KB contiguous per wave load) when the shapes allow
         self.fragment_major = D % 64 == 0 and F % 64 == 0 and V % 16 == 0 and cfg.head_dim % 16 == 0
+        # every re-laid-out weight copy is made HERE, by the instance that owns the weights, and the device is
+        # synchronised before anyone else can see them: replicas (shared_weights) run on other streams / host
+        # threads and must never reach a cold cache (ConcurrentOffline)
+        if shared_weights is None:
+            self._pack_all()
 
     # the agent reads decoder.layers[0].encoder_attn.pre_decision_ratio (agents/default_agent.py:157-161)
     @property
@@ -163,11 +168,8 @@ class MMADecoder:
                 for Wt, bt, dst in jobs:
                     hd = cfg.head_dim                # head-major store: [b][h][r0 + i][c % hd]
                     fm = False
-                    if B * n >= 4096 and Wt.dtype == torch.bfloat16 and D <= 256:     # row-panel kernel's domain
-                        cache = self.w.__dict__.setdefault("kv_packed", {})
-                        if Wt.data_ptr() not in cache:
-                            cache[Wt.data_ptr()] = ops.pack_fragment_major(Wt)
-                        Wt, fm = cache[Wt.data_ptr()], True
+                    if B * n >= 4096 and Wt.data_ptr() in self.w.kv_packed:           # row-panel kernel's domain
+                        Wt, fm = self.w.kv_packed[Wt.data_ptr()], True
                     ops.linear_raw(enc_new, Wt, bt, dst[:, :, r0:], M_batches=B, rows_per_batch=n, N=D, K=D,
                                    a_bs=a_bs, a_rs=D, c_bs=cfg.num_heads * st.S_cap * hd, c_rs=hd, epilogue=EPI_BIAS,
                                    c_head_dim=hd, c_head_stride=st.S_cap * hd, w_fragment_major=fm)
@@ -235,14 +237,26 @@ class MMADecoder:
         return None
 
     # ------------------------------------------------------------------ device-resident step loop
-    def _packed(self):
-        """Fragment-major copies of the decode-loop weight matrices (made once, shared through the weights object)."""
-        w = self.w
-        if not hasattr(w, "packed"):
+    def _pack_all(self):
+        """Fragment-major copies of the decode-loop weight matrices and of the cross-attention K/V projections
+        (bf16, D <= 256: the row-panel kernel's domain), made once at construction and published together."""
+        w, cfg = self.w, self.cfg
+        packed, out_proj_packed, kv_packed = None, None, {}
+        if self.fragment_major and cfg.model != "cif_transformer":
             names = ["wqkv", "wo", "c_wq", "c_wo", "fc1", "fc2"] + (["c_wq_soft"] if self.separate_soft else [])
-            w.packed = [{n: self.ops.pack_fragment_major(L[n]) for n in names} for L in w.layers]
-            w.out_proj_packed = self.ops.pack_fragment_major(w.out_proj)
-        return w.packed
+            packed = [{n: self.ops.pack_fragment_major(L[n]) for n in names} for L in w.layers]
+            out_proj_packed = self.ops.pack_fragment_major(w.out_proj)
+        if self.dtype == torch.bfloat16 and cfg.embed_dim <= 256 and cfg.embed_dim % 64 == 0 \
+                and cfg.model != "cif_transformer":
+            for L in w.layers:
+                for n in ("c_wk", "c_wv") + (("c_wk_soft",) if self.separate_soft else ()):
+                    kv_packed[L[n].data_ptr()] = self.ops.pack_fragment_major(L[n])
+        w.packed, w.out_proj_packed, w.kv_packed = packed, out_proj_packed, kv_packed
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def _packed(self):
+        return self.w.packed
 
     def _layer_structs(self, st: DecoderState):
         arr = (_lib.DecLayer * self.cfg.decoder_layers)()
@@ -299,8 +313,6 @@ class MMADecoder:
             st.structs_fragment_major = self.fragment_major
         ws = st.ws
         split = self.head_split and self.fragment_major
-        if self.fragment_major:
-            self._packed()
         out_proj = self.w.out_proj_packed if self.fragment_major else self.w.out_proj
         return _lib.DecoderDesc(B, D, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st.cap, st.S_cap,
                                 _lib.F32 if dt_ == torch.float32 else _lib.BF16, self.attn_enum, cfg.pre_decision_ratio,

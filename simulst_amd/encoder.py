@@ -100,8 +100,27 @@ class S2TEmformerEncoder:
         self.stride = cfg.stride
         self.left_context, self.right_context, self.segment_length = cfg.Lc, cfg.R, cfg.S
         self.max_memory_size = cfg.M
+        # re-laid-out weight copies are made by the owning instance, before any replica on another stream / host
+        # thread can look for them (ConcurrentOffline shares self.w)
+        if shared_weights is None:
+            self._pack_all()
 
     use_mfma_conv_pos = True
+
+    def _pack_all(self):
+        """Fragment-major copies of the K = 256 projection weights (bf16: row-panel kernel) and the conv-pos weight in
+        its MFMA order, made once at construction; the device is synchronised before they are published."""
+        w = self.w
+        if self.dtype == torch.bfloat16:
+            for L in w.layers:
+                for name in ("wqkv", "wo", "w1"):
+                    if L[name].shape[1] % 64 == 0 and L[name].shape[0] % 64 == 0:
+                        L[name + "_fm"] = self.ops.pack_fragment_major(L[name])
+        k = w.pos_w.shape[2]
+        ok = w.pos_w.dtype == torch.bfloat16 and w.pos_w.shape[1] == 16 and k in (16, 32, 64)
+        w.pos_w_packed = self.ops.pack_conv_pos_weight(w.pos_w) if ok else False
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def conv_layer_stride(self):
         return self.stride
@@ -141,21 +160,15 @@ class S2TEmformerEncoder:
         """Fragment-major copy of an encoder projection weight (bf16 only, made once): lets simulst_linear take the
         A-stationary row-panel kernel for the K = 256 contractions of tall problems."""
         L = self.w.layers[l]
-        if L[name].dtype != torch.bfloat16 or not self.use_panel_gemm:
-            return L[name], False
         key = name + "_fm"
-        if key not in L:
-            L[key] = self.ops.pack_fragment_major(L[name])
+        if key not in L or not self.use_panel_gemm:
+            return L[name], False
         return L[key], True
 
     def _conv_pos(self, x, hist, lengths_i32):
         """Causal grouped conv-pos + residual + padding mask: matrix-core kernel for bf16 / 16 channels per group /
         kernel width 16, 32 or 64 (the reference configuration), else the VALU kernel."""
         cfg, w = self.cfg, self.w
-        if getattr(w, "pos_w_packed", None) is None:
-            k = w.pos_w.shape[2]
-            ok = w.pos_w.dtype == torch.bfloat16 and w.pos_w.shape[1] == 16 and k in (16, 32, 64)
-            w.pos_w_packed = self.ops.pack_conv_pos_weight(w.pos_w) if ok else False
         if w.pos_w_packed is not False and self.use_mfma_conv_pos:
             return self.ops.conv_pos_mfma(x, hist, w.pos_w_packed, w.pos_b, lengths_i32, cfg.conv_pos_groups)
         return self.ops.conv_pos(x, hist, w.pos_w, w.pos_b, lengths_i32, cfg.conv_pos_groups)

@@ -45,13 +45,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from simulst_amd.config import mma_model_s
     from simulst_amd.model import SimulSTModel
-    from simulst_amd.sharding import gather_records, shard_utterances
+    from simulst_amd.sharding import gather_records
     from simulst_amd.weights import init_model
 
-    g = torch.Generator().manual_seed(999)
-    lengths = torch.exp(torch.randn(args.utterances, generator=g) * 0.55 + 6.6).clamp(100, 3000).long().tolist()
-    mine = shard_utterances(lengths, world, rank)
-    mine.sort(key=lambda i: -lengths[i])
+    from simulst_amd.offline_eval import (decode_batch, make_batch, plan_shard, synthetic_lengths,
+                                          trim_hypotheses)
+    lengths = synthetic_lengths(args.utterances)
     cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=args.waitk)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = f"cuda:{local}"
@@ -61,28 +60,13 @@ def main():
     # ---- this rank's launch sequences: neighbours in length, sizes balanced over the streams; the synthetic fbank is
     #      resident in HBM before the clock starts (as in bench.py)
     from simulst_amd.model import ConcurrentOffline
-    from simulst_amd.sharding import plan_launch_sequences
     S = max(1, args.streams)
-    batches, s0 = [], 0
-    for n in plan_launch_sequences(len(mine), args.batch, S):
-        idx = mine[s0:s0 + n]
-        s0 += n
-        L = torch.tensor([lengths[i] for i in idx])
-        Tmax = int(L.max())
-        Tpad = (Tmax + 255) // 256 * 256
-        gen = torch.Generator(device=dev).manual_seed(999 + idx[0])
-        fb = torch.randn(len(idx), Tpad, 80, device=dev, generator=gen).to(dtype)
-        fb = fb * (torch.arange(Tpad, device=dev).view(1, -1, 1) < L.to(dev).view(-1, 1, 1))
-        batches.append((idx, fb, L.to(dev), L, int(0.1 * Tmax + 10), Tpad))
+    batches = [(idx,) + make_batch(idx, lengths, dev, dtype) for idx in plan_shard(lengths, world, rank, args.batch, S)]
     pipe = ConcurrentOffline(model, weights, S)
     outs = [None] * len(batches)
 
     def decode(m, b):
-        idx, fb, Ld, L, steps, Tpad = b
-        enc = m.encoder.forward(fb, Ld)
-        toks, _ = m.decoder.greedy_offline(enc["encoder_out_btd"], enc["encoder_lengths"], steps, False,
-                                           s_cap=Tpad // 4 + 1, cap=(steps + 2 + 31) // 32 * 32)
-        return toks.clone()
+        return decode_batch(m, b[1:])
 
     def worker(c, which):
         torch.cuda.set_device(local)
@@ -110,10 +94,7 @@ def main():
     n_tokens = 0
     for (idx, fb, Ld, L, steps, Tpad), toks in zip(batches, outs):     # hypotheses: first EOS or the length cap
         toks = toks.cpu()
-        n_b = (0.1 * L.float() + 10).long().clamp(max=steps)
-        is_eos = toks == cfg.eos
-        first = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, n_b)
-        n_b = torch.minimum(n_b, first)
+        n_b = trim_hypotheses(toks, L, cfg.eos)
         pad = torch.full((len(idx), width), cfg.padding_idx, dtype=torch.int64)
         pad[:, :steps] = toks
         ids += idx
