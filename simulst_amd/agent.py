@@ -76,9 +76,10 @@ class FairseqSimulSTAgent:
         new = out["encoder_out_btd"]
         dec = self.model.decoder
         if "dec" not in states.dec_incremental_states:
+            # sized from what this source knows about itself; a longer stream makes the caches grow (DecoderState.grow)
             cap = int(self.max_len(src.fbank.size(0))) + 4
             s_cap = (src.fbank.size(0) // self.model.encoder.stride) + 2 * self.right_context + 8
-            states.dec_incremental_states["dec"] = dec.new_state(1, cap=cap, S_cap=s_cap)
+            states.dec_incremental_states["dec"] = dec.new_state(1, cap=max(cap, 8), S_cap=max(s_cap, 8))
         st = states.dec_incremental_states["dec"]
         dec.append_encoder_out(st, new, torch.tensor([st.enc_rows + new.size(1)]))
         states.has_encoder_states = True
@@ -126,6 +127,12 @@ class FairseqSimulSTAgent:
             if action == READ_ACTION:
                 actions.append("R")
                 if src.finished:
+                    if not getattr(states, "has_encoder_states", False):
+                        # the source ended before a single encoder state existed (empty / sub-frame input): the
+                        # reference's policy keeps answering READ and SimulEval closes the sentence (default_agent.py:
+                        # 370-376); here the hypothesis simply ends empty
+                        actions.pop()
+                        break
                     raise RuntimeError("READ after source finished")
                 src.read(self.expected_frames)
                 self.update_states_read(states)

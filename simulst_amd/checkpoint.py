@@ -13,8 +13,9 @@ module applies the reference's own state-dict migrations before the weights are 
   (modules/monotonic_multihead_attention.py:523-529);
 * best-N averaging (scripts/average_checkpoints.py:16-73).
 
-Reading the pickle itself (``checkpoint_utils.load_checkpoint_to_cpu``, agents/default_agent.py:205) needs
-fairseq's classes and is left to the caller: pass ``state["model"]`` and the model args.
+``load(path)`` reads a fairseq-layout ``.pt`` (``state["cfg"]["model"]``, ``state["model"]``; what
+``checkpoint_utils.load_checkpoint_to_cpu`` returns, agents/default_agent.py:205) without fairseq and builds the model the
+way the agent does; the reference's own hooks are pinned by tests/golden/g18_checkpoint_hooks.json.
 """
 import collections
 import re
@@ -46,12 +47,15 @@ def config_from_args(args: Mapping) -> ModelConfig:
              "energy_bias": "energy_bias", "energy_bias_init": "energy_bias_init",
              "mocha_chunk_size": "mocha_chunk_size", "cif_beta": "cif_beta", "cif_conv_kernel": "cif_conv_kernel",
              "cif_highway": "cif_highway", "max_source_positions": "max_source_positions",
-             "max_target_positions": "max_target_positions", "no_scale_embedding": "no_scale_embedding"}
+             "max_target_positions": "max_target_positions", "no_scale_embedding": "no_scale_embedding",
+             "input_feat_per_channel": "input_feat"}
     for src, dst in names.items():
         if g(src) is not None:
             kw[dst] = g(src)
     if g("conv_kernel_sizes") is not None:
         kw["conv_kernel_sizes"] = tuple(int(k) for k in str(g("conv_kernel_sizes")).split(","))
+    if arch.startswith("mma") and g("mass_preservation") is None:
+        kw["mass_preservation"] = False          # the arch's own default (models/mma_model.py:265), not exp/2-mma.sh's
     if g("waitk_testtime") is not None:          # inference lagging overrides the training one (:504-506)
         kw["waitk_lagging"] = g("waitk_testtime")
     from dataclasses import replace
@@ -121,3 +125,133 @@ def average_checkpoints(states: Iterable[Mapping[str, torch.Tensor]]) -> Dict[st
         else:
             out[k] = v // n
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reading a fairseq-layout checkpoint file (agents/default_agent.py:205-221: state["cfg"]["model"], state["cfg"]["task"],
+# state["model"]) without fairseq.  fairseq >= 0.10 pickles its configs as omegaconf DictConfig objects (older ones as an
+# argparse.Namespace under state["args"]); neither fairseq nor omegaconf is in the images, so classes that cannot be
+# imported are unpickled into inert shells and flattened to plain Python afterwards.  The DictConfig flattening follows
+# omegaconf's pickled attribute names (_content / _val) and is UNVERIFIED against a real omegaconf pickle (none here);
+# Namespace- and dict-typed configs are exercised by tests/test_checkpoint.py.
+class _Shell:
+    """Stand-in for an unpicklable class: keeps whatever state the pickle carried."""
+
+    def __init__(self, *a, **k):
+        self._shell_args = a
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):     # (dict_state, slots_state)
+            state = {**(state[0] or {}), **state[1]}
+        self.__dict__.update(state if isinstance(state, dict) else {"_state": state})
+
+
+def _make_unpickler():
+    import pickle
+
+    class TolerantUnpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            try:
+                return super().find_class(module, name)
+            except Exception:
+                return type(name, (_Shell,), {"__module__": module})
+
+    class _Mod:                      # what torch.load wants from a pickle_module
+        Unpickler = TolerantUnpickler
+        load = staticmethod(lambda f, **kw: TolerantUnpickler(f, **kw).load())
+        __name__ = "simulst_amd.checkpoint.tolerant_pickle"
+    return _Mod
+
+
+def _plain(o):
+    """Inert shells / Namespaces / config nodes -> dicts, lists and scalars."""
+    import argparse
+    if isinstance(o, argparse.Namespace):
+        return {k: _plain(v) for k, v in vars(o).items()}
+    if isinstance(o, _Shell):
+        d = o.__dict__
+        if "_content" in d:                      # omegaconf container node
+            return _plain(d["_content"])
+        if "_val" in d:                          # omegaconf value node
+            return _plain(d["_val"])
+        if "_value_" in d:                       # enum member
+            return d["_value_"]
+        return {k: _plain(v) for k, v in d.items() if not k.startswith("_")}
+    if isinstance(o, Mapping):
+        return {k: _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_plain(v) for v in o]
+    return o
+
+
+def read_checkpoint(path: str) -> Dict:
+    """-> {"cfg": {"model": {...}, "task": {...}}, "model": {name: tensor}} from a fairseq-layout ``.pt``."""
+    state = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_make_unpickler())
+    if not isinstance(state, Mapping) or "model" not in state:
+        raise ValueError(f"{path}: not a fairseq checkpoint (no 'model' entry)")
+    cfg = state.get("cfg")
+    if cfg is not None:
+        cfg = _plain(cfg)
+        model_args, task_args = cfg.get("model") or {}, cfg.get("task") or {}
+    elif state.get("args") is not None:          # pre-hydra layout
+        model_args = task_args = _plain(state["args"])
+    else:
+        raise ValueError(f"{path}: checkpoint carries neither 'cfg' nor 'args'")
+    if "arch" not in model_args and "_name" in model_args:
+        model_args["arch"] = model_args["_name"]
+    return {"cfg": {"model": model_args, "task": task_args}, "model": state["model"]}
+
+
+def load(path: str, arg_overrides: Optional[Mapping] = None, dtype="f32", device="cuda", dictionary=None):
+    """A fairseq-layout checkpoint file -> the MI355X model, by the agent's own route (agents/default_agent.py:205-221):
+    model args (+ overrides) -> arch defaults -> model class of the arch -> load_state_dict(state["model"], strict)."""
+    import argparse
+    from . import cif, model  # noqa: F401  (register the models and archs)
+    from .registry import build_model_from_args
+    st = read_checkpoint(path)
+    args = dict(st["cfg"]["model"])
+    args.update(arg_overrides or {})
+    args["simulst_dtype"] = "bf16" if dtype in ("bf16", torch.bfloat16) else "f32"
+    args["simulst_device"] = device
+    ns = argparse.Namespace(**args)
+    task = argparse.Namespace(target_dictionary=dictionary) if dictionary is not None else None
+    m = build_model_from_args(ns, task)
+    m.load_state_dict(st["model"], strict=True)
+    return m
+
+
+def save_fairseq_layout(path: str, model_args: Mapping, state_dict: Mapping[str, torch.Tensor], task_args=None):
+    """Write {"cfg": {"model", "task"}, "model"} the way fairseq lays a checkpoint out, with argparse Namespaces as the
+    config objects (what fairseq < 0.10 pickled, and what its loader still accepts)."""
+    import argparse
+    torch.save({"cfg": {"model": argparse.Namespace(**dict(model_args)),
+                        "task": argparse.Namespace(**dict(task_args or {"_name": "speech_to_text_infer"}))},
+                "model": collections.OrderedDict(state_dict), "optimizer_history": [], "extra_state": {}}, path)
+
+
+def load_dictionary(data_bin: Optional[str], config_yaml: Optional[str] = None):
+    """The target dictionary of a speech_to_text data directory: ``vocab_filename`` of the config yaml (fairseq's
+    S2TDataConfig; DATA/mustc/prep_mustc_data.py writes both), else ``dict.txt``.  fairseq Dictionary file format:
+    ``<symbol> <count>`` per line behind the four specials.  None if no file is found."""
+    import os
+    from .harness import Dictionary
+    if data_bin is None:
+        return None
+    names = []
+    cfg_path = None if config_yaml is None else (config_yaml if os.path.isabs(config_yaml) else os.path.join(data_bin, config_yaml))
+    if cfg_path and os.path.exists(cfg_path):
+        import yaml
+        y = yaml.safe_load(open(cfg_path)) or {}
+        if y.get("vocab_filename"):
+            names.append(y["vocab_filename"])
+    names.append("dict.txt")
+    for n in names:
+        p = n if os.path.isabs(n) else os.path.join(data_bin, n)
+        if os.path.exists(p):
+            symbols = ["<s>", "<pad>", "</s>", "<unk>"]
+            for line in open(p, encoding="utf-8"):
+                line = line.rstrip("\n")
+                if line:
+                    symbols.append(line.rsplit(" ", 1)[0])
+            return Dictionary(symbols, eos_index=2)
+    return None

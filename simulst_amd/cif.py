@@ -16,7 +16,8 @@ from .config import ModelConfig
 from .decoder import DecoderWeights
 from .encoder import S2TEmformerEncoder
 from .ops import Ops, EPI_BIAS, EPI_BIAS_F32OUT, EPI_BIAS_GELU, EPI_BIAS_RES
-from .registry import register_model
+from .model import FairseqModelSurface
+from .registry import register_model, register_model_architecture
 
 
 class CIFLayer:
@@ -173,11 +174,40 @@ class CIFDecoder:
         st["n_prev_host"] += 1
         assert st["n_prev_host"] < st["cap"]
 
+    STATE_KEY = "simulst_amd.cif_decoder_state"
+
+    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, overshoot_weight=1.0, **unused):
+        """CIFDecoder.forward as the CIF agent calls it (agents/cif_agent.py:399-404; models/cif_transformer.py:692-724):
+        ``encoder_out`` carries ``cif_out`` [n, B, C] and ``cif_lengths`` [B] accumulated by the agent; state lives in
+        the caller's ``incremental_state``.  Returns (logits [B, 1, V] with the EOS overshoot bias applied, {})."""
+        if incremental_state is None:
+            raise NotImplementedError("simulst_amd.CIFDecoder.forward is the incremental (inference) path")
+        B, n_written = prev_output_tokens.size(0), prev_output_tokens.size(1) - 1
+        st = incremental_state.get(self.STATE_KEY)
+        if st is None or n_written + 2 > st["cap"]:
+            new = self.new_state(B, cap=max(64, 2 * (n_written + 8)))
+            if st is not None:
+                for l in range(self.cfg.decoder_layers):
+                    new["k"][l][:, :, :st["cap"]] = st["k"][l]
+                    new["v"][l][:, :, :st["cap"]] = st["v"][l]
+            st = incremental_state[self.STATE_KEY] = new
+        st["n_prev"].fill_(n_written)
+        st["n_prev_host"] = n_written
+        cif = encoder_out["cif_out"][0].to(device=self.device, dtype=self.dtype).transpose(0, 1).contiguous()
+        last = prev_output_tokens[:, -1].to(device=self.device, dtype=torch.int64).contiguous()
+        logits, overshoot = self.step(st, last, cif, encoder_out["cif_lengths"][0], overshoot_weight)
+        logits = logits.clone()
+        logits[:, self.cfg.eos] += overshoot.to(logits.device)
+        return logits.unsqueeze(1), {"attn": [None], "inner_states": None}
+
+    __call__ = forward
+
 
 @register_model("cif_transformer")
-class CIFTransformerModel:
+class CIFTransformerModel(FairseqModelSurface):
     def __init__(self, cfg: ModelConfig, weights, device="cuda", dtype=torch.float32, ops=None):
         self.cfg = cfg
+        self._deferred = None
         self.ops = ops or Ops()
         self.device, self.dtype = torch.device(device), dtype
         self.encoder = CIFEncoder(cfg, weights, device, dtype, self.ops)
@@ -259,3 +289,16 @@ class CIFAgent:
                 break
         return {"tokens": list(states.target), "delays_ms": delays, "actions": "".join(actions),
                 "AL": average_lagging(delays, src.total_ms()), "n_cif": states.cif_len}
+
+
+@register_model_architecture("cif_transformer", "cif_transformer_s")
+def cif_transformer_s_arch(args):
+    """models/cif_transformer.py:727-735."""
+    from .model import _default, s2t_emformer_s
+    for k, v in (("cif_beta", 1.0), ("cif_sg_alpha", False), ("cif_conv_kernel", 3), ("cif_highway", False)):
+        _default(args, k, v)
+    if isinstance(args, dict):
+        args["ctc_layer"] = True
+    else:
+        args.ctc_layer = True
+    s2t_emformer_s(args)

@@ -38,6 +38,7 @@ struct simulst_handle {
   bool force_unfused_decode;   // test hook: 7-launch decoder layer even when the head-split workspace is given
   hipGraphExec_t graph_exec;
   uint64_t graph_key;
+  bool ctc_lds_attr_set;       // simulst_ctc_best_alignment raised its kernel's dynamic-LDS limit through this handle
 };
 
 #define SL_CHECK_NULL(h, p)                                   \

@@ -155,11 +155,10 @@ extern "C" int simulst_ctc_best_alignment(simulst_handle* h, const float* log_pr
   SL_REQUIRE(h, lds <= 144 * 1024, SIMULST_E_SHAPE, "simulst_ctc_best_alignment: LDS");
   if (N <= 0) return SIMULST_OK;
   SL_CHECK_NULL(h, scratch);
-  static bool attr_set = false;
-  if (lds > 48 * 1024 && !attr_set) {            // the kernel also has a few bytes of static LDS: stay below 160 KB
+  if (lds > 48 * 1024 && !h->ctc_lds_attr_set) {   // per handle (no process globals); the kernel also has a few bytes of static LDS: stay below 160 KB
     hipError_t e = hipFuncSetAttribute((const void*)ctc_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     if (e != hipSuccess) { h->err = "simulst_ctc_best_alignment: cannot raise the dynamic LDS limit"; return (int)e; }
-    attr_set = true;
+    h->ctc_lds_attr_set = true;
   }
   KTimer t(h, SIMULST_K_SCAN);
   hipLaunchKernelGGL(ctc_align_kernel, dim3(N), dim3(256), lds, h->stream, log_probs, (long)lp_stride_t,

@@ -371,11 +371,8 @@ extern "C" int simulst_conv_pos(simulst_handle* h, const void* x, const void* hi
   KTimer t(h, SIMULST_K_CONV_POS);
   dim3 grid((T_ + 63) / 64, groups, B);
   DT_SWITCH(dtype, {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (lds > 48 * 1024)     // idempotent host-side attribute; no process-global "already done" flag
       (void)hipFuncSetAttribute((const void*)conv_pos_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
     hipLaunchKernelGGL(conv_pos_kernel<T>, grid, dim3(256), lds, h->stream, (const T*)x, (const T*)hist,
                        (const T*)W, bias, lengths, (T*)y, T_, D, cpg, k);
   });

@@ -106,6 +106,67 @@ class DecoderState:
         self.online = False
         self.lockstep = True                 # every row has written n_prev_host tokens
 
+    def grow(self, cap: Optional[int] = None, S_cap: Optional[int] = None):
+        """Re-allocate the caches with larger capacities, keeping their contents (a streaming source of unknown
+        length: the reference's caches grow by concatenation, modules/monotonic_multihead_attention.py:401)."""
+        def regrow(lst, dim_new):
+            out = []
+            for t in lst:
+                n = torch.zeros(t.shape[0], t.shape[1], dim_new, t.shape[3], device=t.device, dtype=t.dtype)
+                n[:, :, :t.shape[2]] = t
+                out.append(n)
+            return out
+        if cap is not None and cap > self.cap:
+            self.k_cache, self.v_cache, self.cap = regrow(self.k_cache, cap), regrow(self.v_cache, cap), cap
+        if S_cap is not None and S_cap > self.S_cap:
+            self.Kmono, self.V = regrow(self.Kmono, S_cap), regrow(self.V, S_cap)
+            if self.Ksoft is not None:
+                self.Ksoft = regrow(self.Ksoft, S_cap)
+            self.S_cap = S_cap
+        for a in ("ws", "layer_structs", "structs_fragment_major"):     # device-loop descriptors hold raw pointers
+            if hasattr(self, a):
+                delattr(self, a)
+
+
+class _EncoderAttnView:
+    """What the agent reads off ``decoder.layers[0].encoder_attn`` (agents/default_agent.py:157-161)."""
+
+    def __init__(self, cfg: ModelConfig):
+        self.simul_attn_type = cfg.simul_attn_type
+        if cfg.simul_attn_type.endswith("_fixed_pre_decision"):   # only FixedStride* classes carry the attribute
+            self.pre_decision_ratio = cfg.fixed_pre_decision_ratio
+            self.pre_decision_type = cfg.fixed_pre_decision_type
+        self.waitk_lagging = cfg.waitk_lagging
+        self.mass_preservation = cfg.mass_preservation
+
+
+class _DecoderLayerView:
+    def __init__(self, cfg: ModelConfig, index: int):
+        self.index = index
+        self.encoder_attn = _EncoderAttnView(cfg)
+
+
+class _Dictionary:
+    """The slice of fairseq's Dictionary the decoder and the agent touch when no task dictionary is attached."""
+
+    def __init__(self, cfg: ModelConfig):
+        self._pad, self._eos, self._n = cfg.padding_idx, cfg.eos, cfg.vocab
+
+    def pad(self):
+        return self._pad
+
+    def eos(self):
+        return self._eos
+
+    def bos(self):
+        return 0
+
+    def unk(self):
+        return 3
+
+    def __len__(self):
+        return self._n
+
 
 class MMADecoder:
     """Mirror of models/mma_model.py:MMADecoder (inference, incremental)."""
@@ -113,13 +174,19 @@ class MMADecoder:
     def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda", dtype=torch.float32,
                  ops: Optional[Ops] = None, prefix="decoder", shared_weights: Optional[DecoderWeights] = None):
         self.cfg = cfg
+        if cfg.simul_attn_type.endswith("_fixed_pre_decision") and cfg.fixed_pre_decision_type != "average":
+            raise NotImplementedError(
+                f"--fixed-pre-decision-type {cfg.fixed_pre_decision_type!r}: only 'average' pooling is built "
+                "(modules/fixed_pre_decision.py:31-52); refusing to decode with different pooling than the checkpoint's")
         self.device, self.dtype = torch.device(device), dtype
         self.ops = ops or Ops()
         self.w = shared_weights if shared_weights is not None else DecoderWeights(weights, cfg, self.device, dtype, prefix)
         self.attn_enum = _lib.ATTN_ENUM[cfg.attn_type]
         self.soft = cfg.attn_type != "hard_aligned"
         self.separate_soft = cfg.attn_type in ("infinite_lookback", "chunkwise")
-        self.embed_scale = math.sqrt(cfg.embed_dim)
+        self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(cfg.embed_dim)
+        self.layers = [_DecoderLayerView(cfg, l) for l in range(cfg.decoder_layers)]
+        self.dictionary = _Dictionary(cfg)
         # head-split self-attention block (5 launches per decoder layer instead of 7) in the device decode loop.
         # Measured on MI355X (bench.py --batch 64/128, 1-3 streams): it shortens the dependent chain of ONE
         # 64-row sequence (211 k vs 204 k tokens/s) but every (head, row) workgroup re-streams its 128 KB of
@@ -157,7 +224,8 @@ class MMADecoder:
         ops, cfg = self.ops, self.cfg
         B, n, D = enc_new.shape
         r0 = st.enc_rows
-        assert r0 + n <= st.S_cap, "source longer than the state's S_cap"
+        if r0 + n > st.S_cap:                # a source longer than the state was sized for: the caches grow
+            st.grow(S_cap=max(2 * st.S_cap, r0 + n))
         if n > 0:
             a_bs = enc_new.stride(0)
             assert enc_new.stride(2) == 1 and enc_new.stride(1) == D
@@ -229,12 +297,61 @@ class MMADecoder:
         """Advance the target position after a WRITE (the K/V row appended by step() becomes permanent)."""
         st.n_prev += 1
         st.n_prev_host += 1
-        assert st.n_prev_host < st.cap, "decoder state capacity exceeded"
+        if st.n_prev_host + 1 >= st.cap:
+            st.grow(cap=2 * st.cap)
 
-    def clear_cache(self, st: DecoderState):
+    def clear_cache(self, st, end_id: Optional[int] = None):
         """MMADecoder.clear_cache after a completed forward whose token is discarded (force_finish,
-        agents/default_agent.py:426-434): step() never advanced n_prev, so nothing to undo."""
+        agents/default_agent.py:426-434; models/mma_model.py:212-220).  Accepts the caller's incremental_state dict
+        or a DecoderState: step() never advanced n_prev, so the appended K/V row is simply overwritten next time."""
         return None
+
+    STATE_KEY = "simulst_amd.decoder_state"
+
+    def forward(self, prev_output_tokens: torch.Tensor, encoder_out: Optional[Dict[str, List[torch.Tensor]]] = None,
+                incremental_state: Optional[dict] = None, features_only: bool = False, **unused):
+        """MMADecoder.forward as the agent calls it (agents/default_agent.py:394-398; models/mma_model.py:156-220):
+        ``prev_output_tokens`` [B, 1 + written] = [eos] + hypothesis, ``encoder_out["encoder_out"][0]`` [T, B, C] = every
+        encoder state so far, ``incremental_state`` the CALLER's dict (it owns all decoder state; ``["online"]`` is
+        the agent's flag).  Returns (logits [B, 1, V] fp32, {"action": 0 | 1, "attn_list": None}); on action 0 (READ)
+        the first element is None -- the reference returns the unfinished features there and the agent ignores them.
+        Only the rows of encoder_out that are new since the last call are projected (the reference re-projects all
+        of them every step, modules/monotonic_multihead_attention.py:401).  The number of written tokens is taken from
+        prev_output_tokens, so a discarded prediction (force_finish) or a READ needs no rollback."""
+        if incremental_state is None:
+            raise NotImplementedError("simulst_amd.MMADecoder.forward is the incremental (inference) path; "
+                                      "training-mode forward is out of scope (DESIGN.md section 7)")
+        enc = encoder_out["encoder_out"][0]
+        T, B = enc.shape[0], enc.shape[1]
+        n_written = prev_output_tokens.size(1) - 1
+        st = incremental_state.get(self.STATE_KEY)
+        if st is None:
+            st = self.new_state(B, cap=max(32, n_written + 8), S_cap=max(64, T + 32))
+            incremental_state[self.STATE_KEY] = st
+        if n_written + 2 > st.cap:
+            st.grow(cap=max(2 * st.cap, n_written + 8))
+        if T > st.S_cap:
+            st.grow(S_cap=max(2 * st.S_cap, T + 32))
+        if T > st.enc_rows:
+            new = enc[st.enc_rows:T].to(device=self.device, dtype=self.dtype).transpose(0, 1).contiguous()
+            pad = encoder_out.get("encoder_padding_mask") or []
+            lens = (~pad[0]).sum(1) if len(pad) > 0 and pad[0] is not None and pad[0].numel() > 0 \
+                else torch.full((B,), T)
+            self.append_encoder_out(st, new, lens)
+        if st.n_prev_host != n_written:
+            st.n_prev.fill_(n_written)
+            st.n_prev_host = n_written
+        st.online = bool(incremental_state.get("online", False))
+        last = prev_output_tokens[:, -1].to(device=self.device, dtype=torch.int64).contiguous()
+        logits, action = self.step(st, last, stop_on_read=True)
+        return (None if logits is None else logits.unsqueeze(1)), {"action": action, "attn_list": None,
+                                                                 "encoder_out": encoder_out}
+
+    __call__ = forward
+
+    def get_normalized_probs(self, net_output, log_probs: bool = True, sample=None):
+        logits = net_output[0]
+        return torch.log_softmax(logits.float(), -1) if log_probs else torch.softmax(logits.float(), -1)
 
     # ------------------------------------------------------------------ device-resident step loop
     def _pack_all(self):

@@ -27,6 +27,12 @@ class Dictionary:
     def eos(self):
         return self._eos
 
+    def pad(self):
+        return 1
+
+    def __len__(self):
+        return len(self.symbols)
+
     def string(self, tokens, bpe_symbol: Optional[str] = None):
         s = " ".join(self.symbols[int(t)] for t in tokens if int(t) != self._eos)
         if bpe_symbol == "sentencepiece":
@@ -53,33 +59,51 @@ class ListEntry:
         return self.value.pop(index)
 
 
-def units_to_segment(unit_queue: ListEntry, tgt_dict: Dictionary, n_target: int, max_len: float, pre_tokenizer=None):
-    """agents/default_agent.py:248-301: returns DEFAULT_EOS, [hyp, DEFAULT_EOS], [word], [word, DEFAULT_EOS] or None."""
-    if tgt_dict.eos() == unit_queue[0]:
-        return DEFAULT_EOS
-    segment: List[str] = []
-    if None in unit_queue.value:
-        unit_queue.value.remove(None)
-    if (len(unit_queue) > 0 and tgt_dict.eos() == unit_queue[-1]) or n_target > max_len:
-        hyp = tgt_dict.string(unit_queue.value, "sentencepiece")
-        if pre_tokenizer is not None:
-            hyp = pre_tokenizer.decode(hyp)
-        return [hyp] + [DEFAULT_EOS]
-    for index in list(unit_queue.value):
-        token = tgt_dict.string([index])
-        if token.startswith(BOW_PREFIX):
-            if len(segment) == 0:
-                segment += [token.replace(BOW_PREFIX, "")]
-            else:
-                for _ in range(len(segment)):
-                    unit_queue.pop()
-                out = ["".join(segment)]
-                if tgt_dict.eos() == unit_queue[0]:
-                    out += [DEFAULT_EOS]
-                return out
-        else:
-            segment += [token.replace(BOW_PREFIX, "")]
-    return None
+class WordMerger:
+    """Subword units -> words for the SimulEval server, which scores delays per WORD (the contract of
+    agents/default_agent.py:248-301).  Table-driven: per vocabulary id, whether the piece opens a word (starts with
+    the sentencepiece marker) and its text without the marker, both built once; a call is then one scan for the first
+    word-opening piece behind the head of the queue and one slice.
+
+    Outcomes, in this order: the queue starts with EOS -> DEFAULT_EOS; (after dropping one force-finish ``None``) the
+    queue ends with EOS, or the hypothesis has outgrown max_len -> [detokenised queue, DEFAULT_EOS] with the queue left
+    as it is; a word-opening piece at position p >= 1 -> the p pieces before it leave the queue as one word (followed
+    by DEFAULT_EOS when EOS is what remains in front); otherwise None: the word is still open."""
+
+    def __init__(self, tgt_dict):
+        self.dict = tgt_dict
+        self.eos = tgt_dict.eos()
+        n = len(tgt_dict) if hasattr(tgt_dict, "__len__") else len(tgt_dict.symbols)
+        pieces = [tgt_dict.string([i]) for i in range(n)]
+        self.opens_word = [p.startswith(BOW_PREFIX) for p in pieces]
+        self.text = [p.replace(BOW_PREFIX, "") for p in pieces]
+
+    def __call__(self, unit_queue, n_target: int, max_len: float, pre_tokenizer=None):
+        units = unit_queue.value
+        if units[0] == self.eos:
+            return DEFAULT_EOS
+        if None in units:
+            units.remove(None)
+        if (units and units[-1] == self.eos) or n_target > max_len:
+            hyp = self.dict.string(units, "sentencepiece")
+            return [pre_tokenizer.decode(hyp) if pre_tokenizer is not None else hyp, DEFAULT_EOS]
+        cut = next((p for p in range(1, len(units)) if self.opens_word[units[p]]), None)
+        if cut is None:
+            return None
+        word = "".join(self.text[t] for t in units[:cut])
+        del units[:cut]
+        return [word, DEFAULT_EOS] if units[0] == self.eos else [word]
+
+
+_mergers = {}
+
+
+def units_to_segment(unit_queue: ListEntry, tgt_dict, n_target: int, max_len: float, pre_tokenizer=None):
+    """Function form of WordMerger (one merger per dictionary object, built on first use)."""
+    m = _mergers.get(id(tgt_dict))
+    if m is None or m.dict is not tgt_dict:
+        m = _mergers[id(tgt_dict)] = WordMerger(tgt_dict)
+    return m(unit_queue, n_target, max_len, pre_tokenizer)
 
 
 def latency_scores(delays: Sequence[float], elapsed: Sequence[float], src_len_ms: float):

@@ -9,10 +9,93 @@ from .config import ModelConfig
 from .decoder import MMADecoder
 from .encoder import S2TEmformerEncoder
 from .ops import Ops
-from .registry import register_model
+from .registry import register_model, register_model_architecture
 
 
-class SimulSTModel:
+class FairseqModelSurface:
+    """The part of fairseq's model protocol that the reference's agent and generate script use on a model object
+    (agents/default_agent.py:205-224: ``task.build_model(args)`` -> ``load_state_dict(state["model"], strict=True)``
+    -> ``eval()`` -> ``share_memory()`` -> ``cuda()``), for classes whose parameters live in HIP buffers.
+
+    ``build_model(args, task)`` returns an instance WITHOUT device weights; ``load_state_dict`` applies the
+    reference's state-dict migrations (checkpoint.upgrade_state_dict) and builds the encoder / decoder on the device.
+    Dtype and device of the deferred build: ``args.simulst_dtype`` ("bf16" | "f32", default "f32": the reference
+    evaluates in fp32) and ``args.simulst_device`` (default "cuda")."""
+
+    @staticmethod
+    def add_args(parser):
+        """Flags of S2TEmformerModel.add_args / MMAModel.add_args the inference path reads
+        (models/s2t_emformer.py:299-346; models/mma_model.py:225-236), plus the two build knobs of this package."""
+        a = parser.add_argument
+        a("--segment-length", type=int, metavar="N", help="length of each segment (not including left/right context)")
+        a("--segment-left-context", type=int, help="length of left context in a segment")
+        a("--segment-right-context", type=int, help="length of right context in a segment")
+        a("--max-memory-size", type=int, default=-1, help="Right context for the segment.")
+        a("--tanh-on-mem", action="store_true", default=False)
+        a("--conv-pos", type=int, metavar="N")
+        a("--conv-pos-groups", type=int, metavar="N")
+        a("--ctc-layer", action="store_true")
+        a("--load-pretrained-decoder-from", type=str, metavar="STR")
+        a("--simulst-dtype", default="f32", choices=["f32", "bf16"], help="activation / weight dtype on the MI355X")
+        a("--simulst-device", default="cuda")
+
+    @classmethod
+    def build_model(cls, args, task=None):
+        from .checkpoint import config_from_args
+        cfg = config_from_args(vars(args) if not isinstance(args, dict) else args)
+        if task is not None and getattr(task, "target_dictionary", None) is not None:
+            from dataclasses import replace
+            d = task.target_dictionary
+            cfg = replace(cfg, vocab=len(d), padding_idx=d.pad(), eos=d.eos())
+        self = cls.__new__(cls)
+        g = (lambda k, dflt: args.get(k, dflt)) if isinstance(args, dict) else (lambda k, dflt: getattr(args, k, dflt))
+        self.cfg, self.args = cfg, args
+        self._deferred = {"device": g("simulst_device", "cuda"),
+                          "dtype": torch.bfloat16 if g("simulst_dtype", "f32") == "bf16" else torch.float32,
+                          "dictionary": getattr(task, "target_dictionary", None) if task is not None else None}
+        self.encoder = self.decoder = None
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, model_cfg=None, args=None):
+        from .checkpoint import upgrade_state_dict
+        d = getattr(self, "_deferred", None)
+        if d is None:
+            raise RuntimeError("load_state_dict: this model already holds its device weights (rebuild it with "
+                               "build_model(args, task) to load another checkpoint)")
+        weights = upgrade_state_dict(state_dict, self.cfg, strict=strict)
+        type(self).__init__(self, self.cfg, weights, device=d["device"], dtype=d["dtype"])
+        if d["dictionary"] is not None:
+            self.decoder.dictionary = d["dictionary"]
+        self._deferred = None
+        return [], []                        # (missing_keys, unexpected_keys): strict mode raised above if any
+
+    def upgrade_state_dict(self, state_dict):
+        from .checkpoint import upgrade_state_dict
+        return upgrade_state_dict(state_dict, self.cfg, strict=False)
+
+    # nn.Module calls the agent makes on the model object; the weights are device-resident HIP buffers already
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("simulst_amd models are inference only (DESIGN.md section 7)")
+        return self
+
+    def share_memory(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def cpu(self):
+        raise RuntimeError("simulst_amd: the hot path is GPU only (no CPU fallback)")
+
+    def max_positions(self):
+        return (self.cfg.max_source_positions, self.cfg.max_target_positions)
+
+
+class SimulSTModel(FairseqModelSurface):
     """encoder/decoder holder with the attributes the agents use (agents/default_agent.py:157-175,
     394-406,418-420): .encoder, .decoder, get_normalized_probs, max_decoder_positions."""
 
@@ -21,6 +104,7 @@ class SimulSTModel:
         """share_with: another instance whose device weights are reused (replicas that differ only in their
         HIP stream / handle / decoder state, for concurrent batches)."""
         self.cfg = cfg
+        self._deferred = None
         self.ops = ops or Ops()
         self.device, self.dtype = torch.device(device), dtype
         self.encoder = S2TEmformerEncoder(cfg, weights, device, dtype, self.ops,
@@ -55,6 +139,35 @@ class MMAModel(SimulSTModel):
 @register_model("s2t_emformer")
 class S2TEmformerModel(SimulSTModel):
     pass
+
+
+def _default(args, name, value):
+    if isinstance(args, dict):
+        args.setdefault(name, value)
+    elif getattr(args, name, None) is None:
+        setattr(args, name, value)
+
+
+@register_model_architecture("s2t_emformer", "s2t_emformer_s")
+def s2t_emformer_s(args):
+    """models/s2t_emformer.py:398-413 over fairseq's s2t_transformer_s (external; SURVEY.md section 8 dims)."""
+    for k, v in (("segment_length", 64), ("segment_left_context", 128), ("segment_right_context", 32),
+                 ("max_memory_size", 5), ("tanh_on_mem", True), ("conv_pos", 128), ("conv_pos_groups", 16),
+                 ("activation_fn", "gelu"), ("encoder_embed_dim", 256), ("encoder_ffn_embed_dim", 256 * 8),
+                 ("encoder_attention_heads", 4), ("decoder_attention_heads", 4), ("encoder_layers", 12),
+                 ("decoder_layers", 6), ("conv_kernel_sizes", "5,5"), ("conv_channels", 1024),
+                 ("input_feat_per_channel", 80), ("max_source_positions", 6000), ("max_target_positions", 1024),
+                 ("share_decoder_input_output_embed", True), ("no_scale_embedding", False)):
+        _default(args, k, v)
+
+
+@register_model_architecture("mma_model", "mma_model_s")
+def mma_model_s_arch(args):
+    """models/mma_model.py:258-268."""
+    for k, v in (("noise_var", 2.0), ("noise_mean", 0.0), ("energy_bias_init", -2.0), ("attention_eps", 1e-6),
+                 ("mass_preservation", False), ("energy_bias", False)):
+        _default(args, k, v)
+    s2t_emformer_s(args)
 
 
 class OfflinePipeline:
