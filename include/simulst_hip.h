@@ -165,6 +165,22 @@ int simulst_conv_pos_mfma(simulst_handle* h, const void* x, const void* hist, co
                           const int32_t* lengths, void* y, int32_t B, int32_t T, int32_t D, int32_t groups,
                           int32_t k);
 
+/* The Emformer feed-forward block in ONE launch (bf16, D == 256, F % 64 == 0, F <= 4096):
+ *   out[rows][D] = x + W2 . gelu(W1 . LayerNorm(x) + b1) + b2
+ * with the [rows][F] hidden activations kept in registers (the accumulator tile of the first product is the operand of
+ * the second).  Replaces `self.pos_ff(result) + result` of _EmformerLayer._process_attention_output /
+ * _apply_post_attention_ffn (torchaudio_models/emformer.py:365-378,431-441,454-462) -- LayerNorm, Linear, GELU, Linear
+ * and the residual -- i.e. the layernorm + two simulst_linear launches the encoder used before.
+ * Weight images (made once on the host side, simulst_amd/encoder.py ffn_pack_w1 / ffn_pack_w2), in the fragment order of
+ * v_mfma_f32_32x32x16_bf16, 64 hidden units (two 32-unit tiles) per 32 KB chunk, lane < 64, j < 8:
+ *   w1_packed[(((t * 16 + s) * 64 + lane) * 8 + j] = W1[32 t + (lane & 31)][16 s + 8 (lane >> 5) + j]      t < F/32, s < 16
+ *   w2_packed[((((t * 2 + s) * 8 + n) * 64 + lane) * 8 + j]
+ *       = W2[32 n + (lane & 31)][32 t + 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3)]                        s < 2, n < 8
+ * x and out must not alias (the residual rows are re-read at the end).  rows == 0 is a no-op. */
+int simulst_emformer_ffn(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
+                         const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                         int64_t rows, int32_t D, int32_t F, int32_t dtype);
+
 /* ---- Emformer layer pieces ------------------------------------------------------
  * Per-utterance row blocks of a layer buffer Z [B][n_mem + n_rc + T + n_sum][D]:
  *   [memory rows | right-context block rows | utterance rows | summary rows].

@@ -38,6 +38,7 @@ struct simulst_handle {
   bool force_unfused_decode;   // test hook: 7-launch decoder layer even when the head-split workspace is given
   hipGraphExec_t graph_exec;
   uint64_t graph_key;
+  bool ffn_lds_attr_set;       // simulst_emformer_ffn did the same for the fused feed-forward kernel
   bool ctc_lds_attr_set;       // simulst_ctc_best_alignment raised its kernel's dynamic-LDS limit through this handle
 };
 

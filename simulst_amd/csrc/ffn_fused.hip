@@ -1,0 +1,213 @@
+// Fused Emformer feed-forward block for gfx950 (bf16, D = 256):  out = x + W2 . gelu(W1 . LN(x) + b1) + b2
+// (torchaudio_models/emformer.py:365-378 pos_ff = LayerNorm -> Linear -> GELU -> Linear, :437-439 "+ result").
+//
+// The two-launch form wrote the [rows, F] hidden tensor to HBM and read it back: 6.3 GB per layer of a 4096-utterance
+// launch sequence, 47 % of the encoder's HBM traffic, with the matrix cores 20 % (fc1 + GELU) and 31 % (fc2) busy.
+// Here the hidden activations never leave the register file:
+//   * a workgroup (8 waves, one per SIMD pair) owns 256 rows; every wave keeps the LayerNorm-ed fragments of its 32
+//     rows stationary (16 k-steps x 4 VGPRs) and its 32 x 256 output tile in 128 accumulator registers
+//   * per 32 hidden units:  Ht[32 hid x 32 rows] = W1 tile . LN(x)^T  (16 x v_mfma_f32_32x32x16_bf16, the weight tile is
+//     the A operand), bias + GELU on the accumulator, pairwise conversion to bf16 -- and the SAME registers are the A
+//     operand of  Y[32 rows x 256] += H . W2 tile^T  (16 MFMAs): an accumulator tile whose column sits on the lane is,
+//     after conversion, a ready operand for a product that sums over its rows (cdna_hip_programming.md section 3,
+//     "An accumulator tile as the next MFMA's operand").  The permuted k order of that operand is folded into the
+//     packed layout of W2 (ffn_pack_w2 in simulst_amd/encoder.py), so no lane movement and no LDS for H
+//   * W1 / W2 stream from L2 in chunks of 64 hidden units (32 KB + 32 KB, fragment order = LDS order) by LDS-DMA
+//     (global_load_lds_dwordx4) into a double buffer: no staging registers, the next chunk lands while this one is used
+//   * per MFMA one conflict-free 1 KB fragment read from LDS (128 B/clk/CU at full MFMA rate = half the LDS rate)
+//   * epilogue once per workgroup: Y + b2 -> bf16 rows staged in the (free) weight buffers -> + residual x -> 16-byte
+//     row-contiguous stores
+// Algorithmic work per launch: 4 * rows * D * F flop (two contractions), HBM bytes 2 * rows * D * 2 (x read for the
+// contraction, again for the residual: L2/MALL-hot) + rows * D * 2 written; weights 2 * D * F * 2 B from L2 per workgroup.
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int FF_ROWS = 256;          // rows per workgroup (8 waves x 32)
+constexpr int FF_D = 256;             // model width (K of fc1, N of fc2)
+constexpr int FF_CH = 64;             // hidden units per LDS chunk
+constexpr int FF_W1_BYTES = FF_CH * FF_D * 2;      // 32 KB
+constexpr int FF_CHUNK_BYTES = 2 * FF_W1_BYTES;    // W1 tile rows + W2 tile columns of a chunk
+constexpr int FF_MAX_F = 4096;        // hidden units whose fc1 bias fits the LDS budget
+constexpr int FF_LDS = 2 * FF_CHUNK_BYTES + 3072 + FF_MAX_F * 4;  // double buffer + gamma / beta / b2 (3 x 256 fp32) + b1
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  const bf16 l = __float2bfloat16(lo), h = __float2bfloat16(hi);
+  return (unsigned int)(*reinterpret_cast<const unsigned short*>(&l)) |
+         ((unsigned int)(*reinterpret_cast<const unsigned short*>(&h)) << 16);
+}
+
+// one chunk (64 KB = W1 part then W2 part, each already in fragment order) global -> LDS: 8 x 16 B per thread,
+// LDS destination of a wave instruction = wave-uniform base + lane * 16
+__device__ __forceinline__ void stage_chunk(const bf16* __restrict__ w1p, const bf16* __restrict__ w2p, int chunk,
+                                            char* lds, unsigned voff, int wave) {
+  // every address is (wave-uniform base) + (one 32-bit lane offset): scalar bases, ONE address VGPR for all 8 pieces
+  const char* g1 = reinterpret_cast<const char*>(w1p) + (long)chunk * FF_W1_BYTES;
+  const char* g2 = reinterpret_cast<const char*>(w2p) + (long)chunk * FF_W1_BYTES;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g1 + q * 8192 + voff), (lds_void*)(lds + q * 8192 + wave * 1024), 16, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g2 + q * 8192 + voff),
+                                     (lds_void*)(lds + FF_W1_BYTES + q * 8192 + wave * 1024), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const bf16* __restrict__ X, const float* __restrict__ ln_g,
+                                                           const float* __restrict__ ln_b,
+                                                           const bf16* __restrict__ W1p, const float* __restrict__ b1,
+                                                           const bf16* __restrict__ W2p, const float* __restrict__ b2,
+                                                           bf16* __restrict__ out, long M, int F) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* lng = reinterpret_cast<float*>(lds + 2 * FF_CHUNK_BYTES);
+  float* lnb = lng + FF_D;
+  float* b2s = lnb + FF_D;
+  float* b1s = b2s + FF_D;                                   // fc1 bias: an ordinary global load inside the loop would
+                                                             // make hipcc drain the in-flight LDS-DMA (vmcnt(0)) at its use
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const long row0 = (long)blockIdx.x * FF_ROWS + wave * 32;
+  const int n_chunks = F / FF_CH;
+
+  const unsigned voff = (unsigned)tid * 16u;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  stage_chunk(W1p, W2p, 0, lds, voff, wave_u);                       // first weights on their way before anything else
+  for (int k = tid; k < FF_D; k += 512) { lng[k] = ln_g[k]; lnb[k] = ln_b[k]; b2s[k] = b2[k]; }
+  for (int k = tid; k < F; k += 512) b1s[k] = b1[k];
+
+  // ---- this wave's rows as B-operand fragments of Ht = W1 . LN(x)^T: lane (lr, lh) holds x[row lr][16 s + 8 lh + j]
+  uint4 xa[16];
+  {
+    const long r = row0 + lr;
+    const bool ok = r < M;
+    const bf16* xr = X + (ok ? r : 0) * FF_D + lh * 8;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const uint4 v = ld16(xr + s * 16);
+      xa[s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+  }
+  __syncthreads();                                           // gamma / beta / b2 visible
+  {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) moments_mid(xa[s], s1, s2, bf16());
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float mean = s1 * (1.0f / FF_D);
+    const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / FF_D) - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xa[s] = ln_frag_mid(xa[s], mean, rstd, lng, lnb, s * 16 + lh * 8, bf16());
+  }
+
+  f32x16 y[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) y[n][e] = 0.f;
+
+  for (int c = 0; c < n_chunks; ++c) {
+    char* cur = lds + (c & 1) * FF_CHUNK_BYTES;
+    // the DMA of chunk c (issued one iteration ago, or in the prologue) has landed for every wave after this barrier;
+    // every wave has also finished reading the other buffer (chunk c - 1), so it can be refilled
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's own LDS-DMA pieces
+    __syncthreads();
+    if (c + 1 < n_chunks) stage_chunk(W1p, W2p, c + 1, lds + ((c + 1) & 1) * FF_CHUNK_BYTES, voff, wave_u);
+    const uint4* w1 = reinterpret_cast<const uint4*>(cur);                     // [tile 2][k-step 16][lane 64]
+    const uint4* w2 = reinterpret_cast<const uint4*>(cur + FF_W1_BYTES);       // [tile 2][k-step 2][n-tile 8][lane 64]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 hacc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) hacc[e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const uint4 wf = w1[(t * 16 + s) * 64 + lane];
+        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wf),
+                                                       *reinterpret_cast<const bf16x8_t*>(&xa[s]), hacc, 0, 0, 0);
+      }
+      // hacc[e] = H[row lr][hidden h0 + (e & 3) + 8 (e >> 2) + 4 lh]: bias + GELU, then registers 8 s .. 8 s + 7
+      // pairwise to bf16 = A fragment of k-step s of the second product
+      const int h0 = c * FF_CH + t * 32 + 4 * lh;
+      uint4 hb[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(b1s + h0 + 8 * g);
+        const f32x2 v0 = gelu_fast2(f32x2{hacc[4 * g] + bv.x, hacc[4 * g + 1] + bv.y});
+        const f32x2 v1 = gelu_fast2(f32x2{hacc[4 * g + 2] + bv.z, hacc[4 * g + 3] + bv.w});
+        unsigned int* dst = reinterpret_cast<unsigned int*>(&hb[g >> 1]) + (g & 1) * 2;
+        dst[0] = pack_bf16x2(v0.x, v0.y);
+        dst[1] = pack_bf16x2(v1.x, v1.y);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const uint4 wf = w2[((t * 2 + s) * 8 + n) * 64 + lane];
+          y[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&hb[s]),
+                                                         *reinterpret_cast<const bf16x8_t*>(&wf), y[n], 0, 0, 0);
+        }
+    }
+  }
+  // ---- epilogue: y[n][e] = Y[row (e & 3) + 8 (e >> 2) + 4 lh][col 32 n + lr].  Stage as bf16 rows in
+  // this wave's 16 KB slice of the weight buffers, then whole rows leave with the residual added.
+  __syncthreads();                                           // every wave is done with the weight buffers
+  constexpr int RS = FF_D * 2;                               // staged row stride in bytes (8 waves x 16 KB = the two buffers)
+  char* st = lds + wave * (32 * RS);
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const float bv = b2s[n * 32 + lr];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      *reinterpret_cast<bf16*>(st + r * RS + (n * 32 + lr) * 2) = __float2bfloat16(y[n][e] + bv);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int rl = it * 2 + lh;                              // 32 lanes x 16 B = one 512-byte row
+    const long r = row0 + rl;
+    if (r >= M) continue;
+    const uint4 yv = *reinterpret_cast<const uint4*>(st + rl * RS + lr * 16);
+    const uint4 xv = ld16(X + r * FF_D + lr * 8);
+    const unsigned int yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
+    unsigned int ou[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      ou[q] = pack_bf16x2(__uint_as_float(yu[q] << 16) + __uint_as_float(xu[q] << 16),
+                          __uint_as_float(yu[q] & 0xffff0000u) + __uint_as_float(xu[q] & 0xffff0000u));
+    st_stream16(out + r * FF_D + lr * 8, make_uint4(ou[0], ou[1], ou[2], ou[3]));
+  }
+}
+
+}  // namespace
+
+// out[rows, 256] = x + fc2(gelu(fc1(LayerNorm(x)))) in one launch; W1p / W2p are the packed images made by
+// simulst_amd.encoder.ffn_pack_w1 / ffn_pack_w2 (fragment order of v_mfma_f32_32x32x16_bf16, 64 hidden units per chunk).
+extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
+                                    const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
+                                    void* out, int64_t rows, int32_t D, int32_t F, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, ln_gamma); SL_CHECK_NULL(h, ln_beta); SL_CHECK_NULL(h, w1_packed);
+  SL_CHECK_NULL(h, b1); SL_CHECK_NULL(h, w2_packed); SL_CHECK_NULL(h, b2); SL_CHECK_NULL(h, out);
+  SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_emformer_ffn: bf16 only (fp32 keeps the two-launch path)");
+  SL_REQUIRE(h, D == FF_D && F >= FF_CH && F % FF_CH == 0, SIMULST_E_SHAPE, "simulst_emformer_ffn: D == 256, F % 64 == 0");
+  SL_REQUIRE(h, F <= FF_MAX_F, SIMULST_E_SHAPE, "simulst_emformer_ffn: F <= 4096");
+  SL_REQUIRE(h, x != out, SIMULST_E_ARG, "simulst_emformer_ffn: in place (the residual rows are re-read at the end)");
+  if (rows <= 0) return SIMULST_OK;
+  if (!h->ffn_lds_attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+    if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit"; return (int)e; }
+    h->ffn_lds_attr_set = true;
+  }
+  KTimer t(h, SIMULST_K_LINEAR);
+  hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((rows + FF_ROWS - 1) / FF_ROWS)), dim3(512), FF_LDS, h->stream,
+                     (const bf16*)x, ln_gamma, ln_beta, (const bf16*)w1_packed, b1, (const bf16*)w2_packed, b2,
+                     (bf16*)out, (long)rows, F);
+  return sl_launch_status(h, "simulst_emformer_ffn");
+}

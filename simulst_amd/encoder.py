@@ -43,6 +43,37 @@ def prepack_glu_conv(weight: torch.Tensor, bias: torch.Tensor):
     return w[perm].contiguous(), bias[perm].contiguous()
 
 
+def ffn_pack_w1(W1: torch.Tensor) -> torch.Tensor:
+    """fc1 weight [F, D] -> the image simulst_emformer_ffn streams (include/simulst_hip.h): per 32-unit tile t and k-step
+    s, lane (r = lane & 31, h = lane >> 5) holds W1[32 t + r][16 s + 8 h + 0..7]."""
+    F, D = W1.shape
+    assert F % 64 == 0 and D % 16 == 0
+    t = torch.arange(F // 32).view(-1, 1, 1, 1)
+    s = torch.arange(D // 16).view(1, -1, 1, 1)
+    lane = torch.arange(64).view(1, 1, -1, 1)
+    j = torch.arange(8).view(1, 1, 1, -1)
+    rows = (32 * t + (lane & 31)).expand(F // 32, D // 16, 64, 8)
+    cols = (16 * s + 8 * (lane >> 5) + j).expand(F // 32, D // 16, 64, 8)
+    return W1[rows.to(W1.device), cols.to(W1.device)].contiguous()
+
+
+def ffn_pack_w2(W2: torch.Tensor) -> torch.Tensor:
+    """fc2 weight [D, F] -> image for the second product, whose A operand is the converted accumulator of the first: its
+    element j of lane half h at k-step s is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3) of the tile, so W2's columns
+    are gathered in that order: lane (r, h) of (tile t, k-step s, n-tile n) holds W2[32 n + r][32 t + that unit]."""
+    D, F = W2.shape
+    assert F % 64 == 0 and D % 32 == 0
+    t = torch.arange(F // 32).view(-1, 1, 1, 1, 1)
+    s = torch.arange(2).view(1, -1, 1, 1, 1)
+    n = torch.arange(D // 32).view(1, 1, -1, 1, 1)
+    lane = torch.arange(64).view(1, 1, 1, -1, 1)
+    j = torch.arange(8).view(1, 1, 1, 1, -1)
+    shape = (F // 32, 2, D // 32, 64, 8)
+    rows = (32 * n + (lane & 31)).expand(shape)
+    cols = (32 * t + 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)).expand(shape)
+    return W2[rows.to(W2.device), cols.to(W2.device)].contiguous()
+
+
 class EncoderWeights:
     """Device copies of the encoder parameters, re-laid out once for the kernels."""
 
@@ -116,6 +147,10 @@ class S2TEmformerEncoder:
                 for name in ("wqkv", "wo", "w1"):
                     if L[name].shape[1] % 64 == 0 and L[name].shape[0] % 64 == 0:
                         L[name + "_fm"] = self.ops.pack_fragment_major(L[name])
+            # fused feed-forward block (simulst_emformer_ffn): D == 256, F a multiple of 64
+            if self.cfg.embed_dim == 256 and self.cfg.ffn_dim % 64 == 0 and self.cfg.ffn_dim <= 4096:
+                for L in w.layers:
+                    L["w1_ffn"], L["w2_ffn"] = ffn_pack_w1(L["w1"]), ffn_pack_w2(L["w2"])
         k = w.pos_w.shape[2]
         ok = w.pos_w.dtype == torch.bfloat16 and w.pos_w.shape[1] == 16 and k in (16, 32, 64)
         w.pos_w_packed = self.ops.pack_conv_pos_weight(w.pos_w) if ok else False
@@ -155,6 +190,8 @@ class S2TEmformerEncoder:
     # ---------------------------------------------------------------- Emformer
     use_panel_gemm = True
     fuse_ffn_layernorm = True      # bf16 row-panel path: LayerNorm as fc1's prologue instead of its own launch
+    fuse_ffn = True                # bf16, D == 256: LayerNorm + fc1 + GELU + fc2 + residual in ONE launch, hidden on chip
+    fuse_ffn_min_rows = 4096       # below this the two-launch path fills the chip better (256 rows per workgroup)
 
     def _packed(self, l, name):
         """Fragment-major copy of an encoder projection weight (bf16 only, made once): lets simulst_linear take the
@@ -232,6 +269,11 @@ class S2TEmformerEncoder:
                            w_fragment_major=fo)
             # fc1 + GELU on the row panel too since its GELU went to the packed fp32 pipe (1568 vs 1795 us at 605 k rows);
             # there the pre-FFN LayerNorm is the kernel's prologue (once per 128-row panel, on the stationary fragments)
+            if self.fuse_ffn and "w1_ffn" in L and B * rows_x >= self.fuse_ffn_min_rows:
+                ops.emformer_ffn(X1.view(B * rows_x, D), L["ln_ff_g"], L["ln_ff_b"], L["w1_ffn"], L["b1"], L["w2_ffn"],
+                                 L["b2"], X.view(B * rows_x, D))
+                states.append(None)
+                continue
             w1, f1 = self._packed(l, "w1") if tall else (L["w1"], False)
             if f1 and self.fuse_ffn_layernorm:
                 ops.linear(X1.view(B * rows_x, D), w1, L["b1"], epilogue=EPI_BIAS_GELU, out=Hf, w_fragment_major=True,

@@ -62,6 +62,10 @@ class FairseqModelSurface:
         if d is None:
             raise RuntimeError("load_state_dict: this model already holds its device weights (rebuild it with "
                                "build_model(args, task) to load another checkpoint)")
+        emb = state_dict.get("decoder.embed_tokens.weight")
+        if emb is not None and emb.shape[0] != self.cfg.vocab:      # no task dictionary: the checkpoint's own vocabulary
+            from dataclasses import replace
+            self.cfg = replace(self.cfg, vocab=int(emb.shape[0]))
         weights = upgrade_state_dict(state_dict, self.cfg, strict=strict)
         type(self).__init__(self, self.cfg, weights, device=d["device"], dtype=d["dtype"])
         if d["dictionary"] is not None:

@@ -110,6 +110,15 @@ class Ops:
                                                 dt(x)), "simulst_layernorm")
         return out
 
+    def emformer_ffn(self, x, ln_g, ln_b, w1p, b1, w2p, b2, out):
+        """out[rows, D] = x + fc2(gelu(fc1(LayerNorm(x)))) in one launch (simulst_emformer_ffn; bf16, D == 256)."""
+        _chk_contig(x, out, w1p, w2p)
+        rows, D = x.shape
+        F = b1.numel()
+        self.h.check(self.lib.simulst_emformer_ffn(self.h.ptr, _p(x), _p(ln_g), _p(ln_b), _p(w1p), _p(b1), _p(w2p),
+                                                   _p(b2), _p(out), rows, D, F, dt(x)), "simulst_emformer_ffn")
+        return out
+
     def emformer_prenorm(self, X, gamma, beta, lengths, Z, *, T, n_mem, n_rc, n_sum, seg_len):
         B, _, D = X.shape
         self.h.check(self.lib.simulst_emformer_prenorm(self.h.ptr, _p(X), _p(gamma), _p(beta), _p(lengths), _p(Z),

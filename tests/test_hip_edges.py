@@ -84,12 +84,24 @@ def test_scans_edge_shapes(ops):
     torch.testing.assert_close(out[:, :9].cpu(), x, atol=1e-6, rtol=1e-6)
 
 
-def test_state_capacity_errors_are_loud(ops):
+def test_state_grows_with_the_source_and_device_loop_capacity_is_loud(ops):
+    """A streaming source of unknown length makes the caller-owned caches grow (the reference's grow by concatenation);
+    contents written before the growth are kept.  The device-resident step loop works on fixed buffers and refuses to
+    run past them."""
     from simulst_amd.config import tiny
     from simulst_amd.decoder import MMADecoder
     from simulst_amd.weights import init_model
     cfg = tiny()
     dec = MMADecoder(cfg, init_model(cfg, 1), dtype=torch.float32, ops=ops)
     st = dec.new_state(1, cap=4, S_cap=8)
-    with pytest.raises(AssertionError, match="S_cap"):
-        dec.append_encoder_out(st, torch.zeros(1, 9, cfg.embed_dim, device="cuda"), torch.tensor([9]))
+    g = torch.Generator().manual_seed(0)
+    first = torch.randn(1, 6, cfg.embed_dim, generator=g).cuda()
+    dec.append_encoder_out(st, first, torch.tensor([6]))
+    k_before = st.Kmono[0][:, :, :6].clone()
+    dec.append_encoder_out(st, torch.randn(1, 9, cfg.embed_dim, generator=g).cuda(), torch.tensor([15]))
+    assert st.S_cap >= 15 and st.enc_rows == 15 and st.Kmono[0].shape[2] == st.S_cap
+    assert torch.equal(st.Kmono[0][:, :, :6], k_before)
+    big = dec.new_state(1, cap=4, S_cap=16)
+    dec.append_encoder_out(big, torch.cat([first, torch.zeros(1, 0, cfg.embed_dim, device="cuda")], 1), torch.tensor([6]))
+    with pytest.raises(AssertionError, match="capacity"):
+        dec.decode_steps(big, torch.full((1,), cfg.eos, device="cuda"), 8, True)

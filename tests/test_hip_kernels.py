@@ -707,3 +707,78 @@ def test_long_range_attention(ops, dtype):
             qh = f[b, :D].view(H, 1, d) * d ** -0.5
             close(out[b], (torch.softmax(qh @ K.transpose(-1, -2), -1) @ V).view(D), **tol)
         n_prev += 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fused Emformer feed-forward block (simulst_emformer_ffn): LayerNorm + fc1 + GELU + fc2 + residual, hidden on chip
+def _ffn_reference(x, g, b, W1, b1, W2, b2):
+    """torch fp32 on the bf16-rounded operands; the hidden activations are rounded to bf16 like the kernel's operand
+    (torchaudio_models/emformer.py:365-378,437-439)."""
+    xf = x.float()
+    y = torch.nn.functional.layer_norm(xf, (xf.shape[-1],), g, b, 1e-5).to(torch.bfloat16).float()
+    h = torch.nn.functional.gelu(y @ W1.float().t() + b1).to(torch.bfloat16).float()
+    return xf + h @ W2.float().t() + b2
+
+
+@pytest.mark.parametrize("rows,F", [(700, 2048), (256, 64), (1, 128), (5000, 1024)])
+def test_emformer_ffn_fused_vs_torch_reference(ops, rows, F):
+    from simulst_amd.encoder import ffn_pack_w1, ffn_pack_w2
+    g_ = torch.Generator().manual_seed(rows + F)
+    D = 256
+    x = torch.randn(rows, D, generator=g_).to(torch.bfloat16)
+    W1 = (torch.randn(F, D, generator=g_) * D ** -0.5).to(torch.bfloat16)
+    W2 = (torch.randn(D, F, generator=g_) * F ** -0.5).to(torch.bfloat16)
+    b1, b2 = torch.randn(F, generator=g_) * 0.1, torch.randn(D, generator=g_) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(D, generator=g_), 0.1 * torch.randn(D, generator=g_)
+    ref = _ffn_reference(x, gam, bet, W1, b1, W2, b2)
+    xd = x.cuda()
+    out = torch.full_like(xd, float("nan"))
+    ops.emformer_ffn(xd, gam.cuda(), bet.cuda(), ffn_pack_w1(W1.cuda()), b1.cuda(), ffn_pack_w2(W2.cuda()), b2.cuda(), out)
+    torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=2e-2)
+    # against the two-launch path of the same library (LayerNorm prologue + GELU epilogue, then fc2 + residual)
+    from simulst_amd.ops import EPI_BIAS_GELU, EPI_BIAS_RES
+    y = ops.layernorm(xd, gam.cuda(), bet.cuda())
+    hid = ops.linear(y, W1.cuda(), b1.cuda(), epilogue=EPI_BIAS_GELU)
+    two = ops.linear(hid, W2.cuda(), b2.cuda(), epilogue=EPI_BIAS_RES, residual=xd)
+    torch.testing.assert_close(out.float(), two.float(), atol=3e-2, rtol=2e-2)
+    assert float((out.float() - two.float()).abs().mean()) < 2e-3
+
+
+def test_emformer_ffn_exact_integer_operands(ops):
+    """Layout check with exact arithmetic (asymmetric operands; a swapped lane / register map cannot pass): small
+    integers, LayerNorm as the identity map is not available, so gamma scales and beta shifts are folded into the
+    expectation through the torch reference on values that are exactly representable."""
+    from simulst_amd.encoder import ffn_pack_w1, ffn_pack_w2
+    g_ = torch.Generator().manual_seed(5)
+    D, F, rows = 256, 128, 300
+    x = torch.randint(-3, 4, (rows, D), generator=g_).float().to(torch.bfloat16)
+    W1 = (torch.randint(-2, 3, (F, D), generator=g_).float() / 16).to(torch.bfloat16)
+    W2 = (torch.randint(-2, 3, (D, F), generator=g_).float() / 8).to(torch.bfloat16)
+    b1, b2 = torch.zeros(F), torch.arange(D).float() / 64
+    gam, bet = torch.ones(D), torch.zeros(D)
+    ref = _ffn_reference(x, gam, bet, W1, b1, W2, b2)
+    out = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    ops.emformer_ffn(x.cuda(), gam.cuda(), bet.cuda(), ffn_pack_w1(W1.cuda()), b1.cuda(), ffn_pack_w2(W2.cuda()),
+                     b2.cuda(), out)
+    torch.testing.assert_close(out.float().cpu(), ref, atol=6e-2, rtol=1e-2)
+    # every row and every column individually (a permuted map would still pass a loose global tolerance on noise)
+    err = (out.float().cpu() - ref).abs()
+    assert float(err.max(dim=1).values.max()) < 6e-2 and float(err.max(dim=0).values.max()) < 6e-2
+
+
+def test_encoder_with_fused_ffn_equals_two_launch_path(ops):
+    """The full-size bf16 encoder with the fused feed-forward block against the same encoder with it switched off."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.encoder import S2TEmformerEncoder
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=3)
+    enc = S2TEmformerEncoder(cfg, init_model(cfg, seed=999), dtype=torch.bfloat16, ops=ops)
+    fb = torch.randn(24, 1000, 80, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16).cuda()
+    L = torch.full((24,), 1000, device="cuda")
+    L[3], L[7] = 640, 311
+    enc.fuse_ffn, enc.fuse_ffn_min_rows = True, 0
+    a = enc.forward(fb, L)["encoder_out_btd"].float().clone()
+    enc.fuse_ffn = False
+    b = enc.forward(fb, L)["encoder_out_btd"].float().clone()
+    torch.testing.assert_close(a, b, atol=6e-2, rtol=5e-2)
+    assert float((a - b).abs().mean()) < 4e-3

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Fused Emformer feed-forward launch (simulst_emformer_ffn) against the two-launch path it replaces (LayerNorm + fc1 +
+GELU on the row-panel kernel, fc2 + residual on the 128 x 128 tile kernel) at the encoder's row counts: B utterances x
+378 rows (T = 1000 frames), D = 256, F = 2048, bf16.  HIP-event timing on the handle's stream, interleaved rounds in one
+process (cdna_hip_programming.md section 5.4 rule 24), random operands.
+
+    python tools/ffn_bench.py [--rows-per-utt 378] [--utterances 64 256 1280 4096]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows-per-utt", type=int, default=378)
+    ap.add_argument("--utterances", type=int, nargs="+", default=[64, 128, 256, 512, 1280, 4096])
+    ap.add_argument("--rounds", type=int, default=7)
+    args = ap.parse_args()
+    from simulst_amd.encoder import ffn_pack_w1, ffn_pack_w2
+    from simulst_amd.ops import EPI_BIAS_GELU, EPI_BIAS_RES, Ops
+    ops = Ops()
+    D, F = 256, 2048
+    g = torch.Generator().manual_seed(0)
+    W1 = (torch.randn(F, D, generator=g) * D ** -0.5).to(torch.bfloat16).cuda()
+    W2 = (torch.randn(D, F, generator=g) * F ** -0.5).to(torch.bfloat16).cuda()
+    b1, b2 = torch.randn(F, generator=g).cuda() * 0.1, torch.randn(D, generator=g).cuda() * 0.1
+    gam, bet = torch.ones(D).cuda(), torch.zeros(D).cuda()
+    w1p, w2p = ffn_pack_w1(W1), ffn_pack_w2(W2)
+    w1fm = ops.pack_fragment_major(W1)
+    out = {}
+    for B in args.utterances:
+        rows = B * args.rows_per_utt
+        x = torch.randn(rows, D, device="cuda").to(torch.bfloat16)
+        y, hid = torch.empty_like(x), torch.empty(rows, F, device="cuda", dtype=torch.bfloat16)
+
+        def fused():
+            ops.emformer_ffn(x, gam, bet, w1p, b1, w2p, b2, y)
+
+        def two():
+            ops.linear(x, w1fm, b1, epilogue=EPI_BIAS_GELU, out=hid, w_fragment_major=True, ln=(gam, bet))
+            ops.linear(hid, W2, b2, epilogue=EPI_BIAS_RES, residual=x, out=y)
+
+        t = {"fused": [], "two_launch": []}
+        for fn in (fused, two):
+            fn()
+        torch.cuda.synchronize()
+        for _ in range(args.rounds):
+            for name, fn in (("fused", fused), ("two_launch", two)):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                torch.cuda.synchronize()
+                t[name].append(a.elapsed_time(b) * 1e3)
+        flop = 4.0 * rows * D * F
+        out[B] = {k: {"us_median": round(sorted(v)[len(v) // 2], 1), "us_min": round(min(v), 1),
+                      "TFLOPs_median": round(flop / sorted(v)[len(v) // 2] / 1e6, 1)} for k, v in t.items()}
+        out[B]["rows"] = rows
+        print(B, out[B], file=sys.stderr, flush=True)
+    print(json.dumps({"D": D, "F": F, "dtype": "bf16", "by_utterances": out}))
+
+
+if __name__ == "__main__":
+    main()
