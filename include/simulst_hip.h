@@ -86,6 +86,9 @@ int simulst_graph_enable(simulst_handle* h, int on);
 /* test hook: route bf16 Emformer attention through the fp32-VALU kernel instead of the MFMA one */
 /* (also routes the bf16 decoder self-attention through its workgroup kernel instead of the wave-per-head one) */
 int simulst_debug_force_valu_attention(simulst_handle* h, int on);
+/* measurement hook for tools/ffn_bench.py: variant 1 runs simulst_emformer_ffn WITHOUT the GELU arithmetic (a timing
+ * ablation -- its results are not the operator's); 0 restores the operator */
+int simulst_debug_ffn_variant(simulst_handle* h, int variant);
 /* test hook: run simulst_mma_decode / simulst_mma_stream_steps with the 7-launch layer even when the head-split
  * workspace is supplied (A/B parity of the two paths) */
 int simulst_debug_force_unfused_decode(simulst_handle* h, int on);

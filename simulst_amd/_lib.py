@@ -78,6 +78,7 @@ SIGNATURES = {
     "simulst_graph_enable": [_vp, C.c_int],
     "simulst_debug_force_valu_attention": [_vp, C.c_int],
     "simulst_debug_force_unfused_decode": [_vp, C.c_int],
+    "simulst_debug_ffn_variant": [_vp, C.c_int],
     "simulst_pack_fragment_major": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],

@@ -39,6 +39,7 @@ struct simulst_handle {
   hipGraphExec_t graph_exec;
   uint64_t graph_key;
   bool ffn_lds_attr_set;       // simulst_emformer_ffn did the same for the fused feed-forward kernel
+  int ffn_variant;             // simulst_debug_ffn_variant (timing ablations of the fused feed-forward launch)
   bool ctc_lds_attr_set;       // simulst_ctc_best_alignment raised its kernel's dynamic-LDS limit through this handle
 };
 

@@ -17,6 +17,12 @@
 //   * per MFMA one conflict-free 1 KB fragment read from LDS (128 B/clk/CU at full MFMA rate = half the LDS rate)
 //   * epilogue once per workgroup: Y + b2 -> bf16 rows staged in the (free) weight buffers -> + residual x -> 16-byte
 //     row-contiguous stores
+// Measured on MI355X (tools/ffn_bench.py, 1280 utterances = 483,840 rows, F = 2048): 1.30-1.50 ms against 1.79-2.00 ms for
+// the two launches (782 vs 567 TFLOP/s on the same device); without the GELU arithmetic (timing ablation, variant 1)
+// 1.09 ms: the two waves of a SIMD walk [first product | GELU | second product] in lock-step behind the per-chunk
+// barrier, so the GELU is not hidden.  Tried and dropped: deferring the second product by one tile so that it is
+// independent of the current tile's GELU and can issue beside it (+8 VGPRs, a second raw barrier per chunk): hipcc still
+// emits the GELU as a block in front of the MFMAs, sched_group_barrier patterns did not change that, 3 % slower.
 // Algorithmic work per launch: 4 * rows * D * F flop (two contractions), HBM bytes 2 * rows * D * 2 (x read for the
 // contraction, again for the residual: L2/MALL-hot) + rows * D * 2 written; weights 2 * D * F * 2 B from L2 per workgroup.
 #include "gemm_args.h"
@@ -49,13 +55,14 @@ __device__ __forceinline__ void stage_chunk(const bf16* __restrict__ w1p, const 
   const char* g2 = reinterpret_cast<const char*>(w2p) + (long)chunk * FF_W1_BYTES;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    __builtin_amdgcn_global_load_lds((gbl_void*)(g1 + q * 8192 + voff), (lds_void*)(lds + q * 8192 + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g1 + (unsigned)(voff + q * 8192u)), (lds_void*)(lds + q * 8192 + wave * 1024), 16, 0, 0);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    __builtin_amdgcn_global_load_lds((gbl_void*)(g2 + q * 8192 + voff),
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g2 + (unsigned)(voff + q * 8192u)),
                                      (lds_void*)(lds + FF_W1_BYTES + q * 8192 + wave * 1024), 16, 0, 0);
 }
 
+template <int VARIANT>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const bf16* __restrict__ X, const float* __restrict__ ln_g,
                                                            const float* __restrict__ ln_b,
                                                            const bf16* __restrict__ W1p, const float* __restrict__ b1,
@@ -136,8 +143,9 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const bf16* __restric
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 bv = *reinterpret_cast<const float4*>(b1s + h0 + 8 * g);
-        const f32x2 v0 = gelu_fast2(f32x2{hacc[4 * g] + bv.x, hacc[4 * g + 1] + bv.y});
-        const f32x2 v1 = gelu_fast2(f32x2{hacc[4 * g + 2] + bv.z, hacc[4 * g + 3] + bv.w});
+        f32x2 v0 = f32x2{hacc[4 * g] + bv.x, hacc[4 * g + 1] + bv.y};
+        f32x2 v1 = f32x2{hacc[4 * g + 2] + bv.z, hacc[4 * g + 3] + bv.w};
+        if constexpr (VARIANT != 1) { v0 = gelu_fast2(v0); v1 = gelu_fast2(v1); }   // VARIANT 1: timing ablation only
         unsigned int* dst = reinterpret_cast<unsigned int*>(&hb[g >> 1]) + (g & 1) * 2;
         dst[0] = pack_bf16x2(v0.x, v0.y);
         dst[1] = pack_bf16x2(v1.x, v1.y);
@@ -201,13 +209,25 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
   SL_REQUIRE(h, x != out, SIMULST_E_ARG, "simulst_emformer_ffn: in place (the residual rows are re-read at the end)");
   if (rows <= 0) return SIMULST_OK;
   if (!h->ffn_lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
     if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit"; return (int)e; }
     h->ffn_lds_attr_set = true;
   }
   KTimer t(h, SIMULST_K_LINEAR);
-  hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((rows + FF_ROWS - 1) / FF_ROWS)), dim3(512), FF_LDS, h->stream,
-                     (const bf16*)x, ln_gamma, ln_beta, (const bf16*)w1_packed, b1, (const bf16*)w2_packed, b2,
-                     (bf16*)out, (long)rows, F);
+  const dim3 grid((unsigned)((rows + FF_ROWS - 1) / FF_ROWS));
+#define FFN(V)                                                                                                     \
+  hipLaunchKernelGGL(ffn_fused_kernel<V>, grid, dim3(512), FF_LDS, h->stream, (const bf16*)x, ln_gamma, ln_beta, \
+                     (const bf16*)w1_packed, b1, (const bf16*)w2_packed, b2, (bf16*)out, (long)rows, F)
+  if (h->ffn_variant == 1) FFN(1); else FFN(0);
+#undef FFN
   return sl_launch_status(h, "simulst_emformer_ffn");
+}
+
+// measurement hook (tools/ffn_bench.py): 1 = the same launch without the GELU arithmetic (results are NOT the operator's)
+extern "C" int simulst_debug_ffn_variant(simulst_handle* h, int variant) {
+  if (!h) return SIMULST_E_NULL;
+  h->ffn_variant = variant;
+  return SIMULST_OK;
 }

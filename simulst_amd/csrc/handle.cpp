@@ -29,6 +29,7 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->graph_exec = nullptr;
   h->ctc_lds_attr_set = false;
   h->ffn_lds_attr_set = false;
+  h->ffn_variant = 0;
   h->graph_key = 0;
   for (int i = 0; i < SIMULST_K_COUNT; ++i) { h->timer_on[i] = false; h->timer_ms[i] = 0.0; h->timer_n[i] = 0; }
   *out = h;

@@ -46,12 +46,21 @@ def main():
             ops.linear(x, w1fm, b1, epilogue=EPI_BIAS_GELU, out=hid, w_fragment_major=True, ln=(gam, bet))
             ops.linear(hid, W2, b2, epilogue=EPI_BIAS_RES, residual=x, out=y)
 
-        t = {"fused": [], "two_launch": []}
-        for fn in (fused, two):
+        def variant(v):
+            def run():
+                ops.lib.simulst_debug_ffn_variant(ops.h.ptr, v)
+                fused()
+                ops.lib.simulst_debug_ffn_variant(ops.h.ptr, 0)
+            return run
+
+        # variant 1: the kernel WITHOUT the GELU arithmetic -- a timing ablation, how much of the launch the un-hidden GELU is
+        fns = (("fused", fused), ("two_launch", two), ("fused_no_gelu_ablation", variant(1)))
+        t = {name: [] for name, _ in fns}
+        for _, fn in fns:
             fn()
         torch.cuda.synchronize()
         for _ in range(args.rounds):
-            for name, fn in (("fused", fused), ("two_launch", two)):
+            for name, fn in fns:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 fn()
