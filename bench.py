@@ -67,6 +67,12 @@ def parse_args(argv=None):
     ap.add_argument("--group", type=int, default=64,
                     help="independent 64-utterance batches stacked into one launch sequence (fewer when --steps "
                          "does not fill group x concurrency sequences)")
+    ap.add_argument("--min-per-sequence", type=int, default=24,
+                    help="with few steps, launch sequences are not split below this many batches just to occupy streams")
+    ap.add_argument("--min-warmup-seconds", type=float, default=0.75,
+                    help="the warm-up repeats the timed plan until W steps AND this much wall time have passed: a cold "
+                         "GPU runs its first ~0.5 s of launches at ramping clocks (measured: the 2nd pass of a fresh "
+                         "process 141 ms, the 4th 119 ms)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode loop of each batch strictly one after the other")
     ap.add_argument("--graph", action="store_true",
@@ -243,7 +249,7 @@ def dry_run_gloo(args):
     os.environ.setdefault("MASTER_PORT", "29531")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     B, G = args.batch, max(1, args.group)
-    plan = plan_launch_sequences(args.steps, G, args.concurrency, min_per_sequence=24)
+    plan = plan_launch_sequences(args.steps, G, args.concurrency, min_per_sequence=args.min_per_sequence)
     dist.barrier()
     t0 = time.perf_counter()
     rows, base = [], rank * B * args.steps
@@ -309,7 +315,7 @@ def main(argv=None):
     B = args.batch
     G = max(1, args.group)
     # the plan that is executed: batches per launch sequence, sequences dealt round-robin to the streams
-    plan = plan_launch_sequences(args.steps, G, args.concurrency, min_per_sequence=24)
+    plan = plan_launch_sequences(args.steps, G, args.concurrency, min_per_sequence=args.min_per_sequence)
     g_max = max(plan) if plan else 1
     streams_used = min(args.concurrency, len(plan)) if args.concurrency > 1 else 1
     # synthetic fbank, seed 999 + global utterance id, resident in HBM before the clock starts: g_max batches of B
@@ -345,8 +351,11 @@ def main(argv=None):
     log(f"model + inputs resident on {dev}; host cores {os.cpu_count()}; plan {plan} on {streams_used} stream(s)")
     warm_done = 0
     with torch.no_grad():
-        while args.warmup > 0 and warm_done < args.warmup:     # the timed plan's own sequences: same shapes, same
+        tw0 = time.perf_counter()
+        while args.warmup > 0 and (warm_done < args.warmup or time.perf_counter() - tw0 < args.min_warmup_seconds) \
+                and warm_done < 64 * max(sum(plan), 1):            # the timed plan's own sequences: same shapes, same
             run_plan(plan)                                      # buffers, same kernel selections as the timed pass
+            torch.cuda.synchronize()
             warm_done += sum(plan)
         torch.cuda.synchronize()
         log(f"warm-up: {warm_done} steps (asked for {args.warmup}) as the timed plan's launch sequences")
