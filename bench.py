@@ -67,7 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--group", type=int, default=64,
                     help="independent 64-utterance batches stacked into one launch sequence (fewer when --steps "
                          "does not fill group x concurrency sequences)")
-    ap.add_argument("--min-per-sequence", type=int, default=24,
+    ap.add_argument("--min-per-sequence", type=int, default=6,
                     help="with few steps, launch sequences are not split below this many batches just to occupy streams")
     ap.add_argument("--min-warmup-seconds", type=float, default=0.75,
                     help="the warm-up repeats the timed plan until W steps AND this much wall time have passed: a cold "

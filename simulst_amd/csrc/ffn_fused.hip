@@ -34,6 +34,7 @@ constexpr int FF_D = 256;             // model width (K of fc1, N of fc2)
 constexpr int FF_CH = 64;             // hidden units per LDS chunk
 constexpr int FF_W1_BYTES = FF_CH * FF_D * 2;      // 32 KB
 constexpr int FF_CHUNK_BYTES = 2 * FF_W1_BYTES;    // W1 tile rows + W2 tile columns of a chunk
+constexpr int FF_PF = 4;               // weight fragments requested ahead of the MFMA that consumes them
 constexpr int FF_MAX_F = 4096;        // hidden units whose fc1 bias fits the LDS budget
 constexpr int FF_LDS = 2 * FF_CHUNK_BYTES + 3072 + FF_MAX_F * 4;  // double buffer + gamma / beta / b2 (3 x 256 fp32) + b1
 
@@ -130,11 +131,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const bf16* __restric
       f32x16 hacc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) hacc[e] = 0.f;
+      {  // fragment reads run FF_PF MFMAs ahead (a read issued right in front of its MFMA exposes the LDS latency)
+        uint4 wf[FF_PF];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const uint4 wf = w1[(t * 16 + s) * 64 + lane];
-        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wf),
-                                                       *reinterpret_cast<const bf16x8_t*>(&xa[s]), hacc, 0, 0, 0);
+        for (int i = 0; i < FF_PF; ++i) wf[i] = w1[(t * 16 + i) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wf[s % FF_PF]),
+                                                         *reinterpret_cast<const bf16x8_t*>(&xa[s]), hacc, 0, 0, 0);
+          if (s + FF_PF < 16) wf[s % FF_PF] = w1[(t * 16 + s + FF_PF) * 64 + lane];
+        }
       }
       // hacc[e] = H[row lr][hidden h0 + (e & 3) + 8 (e >> 2) + 4 lh]: bias + GELU, then registers 8 s .. 8 s + 7
       // pairwise to bf16 = A fragment of k-step s of the second product
@@ -150,14 +156,17 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const bf16* __restric
         dst[0] = pack_bf16x2(v0.x, v0.y);
         dst[1] = pack_bf16x2(v1.x, v1.y);
       }
+      {
+        uint4 wf[FF_PF];
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < FF_PF; ++i) wf[i] = w2[(t * 16 + i) * 64 + lane];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          const uint4 wf = w2[((t * 2 + s) * 8 + n) * 64 + lane];
-          y[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&hb[s]),
-                                                         *reinterpret_cast<const bf16x8_t*>(&wf), y[n], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) {                      // i = s * 8 + n
+          y[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&hb[i >> 3]),
+                                                             *reinterpret_cast<const bf16x8_t*>(&wf[i % FF_PF]), y[i & 7], 0, 0, 0);
+          if (i + FF_PF < 16) wf[i % FF_PF] = w2[(t * 16 + i + FF_PF) * 64 + lane];
         }
+      }
     }
   }
   // ---- epilogue: y[n][e] = Y[row (e & 3) + 8 (e >> 2) + 4 lh][col 32 n + lr].  Stage as bf16 rows in

@@ -20,7 +20,7 @@ from collections import defaultdict
 
 CLASSES = (("decoder_cross_attention", r"cross_attn_kernel"), ("decoder_self_attention", r"self_attn"),
            ("linear_tile64", r"mid_kernel|panel_kernel<\d+, true>"), ("linear_skinny", r"skinny_kernel|wave_tile_kernel|splitk"),
-           ("linear", r"linear_kernel|panel_kernel"), ("emformer_attention", r"emformer_attn"),
+           ("linear", r"linear_kernel|panel_kernel|ffn_fused_kernel"), ("emformer_attention", r"emformer_attn"),
            ("layernorm", r"layernorm_kernel|emformer_prenorm"), ("conv_pos", r"conv_pos"), ("argmax", r"argmax"))
 
 
