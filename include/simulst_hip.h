@@ -286,6 +286,11 @@ int simulst_expected_soft_attention(simulst_handle* h, const float* alpha, const
  *   (monotonic_multihead_attention.py:88-149, utils/p_choose_strategy.py:56-76, eval mode) is
  *   upsampled by zero insertion to frame (j+1)*ratio-1, cropped/padded to len with the last
  *   column overwritten when cropped (:85-95,143-159).  ratio == 1 = no pre-decision.
+ *   A NEGATIVE ratio selects --fixed-pre-decision-type last with ratio |ratio| (:38-52): pooled key j is the single
+ *   frame (j+1)*|ratio| - 1 (the last frame for a ragged final window of a training-mode forward); while
+ *   len < |ratio| the reference leaves the keys unpooled (:38-40) and its floor-trim drops one, so there are
+ *   max(1, len - 1) pooled positions, position j = frame j.  The same sign convention holds for the `ratio` of
+ *   simulst_policy_cross_attention and of simulst_decoder_desc.
  *   WAITK: p_j = (j == min(tgt_idx[b] + k - 1, online ? inf : P-1)) (p_choose_strategy.py:6-53),
  *   q/Kmono unused.
  * Per-utterance (B == 1) semantics for ragged batches: windows never mix padded frames. */

@@ -98,6 +98,28 @@ static inline int sl_launch_status(simulst_handle* h, const char* what) {
   return SIMULST_OK;
 }
 
+// ---- fixed pre-decision pooling (modules/fixed_pre_decision.py:23-52,97-131) ------------------------------------
+// The C ABI carries the pooling type in the SIGN of `ratio`: ratio > 0 is --fixed-pre-decision-type average,
+// ratio < 0 is 'last' with ratio |ratio|.  pooled_count: number of pooled positions of a source of len frames --
+// ceil(len / ratio) in a training-mode forward, floor-trimmed to max(1, len / ratio) with incremental state; the
+// reference's 'last' pooling returns the keys UNPOOLED while len < ratio (:38-40), the floor-trim then drops one.
+// pooled_frames: the source frames [f0, f1) whose mean is pooled position j (one frame for 'last').
+__host__ __device__ __forceinline__ int pooled_count(int len, int ratio, bool incremental, bool last) {
+  if (last && len < ratio) return incremental ? (len - 1 > 1 ? len - 1 : 1) : len;
+  int P = (len + ratio - 1) / ratio;
+  if (incremental) { const int fl = len / ratio > 1 ? len / ratio : 1; P = P < fl ? P : fl; }
+  return P;
+}
+__device__ __forceinline__ void pooled_frames(int j, int len, int ratio, bool last, int& f0, int& f1) {
+  if (last) {
+    f1 = len < ratio ? j + 1 : min((j + 1) * ratio, len);
+    f0 = f1 - 1;
+  } else {
+    f0 = j * ratio;
+    f1 = min(f0 + ratio, len);
+  }
+}
+
 // ---- dtype helpers ------------------------------------------------------------
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16 v) { return __bfloat162float(v); }

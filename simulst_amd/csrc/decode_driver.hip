@@ -82,8 +82,9 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
   const int D = H * d;
   const int len = key_len ? key_len[b] : S_cap;
   const int r = b * H + h;
-  int P = (len + ratio - 1) / ratio;
-  P = min(P, max(1, len / ratio));           // inference: floor-trimmed, at least one (:123-131)
+  const bool pool_last = ratio < 0;          // sign of ratio = --fixed-pre-decision-type (common.h)
+  ratio = ratio < 0 ? -ratio : ratio;
+  const int P = pooled_count(len, ratio, true, pool_last);   // inference: floor-trimmed, at least one (:123-131)
   // ---- 0. every load of the value-aggregation phase goes out first (soft attention over <= 256 keys):
   //         the policy below then runs under their latency
   // cached projections are HEAD-MAJOR [B][H][S_cap][d]: a head's key rows are contiguous 128-byte lines (measured
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
       __syncthreads();
     }
     for (int j = tid; j < P; j += 256) {
-      const int f0 = j * ratio, f1 = min(f0 + ratio, len);
+      int f0, f1;
+      pooled_frames(j, len, ratio, pool_last, f0, f1);
       float en = 0.f;
       for (int c = 0; c < d; c += W) {
         float accv[W];
@@ -463,7 +465,7 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
   if (attn_type != SIMULST_ATTN_HARD) { if (!xres) SL_CHECK_NULL(h, qs); SL_CHECK_NULL(h, Ksoft); }
   if (xres) { SL_CHECK_NULL(h, ln_g); SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, Wqm);
               SL_REQUIRE(h, (H * d) % 32 == 0, SIMULST_E_SHAPE, "simulst_policy_cross_attention: D % 32 for the fused projection"); }
-  SL_REQUIRE(h, H > 0 && d >= 8 && d <= 64 && d % 8 == 0 && S_cap > 0 && ratio >= 1, SIMULST_E_SHAPE,
+  SL_REQUIRE(h, H > 0 && d >= 8 && d <= 64 && d % 8 == 0 && S_cap > 0 && ratio != 0, SIMULST_E_SHAPE,
              "simulst_policy_cross_attention: head_dim must be a multiple of 8, <= 64");
   SL_REQUIRE(h, (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float) <= 64 * 1024, SIMULST_E_SHAPE,
              "simulst_policy_cross_attention: source too long for the LDS rows");
@@ -589,7 +591,7 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
       // each (head, utterance) workgroup normalises its residual row and projects its own 64 query channels
       const int n_hint = device_indexed ? -1
                          : (dd->attn_type == SIMULST_ATTN_WAITK && np_uniform >= 0)
-                               ? (np_uniform + s + dd->waitk_k) * dd->ratio : dd->S_cap;
+                               ? (np_uniform + s + dd->waitk_k) * (dd->ratio < 0 ? -dd->ratio : dd->ratio) : dd->S_cap;
       ctl.layer = l + 1;
       if (fuse_q) {
         if ((rc = policy_cross(h, nullptr, nullptr, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,

@@ -188,14 +188,15 @@ __global__ __launch_bounds__(256) void step_p_choose_kernel(const T* __restrict_
                                                             int ratio, int incremental, int attn_type, int waitk_k,
                                                             const int* __restrict__ tgt_idx, int online) {
   extern __shared__ float sm[];
+  const bool pool_last = ratio < 0;                          // sign of ratio = pooling type (common.h)
+  ratio = ratio < 0 ? -ratio : ratio;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = H * d;
   const int len = key_len ? key_len[b] : S_cap;
   float* pp = sm + wave * S_cap;                             // pooled probabilities of this wave's head
   for (int h = wave; h < H; h += 4) {
     float* pr = p + ((long)b * H + h) * S_cap;
-    int P = (len + ratio - 1) / ratio;                       // ceil pooling
-    if (incremental) P = min(P, max(1, len / ratio));        // floor at inference, at least 1
+    const int P = pooled_count(len, ratio, incremental != 0, pool_last);   // ceil pooling; floor at inference, at least 1
     const float qv = (attn_type != SIMULST_ATTN_WAITK && lane < d)
                          ? to_f32(q[(long)b * D + h * d + lane]) * rsqrtf((float)d) : 0.f;
     if (attn_type == SIMULST_ATTN_WAITK) {
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(256) void step_p_choose_kernel(const T* __restrict_
       for (int j = lane; j < P; j += 64) pp[j] = (j == wk_step) ? 1.f : 0.f;
     } else {
       for (int j = 0; j < P; ++j) {
-        const int f0 = j * ratio, f1 = min(f0 + ratio, len);
+        int f0, f1;
+        pooled_frames(j, len, ratio, pool_last, f0, f1);
         float acc = 0.f;
         if (lane < d)
           for (int f = f0; f < f1; ++f) acc += to_f32(Km[(((long)b * H + h) * S_cap + f) * d + lane]);
@@ -468,7 +470,7 @@ extern "C" int simulst_step_p_choose(simulst_handle* h, const void* q, const voi
              "simulst_step_p_choose: attn_type");
   if (attn_type == SIMULST_ATTN_WAITK) { SL_CHECK_NULL(h, tgt_idx); SL_REQUIRE(h, waitk_k > 0, SIMULST_E_ARG, "simulst_step_p_choose: waitk lagging"); }
   else { SL_CHECK_NULL(h, q); SL_CHECK_NULL(h, Kmono); }
-  SL_REQUIRE(h, ratio >= 1 && S_cap > 0 && H > 0 && d > 0 && d <= 64 && S_cap <= 4096, SIMULST_E_SHAPE,
+  SL_REQUIRE(h, ratio != 0 && S_cap > 0 && H > 0 && d > 0 && d <= 64 && S_cap <= 4096, SIMULST_E_SHAPE,
              "simulst_step_p_choose: shape (head_dim <= 64, S_cap <= 4096)");
   if (B <= 0) return SIMULST_OK;
   const size_t lds = (size_t)4 * S_cap * sizeof(float);

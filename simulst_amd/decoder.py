@@ -174,10 +174,12 @@ class MMADecoder:
     def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda", dtype=torch.float32,
                  ops: Optional[Ops] = None, prefix="decoder", shared_weights: Optional[DecoderWeights] = None):
         self.cfg = cfg
-        if cfg.simul_attn_type.endswith("_fixed_pre_decision") and cfg.fixed_pre_decision_type != "average":
-            raise NotImplementedError(
-                f"--fixed-pre-decision-type {cfg.fixed_pre_decision_type!r}: only 'average' pooling is built "
-                "(modules/fixed_pre_decision.py:31-52); refusing to decode with different pooling than the checkpoint's")
+        if cfg.simul_attn_type.endswith("_fixed_pre_decision") and cfg.fixed_pre_decision_type not in ("average", "last"):
+            raise NotImplementedError(f"--fixed-pre-decision-type {cfg.fixed_pre_decision_type!r} "
+                                      "(modules/fixed_pre_decision.py:31-52 knows 'average' and 'last')")
+        # the C ABI carries the pooling type in the sign of the ratio: negative = 'last' (include/simulst_hip.h)
+        self.ratio_arg = -cfg.pre_decision_ratio if (cfg.fixed_pre_decision_type == "last" and
+                                                     cfg.pre_decision_ratio > 1) else cfg.pre_decision_ratio
         self.device, self.dtype = torch.device(device), dtype
         self.ops = ops or Ops()
         self.w = shared_weights if shared_weights is not None else DecoderWeights(weights, cfg, self.device, dtype, prefix)
@@ -265,7 +267,7 @@ class MMADecoder:
             p = torch.empty(B * H, st.S_cap, device=self.device, dtype=torch.float32)
             q = None
             if cfg.attn_type == "waitk":
-                ops.step_p_choose(None, None, p, B=B, S_cap=st.S_cap, H=H, d=d, ratio=cfg.pre_decision_ratio,
+                ops.step_p_choose(None, None, p, B=B, S_cap=st.S_cap, H=H, d=d, ratio=self.ratio_arg,
                                   incremental=incremental, attn_type=_lib.ATTN_WAITK, key_len=st.enc_len,
                                   waitk_k=cfg.waitk_lagging, tgt_idx=st.n_prev, online=st.online,
                                   dtype=_lib.F32)
@@ -273,7 +275,7 @@ class MMADecoder:
             else:
                 qm = ops.linear(y, L["c_wq"], L["c_bq"])
                 ops.step_p_choose(qm, st.Kmono[l], p, B=B, S_cap=st.S_cap, H=H, d=d,
-                                  ratio=cfg.pre_decision_ratio, incremental=incremental,
+                                  ratio=self.ratio_arg, incremental=incremental,
                                   attn_type=self.attn_enum, key_len=st.enc_len, energy_bias=L["energy_bias"])
                 if self.separate_soft:
                     q = ops.linear(y, L["c_wq_soft"], L["c_bq_soft"])
@@ -432,7 +434,7 @@ class MMADecoder:
         split = self.head_split and self.fragment_major
         out_proj = self.w.out_proj_packed if self.fragment_major else self.w.out_proj
         return _lib.DecoderDesc(B, D, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st.cap, st.S_cap,
-                                _lib.F32 if dt_ == torch.float32 else _lib.BF16, self.attn_enum, cfg.pre_decision_ratio,
+                                _lib.F32 if dt_ == torch.float32 else _lib.BF16, self.attn_enum, self.ratio_arg,
                                 cfg.waitk_lagging, int(cfg.mass_preservation), int(st.online), cfg.padding_idx, cfg.eos,
                                 np_uniform, self.embed_scale, self.w.E.data_ptr(), out_proj.data_ptr(),
                                 self.w.pos.data_ptr(), self.w.ln_g.data_ptr(), self.w.ln_b.data_ptr(),

@@ -125,11 +125,12 @@ def test_local_registries_without_fairseq():
         m.cpu()
 
 
-def test_fixed_pre_decision_type_last_is_rejected_loudly():
+def test_unknown_fixed_pre_decision_type_is_rejected_loudly():
+    """'average' and 'last' are built (modules/fixed_pre_decision.py:31-52); anything else must not decode silently."""
     from simulst_amd.checkpoint import config_from_args
     from simulst_amd.decoder import MMADecoder
     cfg = config_from_args({"arch": "mma_model_s", "simul_attn_type": "hard_aligned_fixed_pre_decision",
-                            "fixed_pre_decision_ratio": 8, "fixed_pre_decision_type": "last"})
+                            "fixed_pre_decision_ratio": 8, "fixed_pre_decision_type": "median"})
     with pytest.raises(NotImplementedError, match="fixed-pre-decision-type"):
         MMADecoder(cfg, {}, device="cpu")
 

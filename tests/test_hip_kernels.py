@@ -782,3 +782,76 @@ def test_encoder_with_fused_ffn_equals_two_launch_path(ops):
     b = enc.forward(fb, L)["encoder_out_btd"].float().clone()
     torch.testing.assert_close(a, b, atol=6e-2, rtol=5e-2)
     assert float((a - b).abs().mean()) < 4e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --fixed-pre-decision-type last (modules/fixed_pre_decision.py:38-52): negative ratio in the C ABI
+@pytest.mark.parametrize("name", ["hard_aligned_fixed_pre_decision", "infinite_lookback_fixed_pre_decision",
+                                  "waitk_fixed_pre_decision"])
+@pytest.mark.parametrize("ratio", [2, 4])
+def test_g19_pre_decision_last_vs_golden(ops, name, ratio):
+    """One decode step of simulst_step_p_choose (incremental and training-mode pooling) and the growing-source traces of
+    the fused policy + cross-attention launch against the fixture recorded from the reference with
+    fixed_pre_decision_type = 'last': step probabilities to 1e-5, head_step / head_read exact."""
+    from simulst_amd import _lib
+    a, _ = load_golden("g19_predecision_last")
+    tag = f"{name}.r{ratio}"
+    w = split_weights(a, tag)
+    H, d, D, S_cap = 2, 16, 32, 24
+    base = name.replace("_fixed_pre_decision", "")
+    q, keys = a["q"], a["keys"]
+    lin = torch.nn.functional.linear
+
+    def head_major(t):                                       # [S, B, D] -> [B, H, S_cap, d]
+        out = torch.zeros(2, S_cap, D)
+        out[:, :t.size(0)] = t.transpose(0, 1)
+        return out.view(2, S_cap, H, d).permute(0, 2, 1, 3).contiguous()
+
+    km = head_major(lin(keys, w["k_proj.weight"], w["k_proj.bias"]))
+    for sl in (1, 2, 3, 4, 5, 7, 8, 9, 21):
+        kl = dev(torch.tensor([sl, sl], dtype=torch.int32))
+        p = torch.full((2 * H, S_cap), -1.0, device="cuda")
+        if base == "waitk":
+            ops.step_p_choose(None, None, p, B=2, S_cap=S_cap, H=H, d=d, ratio=-ratio, incremental=True,
+                              attn_type=_lib.ATTN_WAITK, key_len=kl, waitk_k=3,
+                              tgt_idx=dev(torch.zeros(2, dtype=torch.int32)), online=True, dtype=_lib.F32)
+        else:
+            qp = lin(q[0], w["q_proj.weight"], w["q_proj.bias"])
+            ops.step_p_choose(dev(qp), dev(km), p, B=2, S_cap=S_cap, H=H, d=d, ratio=-ratio, incremental=True,
+                              attn_type=_lib.ATTN_ENUM[base], key_len=kl)
+            close(p[:, :sl], a[f"{tag}.incr.{sl}"][:, 0], atol=1e-5, rtol=1e-4)
+            # training-mode pooling (no floor trim): query 0 of the 3-query fixture
+            qt = lin(keys[0], w["q_proj.weight"], w["q_proj.bias"])
+            pt = torch.full((2 * H, S_cap), -1.0, device="cuda")
+            ops.step_p_choose(dev(qt), dev(km), pt, B=2, S_cap=S_cap, H=H, d=d, ratio=-ratio, incremental=False,
+                              attn_type=_lib.ATTN_ENUM[base], key_len=kl)
+            close(pt[:, :sl], a[f"{tag}.train.{sl}"][:, 0], atol=1e-5, rtol=1e-4)
+        if base == "waitk":
+            close(p[:, :sl], a[f"{tag}.incr.{sl}"][:, 0], atol=0, rtol=0)
+        assert float(p[:, sl:].abs().max()) == 0.0
+    # ---- growing-source traces through the fused policy + cross-attention launch
+    soft = base != "hard_aligned"
+    ks_name = "k_proj_soft" if f"{'k_proj_soft'}.weight" in w and base == "infinite_lookback" else "k_proj"
+    Ksoft = head_major(lin(keys, w[ks_name + ".weight"], w[ks_name + ".bias"]))
+    Vc = head_major(lin(keys, w["v_proj.weight"], w["v_proj.bias"]))
+    for online in (True, False):
+        hs = torch.zeros(2 * H, dtype=torch.int64, device="cuda")
+        tgt = torch.zeros(2, dtype=torch.int32)
+        for step, sl in enumerate(a[f"{tag}.src_sizes"].tolist()):
+            pre = f"{tag}.on{int(online)}.{step}"
+            qs_in = a[pre + ".q"][0]
+            qm = lin(qs_in, w["q_proj.weight"], w["q_proj.bias"])
+            qsn = "q_proj_soft" if ks_name == "k_proj_soft" else "q_proj"
+            qsoft = lin(qs_in, w[qsn + ".weight"], w[qsn + ".bias"])
+            kl = dev(torch.tensor([sl, sl], dtype=torch.int32))
+            ctx, hr = ops.policy_cross_attention(dev(qm), dev(qsoft) if soft else None, dev(km), dev(Ksoft) if soft else None,
+                                                 dev(Vc), hs, H=H, ratio=-ratio, attn_type=_lib.ATTN_ENUM[base], key_len=kl,
+                                                 tgt_idx=dev(tgt), waitk_k=3, online=online, mass_preservation=True)
+            assert torch.equal(hs.cpu().reshape(-1), a[pre + ".head_step"].reshape(-1)), pre
+            assert torch.equal(hr.cpu().bool().reshape(-1), a[pre + ".head_read"].reshape(-1)), pre
+            attn_out = lin(ctx.float().cpu(), w["out_proj.weight"], w["out_proj.bias"])
+            close(attn_out, a[pre + ".out"][0], atol=2e-4, rtol=1e-3)
+            if base == "waitk":
+                read = bool(a[pre + ".head_read"].any())
+                if not (online and read):
+                    tgt += 1

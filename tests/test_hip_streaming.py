@@ -67,7 +67,11 @@ def test_streaming_batch_equals_single(ops):
 
 @pytest.mark.parametrize("attn,kw", [("waitk_fixed_pre_decision", dict(waitk_lagging=3)),
                                      ("hard_aligned_fixed_pre_decision", {}),
-                                     ("infinite_lookback_fixed_pre_decision", {})])
+                                     ("infinite_lookback_fixed_pre_decision", {}),
+                                     # --fixed-pre-decision-type last (modules/fixed_pre_decision.py:38-52), per-op step,
+                                     # device step loop and batched streaming all take the pooling type
+                                     ("hard_aligned_fixed_pre_decision", dict(fixed_pre_decision_type="last")),
+                                     ("infinite_lookback_fixed_pre_decision", dict(fixed_pre_decision_type="last"))])
 def test_agent_actions_tokens_al_identical_to_oracle(ops, attn, kw):
     """BASELINE config 1 shape at reduced depth: B=1 streaming through the agent schedule; READ/WRITE
     sequence, greedy tokens and per-token delays must be IDENTICAL to the CPU oracle => identical AL."""
@@ -94,6 +98,10 @@ def test_agent_actions_tokens_al_identical_to_oracle(ops, attn, kw):
         assert got["delays_ms"] == ref["delays_ms"]
         assert got["AL"] == ref["AL"]
         assert got["n_enc"] == ref["n_enc"]
+        if kw.get("fixed_pre_decision_type") == "last":      # the fused policy kernel inside the device-side step loop
+            from simulst_amd.agent import BatchedStreamingAgent
+            dev_run = BatchedStreamingAgent(model, steps_per_call=2).run_batch(fb.cuda().unsqueeze(0))[0]
+            assert all(dev_run[k] == ref[k] for k in ("actions", "tokens", "delays_ms")), (attn, T)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

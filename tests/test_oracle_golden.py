@@ -357,3 +357,39 @@ def test_cif_known_answer_survey_appendix_c():
     o = ocif.cif_function(h, al, beta=1.0, tail_thres=0.0)
     assert int(o["cif_lengths"][0]) == 3
     close(o["cif_out"][0][0, 2], torch.tensor([0, 0, 0, 1.0]), atol=1e-6)
+
+
+# ------------------------------------------------------------------ g19: --fixed-pre-decision-type last
+LAST_NAMES = ["hard_aligned_fixed_pre_decision", "infinite_lookback_fixed_pre_decision", "waitk_fixed_pre_decision"]
+
+
+def _cfg_last(name, ratio):
+    base = name.replace("_fixed_pre_decision", "")
+    return omo.AttnCfg(attn_type=base, num_heads=2, mass_preservation=True, eps=1e-6, waitk_lagging=3, chunk_size=None,
+                       pre_decision_ratio=ratio, pre_decision_type="last")
+
+
+@pytest.mark.parametrize("name", LAST_NAMES)
+@pytest.mark.parametrize("ratio", [2, 4])
+def test_g19_fixed_pre_decision_last(name, ratio):
+    """modules/fixed_pre_decision.py:38-52: the last frame of every window, the keys unpooled while src < ratio."""
+    a, _ = load_golden("g19_predecision_last")
+    tag = f"{name}.r{ratio}"
+    w = {"a." + k: v for k, v in split_weights(a, tag).items()}
+    cfg = _cfg_last(name, ratio)
+    for sl in (1, 2, 3, 4, 5, 7, 8, 9, 21):
+        if "waitk" not in name:
+            close(omo.p_choose(w, "a", cfg, a["keys"][:3], a["keys"][:sl], None, {}, False), a[f"{tag}.train.{sl}"])
+        close(omo.p_choose(w, "a", cfg, a["q"], a["keys"][:sl], None, {"online": True}, True), a[f"{tag}.incr.{sl}"])
+    for online in (True, False):
+        st = {"online": online}
+        for step, sl in enumerate(a[f"{tag}.src_sizes"].tolist()):
+            pre = f"{tag}.on{int(online)}.{step}"
+            out, ex = omo.attention_forward(w, "a", cfg, a[pre + ".q"], a["keys"][:sl], a["keys"][:sl], None, st)
+            assert torch.equal(st["head_step"], a[pre + ".head_step"]), pre
+            assert torch.equal(st["head_read"], a[pre + ".head_read"]), pre
+            assert torch.equal(ex["alpha"], a[pre + ".alpha"]), pre
+            close(ex["p_choose"], a[pre + ".p_choose"], atol=1e-5)
+            close(out, a[pre + ".out"], atol=1e-4)
+            if online and bool(st["head_read"].any()) and "tgt_len" in st:
+                st["tgt_len"] -= 1
