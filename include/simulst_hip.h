@@ -268,6 +268,24 @@ enum { SIMULST_LATENCY_AL = 0, SIMULST_LATENCY_AP = 1, SIMULST_LATENCY_DAL = 2 }
 int simulst_latency_metric(simulst_handle* h, const float* delays, const float* src_len, const float* tgt_len,
                            const uint8_t* target_padding_mask, float* out, int32_t B, int32_t T, int32_t metric);
 
+/* ---- gradients of the training-mode scans and latency reductions (the criteria back-propagate through
+ * them, criterion/mma_criterion.py:138-207 -> modules/monotonic_multihead_attention.py:301-352 ->
+ * utils/monotonic_attention.py:12-76).  All fp32; same shapes as the forward entry points.
+ * simulst_expected_alignment_backward: grad_p = d L / d p_choose given grad_alpha = d L / d alpha and the SAVED p / alpha of
+ *   simulst_expected_alignment (one wave per row, targets in reverse, two reverse wavefront scans per target; the clamps
+ *   pass the gradient inside their closed ranges like torch.clamp).  Padded source positions (>= key_len) get 0.
+ * simulst_expected_delays_backward: grad_alpha[r][j] = grad_out[r] * (j + 1).
+ * simulst_latency_metric_backward: grad_delays[b][i] = grad_out[b] * d metric / d delays[b][i]; the cut-off of
+ *   AverageLagging and the padding are constants of the row, DifferentiableAverageLagging routes through its running
+ *   maximum. */
+int simulst_expected_alignment_backward(simulst_handle* h, const float* p, const float* alpha, const float* grad_alpha,
+                                        float* grad_p, const int32_t* key_len, int32_t BH, int32_t U, int32_t S,
+                                        float eps);
+int simulst_expected_delays_backward(simulst_handle* h, const float* grad_out, float* grad_alpha, int64_t rows, int32_t S);
+int simulst_latency_metric_backward(simulst_handle* h, const float* delays, const float* src_len, const float* tgt_len,
+                                    const uint8_t* target_padding_mask, const float* grad_out, float* grad_delays,
+                                    int32_t B, int32_t T, int32_t metric);
+
 /* Expected soft attention beta from alpha and soft energy; chunk_size <= 0 = infinite lookback.
  * utils/monotonic_attention.py:79-152 (+ moving_sum utils/functions.py:69-125). */
 int simulst_expected_soft_attention(simulst_handle* h, const float* alpha, const float* energy,

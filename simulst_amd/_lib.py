@@ -98,6 +98,9 @@ SIGNATURES = {
     "simulst_mass_preservation": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_expected_delays": [_vp, _vp, _vp, _i64, _i32],
     "simulst_latency_metric": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
+    "simulst_expected_alignment_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32],
+    "simulst_expected_delays_backward": [_vp, _vp, _vp, _i64, _i32],
+    "simulst_latency_metric_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_expected_soft_attention": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32],
     "simulst_step_p_choose": [_vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                               _vp, _i32, _i32],

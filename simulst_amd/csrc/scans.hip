@@ -56,6 +56,10 @@ __global__ __launch_bounds__(256) void step_search_kernel(const float* __restric
 
 // ---- expected alignment (utils/monotonic_attention.py:12-76) ----------------------------
 // one wave per row bh; sequential over targets, two wavefront scans over the source per target.
+// The recurrence is a chain of (target, 64-wide chunk) steps whose only global input, p, does not depend on it: the p
+// values of the next EA_PF steps are requested ahead (register ring), so a step costs its two scans, not an HBM round
+// trip (rocprofv3, (1536, 110, 32): 116 us with the load inside the step).
+constexpr int EA_PF = 4;
 __global__ __launch_bounds__(256) void expected_alignment_kernel(const float* __restrict__ p,
                                                                  float* __restrict__ alpha,
                                                                  const int* __restrict__ key_len, int BH, int U,
@@ -68,14 +72,34 @@ __global__ __launch_bounds__(256) void expected_alignment_kernel(const float* __
   const int len = key_len ? key_len[r] : S;
   for (int s = lane; s < S; s += 64) prev[s] = (s == 0) ? 1.f : 0.f;
   const float lead = logf(1.0f + eps);           // the prepended 1 also passes through log(. + eps)
-  for (int i = 0; i < U; ++i) {
-    const float* pi = p + ((long)r * U + i) * S;
-    float* ai = alpha + ((long)r * U + i) * S;
-    float carry_log = lead, carry_sum = 0.f;
-    for (int s0 = 0; s0 < S; s0 += 64) {
-      const int s = s0 + lane;
+  const int n_chunks = (S + 63) / 64;
+  const long total = (long)U * n_chunks;
+  const float* prow = p + (long)r * U * S;
+  float* arow = alpha + (long)r * U * S;
+  // step t = (target t / n_chunks, chunk t % n_chunks); the prefetch walks its own (target, chunk) counters
+  int li = 0, lk = 0;
+  auto load_next = [&]() -> float {
+    float v = 0.f;
+    if (li < U) {
+      const int s = lk * 64 + lane;
+      if (s < S && s < len) v = prow[(long)li * S + s];
+      if (++lk == n_chunks) { lk = 0; ++li; }
+    }
+    return v;
+  };
+  float q[EA_PF];
+#pragma unroll
+  for (int j = 0; j < EA_PF; ++j) q[j] = load_next();
+  int i = 0, k = 0;
+  float carry_log = lead, carry_sum = 0.f;
+  for (long t0 = 0; t0 < total; t0 += EA_PF) {
+#pragma unroll
+    for (int j = 0; j < EA_PF; ++j) {
+      if (t0 + j >= total) break;
+      const float pv = q[j];
+      q[j] = load_next();
+      const int s = k * 64 + lane;
       const bool in = s < S;
-      float pv = (in && s < len) ? pi[s] : 0.f;
       float lg = in ? logf(1.0f - pv + eps) : 0.f;
       float incl = wave_scan_incl(lg, lane);
       float cp = expf(carry_log + incl - lg);    // exclusive cumprod of (1 - p)
@@ -87,11 +111,106 @@ __global__ __launch_bounds__(256) void expected_alignment_kernel(const float* __
       carry_sum += __shfl(tin, 63, 64);
       a = fminf(fmaxf(a, 0.f), 1.f);
       __builtin_amdgcn_wave_barrier();
-      if (in) { ai[s] = a; }
-      // prev[s] for this chunk is consumed; overwrite for the next target row
-      if (in) prev[s] = a;
+      if (in) {
+        arow[(long)i * S + s] = a;
+        prev[s] = a;                             // this chunk of alpha_{i-1} is consumed: it becomes alpha_i
+      }
+      if (++k == n_chunks) {                     // next target: the scans restart
+        k = 0;
+        ++i;
+        carry_log = lead;
+        carry_sum = 0.f;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
+// ---- expected alignment, backward (training-mode forward of utils/monotonic_attention.py:12-76) ---------------------
+// Given g = dL/dalpha [BH][U][S], the saved p and alpha: dL/dp.  One wave per row; targets are walked in REVERSE with
+// the gradient that target i + 1 sends to alpha_i carried in LDS.  Per target (c = exclusive cumprod of (1 - p + eps)
+// incl. the prepended one, cc = clamp(c, eps, 1), r = alpha_{i-1} / cc, R = cumsum(r), u = p c R, alpha_i = clamp(u, 0, 1)):
+//   gu = g 1[0 <= u <= 1];  gp = gu c R;  gc = gu p R;  gR = gu p c;  gr = reverse cumsum(gR)
+//   d alpha_{i-1} = gr / cc;  gc -= gr alpha_{i-1} / cc^2 where eps <= c <= 1
+//   c_j = exp(log(1 + eps) + sum_{k<j} log(1 - p_k + eps))  =>  gp_k -= (sum_{j>k} gc_j c_j) / (1 - p_k + eps)
+// i.e. a forward pass over the source chunks that rebuilds c and R (the two scans of the forward kernel) and a reverse
+// pass with two reverse wavefront scans.  Same fp32 operation order as autograd through the reference's formulation up
+// to the association of the scans.
+__device__ __forceinline__ float wave_rev_incl(float v, int lane, float& total) {
+  // a true suffix scan: total - prefix would cancel catastrophically where the suffix is many orders of magnitude below
+  // the total, and the result is divided by clamp(c, eps, 1) afterwards
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_down(v, o, 64);
+    if (lane + o < 64) v += t;
+  }
+  total = __shfl(v, 0, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void expected_alignment_bwd_kernel(const float* __restrict__ p,
+                                                                    const float* __restrict__ alpha,
+                                                                    const float* __restrict__ g_alpha,
+                                                                    float* __restrict__ g_p,
+                                                                    const int* __restrict__ key_len, int U, int S,
+                                                                    float eps) {
+  extern __shared__ float sm[];
+  float* carry = sm;                 // dL/d alpha_i sent by target i + 1
+  float* cbuf = sm + S;              // c of the current target
+  float* rbuf = sm + 2 * S;          // R of the current target
+  const int lane = threadIdx.x, r = blockIdx.x;
+  const int len = key_len ? key_len[r] : S;
+  for (int s = lane; s < S; s += 64) carry[s] = 0.f;
+  const float lead = logf(1.0f + eps);
+  const int n_chunks = (S + 63) / 64;
+  for (int i = U - 1; i >= 0; --i) {
+    const float* pi = p + ((long)r * U + i) * S;
+    const float* ap = i > 0 ? alpha + ((long)r * U + i - 1) * S : nullptr;
+    const float* gi = g_alpha + ((long)r * U + i) * S;
+    float* go = g_p + ((long)r * U + i) * S;
+    __builtin_amdgcn_wave_barrier();
+    float carry_log = lead, carry_sum = 0.f;
+    for (int k = 0; k < n_chunks; ++k) {                     // rebuild c and R
+      const int s = k * 64 + lane;
+      const bool in = s < S;
+      const float pv = (in && s < len) ? pi[s] : 0.f;
+      const float lg = in ? logf(1.0f - pv + eps) : 0.f;
+      const float incl = wave_scan_incl(lg, lane);
+      const float c = expf(carry_log + incl - lg);
+      carry_log += __shfl(incl, 63, 64);
+      const float cc = fminf(fmaxf(c, eps), 1.0f);
+      const float a_prev = in ? (ap ? ap[s] : (s == 0 ? 1.f : 0.f)) : 0.f;
+      const float tin = wave_scan_incl(in ? a_prev / cc : 0.f, lane);
+      if (in) { cbuf[s] = c; rbuf[s] = carry_sum + tin; }
+      carry_sum += __shfl(tin, 63, 64);
     }
     __builtin_amdgcn_wave_barrier();
+    float carry_gr = 0.f, carry_gs = 0.f;
+    for (int k = n_chunks - 1; k >= 0; --k) {                // reverse pass
+      const int s = k * 64 + lane;
+      const bool in = s < S;
+      const float pv = (in && s < len) ? pi[s] : 0.f;
+      const float c = in ? cbuf[s] : 1.f, R = in ? rbuf[s] : 0.f;
+      const float cc = fminf(fmaxf(c, eps), 1.0f);
+      const float a_prev = in ? (ap ? ap[s] : (s == 0 ? 1.f : 0.f)) : 0.f;
+      const float u = pv * c * R;
+      const float gu = (in && u >= 0.f && u <= 1.f) ? gi[s] + carry[s] : 0.f;
+      float gp = gu * c * R;
+      float gc = gu * pv * R;
+      float tot;
+      const float gr = carry_gr + wave_rev_incl(gu * pv * c, lane, tot);
+      carry_gr += tot;
+      if (c >= eps && c <= 1.0f) gc -= gr * a_prev / (cc * cc);
+      const float gs = in ? gc * c : 0.f;
+      const float rgs = wave_rev_incl(gs, lane, tot);
+      const float gl = carry_gs + rgs - gs;                  // exclusive reverse cumsum
+      carry_gs += tot;
+      gp -= gl / (1.0f - pv + eps);
+      if (in) {
+        go[s] = s < len ? gp : 0.f;
+        carry[s] = gr / cc;                                  // becomes dL/d alpha_{i-1}
+      }
+    }
   }
 }
 
@@ -429,6 +548,20 @@ extern "C" int simulst_expected_alignment(simulst_handle* h, const float* p, flo
   hipLaunchKernelGGL(expected_alignment_kernel, dim3((BH + 3) / 4), dim3(256), 4 * S * sizeof(float), h->stream, p,
                      alpha, key_len, BH, U, S, eps);
   return sl_launch_status(h, "simulst_expected_alignment");
+}
+
+extern "C" int simulst_expected_alignment_backward(simulst_handle* h, const float* p, const float* alpha,
+                                                   const float* grad_alpha, float* grad_p, const int32_t* key_len,
+                                                   int32_t BH, int32_t U, int32_t S, float eps) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, p); SL_CHECK_NULL(h, alpha); SL_CHECK_NULL(h, grad_alpha); SL_CHECK_NULL(h, grad_p);
+  SL_REQUIRE(h, S > 0 && U >= 0 && BH >= 0 && (size_t)3 * S * sizeof(float) <= 48 * 1024, SIMULST_E_SHAPE,
+             "simulst_expected_alignment_backward: shape (S <= 4096)");
+  if (BH == 0 || U == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_SCAN);
+  hipLaunchKernelGGL(expected_alignment_bwd_kernel, dim3(BH), dim3(64), 3 * S * sizeof(float), h->stream, p, alpha,
+                     grad_alpha, grad_p, key_len, U, S, eps);
+  return sl_launch_status(h, "simulst_expected_alignment_backward");
 }
 
 extern "C" int simulst_mass_preservation(simulst_handle* h, float* alpha, const int32_t* key_len, int32_t BH,

@@ -8,9 +8,12 @@ Mirrors, with the reference's argument meaning:
 The reductions over the expected alignments (`simulst_expected_delays`), the latency metrics
 (`simulst_latency_metric`: AL / AP / DAL, SimulEval's tensor metrics) and the CTC Viterbi alignment behind the "align"
 quantity targets (`simulst_ctc_best_alignment`) are HIP kernels behind the C ABI; what is left here is the criterion's
-scalar bookkeeping on a handful of [B]-sized tensors.  Forward only: these are the values the reference logs as
-`latency`, `delays_var`, `latency_loss`, `quantity`, `q_acc` (validation / evaluation); there is no autograd through
-the kernels.  No CPU fallback: CPU tensors raise.
+scalar bookkeeping on a handful of [B]-sized tensors.  The values are what the reference logs as `latency`,
+`delays_var`, `latency_loss`, `quantity`, `q_acc`.  The MMA latency chain is differentiable end to end on the device:
+`expected_alignment` (simulst_expected_alignment / _backward), `expected_delays` and `latency_metric` are
+torch.autograd Functions whose backward passes are HIP kernels too, so `mma_latency_loss(...)[0].backward()` delivers
+d loss / d p_choose like autograd through the reference's formulation does (gradient-checked against the oracle in
+tests/test_losses.py).  No CPU fallback: CPU tensors raise.
 """
 from typing import List, Optional
 
@@ -37,38 +40,107 @@ def _need_cuda(*ts):
             raise RuntimeError("simulst_amd.losses: tensors must live on the GPU (no CPU fallback)")
 
 
+class _ExpectedAlignment(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, key_len, eps):
+        ops = _get_ops()
+        ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
+        p = p.float().contiguous()
+        alpha = ops.expected_alignment(p, key_len, eps)
+        ctx.save_for_backward(p, alpha, key_len if key_len is not None else torch.empty(0))
+        ctx.eps = eps
+        return alpha
+
+    @staticmethod
+    def backward(ctx, g):
+        p, alpha, key_len = ctx.saved_tensors
+        ops = _get_ops()
+        ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
+        g = g.float().contiguous()
+        gp = torch.empty_like(p)
+        BH, U, S = p.shape
+        ops.h.check(ops.lib.simulst_expected_alignment_backward(ops.h.ptr, _p(p), _p(alpha), _p(g), _p(gp),
+                                                                _p(key_len if key_len.numel() else None), BH, U, S,
+                                                                float(ctx.eps)), "simulst_expected_alignment_backward")
+        return gp, None, None
+
+
+def expected_alignment(p_choose: torch.Tensor, key_len: Optional[torch.Tensor] = None, eps: float = 1e-6):
+    """expected_alignment_from_p_choose (utils/monotonic_attention.py:12-76) on p_choose [B*H, U, S] with autograd:
+    key_len [B*H] int32 = valid source length per row (the reference's padding_mask, right padding)."""
+    _need_cuda(p_choose, key_len)
+    return _ExpectedAlignment.apply(p_choose, key_len, eps)
+
+
+class _ExpectedDelays(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alpha):
+        ops = _get_ops()
+        a = alpha.float().contiguous()
+        S = a.size(-1)
+        out = torch.empty(a.shape[:-1], device=a.device, dtype=torch.float32)
+        ctx.shape = a.shape
+        if a.numel():
+            ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
+            ops.h.check(ops.lib.simulst_expected_delays(ops.h.ptr, _p(a), _p(out), a.numel() // S, S),
+                        "simulst_expected_delays")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ops = _get_ops()
+        g = g.float().contiguous()
+        ga = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        if ga.numel():
+            ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
+            ops.h.check(ops.lib.simulst_expected_delays_backward(ops.h.ptr, _p(g), _p(ga), g.numel(), ctx.shape[-1]),
+                        "simulst_expected_delays_backward")
+        return ga
+
+
 def expected_delays(alpha: torch.Tensor, ops: Optional[Ops] = None) -> torch.Tensor:
     """alpha [..., S] (fp32, expected alignment) -> [...]: sum_j (j + 1) * alpha[..., j]  (mma_criterion.py:147-156)"""
     _need_cuda(alpha)
-    ops = ops or _get_ops()
-    a = alpha.float().contiguous()
-    S = a.size(-1)
-    out = torch.empty(a.shape[:-1], device=a.device, dtype=torch.float32)
-    if a.numel() == 0:
+    return _ExpectedDelays.apply(alpha)
+
+
+class _LatencyMetric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, delays, src, tgt, pm, metric):
+        ops = _get_ops()
+        d = delays.float().contiguous()
+        B, T = d.shape
+        out = torch.empty(B, device=d.device, dtype=torch.float32)
+        if B:
+            ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
+            ops.h.check(ops.lib.simulst_latency_metric(ops.h.ptr, _p(d), _p(src), _p(tgt), _p(pm), _p(out), B, T, metric),
+                        "simulst_latency_metric")
+        ctx.save_for_backward(d, src, tgt, pm if pm is not None else torch.empty(0))
+        ctx.metric = metric
         return out
-    ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
-    ops.h.check(ops.lib.simulst_expected_delays(ops.h.ptr, _p(a), _p(out), a.numel() // S, S), "simulst_expected_delays")
-    return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d, src, tgt, pm = ctx.saved_tensors
+        ops = _get_ops()
+        g = g.float().contiguous()
+        gd = torch.zeros_like(d)
+        B, T = d.shape
+        if B:
+            ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
+            ops.h.check(ops.lib.simulst_latency_metric_backward(ops.h.ptr, _p(d), _p(src), _p(tgt),
+                                                                _p(pm if pm.numel() else None), _p(g), _p(gd), B, T,
+                                                                ctx.metric), "simulst_latency_metric_backward")
+        return gd, None, None, None, None
 
 
 def latency_metric(name: str, delays, src_lens, tgt_lens, target_padding_mask=None, ops: Optional[Ops] = None):
-    """SimulEval's tensor latency metrics on delays [B, T] (source steps): returns [B] fp32."""
+    """SimulEval's tensor latency metrics on delays [B, T] (source steps): returns [B] fp32 (differentiable in delays)."""
     _need_cuda(delays, src_lens, tgt_lens, target_padding_mask)
     if name not in _METRIC:
         raise KeyError(f"unknown latency metric {name!r} (have {sorted(_METRIC)})")
-    ops = ops or _get_ops()
-    d = delays.float().contiguous()
-    B, T = d.shape
-    src = src_lens.float().contiguous()
-    tgt = tgt_lens.float().contiguous()
     pm = None if target_padding_mask is None else target_padding_mask.to(torch.uint8).contiguous()
-    out = torch.empty(B, device=d.device, dtype=torch.float32)
-    if B == 0:
-        return out
-    ops.h.set_stream(torch.cuda.current_stream().cuda_stream)
-    ops.h.check(ops.lib.simulst_latency_metric(ops.h.ptr, _p(d), _p(src), _p(tgt), _p(pm), _p(out), B, T, _METRIC[name]),
-                "simulst_latency_metric")
-    return out
+    return _LatencyMetric.apply(delays, src_lens.float().contiguous(), tgt_lens.float().contiguous(), pm, _METRIC[name])
 
 
 def mma_latency_loss(alpha_list: List[torch.Tensor], target_padding_mask, encoder_padding_mask, src_lengths, *,

@@ -151,3 +151,103 @@ def test_hip_train_mode_chain_p_choose_to_latency():
     dal = hl.latency_metric("differentiable_average_lagging", d, src.cuda(), tgt.cuda())
     torch.testing.assert_close(dal.cpu(), ol.differentiable_average_lagging(ol.expected_delays(alpha_ref), src, tgt),
                                rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gradients: HIP backward kernels against torch autograd through the oracle's (reference-shaped) formulation
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,pad", [((6, 7, 33), False), ((5, 4, 150), True), ((3, 12, 64), True), ((2, 3, 1), False)])
+def test_expected_alignment_backward_vs_autograd(shape, pad):
+    """d L / d p_choose through expected_alignment_from_p_choose (utils/monotonic_attention.py:12-76): the oracle keeps
+    the reference's python loop over targets and torch's autograd differentiates it; the HIP kernel walks the targets in
+    reverse.  Random upstream gradient, p spread over (0, 1) incl. values that saturate the clamps."""
+    from oracle import monotonic as omo
+    from simulst_amd import losses as sl
+    BH, U, S = shape
+    g_ = torch.Generator().manual_seed(BH * 100 + S)
+    p0 = torch.sigmoid(torch.randn(BH, U, S, generator=g_) * 2.5)
+    p0[0, :, : min(3, S)] = 0.0                        # exact zeros: c = (1 + eps)^j sits above the clamp's upper end
+    if S > 4:
+        p0[1 % BH, 0, 4] = 0.97                        # (an exact 1.0 puts c ON the clamp's lower end eps, where the
+                                                       #  reference's own gradient jumps with the rounding of exp())
+    lens = torch.randint(max(1, S // 2), S + 1, (BH,), generator=g_) if pad else torch.full((BH,), S)
+    mask = torch.arange(S).view(1, -1) >= lens.view(-1, 1) if pad else None
+    up = torch.randn(BH, U, S, generator=g_)
+    pr = p0.clone().requires_grad_(True)
+    ref = omo.expected_alignment_from_p_choose(pr, mask, 1e-6)
+    (ref * up).sum().backward()
+    pd = p0.cuda().requires_grad_(True)
+    got = sl.expected_alignment(pd, lens.to(torch.int32).cuda() if pad else None, 1e-6)
+    torch.testing.assert_close(got.detach().cpu(), ref.detach(), atol=1e-5, rtol=1e-4)
+    (got * up.cuda()).sum().backward()
+    gref, ggot = pr.grad, pd.grad.cpu()
+    if pad:
+        assert float(ggot[mask.unsqueeze(1).expand_as(ggot)].abs().max()) == 0.0
+        gref = gref.masked_fill(mask.unsqueeze(1), 0.0)
+    scale = float(gref.abs().max()) + 1e-6
+    assert float((ggot - gref).abs().max()) / scale < 2e-4, float((ggot - gref).abs().max()) / scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("avg_type,gather", MMA_CASES)
+def test_mma_latency_loss_gradient_vs_oracle_autograd(avg_type, gather):
+    """MMACriterion.compute_latency_loss (criterion/mma_criterion.py:138-207) back to p_choose: expected alignment ->
+    expected delays -> latency metric -> gather over heads / variance, all device-side with HIP backward kernels, against
+    autograd through the oracle on the CPU."""
+    from oracle import monotonic as omo
+    from simulst_amd import losses as sl
+    g_ = torch.Generator().manual_seed(17)
+    B, H, L, T, S = 3, 2, 2, 6, 19
+    p_layers = [torch.sigmoid(torch.randn(B, H, T, S, generator=g_) * 2) for _ in range(L)]
+    tgt_len = torch.tensor([6, 4, 5])
+    enc_len = torch.tensor([19, 15, 11])
+    tpad = torch.arange(T).view(1, -1) >= tgt_len.view(-1, 1)
+    epad = torch.arange(S).view(1, -1) >= enc_len.view(-1, 1)
+    src_lengths = enc_len * 4
+    kw = dict(latency_avg_type=avg_type, latency_gather_method=gather, latency_avg_weight=0.7, latency_var_weight=0.3,
+              ms_per_frame_shift=10)
+    # oracle, CPU autograd
+    pr = [p.clone().requires_grad_(True) for p in p_layers]
+    al_ref = [omo.mass_preservation(omo.expected_alignment_from_p_choose(p.view(B * H, T, S), epad.repeat_interleave(H, 0), 1e-6),
+                                    epad.repeat_interleave(H, 0)).view(B, H, T, S) for p in pr]
+    loss_ref = ol.mma_latency_loss(al_ref, tpad, epad, src_lengths, **kw)[0]
+    loss_ref.backward()
+    # device
+    pdv = [p.cuda().requires_grad_(True) for p in p_layers]
+    kl = enc_len.repeat_interleave(H).to(torch.int32).cuda()
+    al = []
+    for p in pdv:
+        a = sl.expected_alignment(p.view(B * H, T, S), kl, 1e-6)
+        # mass preservation (utils/monotonic_attention.py:155-197) as differentiable torch ops on the device: the residual
+        # 1 - clamp(sum) goes to the last valid source position
+        resid = 1 - a.sum(-1).clamp(0, 1)
+        idx = (kl.long() - 1).view(-1, 1, 1).expand(-1, T, 1)
+        a = a.scatter_add(2, idx, resid.unsqueeze(-1))
+        al.append(a.view(B, H, T, S))
+    loss = sl.mma_latency_loss(al, tpad.cuda(), epad.cuda(), src_lengths.cuda(), **kw)[0]
+    assert abs(float(loss) - float(loss_ref)) <= 1e-4 * max(1.0, abs(float(loss_ref)))
+    loss.backward()
+    for a, b in zip(pdv, pr):
+        gref = b.grad.masked_fill(epad.view(B, 1, 1, S), 0.0)
+        scale = float(gref.abs().max()) + 1e-6
+        assert float((a.grad.cpu() - gref).abs().max()) / scale < 5e-4
+
+
+@pytest.mark.gpu
+def test_latency_metric_backward_each_metric():
+    from simulst_amd import losses as sl
+    g_ = torch.Generator().manual_seed(3)
+    B, T = 5, 9
+    d0 = torch.cumsum(torch.rand(B, T, generator=g_) * 3, 1)
+    src = torch.tensor([20.0, 9.0, 14.0, 30.0, 12.0])
+    tgt = torch.tensor([9.0, 7.0, 9.0, 5.0, 8.0])
+    pm = torch.arange(T).view(1, -1) >= tgt.view(-1, 1)
+    up = torch.randn(B, generator=g_)
+    for name, fn in ol.LATENCY_METRICS.items():
+        dr = d0.clone().requires_grad_(True)
+        (fn(dr, src, tgt, pm) * up).sum().backward()
+        dd = d0.cuda().requires_grad_(True)
+        out = sl.latency_metric(name, dd, src.cuda(), tgt.cuda(), pm.cuda())
+        torch.testing.assert_close(out.detach().cpu(), fn(d0, src, tgt, pm), atol=1e-5, rtol=1e-5)
+        (out * up.cuda()).sum().backward()
+        torch.testing.assert_close(dd.grad.cpu(), dr.grad, atol=1e-6, rtol=1e-5)
