@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 # Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 PMC_COUNTERS_FILE = "r01_n_counters.json"      # per kernel: HBM GB/s + MFMA utilisation from the same passes
+ENCODER_TRAFFIC_FILE = "r02_encoder_traffic.json"   # tools/encoder_traffic.py: PMC passes of one encoder pass
 PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py
 
 B_PER_GPU, T_FRAMES, N_STEPS_DECODE, WAITK = 64, 1000, 110, 5
@@ -196,7 +197,9 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name):
     elif name == "decoder_self_attention":
         byts = Ld * Bs * sum((2 * (u + 1) * D + 4 * D) for u in range(U)) * esz
     elif name == "layernorm":
-        byts = (cfg.encoder_layers * 2 * Bs * dims["rows_x"] * 2 * D) * esz
+        # one pre-attention LayerNorm per layer (reads X, writes Z with the summary rows) + the final one; the pre-FFN
+        # LayerNorm lives in the fused feed-forward launch
+        byts = (cfg.encoder_layers * Bs * (dims["rows_x"] + dims["rows_z"]) * D + 2 * Bs * dims["rows_x"] * D) * esz
     else:
         return None
     if byts <= 0:
@@ -441,6 +444,17 @@ def main(argv=None):
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
             rec_rows = pmc.get("rows_per_sequence", 1536)
             for e in [roofline] + ([roofline["other_bound_class"]] if other else []):
+                if e["kernel"] == "linear" and args.dtype == "bf16":
+                    # the encoder contractions changed in round 2 (fused feed-forward block): their HBM bytes come from the
+                    # FETCH_SIZE / WRITE_SIZE passes of one encoder pass (tools/encoder_traffic.py)
+                    enc = json.load(open(os.path.join(ROOT, "profiles", ENCODER_TRAFFIC_FILE)))
+                    gemm = sum(v["hbm_bytes_per_pass"] for k, v in enc["per_kernel"].items()
+                               if k.startswith(("ffn_fused_kernel", "panel_kernel", "linear_kernel")))
+                    e["traffic"] = round(gemm / enc["utterances"] * Bs / e["launches_per_sequence"])
+                    e["traffic_source"] = (f"profiles/{ENCODER_TRAFFIC_FILE}: FETCH_SIZE / WRITE_SIZE passes of one encoder pass over "
+                                           f"{enc['utterances']} utterances (encoder total {enc['encoder_hbm_MB_per_utterance']} MB per "
+                                           f"utterance), contraction kernels only, scaled to {Bs} rows")
+                    continue
                 if e["kernel"] in pmc and args.dtype == "bf16":
                     e["traffic"] = round(pmc[e["kernel"]]["traffic_bytes_per_launch"] * Bs / rec_rows)
                     e["traffic_source"] = (f"profiles/{PMC_TRAFFIC_FILE}: recorded at {rec_rows} rows per sequence, bf16, "
