@@ -152,6 +152,28 @@ __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
   return v;
 }
 
+// The same scan on the DPP data path (row shifts inside 16-lane rows, then the two row broadcasts of gfx9): each step is
+// a VALU instruction with a DPP operand instead of a ds_bpermute round trip through the LDS crossbar, which is what a
+// chain of DEPENDENT scans (the expected-alignment recurrence: two per target, 110 targets) waits for.  Association
+// differs from wave_scan_incl (rows first, then row totals), so it is used where results are compared with a
+// tolerance, not where an integer decision hangs on the last bit (CIF fire indices keep the shuffle scan).
+__device__ __forceinline__ float wave_scan_incl_dpp(float v) {
+  // row_shr:n = 0x110 + n with bound_ctrl (zeros shifted in); row_bcast:15 = 0x142 (rows 1, 3), row_bcast:31 = 0x143 (rows 2, 3)
+#define SL_DPP_ADD(ctrl, row_mask, bound)                                                                              \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, bound))
+  SL_DPP_ADD(0x111, 0xf, true);
+  SL_DPP_ADD(0x112, 0xf, true);
+  SL_DPP_ADD(0x114, 0xf, true);
+  SL_DPP_ADD(0x118, 0xf, true);
+  SL_DPP_ADD(0x142, 0xa, false);
+  SL_DPP_ADD(0x143, 0xc, false);
+#undef SL_DPP_ADD
+  return v;
+}
+__device__ __forceinline__ float wave_last(float v) {        // lane 63's value in every lane (scalar broadcast)
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // GELU for bf16 outputs, two elements per call so that every multiply-add issues on the packed fp32 pipe
 // (v_pk_fma_f32): x*Phi(x) = h + |h| - |h| * erfc(|x|/sqrt2), h = x/2, with erfc(z) = (1 + a1 z + ... + a6 z^6)^-16

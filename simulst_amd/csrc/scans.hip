@@ -101,14 +101,14 @@ __global__ __launch_bounds__(256) void expected_alignment_kernel(const float* __
       const int s = k * 64 + lane;
       const bool in = s < S;
       float lg = in ? logf(1.0f - pv + eps) : 0.f;
-      float incl = wave_scan_incl(lg, lane);
+      float incl = wave_scan_incl_dpp(lg);
       float cp = expf(carry_log + incl - lg);    // exclusive cumprod of (1 - p)
-      carry_log += __shfl(incl, 63, 64);
+      carry_log += wave_last(incl);
       float cpc = fminf(fmaxf(cp, eps), 1.0f);
       float term = in ? prev[s] / cpc : 0.f;
-      float tin = wave_scan_incl(term, lane);
+      float tin = wave_scan_incl_dpp(term);
       float a = pv * cp * (carry_sum + tin);
-      carry_sum += __shfl(tin, 63, 64);
+      carry_sum += wave_last(tin);
       a = fminf(fmaxf(a, 0.f), 1.f);
       __builtin_amdgcn_wave_barrier();
       if (in) {
