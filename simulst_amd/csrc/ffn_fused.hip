@@ -29,14 +29,23 @@
 
 namespace {
 
-constexpr int FF_ROWS = 256;          // rows per workgroup (8 waves x 32)
+// Two geometries of the same kernel: WAVES = 8 (512 threads, 256 rows, 64 hidden units per chunk, one workgroup per CU)
+// and WAVES = 4 (256 threads, 128 rows, 32 hidden units per chunk, 75 KB of LDS: TWO workgroups per CU, which drift out
+// of phase, so that one's GELU arithmetic runs beside the other's MFMAs; each streams the weights for half as many rows).
 constexpr int FF_D = 256;             // model width (K of fc1, N of fc2)
-constexpr int FF_CH = 64;             // hidden units per LDS chunk
-constexpr int FF_W1_BYTES = FF_CH * FF_D * 2;      // 32 KB
-constexpr int FF_CHUNK_BYTES = 2 * FF_W1_BYTES;    // W1 tile rows + W2 tile columns of a chunk
+constexpr bool FF_DEFAULT_FOUR_WAVES = true;
+template <int WAVES> struct FFG {
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr int ROWS = 32 * WAVES;            // rows per workgroup
+  static constexpr int TILES = WAVES / 4;            // 32-unit tiles per LDS chunk
+  static constexpr int CH = 32 * TILES;              // hidden units per LDS chunk
+  static constexpr int W1_BYTES = CH * FF_D * 2;     // W1 rows of a chunk (W2 columns: the same size)
+  static constexpr int CHUNK_BYTES = 2 * W1_BYTES;
+  static constexpr int PIECE = THREADS * 16;         // bytes one LDS-DMA instruction of the whole workgroup moves
+  static constexpr int MAX_F = WAVES == 8 ? 4096 : 2048;   // fc1 bias lives in LDS
+  static constexpr int LDS = 2 * CHUNK_BYTES + 3072 + MAX_F * 4;
+};
 constexpr int FF_PF = 4;               // weight fragments requested ahead of the MFMA that consumes them
-constexpr int FF_MAX_F = 4096;        // hidden units whose fc1 bias fits the LDS budget
-constexpr int FF_LDS = 2 * FF_CHUNK_BYTES + 3072 + FF_MAX_F * 4;  // double buffer + gamma / beta / b2 (3 x 256 fp32) + b1
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -47,44 +56,47 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
          ((unsigned int)(*reinterpret_cast<const unsigned short*>(&h)) << 16);
 }
 
-// one chunk (64 KB = W1 part then W2 part, each already in fragment order) global -> LDS: 8 x 16 B per thread,
+// one chunk (W1 part then W2 part, each already in fragment order) global -> LDS: 4 + 4 x 16 B per thread,
 // LDS destination of a wave instruction = wave-uniform base + lane * 16
+template <int WAVES>
 __device__ __forceinline__ void stage_chunk(const bf16* __restrict__ w1p, const bf16* __restrict__ w2p, int chunk,
                                             char* lds, unsigned voff, int wave) {
+  using G = FFG<WAVES>;
   // every address is (wave-uniform base) + (one 32-bit lane offset): scalar bases, ONE address VGPR for all 8 pieces
-  const char* g1 = reinterpret_cast<const char*>(w1p) + (long)chunk * FF_W1_BYTES;
-  const char* g2 = reinterpret_cast<const char*>(w2p) + (long)chunk * FF_W1_BYTES;
+  const char* g1 = reinterpret_cast<const char*>(w1p) + (long)chunk * G::W1_BYTES;
+  const char* g2 = reinterpret_cast<const char*>(w2p) + (long)chunk * G::W1_BYTES;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    __builtin_amdgcn_global_load_lds((gbl_void*)(g1 + (unsigned)(voff + q * 8192u)), (lds_void*)(lds + q * 8192 + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g1 + (unsigned)(voff + q * G::PIECE)), (lds_void*)(lds + q * G::PIECE + wave * 1024), 16, 0, 0);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    __builtin_amdgcn_global_load_lds((gbl_void*)(g2 + (unsigned)(voff + q * 8192u)),
-                                     (lds_void*)(lds + FF_W1_BYTES + q * 8192 + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g2 + (unsigned)(voff + q * G::PIECE)),
+                                     (lds_void*)(lds + G::W1_BYTES + q * G::PIECE + wave * 1024), 16, 0, 0);
 }
 
-template <int VARIANT>
-__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const bf16* __restrict__ X, const float* __restrict__ ln_g,
+template <int VARIANT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void ffn_fused_kernel(const bf16* __restrict__ X, const float* __restrict__ ln_g,
                                                            const float* __restrict__ ln_b,
                                                            const bf16* __restrict__ W1p, const float* __restrict__ b1,
                                                            const bf16* __restrict__ W2p, const float* __restrict__ b2,
                                                            bf16* __restrict__ out, long M, int F) {
+  using G = FFG<WAVES>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  float* lng = reinterpret_cast<float*>(lds + 2 * FF_CHUNK_BYTES);
+  float* lng = reinterpret_cast<float*>(lds + 2 * G::CHUNK_BYTES);
   float* lnb = lng + FF_D;
   float* b2s = lnb + FF_D;
   float* b1s = b2s + FF_D;                                   // fc1 bias: an ordinary global load inside the loop would
                                                              // make hipcc drain the in-flight LDS-DMA (vmcnt(0)) at its use
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const long row0 = (long)blockIdx.x * FF_ROWS + wave * 32;
-  const int n_chunks = F / FF_CH;
+  const long row0 = (long)blockIdx.x * G::ROWS + wave * 32;
+  const int n_chunks = F / G::CH;
 
   const unsigned voff = (unsigned)tid * 16u;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  stage_chunk(W1p, W2p, 0, lds, voff, wave_u);                       // first weights on their way before anything else
-  for (int k = tid; k < FF_D; k += 512) { lng[k] = ln_g[k]; lnb[k] = ln_b[k]; b2s[k] = b2[k]; }
-  for (int k = tid; k < F; k += 512) b1s[k] = b1[k];
+  stage_chunk<WAVES>(W1p, W2p, 0, lds, voff, wave_u);                       // first weights on their way before anything else
+  for (int k = tid; k < FF_D; k += G::THREADS) { lng[k] = ln_g[k]; lnb[k] = ln_b[k]; b2s[k] = b2[k]; }
+  for (int k = tid; k < F; k += G::THREADS) b1s[k] = b1[k];
 
   // ---- this wave's rows as B-operand fragments of Ht = W1 . LN(x)^T: lane (lr, lh) holds x[row lr][16 s + 8 lh + j]
   uint4 xa[16];
@@ -118,16 +130,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const bf16* __restric
     for (int e = 0; e < 16; ++e) y[n][e] = 0.f;
 
   for (int c = 0; c < n_chunks; ++c) {
-    char* cur = lds + (c & 1) * FF_CHUNK_BYTES;
+    char* cur = lds + (c & 1) * G::CHUNK_BYTES;
     // the DMA of chunk c (issued one iteration ago, or in the prologue) has landed for every wave after this barrier;
     // every wave has also finished reading the other buffer (chunk c - 1), so it can be refilled
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's own LDS-DMA pieces
     __syncthreads();
-    if (c + 1 < n_chunks) stage_chunk(W1p, W2p, c + 1, lds + ((c + 1) & 1) * FF_CHUNK_BYTES, voff, wave_u);
+    if (c + 1 < n_chunks) stage_chunk<WAVES>(W1p, W2p, c + 1, lds + ((c + 1) & 1) * G::CHUNK_BYTES, voff, wave_u);
     const uint4* w1 = reinterpret_cast<const uint4*>(cur);                     // [tile 2][k-step 16][lane 64]
-    const uint4* w2 = reinterpret_cast<const uint4*>(cur + FF_W1_BYTES);       // [tile 2][k-step 2][n-tile 8][lane 64]
+    const uint4* w2 = reinterpret_cast<const uint4*>(cur + G::W1_BYTES);       // [tile 2][k-step 2][n-tile 8][lane 64]
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < G::TILES; ++t) {
       f32x16 hacc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) hacc[e] = 0.f;
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(const bf16* __restric
       }
       // hacc[e] = H[row lr][hidden h0 + (e & 3) + 8 (e >> 2) + 4 lh]: bias + GELU, then registers 8 s .. 8 s + 7
       // pairwise to bf16 = A fragment of k-step s of the second product
-      const int h0 = c * FF_CH + t * 32 + 4 * lh;
+      const int h0 = c * G::CH + t * 32 + 4 * lh;
       uint4 hb[2];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -213,23 +225,30 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
   SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, ln_gamma); SL_CHECK_NULL(h, ln_beta); SL_CHECK_NULL(h, w1_packed);
   SL_CHECK_NULL(h, b1); SL_CHECK_NULL(h, w2_packed); SL_CHECK_NULL(h, b2); SL_CHECK_NULL(h, out);
   SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_emformer_ffn: bf16 only (fp32 keeps the two-launch path)");
-  SL_REQUIRE(h, D == FF_D && F >= FF_CH && F % FF_CH == 0, SIMULST_E_SHAPE, "simulst_emformer_ffn: D == 256, F % 64 == 0");
-  SL_REQUIRE(h, F <= FF_MAX_F, SIMULST_E_SHAPE, "simulst_emformer_ffn: F <= 4096");
+  SL_REQUIRE(h, D == FF_D && F >= 64 && F % 64 == 0, SIMULST_E_SHAPE, "simulst_emformer_ffn: D == 256, F % 64 == 0");
+  SL_REQUIRE(h, F <= FFG<8>::MAX_F, SIMULST_E_SHAPE, "simulst_emformer_ffn: F <= 4096");
   SL_REQUIRE(h, x != out, SIMULST_E_ARG, "simulst_emformer_ffn: in place (the residual rows are re-read at the end)");
   if (rows <= 0) return SIMULST_OK;
   if (!h->ffn_lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<8>::LDS);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ffn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+      e = hipFuncSetAttribute((const void*)ffn_fused_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<8>::LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ffn_fused_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
     if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit"; return (int)e; }
     h->ffn_lds_attr_set = true;
   }
   KTimer t(h, SIMULST_K_LINEAR);
-  const dim3 grid((unsigned)((rows + FF_ROWS - 1) / FF_ROWS));
-#define FFN(V)                                                                                                     \
-  hipLaunchKernelGGL(ffn_fused_kernel<V>, grid, dim3(512), FF_LDS, h->stream, (const bf16*)x, ln_gamma, ln_beta, \
+#define FFN(V, W)                                                                                                  \
+  hipLaunchKernelGGL((ffn_fused_kernel<V, W>), dim3((unsigned)((rows + FFG<W>::ROWS - 1) / FFG<W>::ROWS)),         \
+                     dim3(FFG<W>::THREADS), FFG<W>::LDS, h->stream, (const bf16*)x, ln_gamma, ln_beta,             \
                      (const bf16*)w1_packed, b1, (const bf16*)w2_packed, b2, (bf16*)out, (long)rows, F)
-  if (h->ffn_variant == 1) FFN(1); else FFN(0);
+  // geometry: two 4-wave workgroups per CU when the fc1 bias fits their LDS budget (F <= 2048), else one 8-wave workgroup;
+  // simulst_debug_ffn_variant: 1 = no-GELU timing ablation (8 waves), 2 / 3 = force the 8- / 4-wave geometry
+  const bool four = h->ffn_variant == 3 || (h->ffn_variant == 0 && FF_DEFAULT_FOUR_WAVES);
+  if (h->ffn_variant == 1) FFN(1, 8);
+  else if (four && F <= FFG<4>::MAX_F) FFN(0, 4);
+  else FFN(0, 8);
 #undef FFN
   return sl_launch_status(h, "simulst_emformer_ffn");
 }
