@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _restore_torch_globals():
+    """The SimulEval-facing agent does what the reference's does at construction -- torch.set_grad_enabled(False),
+    torch.set_num_threads(workers) (agents/default_agent.py:178-179) -- which must not leak into the gradient tests."""
+    grad, threads = torch.is_grad_enabled(), torch.get_num_threads()
+    yield
+    torch.set_grad_enabled(grad)
+    torch.set_num_threads(threads)
+
+
 def load_golden(name):
     """-> (arrays: dict name->torch tensor, weights: dict refname->torch tensor)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
