@@ -23,7 +23,9 @@
 // barrier, so the GELU is not hidden.  Tried and dropped: deferring the second product by one tile so that it is
 // independent of the current tile's GELU and can issue beside it (+8 VGPRs, a second raw barrier per chunk): hipcc still
 // emits the GELU as a block in front of the MFMAs, sched_group_barrier patterns did not change that, 3 % slower.  The GELU on
-// scalar fp32 instructions instead of the packed forms (-fno-slp-vectorize): 1 % faster at 4096 utterances, 9 % slower at 64.
+// scalar fp32 instructions instead of the packed forms (-fno-slp-vectorize): 1 % faster at 4096 utterances, 9 % slower at 64;
+// __builtin_amdgcn_iglp_opt(0 / 1) (fragment reads four ahead of the MFMAs instead of two): 2-3 % slower -- the LDS read
+// latency is not what the remaining distance to the MFMA rate is made of.
 // Algorithmic work per launch: 4 * rows * D * F flop (two contractions), HBM bytes 2 * rows * D * 2 (x read for the
 // contraction, again for the residual: L2/MALL-hot) + rows * D * 2 written; weights 2 * D * F * 2 B from L2 per workgroup.
 #include "gemm_args.h"
