@@ -126,8 +126,17 @@ class CIFDecoder:
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.ops = ops or Ops()
         self.w = DecoderWeights(weights, cfg, self.device, dtype, prefix)
-        self.embed_scale = math.sqrt(cfg.embed_dim)
+        self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(cfg.embed_dim)
         self.pre_decision_ratio = 1
+        # what the agent reads off the decoder (agents/cif_agent.py:150-155,372-405,428-433)
+        from types import SimpleNamespace
+        from .decoder import _Dictionary
+        self.dictionary = _Dictionary(cfg)
+        self.layers = [SimpleNamespace(index=l, encoder_attn=SimpleNamespace()) for l in range(cfg.decoder_layers)]
+
+    def clear_cache(self, incremental_state, end_id=None):
+        """a discarded prediction needs no rollback: forward() takes the written-token count from prev_output_tokens"""
+        return None
 
     def max_positions(self):
         return self.cfg.max_target_positions

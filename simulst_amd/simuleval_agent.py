@@ -294,3 +294,57 @@ class FairseqSimulSTAgent(SpeechAgent):
             self.model.decoder.clear_cache(states.dec_incremental_states)      # token discarded: retry after more source
             return None
         return index
+
+
+class CIFSimulSTAgent(FairseqSimulSTAgent):
+    """The CIF agent's surface (agents/cif_agent.py:96-436, its own `FairseqSimulSTAgent`): READ while the integrate-and-
+    fire layer has produced no more slots than tokens were written and the source goes on (:385-389), otherwise ONE decoder
+    step and WRITE; `cif_out` / `cif_lengths` accumulate across READs in `states.encoder_states` (:327-343)."""
+
+    @staticmethod
+    def add_args(parser):
+        FairseqSimulSTAgent.add_args(parser)
+        parser.add_argument("--overshoot-weight", type=float, default=1.0)
+        return parser
+
+    def __init__(self, args, model=None, tgt_dict=None):
+        super().__init__(args, model=model, tgt_dict=tgt_dict)
+        self.overshoot_weight = getattr(args, "overshoot_weight", 1.0)
+
+    def update_model_encoder(self, states):
+        n_src = len(states.units.source)
+        update_len = n_src - getattr(states, "last_update_source_len", 0)
+        if update_len == 0 and states.finish_read():
+            return
+        finish = update_len < self.expected_frames or states.finish_read()
+        frames = states.units.source.value
+        out = self.model.encoder.infer(self.to_device(frames.unsqueeze(0)), self.to_device(torch.LongTensor([frames.size(0)])),
+                                       states.enc_incremental_states, finish=finish)
+        if hasattr(states, "encoder_states"):
+            cur = states.encoder_states
+            cur.update({"cif_out": [torch.cat([cur["cif_out"][0], out["cif_out"][0]], dim=0)],
+                        "cif_lengths": [cur["cif_lengths"][0] + out["cif_lengths"][0].to(cur["cif_lengths"][0].device)]})
+        else:
+            states.encoder_states = out
+        n_slots, n_len = states.encoder_states["cif_out"][0].size(0), int(states.encoder_states["cif_lengths"][0].item())
+        assert n_slots == n_len, f"length mismatch {n_slots} != {n_len}."
+        states.last_update_source_len = n_src
+
+    def policy(self, states):
+        if not hasattr(states, "encoder_states"):
+            self._expect(first=True)
+            if states.finish_read():
+                self.update_states_read(states)
+            return READ_ACTION
+        enc_len = int(states.encoder_states["cif_lengths"][0].item())
+        dec_len = len(states.units.target)
+        if (enc_len <= dec_len or self.full_sentence) and not states.finish_read():
+            self._expect(first=False)
+            return READ_ACTION
+        dec = self.model.decoder
+        hyp = [t for t in states.units.target.value if t is not None]
+        prev = self.to_device(torch.LongTensor([dec.dictionary.eos()] + hyp).unsqueeze(0))
+        x, extra = dec.forward(prev_output_tokens=prev, encoder_out=states.encoder_states,
+                               incremental_state=states.dec_incremental_states, overshoot_weight=self.overshoot_weight)
+        states.decoder_out, states.decoder_out_extra = x, extra
+        return WRITE_ACTION

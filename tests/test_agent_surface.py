@@ -373,3 +373,45 @@ def test_simuleval_agent_on_the_hip_model_equals_frame_agent(attn, extra):
     assert "".join(actions) == want["actions"] and toks == want["tokens"]
     assert isinstance(states.dec_incremental_states.get("online"), bool)
     assert model.decoder.STATE_KEY in states.dec_incremental_states          # all decoder state in the caller's dict
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta", [1.0, 0.8])
+def test_cif_simuleval_agent_on_the_hip_model_equals_frame_agent(beta):
+    """agents/cif_agent.py's surface (READ while cif_lengths <= written tokens, one decoder step per WRITE with the
+    overshoot weight) over the HIP CIF model equals the frame-granular CIFAgent, which test_hip_cif.py pins to the oracle."""
+    from simulst_amd import simuleval_agent as se
+    from simulst_amd.cif import CIFAgent, CIFTransformerModel
+    from simulst_amd.config import tiny
+    from simulst_amd.weights import init_model
+    cfg = tiny(model="cif_transformer", ctc_layer=True, simul_attn_type="none", cif_beta=beta, max_target_positions=40)
+    w = init_model(cfg, seed=999)
+    w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
+    w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.0
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0
+    model = CIFTransformerModel(cfg, w, dtype=torch.float32)
+    fb = torch.randn(400, 80, generator=torch.Generator().manual_seed(8)).cuda()
+    want = CIFAgent(model, overshoot_weight=1.0).run_utterance(fb)
+    agent = se.CIFSimulSTAgent(argparse.Namespace(max_len_a=1, max_len_b=0, overshoot_weight=1.0), model=model)
+    states = agent.build_states(None, None, 0)
+    pos, actions, toks = 0, [], []
+    for _ in range(800):
+        a = agent.policy(states)
+        if a == se.READ_ACTION:
+            actions.append("R")
+            assert pos < fb.size(0), "READ after the source ended"
+            n = min(agent.expected_frames, fb.size(0) - pos)
+            states.units.source.append(fb[pos:pos + n])
+            pos += n
+            if pos >= fb.size(0):
+                states.status["read"] = False
+            agent.update_states_read(states)
+            continue
+        actions.append("W")
+        t = agent.predict(states)
+        states.units.target.append(t)
+        toks.append(t)
+        if t == cfg.eos or len(toks) > agent.max_len(pos):
+            break
+    assert "".join(actions) == want["actions"] and toks == want["tokens"]
+    assert int(states.encoder_states["cif_lengths"][0].item()) == want["n_cif"]
