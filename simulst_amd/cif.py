@@ -153,6 +153,8 @@ class CIFDecoder:
         device ints). Returns logits [B,V] fp32 with the EOS overshoot bias applied."""
         ops, cfg, Wd = self.ops, self.cfg, self.w
         B = last_tokens.size(0)
+        from .decoder import ensure_positions
+        ensure_positions(Wd, st["cap"] + cfg.padding_idx + 2)
         u = st["n_prev_host"] + 1                             # len([eos] + hyp)
         cl = cif_lengths.to(self.device).to(torch.int64)
         idx = (cl.clamp(max=u) - 1).clamp(min=0)

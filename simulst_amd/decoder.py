@@ -50,6 +50,7 @@ class DecoderWeights:
         self.out_proj = W(f"{p}.output_projection.weight")
         self.pos = sinusoidal_table(cfg.max_target_positions + cfg.padding_idx + 2, cfg.embed_dim,
                                     cfg.padding_idx).to(**f32)
+        self._pos_args = (cfg.embed_dim, cfg.padding_idx, f32)
         self.ln_g, self.ln_b = Bv(f"{p}.layer_norm.weight"), Bv(f"{p}.layer_norm.bias")
         self.layers = []
         cif = cfg.model == "cif_transformer"
@@ -81,6 +82,17 @@ class DecoderWeights:
             L["fc1"], L["b1"] = W(f"{lp}.fc1.weight"), Bv(f"{lp}.fc1.bias")
             L["fc2"], L["b2"] = W(f"{lp}.fc2.weight"), Bv(f"{lp}.fc2.bias")
             self.layers.append(L)
+
+
+def ensure_positions(w: "DecoderWeights", n_rows: int):
+    """fairseq's SinusoidalPositionalEmbedding grows its table on demand (a hypothesis may outrun --max-target-positions:
+    the CIF agent's max_len has no such cap, agents/cif_agent.py:168-169); the kernels index the table by position, so it
+    must cover every position a state can reach.  Rebuilt (doubling) when short; callers read `w.pos` afresh per launch."""
+    if n_rows > w.pos.size(0):
+        D, pad, f32 = w._pos_args
+        w.__dict__.setdefault("_pos_retired", []).append(w.pos)     # launches of other streams may still read the old one
+        w.pos = sinusoidal_table(max(n_rows, 2 * w.pos.size(0)), D, pad).to(**f32)
+    return w.pos
 
 
 class DecoderState:
@@ -213,6 +225,7 @@ class MMADecoder:
         return self.cfg.max_target_positions
 
     def new_state(self, B: int, cap: int = 128, S_cap: int = 256) -> DecoderState:
+        ensure_positions(self.w, cap + self.cfg.padding_idx + 2)
         st = DecoderState(self.cfg, B, cap, S_cap, self.device, self.dtype)
         if self.separate_soft:
             st.Ksoft = [torch.zeros(B, self.cfg.num_heads, S_cap, self.cfg.head_dim, device=self.device, dtype=self.dtype)
@@ -255,6 +268,7 @@ class MMADecoder:
         reference's head_read.any(), mma_model.py:196-210), 1 = WRITE."""
         ops, cfg, Wd = self.ops, self.cfg, self.w
         B, D, H, d = st.B, cfg.embed_dim, cfg.num_heads, cfg.head_dim
+        ensure_positions(Wd, st.cap + cfg.padding_idx + 2)          # a grown state may have outrun the table
         pos_row = (st.n_prev + (cfg.padding_idx + 1)).contiguous()
         x = ops.embed_tokens(last_tokens, Wd.E, Wd.pos, pos_row, self.embed_scale)
         incremental = True
@@ -431,6 +445,7 @@ class MMADecoder:
             st.layer_structs = self._layer_structs(st)
             st.structs_fragment_major = self.fragment_major
         ws = st.ws
+        ensure_positions(self.w, st.cap + cfg.padding_idx + 2)
         split = self.head_split and self.fragment_major
         out_proj = self.w.out_proj_packed if self.fragment_major else self.w.out_proj
         return _lib.DecoderDesc(B, D, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st.cap, st.S_cap,

@@ -384,7 +384,7 @@ def test_cif_simuleval_agent_on_the_hip_model_equals_frame_agent(beta):
     from simulst_amd.cif import CIFAgent, CIFTransformerModel
     from simulst_amd.config import tiny
     from simulst_amd.weights import init_model
-    cfg = tiny(model="cif_transformer", ctc_layer=True, simul_attn_type="none", cif_beta=beta, max_target_positions=40)
+    cfg = tiny(model="cif_transformer", ctc_layer=True, simul_attn_type="none", cif_beta=beta, max_target_positions=1024)
     w = init_model(cfg, seed=999)
     w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
     w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.0
