@@ -6,13 +6,18 @@
 //     16-byte fragments): each lane then holds, for ONE query (its column), 32 of the 64 key scores in
 //     registers -- the row max / sum are in-register plus one lane<->lane+32 exchange
 //   * P^T stays in the accumulator registers and is fed back as the A operand of the second product
-//     (X^T . B form: no LDS round trip for P); V is staged TRANSPOSED in LDS ([channel][key], 136-byte
-//     rows: conflict-free 8-byte reads) in exactly the permuted key order the accumulator layout imposes
+//     (X^T . B form: no LDS round trip for P); V is staged ROW-MAJOR in LDS ([key][64 channels], 192-byte rows, eight
+//     16-byte writes per lane) and read back as the B operand by the hardware transpose read ds_read_b64_tr_b16
+//     (four keys of one channel per lane and read, conflict-free with that row stride) in exactly the permuted key order
+//     the accumulator layout imposes.  The first version scattered V transposed with 64 two-byte LDS writes per lane,
+//     8-way bank-conflicted: half of a workgroup's life
 //   * fp32 softmax, 1/sum applied to the fp32 output accumulators
 // The T x T mask of Emformer._gen_attention_mask is never built: key ranges come from (i, S, R, Lc, M, len).
 #include "common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short tr_v4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tr_v4 lds_v4;
 
 namespace {
 
@@ -22,7 +27,8 @@ struct EmfArgsM {
   int rows_z, rows_c;
 };
 
-constexpr int VT_STRIDE = 68;   // bf16 elements per Vt row (64 keys + pad): 136 B
+constexpr int VR_STRIDE = 96;   // bf16 elements per staged V row (64 channels + pad): 192 B -- rows k, k+1, k+2, k+3 of a
+                                // transpose read then start at banks 0, 48, 32, 16 of 64
 
 __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
   bf16 l = __float2bfloat16(lo), h = __float2bfloat16(hi);
@@ -34,7 +40,7 @@ __global__ __launch_bounds__(256, 3) void emformer_attn_mfma_kernel(
     const bf16* __restrict__ QKV, const int* __restrict__ lengths, const bf16* __restrict__ lc_k,
     const bf16* __restrict__ lc_v, const int* __restrict__ lc_valid, const int* __restrict__ n_mem_valid,
     bf16* __restrict__ CTX, EmfArgsM a) {
-  __shared__ __attribute__((aligned(16))) unsigned short vt_all[4][64 * VT_STRIDE];
+  __shared__ __attribute__((aligned(16))) unsigned short vt_all[4][64 * VR_STRIDE];
   __shared__ float inv_all[4][32];
   // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs; permuting them makes every XCD walk through
   // consecutive (utterance, segment) pairs, so the left-context / memory rows a segment shares with its two
@@ -125,19 +131,9 @@ __global__ __launch_bounds__(256, 3) void emformer_attn_mfma_kernel(
         qf[kk] = q_ok ? v : zero4;
       }
     }
-    // ---- S^T tiles: st[t][e] = score(key 32t + (e&3) + 8(e>>2) + 4lh, query lr)
-    f32x16 st[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&kf[t][kk]),
-                                                        *reinterpret_cast<const bf16x8_t*>(&qf[kk]), st[t], 0, 0, 0);
-    }
-    // ---- V rows requested now (the K / Q fragments are consumed, their registers are free): 16-byte chunks, 8 lanes
-    //      per key row, 8 rows per wave load; they land while the softmax below runs
+    // ---- V rows are requested TOGETHER with K and Q (16-byte chunks, 8 lanes per key row, 8 rows per wave load): a wave's
+    //      life is its chain of dependent HBM round trips (3-5 us each under load), so the V request must not wait for the
+    //      scores -- 32 more VGPRs, still 3 workgroups per CU
     uint4 vrows[8];
     const int vc8 = (lane & 7) * 8;
 #pragma unroll
@@ -149,6 +145,17 @@ __global__ __launch_bounds__(256, 3) void emformer_attn_mfma_kernel(
       const uint4 v = *reinterpret_cast<const uint4*>(vp + hc + vc8);
       vrows[it] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);   // per-component select:
                                                       // `ok ? v : zero4` on the struct went through scratch memory
+    }
+    // ---- S^T tiles: st[t][e] = score(key 32t + (e&3) + 8(e>>2) + 4lh, query lr)
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&kf[t][kk]),
+                                                        *reinterpret_cast<const bf16x8_t*>(&qf[kk]), st[t], 0, 0, 0);
     }
     // ---- fp32 softmax over the keys of query lr (half in this lane, half in lane ^ 32)
     const float scaling = 0.125f;     // 64^-0.5
@@ -176,15 +183,13 @@ __global__ __launch_bounds__(256, 3) void emformer_attn_mfma_kernel(
       }
     sum += __shfl_xor(sum, 32, 64);
     if (lh == 0) invs[lr] = 1.0f / sum;
-    // ---- V transposed into LDS: vt[channel][key], zero beyond nk (P is 0 there, but 0 * garbage != 0)
+    // ---- V rows into LDS as they came (row-major), zero beyond nk (P is 0 there, but 0 * garbage != 0)
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int j = 8 * it + (lane >> 3);
-      const unsigned int u[4] = {vrows[it].x, vrows[it].y, vrows[it].z, vrows[it].w};
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        vt[(vc8 + q) * VT_STRIDE + j] = (unsigned short)((q & 1) ? (u[q >> 1] >> 16) : (u[q >> 1] & 0xffffu));
+      *reinterpret_cast<uint4*>(vt + j * VR_STRIDE + vc8) = vrows[it];
     }
+    __builtin_amdgcn_wave_barrier();
     // ---- O = P . V: A = P^T fragments from the accumulators (registers 8s..8s+7 of tile t = keys
     //      32t + 16s + 8(j>>2) + 4lh + (j&3)), B = V from vt in the same key order
     f32x16 o[2];
@@ -204,10 +209,15 @@ __global__ __launch_bounds__(256, 3) void emformer_attn_mfma_kernel(
         const int key0 = 32 * t + 16 * s + 4 * lh;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const unsigned short* vr = vt + (32 * nt + lr) * VT_STRIDE + key0;
-          const uint2 lo = *reinterpret_cast<const uint2*>(vr);        // keys key0 .. key0+3
-          const uint2 hi = *reinterpret_cast<const uint2*>(vr + 8);    // keys key0+8 .. key0+11
-          uint4 vb = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          // transpose read: the 16-lane group (channels 32 nt + 16 (lane >> 4 & 1) ..+15) reads 4 keys x 16 channels;
+          // lane 4q + p of the group supplies the address of key q, channels 4p..4p+3, and receives ITS channel of the 4 keys
+          const int li = lane & 15;
+          const unsigned short* blk = vt + (key0 + (li >> 2)) * VR_STRIDE + 32 * nt + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+          const tr_v4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)blk);                      // keys key0 .. key0+3
+          const tr_v4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(blk + 8 * VR_STRIDE));    // keys key0+8 .. key0+11
+          uint4 vb;
+          __builtin_memcpy(&vb.x, &lo, 8);
+          __builtin_memcpy(&vb.z, &hi, 8);
           o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&pa),
                                                           *reinterpret_cast<const bf16x8_t*>(&vb), o[nt], 0, 0, 0);
         }
