@@ -168,6 +168,13 @@ int simulst_conv_pos_mfma(simulst_handle* h, const void* x, const void* hist, co
                           const int32_t* lengths, void* y, int32_t B, int32_t T, int32_t D, int32_t groups,
                           int32_t k);
 
+/* First-layer Emformer input X [B][n_seg * R + T][D] from the encoder front-end's x [B][T][D]: the right-context block rows
+ * (row (i, r) = frame (i + 1) * S + r of the utterance, zero for the last segment and past the utterance) in front of the
+ * utterance rows.  Replaces F.pad(R zero frames) + Emformer._gen_right_context + the concatenation with the utterance
+ * (models/s2t_emformer.py:153, torchaudio_models/emformer.py:700-709,810-818) in one pass. */
+int simulst_emformer_pack_rows(simulst_handle* h, const void* x, void* X, int32_t B, int32_t T, int32_t D, int32_t seg_len,
+                               int32_t right_context, int32_t n_seg, int32_t dtype);
+
 /* The Emformer feed-forward block in ONE launch (bf16, D == 256, F % 64 == 0, F <= 4096):
  *   out[rows][D] = x + W2 . gelu(W1 . LayerNorm(x) + b1) + b2
  * with the [rows][F] hidden activations kept in registers (the accumulator tile of the first product is the operand of

@@ -87,6 +87,7 @@ SIGNATURES = {
                                    _vp, _vp],
     "simulst_fbank": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _i32],
     "simulst_conv_pos_mfma": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
+    "simulst_emformer_pack_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_emformer_ffn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32],
     "simulst_emformer_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_layernorm": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i32],

@@ -291,6 +291,31 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
   }
 }
 
+// ---- first-layer Emformer input: right-context block rows in front of the utterance rows ------------------------------
+// X[b] = [ rc rows of segments 0 .. N-1 | utterance rows ]: rc row (i, r) is utterance frame (i + 1) * S + r, zero for the
+// last segment and beyond the utterance (Emformer._gen_right_context over the R zero frames S2TEmformerEncoder._forward
+// appends, torchaudio_models/emformer.py:700-709, models/s2t_emformer.py:153).  One pass, 16 bytes per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void emformer_pack_rows_kernel(const T* __restrict__ x, T* __restrict__ X, int T_,
+                                                                 int D, int S, int R, int N) {
+  constexpr int V = 16 / sizeof(T);
+  const int b = blockIdx.y;
+  const int rows = N * R + T_;
+  const int cpr = D / V;                                       // 16-byte chunks per row
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)rows * cpr; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / cpr), c = (int)(i - (long)row * cpr);
+    int src = row - N * R;                                     // utterance rows
+    if (row < N * R) {
+      const int seg = row / R, r = row - seg * R;
+      src = (seg + 1) * S + r;
+      if (seg >= N - 1 || src >= T_) src = -1;
+    }
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (src >= 0) v = *reinterpret_cast<const uint4*>(x + ((long)b * T_ + src) * D + c * V);
+    *reinterpret_cast<uint4*>(X + ((long)b * rows + row) * D + c * V) = v;
+  }
+}
+
 }  // namespace
 
 #define DT_SWITCH(dtype, ...)                               \
@@ -339,6 +364,22 @@ extern "C" int simulst_emformer_prenorm(simulst_handle* h, const void* X, const 
                                         seg_len, n_seg));
   }
   return sl_launch_status(h, "simulst_emformer_prenorm");
+}
+
+extern "C" int simulst_emformer_pack_rows(simulst_handle* h, const void* x, void* X, int32_t B, int32_t T_, int32_t D,
+                                          int32_t seg_len, int32_t right_context, int32_t n_seg, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, X);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_emformer_pack_rows: dtype");
+  SL_REQUIRE(h, T_ > 0 && seg_len > 0 && right_context >= 0 && n_seg == (T_ + seg_len - 1) / seg_len &&
+                 D > 0 && D % 8 == 0, SIMULST_E_SHAPE, "simulst_emformer_pack_rows: shape (n_seg = ceil(T / S), D % 8 == 0)");
+  if (B <= 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_MISC);
+  const long chunks = (long)(n_seg * right_context + T_) * (D / 4);
+  const int gx = (int)((chunks + 255) / 256 < 64 ? (chunks + 255) / 256 : 64);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(emformer_pack_rows_kernel<T>, dim3(gx, B), dim3(256), 0, h->stream, (const T*)x,
+                                      (T*)X, T_, D, seg_len, right_context, n_seg));
+  return sl_launch_status(h, "simulst_emformer_pack_rows");
 }
 
 extern "C" int simulst_segment_mean(simulst_handle* h, const void* X, const int32_t* lengths, void* out,

@@ -210,19 +210,6 @@ class S2TEmformerEncoder:
             return self.ops.conv_pos_mfma(x, hist, w.pos_w_packed, w.pos_b, lengths_i32, cfg.conv_pos_groups)
         return self.ops.conv_pos(x, hist, w.pos_w, w.pos_b, lengths_i32, cfg.conv_pos_groups)
 
-    def _rc_index(self, T: int, device):
-        """Row gather for the right-context blocks (Emformer._gen_right_context,
-        torchaudio_models/emformer.py:700-709) over an input extended by one all-zero row T."""
-        S, R = self.cfg.S, self.cfg.R
-        N = math.ceil(T / S)
-        idx = torch.full((N * R,), T, dtype=torch.long)
-        for i in range(N - 1):
-            for r in range(R):
-                t = (i + 1) * S + r
-                if t < T:
-                    idx[i * R + r] = t
-        return idx.to(device), N
-
     def _emformer_layers(self, X, lengths_i32, T, N, mems0):
         """X [B][N*R + T][D] activations; mems0 [B][N-1][D] first-layer memory. Returns X_out."""
         cfg, ops, W = self.cfg, self.ops, self.w
@@ -298,9 +285,8 @@ class S2TEmformerEncoder:
         len_i32 = enc_len.to(torch.int32)
         x = self._conv_pos(x, None, len_i32)
         D, R, S = cfg.embed_dim, cfg.R, cfg.S
-        idx, N = self._rc_index(Te, x.device)
-        xz = torch.cat([x, x.new_zeros(B, 1, D)], dim=1)
-        X = torch.cat([xz.index_select(1, idx), x], dim=1).contiguous()     # [rc blocks | utterance]
+        N = math.ceil(Te / S)
+        X = ops.emformer_pack_rows(x, S, R, N)                              # [rc blocks | utterance]
         mems0 = None
         if cfg.M > 0 and N > 1:
             mems0 = torch.empty(B, N - 1, D, device=x.device, dtype=x.dtype)

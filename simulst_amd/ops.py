@@ -110,6 +110,15 @@ class Ops:
                                                 dt(x)), "simulst_layernorm")
         return out
 
+    def emformer_pack_rows(self, x, S, R, N):
+        """x [B, T, D] -> X [B, N*R + T, D]: right-context block rows (first-layer copies), then the utterance rows."""
+        _chk_contig(x)
+        B, T, D = x.shape
+        X = torch.empty(B, N * R + T, D, device=x.device, dtype=x.dtype)
+        self.h.check(self.lib.simulst_emformer_pack_rows(self.h.ptr, _p(x), _p(X), B, T, D, S, R, N, dt(x)),
+                     "simulst_emformer_pack_rows")
+        return X
+
     def emformer_ffn(self, x, ln_g, ln_b, w1p, b1, w2p, b2, out):
         """out[rows, D] = x + fc2(gelu(fc1(LayerNorm(x)))) in one launch (simulst_emformer_ffn; bf16, D == 256)."""
         _chk_contig(x, out, w1p, w2p)
