@@ -31,6 +31,7 @@ struct simulst_handle {
   bool force_valu_attention;   // test hook: route bf16 Emformer attention through the VALU kernel
   int panel_split_min_rows;    // co-scheduled decode GEMMs (K <= 256, N >= 512): rows from which the row-panel kernel with
   int panel_split_blocks;      //   split column ranges replaces the 64 x 64 tile kernel, and its target workgroup count
+  int mid_min_blocks;          // 64 x 64 tiles from which the tile kernel takes N >= 512 decode GEMMs (QKV, fc1, vocabulary)
   int mid_narrow_min_rows;     // rows from which N < 512, K <= 256 decode GEMMs (out-proj, q-proj) take the 64 x 64 tile kernel
   int skinny_min_blocks_tall;  // k-split decode GEMM with more rows than columns (fc2 of co-scheduled batches): workgroups
                                //   down to which the tile chooser keeps the 64 x 32 tile

@@ -383,7 +383,7 @@ bool sl_mid_wanted(const simulst_handle* h, int dtype, const LinArgs& p) {
   // one wave per 16 x 16 tile re-reads 16 KB of operands per 131 kflop and is L2-bound there (4096 rows: 9.3 -> 7.9 us
   // out-proj, 12.8 -> 7.6 us LN + q-proj).  fc2 (K = 2048) measured the same on both kernels and keeps the k-split one.
   const bool narrow = p.N >= 64 && p.N < 512 && p.K <= 8 * KS && p.M >= h->mid_narrow_min_rows;
-  return p.M >= 256 && (p.N >= 512 || narrow) && blocks >= 192 && p.K % KS == 0 && (!p.ln_g || p.K <= 8 * KS);
+  return p.M >= 256 && (p.N >= 512 || narrow) && blocks >= h->mid_min_blocks && p.K % KS == 0 && (!p.ln_g || p.K <= 8 * KS);
 }
 
 // narrow outputs of co-scheduled batches with a short contraction: one wave per tile

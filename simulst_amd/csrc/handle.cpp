@@ -20,6 +20,8 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_PANEL_SPLIT_MIN_ROWS")) h->panel_split_min_rows = atoi(e);
   h->panel_split_blocks = 256;
   if (const char* e = getenv("SIMULST_PANEL_SPLIT_BLOCKS")) h->panel_split_blocks = atoi(e);
+  h->mid_min_blocks = 48;      // measured with three 448-row sequences in flight (bench.py --steps 20): 192 -> 1.25 M, <= 64 -> 1.29-1.30 M tokens/s
+  if (const char* e = getenv("SIMULST_MID_MIN_BLOCKS")) h->mid_min_blocks = atoi(e);
   h->mid_narrow_min_rows = 3072;
   if (const char* e = getenv("SIMULST_MID_NARROW_MIN_ROWS")) h->mid_narrow_min_rows = atoi(e);
   h->skinny_min_blocks_tall = 192;
