@@ -74,6 +74,8 @@ def parse_args(argv=None):
                     help="the warm-up repeats the timed plan until W steps AND this much wall time have passed: a cold "
                          "GPU runs its first ~0.5 s of launches at ramping clocks (measured: the 2nd pass of a fresh "
                          "process 141 ms, the 4th 119 ms)")
+    ap.add_argument("--stagger", action="store_true",
+                    help="chain the encoder passes of the streams instead of running them side by side (measured slower)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decode loop of each batch strictly one after the other")
     ap.add_argument("--graph", action="store_true",
@@ -333,7 +335,7 @@ def main(argv=None):
     pipe = None
     if args.concurrency > 1:
         from simulst_amd.model import ConcurrentOffline
-        pipe = ConcurrentOffline(model, weights, args.concurrency, graph=args.graph)
+        pipe = ConcurrentOffline(model, weights, args.concurrency, graph=args.graph, stagger_encoders=args.stagger)
     elif not args.no_pipeline:
         from simulst_amd.model import OfflinePipeline
         pipe = OfflinePipeline(model)

@@ -233,9 +233,18 @@ class ConcurrentOffline:
     plenty of (eval/generate.py:187-209 iterates over them) -- fill it.  Each batch runs exactly the kernels of
     generate_offline; replicas share the device weights and own their stream, handle and decoder state."""
 
-    def __init__(self, model: SimulSTModel, weights, concurrency: int = 4, graph: bool = False):
+    def __init__(self, model: SimulSTModel, weights, concurrency: int = 4, graph: bool = False,
+                 stagger_encoders: bool = False):
+        """stagger_encoders chains the encoder passes of the streams on the device (each waits for the previous
+        stream's). Measured on MI355X it is SLOWER than letting them run side by side (20-step form 1.235 M vs
+        1.290 M tokens/s, 384-step form 1.757 M vs 1.786 M): the side-by-side encoders already share the MFMA pipes
+        without loss, and the chain only delays the last stream's decode loop. Off by default; kept as a switch so the
+        measurement can be repeated."""
+        import threading
         from . import _lib
         self.models, self.streams = [], []
+        self.stagger_encoders = stagger_encoders
+        self._enc_lock, self._enc_event = threading.Lock(), None
         dev = model.device
         for c in range(concurrency):
             st = torch.cuda.Stream(device=dev)
@@ -246,6 +255,20 @@ class ConcurrentOffline:
                 self.models.append(SimulSTModel(model.cfg, weights, device=dev, dtype=model.dtype, ops=ops,
                                                 share_with=model))
             self.streams.append(st)
+
+    def _generate(self, c, src_tokens, src_lengths, n_steps, mask_eos):
+        """generate_offline of replica c with the encoder pass placed in the chain"""
+        m, st = self.models[c], self.streams[c]
+        if not self.stagger_encoders:
+            return m.generate_offline(src_tokens, src_lengths, n_steps=n_steps, mask_eos=mask_eos)[0]
+        with self._enc_lock:                       # host-side order of the encoder submissions = their device order
+            if self._enc_event is not None:
+                st.wait_event(self._enc_event)
+            enc = m.encoder.forward(src_tokens, src_lengths)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._enc_event = ev
+        return m.decoder.greedy_offline(enc["encoder_out_btd"], enc["encoder_lengths"], n_steps, mask_eos)[0]
 
     def run(self, batches, n_steps: int, mask_eos: bool = False, on_tokens=None):
         import threading
@@ -263,8 +286,7 @@ class ConcurrentOffline:
                     torch.cuda.set_device(dev_index)
                 with torch.no_grad(), torch.cuda.stream(self.streams[c]):
                     for i in range(c, len(batches), len(self.models)):
-                        toks, _ = self.models[c].generate_offline(*batches[i], n_steps=n_steps, mask_eos=mask_eos)
-                        toks = toks.clone()
+                        toks = self._generate(c, batches[i][0], batches[i][1], n_steps, mask_eos).clone()
                         out[i] = on_tokens(toks) if on_tokens is not None else toks
             except Exception as e:          # surfaced to the caller below
                 errs.append(e)
