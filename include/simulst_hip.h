@@ -447,6 +447,12 @@ typedef struct {
                                                     fragment-major order of simulst_linear_desc.w_fragment_major
                                                     (E stays row-major: it is read by row); required by the
                                                     head-split block */
+  /* optional workspace of the row-local layer chains (both non-NULL, bf16, D == 256, F % 256 == 0, fragment-major
+   * weights, more than 128 rows): { out-proj + residual, LN + q-proj } become one launch and { cross out-proj +
+   * residual, LN + fc1 + GELU, fc2 + residual } another, the hidden units split over F / 256 workgroups per row tile
+   * whose fp32 slabs the last-arriving workgroup adds in split order (deterministic).  NULL: one launch per GEMM. */
+  float* ffn_partial;                            /* [F / 256][B][D] */
+  int32_t* ffn_sem;                              /* [(B + 15) / 16] zero-initialised tickets (left zero by every call) */
 } simulst_decoder_desc;
 
 /* tokens_io [B] int64: in = newest token of [eos]+hyp, out = last token picked.
@@ -475,6 +481,23 @@ typedef struct {
 
 int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,
                              int64_t* tokens_io, const simulst_stream_ctl* ctl, int32_t n_iter);
+
+/* Row-local chains of the decoder layer for co-scheduled batches (bf16, D == 256, fragment-major weights); the decode
+ * loop uses them from 129 rows on when simulst_decoder_desc.ffn_partial / ffn_sem are given.  Same rounding points as the
+ * launches they replace (bf16 after bias + residual, after LayerNorm, after GELU).
+ *   proj chain:  x <- bf16(x + Wo ctx + bo);  q <- Wq LN(x) + bq;  q2 <- Wq2 LN(x) + bq2 (wq2_fm may be NULL)
+ *                = the self-attention output projection + residual of fairseq's TransformerDecoderLayer followed by
+ *                encoder_attn_layer_norm and the (monotonic / soft) query projections of
+ *                modules/monotonic_multihead_attention.py as run by models/mma_model.py:99-135
+ *   ffn chain:   x' = bf16(x + Wco ctx + bco);  x <- bf16(x' + W2 gelu(W1 LN(x') + b1) + b2)
+ *                = encoder_attn out_proj + residual, final_layer_norm, fc1, activation, fc2, residual of the same layer.
+ *                partial: fp32 [F / 256][B][D] scratch; sem: (B + 15) / 16 int32, zero on entry, zero on return. */
+int simulst_decoder_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* wo_fm, const float* bo,
+                               const float* ln_g, const float* ln_b, const void* wq_fm, const float* bq, void* q,
+                               const void* wq2_fm, const float* bq2, void* q2, int32_t B, int32_t D, int32_t dtype);
+int simulst_decoder_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* wco_fm, const float* bco,
+                              const float* ln_g, const float* ln_b, const void* w1_fm, const float* b1, const void* w2_fm,
+                              const float* b2, float* partial, int32_t* sem, int32_t B, int32_t D, int32_t F, int32_t dtype);
 
 /* policy + cross-attention of one layer for one step in ONE launch (simulst_step_p_choose +
  * simulst_mma_step_search + simulst_decoder_cross_attention, same results). qm/qs: monotonic / soft

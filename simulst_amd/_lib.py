@@ -58,7 +58,7 @@ class DecoderDesc(C.Structure):
                [("embed_scale", C.c_float)] + \
                [(n, C.c_void_p) for n in ("E", "out_proj", "pos_table", "ln_g", "ln_b", "enc_len", "n_prev", "x", "qkv",
                                           "ctx", "q", "q2", "hidden", "logits", "x_mid", "partial_self")] + \
-               [("weights_fragment_major", C.c_int32)]
+               [("weights_fragment_major", C.c_int32), ("ffn_partial", C.c_void_p), ("ffn_sem", C.c_void_p)]
 
 class StreamCtl(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("active", "read_flag", "online", "done", "delays_ms", "hyp")] + \
@@ -116,6 +116,8 @@ SIGNATURES = {
     "simulst_mma_stream_steps": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, C.POINTER(StreamCtl), _i32],
     "simulst_policy_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                        _i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "simulst_decoder_proj_chain": [_vp] * 13 + [_i32, _i32, _i32],
+    "simulst_decoder_ffn_chain": [_vp] * 13 + [_i32, _i32, _i32, _i32],
 }
 
 _lib = None

@@ -42,6 +42,14 @@ struct simulst_handle {
   bool ffn_lds_attr_set;       // simulst_emformer_ffn did the same for the fused feed-forward kernel
   int ffn_variant;             // simulst_debug_ffn_variant (timing ablations of the fused feed-forward launch)
   bool ctc_lds_attr_set;       // simulst_ctc_best_alignment raised its kernel's dynamic-LDS limit through this handle
+  // row-local chains of the decoder layer (dec_chain.hip) for co-scheduled bf16 batches
+  bool dec_chain_on;
+  int dec_chain_min_rows;      // rows from which the chains replace the per-GEMM launches (below: head-split block)
+  int dec_chain_rt16_max_rows; // rows up to which a workgroup owns 16 rows (more workgroups, shorter chains),
+  int dec_chain_rt32_max_rows; //   32 rows; above: 64
+  int dec_chain_max_rows;      // rows above which the per-GEMM launches are kept
+  int dec_chain_ffn_max_rows;  // rows up to which the feed-forward chain is used as well
+  bool dec_chain_lds_attr_set;
 };
 
 #define SL_CHECK_NULL(h, p)                                   \
@@ -243,6 +251,14 @@ int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v
 static inline bool sl_self_attention_fused_ok(int H, int d, int cap) {
   return (d == 32 || d == 64) && H * d <= 1024 && cap <= 256;
 }
+// row-local chains of the decoder layer for co-scheduled bf16 batches (dec_chain.hip)
+bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bool packed);
+int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* Wo, const float* bo, const float* ln_g,
+                      const float* ln_b, const void* Wq, const float* bq, void* q, const void* Wq2, const float* bq2,
+                      void* q2, int B);
+int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
+                     const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
+                     int32_t* sem, int B, int F);
 int sl_self_attention_fused(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* Wqkv,
                             const float* bqkv, const void* Wo, void* k_cache, void* v_cache, const int32_t* n_prev,
                             int np_uniform, float* partial, int32_t B, int32_t H, int32_t d, int32_t cap,

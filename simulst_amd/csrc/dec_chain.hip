@@ -1,0 +1,474 @@
+// Row-local chains of the decoder layer for CO-SCHEDULED batches (129 .. a few thousand rows), gfx950, bf16, D = 256.
+//
+// With several 64-utterance batches stacked into one launch sequence a decoder layer was 8-9 dependent launches, six of
+// them GEMMs of 4-9 us that do a few hundred kflop per row: at 448 rows the decode GEMMs were 45 % of a sequence's device
+// time at ~20 TFLOP/s -- launch ramp, operand latency and kernel boundary, not arithmetic.  Every one of these
+// contractions is ROW-LOCAL (utterance b's row never meets another utterance's), so consecutive ones can run inside one
+// workgroup that owns a tile of rows, with no grid-wide hand-off in between:
+//
+//   dec_proj_chain_kernel   ctx -> out-proj + bias + residual -> x (written) -> LayerNorm 2 -> q-proj (+ the soft-energy
+//                           q-proj of MMA variants) -> q (q2)          replaces 2 (3) launches
+//                           (fairseq TransformerDecoderLayer self-attention output / encoder_attn query,
+//                            modules/monotonic_multihead_attention.py q_proj as used by models/mma_model.py:99-135)
+//   dec_ffn_chain_kernel    ctx -> cross out-proj + bias + residual -> LayerNorm 3 -> fc1 + bias + GELU -> fc2, hidden units
+//                           split over F / 256 workgroups per row tile, fp32 partial slabs, the LAST-ARRIVING workgroup
+//                           of a row tile adds them in split order with b2 and the residual and writes x   replaces 3 launches
+//
+// Geometry (both): 256 threads, the 4 waves share RT = 16 * RTL rows and split the 256 output columns of every
+// 256 x 256 weight block (wave w: columns 64 w .. 64 w + 63).  Activations of the tile live in LDS as bf16 rows (stride
+// 272 elements: a 16-byte fragment read per lane is conflict-free); weights come straight from L2 into registers as
+// fragment-major 1 KB pieces (simulst_linear_desc.w_fragment_major), the whole 32 KB of a wave's block in flight at once
+// and the NEXT block requested before the current one is multiplied.  v_mfma_f32_16x16x32_bf16 with the weights as the
+// A operand: a lane then holds 4 consecutive output columns of ONE row, i.e. an 8-byte LDS / global write.
+// Rounding points are those of the launches replaced (bf16 after bias + residual, after LayerNorm, after GELU).
+// Every variant is built for ONE wave per SIMD (__launch_bounds__(256, 1)): the 32-row feed-forward variant built for two
+// produced run-to-run different rows (whole slab rows off by ~1e-2, different rows every launch) on MI355X, with
+// __syncthreads() in place of the LDS-only barrier as well, while the one-wave builds of all three tile heights repeat
+// bit for bit (tests/test_hip_dec_chain.py repeats them).  The cause was not found (the two-wave ISA differs in register
+// allocation only: accumulators in VGPRs, some MFMA destinations on their own operand registers); the chains put at most
+// one workgroup on a CU anyway.
+//
+// The slab hand-off follows cdna_hip_programming.md section 5.4 item 2 (plain stores, vmcnt drain, barrier, lane 0
+// agent-scope release fence + ticket; last arriver: agent-scope acquire fence, barrier, plain loads): placement-
+// independent, no waiting anywhere (nothing can hang), deterministic (fixed split order in one workgroup).
+#include "gemm_args.h"
+
+namespace {
+
+constexpr int CD = 256;            // model width
+constexpr int XS = CD + 16;        // LDS row stride in elements (544 B: rows shift by 8 banks)
+constexpr int NKS = CD / 32;       // k-steps of a 256-deep contraction
+
+#ifdef SL_PROBE
+__device__ long sl_probe_chain[32];
+#define PROBE(i) do { if (blockIdx.x == 9 && threadIdx.x == 0) sl_probe_chain[i] = wall_clock64(); } while (0)
+#define PROBE_LAST(i) do { if (blockIdx.x / splits == 1 && threadIdx.x == 0) sl_probe_chain[16 + (i)] = wall_clock64(); } while (0)
+#else
+#define PROBE(i)
+#define PROBE_LAST(i)
+#endif
+
+// workgroup barrier for LDS hand-offs only: __syncthreads() also drains vmcnt, i.e. it would wait for the weight block that
+// was requested on purpose BEFORE the barrier so that it lands during the next phase (measured: 2.7 us per barrier)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// A wave's share of a 256 x 256 weight block is 4 column tiles x 8 k-steps = 32 KB; it is handled as two UNITS of 2 column
+// tiles (16 fragments = 64 VGPRs): two units live in registers at any time, the one being multiplied and the next one in
+// flight.  (Holding two whole blocks -- 256 VGPRs of weights -- made hipcc park fragments in AGPRs behind vmcnt(0) waits:
+// every load became a dependent round trip, 2.7 us per phase.)
+struct WUnit { uint4 f[2][NKS]; };
+
+// fragments (tn, s0 + s) and (tn + 1, s0 + s), s < 8, of a fragment-major matrix with nksT k-steps per column tile
+__device__ __forceinline__ void load_unit(WUnit& u, const uint4* __restrict__ w, int tn, int nksT, int s0, int lane) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) u.f[c][s] = w[((long)(tn + c) * nksT + s0 + s) * 64 + lane];
+}
+
+// acc[rt][C0 + c][e] += X[row 16 rt + lr][:] . W[col 16 (tn + c) + 4 lg + e][:]   (X rows from LDS, K = 256)
+template <int RTL, int C0>
+__device__ __forceinline__ void mma_unit(f32x4 (&acc)[RTL][4], const WUnit& u, const unsigned short* xs, int lr, int lg) {
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    uint4 xf[RTL];
+#pragma unroll
+    for (int rt = 0; rt < RTL; ++rt) xf[rt] = *reinterpret_cast<const uint4*>(xs + (rt * 16 + lr) * XS + 32 * s + 8 * lg);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int rt = 0; rt < RTL; ++rt)
+        acc[rt][C0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&u.f[c][s]),
+                                                                  *reinterpret_cast<const bf16x8_t*>(&xf[rt]), acc[rt][C0 + c], 0, 0, 0);
+  }
+}
+
+template <int RTL>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[RTL][4]) {
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  const bf16 v[4] = {__float2bfloat16(a), __float2bfloat16(b), __float2bfloat16(c), __float2bfloat16(d)};
+  uint2 r;
+  __builtin_memcpy(&r, v, 8);
+  return r;
+}
+__device__ __forceinline__ void unpack4(uint2 u, float (&o)[4]) {
+  o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+  o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+
+// rows of the tile from global memory (row-major, 256 bf16) into LDS, 16 bytes per thread and pass; rows >= M are zero
+template <int RTL>
+__device__ __forceinline__ void rows_to_lds(const bf16* __restrict__ src, unsigned short* dst, int m0, int M, int tid) {
+#pragma unroll
+  for (int p = 0; p < 2 * RTL; ++p) {
+    const int row = p * 8 + (tid >> 5), c = (tid & 31) * 8;
+    const int g = m0 + row;
+    const uint4 v = ld16(src + (long)(g < M ? g : 0) * CD + c);
+    *reinterpret_cast<uint4*>(dst + row * XS + c) = g < M ? v : make_uint4(0, 0, 0, 0);
+  }
+}
+
+// LayerNorm of the tile's rows, src -> dst (both LDS, bf16), wave w takes rows w, w + 4, ...; one-pass moments in fp32 as
+// in the LayerNorm prologue of the GEMM kernels this chain replaces (gemm_mid.hip)
+template <int RTL>
+__device__ __forceinline__ void ln_rows(const unsigned short* src, unsigned short* dst, float4 g, float4 b, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4 * RTL; ++i) {
+    const int row = wave + 4 * i;
+    float v[4];
+    unpack4(*reinterpret_cast<const uint2*>(src + row * XS + 4 * lane), v);
+    float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+    float s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float mean = s1 * (1.0f / CD);
+    const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / CD) - mean * mean, 0.f) + 1e-5f);
+    *reinterpret_cast<uint2*>(dst + row * XS + 4 * lane) =
+        pack4((v[0] - mean) * rstd * g.x + b.x, (v[1] - mean) * rstd * g.y + b.y, (v[2] - mean) * rstd * g.z + b.z,
+              (v[3] - mean) * rstd * g.w + b.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ctx [M][256] --Wo, bo, + x--> x (in place) --LN--> --Wq, bq--> q   (--Wq2, bq2--> q2 when Wq2 != nullptr)
+template <int RTL>
+__global__ __launch_bounds__(256, 1) void dec_proj_chain_kernel(
+    const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ Wq,
+    const float* __restrict__ bq, bf16* __restrict__ q, const uint4* __restrict__ Wq2, const float* __restrict__ bq2,
+    bf16* __restrict__ q2, int M) {
+  constexpr int RT = 16 * RTL;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // 2 * RT * XS elements
+  unsigned short* bufA = lds;
+  unsigned short* bufB = lds + RT * XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * RT;
+  const int tw = 4 * wave;                               // this wave's first column tile of every 256-column block
+  WUnit u0, u1;
+  load_unit(u0, Wo, tw, NKS, 0, lane);
+  rows_to_lds<RTL>(ctx, bufA, m0, M, tid);
+  load_unit(u1, Wo, tw + 2, NKS, 0, lane);
+  // epilogue operands: columns n(ct) = 64 wave + 16 ct + 4 lg .. + 3 of row 16 rt + lr; the bias / LayerNorm vectors wait
+  // in LDS (registers are for the weight units)
+  const int nb = 64 * wave + 4 * lg;
+  float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS);     // [bo | bq | bq2 | gamma | beta] x 256
+  vec[tid] = bo[tid]; vec[256 + tid] = bq[tid]; vec[512 + tid] = Wq2 ? bq2[tid] : 0.f;
+  vec[768 + tid] = ln_g[tid]; vec[1024 + tid] = ln_b[tid];
+  uint2 res[RTL][4];
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int g = m0 + rt * 16 + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      res[rt][ct] = *reinterpret_cast<const uint2*>(x + (long)(g < M ? g : 0) * CD + nb + 16 * ct);
+  }
+  lds_barrier();
+  f32x4 acc[RTL][4];
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  load_unit(u0, Wq, tw, NKS, 0, lane);                   // next block's first unit lands while this block finishes
+  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  load_unit(u1, Wq, tw + 2, NKS, 0, lane);
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int row = rt * 16 + lr, g = m0 + row;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float r[4];
+      unpack4(res[rt][ct], r);
+      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
+      const uint2 o = pack4(acc[rt][ct][0] + bv.x + r[0], acc[rt][ct][1] + bv.y + r[1], acc[rt][ct][2] + bv.z + r[2],
+                            acc[rt][ct][3] + bv.w + r[3]);
+      *reinterpret_cast<uint2*>(bufB + row * XS + nb + 16 * ct) = o;
+      if (g < M) *reinterpret_cast<uint2*>(x + (long)g * CD + nb + 16 * ct) = o;
+    }
+  }
+  lds_barrier();                                       // x rows complete in bufB; every wave is past its reads of bufA
+  ln_rows<RTL>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
+               *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane), wave, lane);
+  lds_barrier();
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  if (Wq2) load_unit(u0, Wq2, tw, NKS, 0, lane);
+  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  if (Wq2) load_unit(u1, Wq2, tw + 2, NKS, 0, lane);
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int g = m0 + rt * 16 + lr;
+    if (g >= M) continue;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const float4 bv = *reinterpret_cast<const float4*>(vec + 256 + nb + 16 * ct);
+      *reinterpret_cast<uint2*>(q + (long)g * CD + nb + 16 * ct) =
+          pack4(acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w);
+    }
+  }
+  if (Wq2) {
+    zero_acc<RTL>(acc);
+    mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+    mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+#pragma unroll
+    for (int rt = 0; rt < RTL; ++rt) {
+      const int g = m0 + rt * 16 + lr;
+      if (g >= M) continue;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float4 bv = *reinterpret_cast<const float4*>(vec + 512 + nb + 16 * ct);
+        *reinterpret_cast<uint2*>(q2 + (long)g * CD + nb + 16 * ct) =
+            pack4(acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// x <- x' + fc2(gelu(fc1(LN(x')))) + b2  with  x' = x + Wco . ctx + bco;   grid = row tiles x splits, split sp owns hidden
+// units [256 sp, 256 sp + 256).  partial: [splits][M][256] fp32 slabs; sem: one zeroed int per row tile (left zero).
+template <int RTL>
+__global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
+    const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wco, const float* __restrict__ bco,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W1,
+    const float* __restrict__ b1, const uint4* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ partial,
+    int* __restrict__ sem, int M, int F, int splits) {
+  constexpr int RT = 16 * RTL;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];           // 2 * RT * XS + 8 elements: ONE LDS object
+  unsigned short* bufA = lds;
+  unsigned short* bufB = lds + RT * XS;
+  int* flag = reinterpret_cast<int*>(lds + 2 * RT * XS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  // split index fastest: the 8 XCDs each see ONE split's slice of W1 / W2 (workgroup ids are dealt round-robin), so a
+  // layer's 2 MB of feed-forward weights are 256 KB per XCD L2
+  const int sp = blockIdx.x % splits, tile = blockIdx.x / splits;
+  const int m0 = tile * RT;
+  PROBE(0);
+  const int tw = 4 * wave;                               // this wave's first column tile of every 256-column block
+  const int nks2 = F / 32;                               // k-steps of a whole fc2 row
+  WUnit u0, u1;
+  load_unit(u0, Wco, tw, NKS, 0, lane);
+  rows_to_lds<RTL>(ctx, bufA, m0, M, tid);
+  load_unit(u1, Wco, tw + 2, NKS, 0, lane);
+  const int nb = 64 * wave + 4 * lg;
+  float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS + 8);  // [bco | b1 of this split | b2 | gamma | beta] x 256
+  vec[tid] = bco[tid]; vec[256 + tid] = b1[256 * sp + tid]; vec[512 + tid] = b2[tid];
+  vec[768 + tid] = ln_g[tid]; vec[1024 + tid] = ln_b[tid];
+  uint2 res[RTL][4];
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int g = m0 + rt * 16 + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      res[rt][ct] = *reinterpret_cast<const uint2*>(x + (long)(g < M ? g : 0) * CD + nb + 16 * ct);
+  }
+  lds_barrier();
+  PROBE(1);
+  f32x4 acc[RTL][4];
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  load_unit(u0, W1, 16 * sp + tw, NKS, 0, lane);         // fc1 rows (hidden units) of this split, this wave's 64
+  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  load_unit(u1, W1, 16 * sp + tw + 2, NKS, 0, lane);
+  PROBE(2);
+  // x' = bf16(x + Wco . ctx + bco) -> bufB (kept to the end: the residual of the reduction)
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int row = rt * 16 + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float r[4];
+      unpack4(res[rt][ct], r);
+      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
+      *reinterpret_cast<uint2*>(bufB + row * XS + nb + 16 * ct) =
+          pack4(acc[rt][ct][0] + bv.x + r[0], acc[rt][ct][1] + bv.y + r[1], acc[rt][ct][2] + bv.z + r[2],
+                acc[rt][ct][3] + bv.w + r[3]);
+    }
+  }
+  lds_barrier();
+  ln_rows<RTL>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
+               *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane), wave, lane);
+  lds_barrier();
+  PROBE(3);
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  load_unit(u0, W2, tw, nks2, NKS * sp, lane);           // fc2 columns of this wave, k-steps (hidden units) of this split
+  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  load_unit(u1, W2, tw + 2, nks2, NKS * sp, lane);
+  PROBE(4);
+  lds_barrier();                                               // every wave is done reading LN(x') from bufA
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int row = rt * 16 + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const float4 bv = *reinterpret_cast<const float4*>(vec + 256 + nb + 16 * ct);
+      const f32x2 h0 = gelu_fast2(f32x2{acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y});
+      const f32x2 h1 = gelu_fast2(f32x2{acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w});
+      *reinterpret_cast<uint2*>(bufA + row * XS + nb + 16 * ct) = pack4(h0.x, h0.y, h1.x, h1.y);
+    }
+  }
+  lds_barrier();
+  PROBE(5);
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  PROBE(6);
+  float* slab = partial + (long)sp * M * CD;
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int g = m0 + rt * 16 + lr;
+    if (g >= M) continue;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      *reinterpret_cast<float4*>(slab + (long)g * CD + nb + 16 * ct) =
+          float4{acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};
+  }
+  // ---- hand-off: publish the slab, draw a ticket; the last arriver of the row tile reduces
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  PROBE(7);
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(sem + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == splits - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  PROBE(8);
+  if (!*flag) return;
+  PROBE_LAST(0);
+#pragma unroll
+  for (int i = 0; i < 4 * RTL; ++i) {
+    const int row = wave + 4 * i, g = m0 + row;
+    if (g >= M) continue;
+    float r[4];
+    unpack4(*reinterpret_cast<const uint2*>(bufB + row * XS + 4 * lane), r);
+    const float4 bo4 = *reinterpret_cast<const float4*>(vec + 512 + 4 * lane);
+    float4 s = float4{bo4.x + r[0], bo4.y + r[1], bo4.z + r[2], bo4.w + r[3]};
+    for (int k0 = 0; k0 < splits; k0 += 8) {                       // fixed order: the sum does not depend on who is last
+      float4 p[8];                                                 // 8 slab reads in flight (one dependent round trip,
+#pragma unroll                                                     //  not eight); out-of-range slots re-read the last slab
+      for (int j = 0; j < 8; ++j)
+        p[j] = *reinterpret_cast<const float4*>(partial + ((long)min(k0 + j, splits - 1) * M + g) * CD + 4 * lane);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float m = k0 + j < splits ? 1.f : 0.f;
+        s.x = fmaf(p[j].x, m, s.x); s.y = fmaf(p[j].y, m, s.y); s.z = fmaf(p[j].z, m, s.z); s.w = fmaf(p[j].w, m, s.w);
+      }
+    }
+    *reinterpret_cast<uint2*>(x + (long)g * CD + 4 * lane) = pack4(s.x, s.y, s.z, s.w);
+  }
+  PROBE_LAST(1);
+  if (tid == 0) __hip_atomic_store(sem + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
+
+}  // namespace
+
+bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bool packed) {
+  return h->dec_chain_on && packed && dtype == SIMULST_BF16 && D == CD && F >= 256 && F % 256 == 0 && F / 256 <= 32 &&
+         B >= h->dec_chain_min_rows && B <= h->dec_chain_max_rows;
+}
+
+static int rtl_for(const simulst_handle* h, int B) { return B <= h->dec_chain_rt16_max_rows ? 1 : (B <= h->dec_chain_rt32_max_rows ? 2 : 4); }
+constexpr int lds_bytes(int rtl) { return (2 * 16 * rtl * XS + 8) * 2 + 5 * 256 * 4; }   // row buffers, flag, 5 vectors
+
+// 64-row tiles need 70 KB of LDS: above the 64 KB a kernel gets without asking
+static int raise_lds_limits(simulst_handle* h) {
+  if (h->dec_chain_lds_attr_set) return SIMULST_OK;
+  hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
+  if (e != hipSuccess) { h->err = "simulst_mma_decode: cannot raise the dynamic LDS limit of the layer chains"; return (int)e; }
+  h->dec_chain_lds_attr_set = true;
+  return SIMULST_OK;
+}
+
+int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* Wo, const float* bo, const float* ln_g,
+                      const float* ln_b, const void* Wq, const float* bq, void* q, const void* Wq2, const float* bq2,
+                      void* q2, int B) {
+  if (int rc = raise_lds_limits(h)) return rc;
+  KTimer t(h, SIMULST_K_LINEAR_SKINNY);
+  const int rtl = rtl_for(h, B);
+#define PC(R)                                                                                                          \
+  hipLaunchKernelGGL((dec_proj_chain_kernel<R>), dim3((B + 16 * R - 1) / (16 * R)), dim3(256), lds_bytes(R), h->stream, \
+                     (const bf16*)ctx, (bf16*)x, (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q,     \
+                     (const uint4*)Wq2, bq2, (bf16*)q2, B)
+  if (rtl == 1) PC(1); else if (rtl == 2) PC(2); else PC(4);
+#undef PC
+  return sl_launch_status(h, "simulst_mma_decode(out-proj + LN + q-proj chain)");
+}
+
+int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
+                     const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
+                     int32_t* sem, int B, int F) {
+  if (int rc = raise_lds_limits(h)) return rc;
+  KTimer t(h, SIMULST_K_LINEAR_SKINNY);
+  const int rtl = rtl_for(h, B), splits = F / 256;
+#define FC(R)                                                                                                          \
+  hipLaunchKernelGGL((dec_ffn_chain_kernel<R>), dim3(((B + 16 * R - 1) / (16 * R)) * splits), dim3(256), lds_bytes(R), h->stream, \
+                     (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,             \
+                     (const uint4*)W2, b2, partial, sem, B, F, splits)
+  if (rtl == 1) FC(1); else if (rtl == 2) FC(2); else FC(4);
+#undef FC
+#ifdef SL_PROBE
+  {
+    static int calls = 0;
+    if ((++calls % 197) == 0) {
+      (void)hipStreamSynchronize(h->stream);
+      long t[32];
+      (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(sl_probe_chain), sizeof t);
+      fprintf(stderr, "[probe ffn chain] B=%d: ctx+Wco landed %.2f  mma0 %.2f  epi0+LN %.2f  mma1 %.2f  gelu %.2f  mma2 %.2f  slab stored %.2f  ticket %.2f | total %.2f us; last arriver of tile 1: reduce %.2f us, ends %.2f us after block 9 started\n",
+              B, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01,
+              (t[6] - t[5]) * 0.01, (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[8] - t[0]) * 0.01, (t[17] - t[16]) * 0.01,
+              (t[17] - t[0]) * 0.01);
+    }
+  }
+#endif
+  return sl_launch_status(h, "simulst_mma_decode(feed-forward chain)");
+}
+
+// C-ABI entry points of the two chains (the decode loop calls the internal forms above; these exist so that each chain
+// can be checked against a plain fp32 reference on its own, tests/test_hip_dec_chain.py)
+extern "C" int simulst_decoder_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* wo_fm, const float* bo,
+                                          const float* ln_g, const float* ln_b, const void* wq_fm, const float* bq, void* q,
+                                          const void* wq2_fm, const float* bq2, void* q2, int32_t B, int32_t D,
+                                          int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, ctx); SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, wo_fm); SL_CHECK_NULL(h, bo); SL_CHECK_NULL(h, ln_g);
+  SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, wq_fm); SL_CHECK_NULL(h, bq); SL_CHECK_NULL(h, q);
+  if (wq2_fm) { SL_CHECK_NULL(h, bq2); SL_CHECK_NULL(h, q2); }
+  SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_decoder_proj_chain: bf16 only (fp32 keeps one launch per GEMM)");
+  SL_REQUIRE(h, D == CD && B >= 0, SIMULST_E_SHAPE, "simulst_decoder_proj_chain: D == 256");
+  if (B == 0) return SIMULST_OK;
+  return sl_dec_proj_chain(h, ctx, x, wo_fm, bo, ln_g, ln_b, wq_fm, bq, q, wq2_fm, bq2, q2, B);
+}
+
+extern "C" int simulst_decoder_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* wco_fm, const float* bco,
+                                         const float* ln_g, const float* ln_b, const void* w1_fm, const float* b1,
+                                         const void* w2_fm, const float* b2, float* partial, int32_t* sem, int32_t B,
+                                         int32_t D, int32_t F, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, ctx); SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, wco_fm); SL_CHECK_NULL(h, bco); SL_CHECK_NULL(h, ln_g);
+  SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, w1_fm); SL_CHECK_NULL(h, b1); SL_CHECK_NULL(h, w2_fm); SL_CHECK_NULL(h, b2);
+  SL_CHECK_NULL(h, partial); SL_CHECK_NULL(h, sem);
+  SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_decoder_ffn_chain: bf16 only (fp32 keeps one launch per GEMM)");
+  SL_REQUIRE(h, D == CD && B >= 0 && F >= 256 && F % 256 == 0 && F / 256 <= 32, SIMULST_E_SHAPE,
+             "simulst_decoder_ffn_chain: D == 256, F a multiple of 256 up to 8192");
+  if (B == 0) return SIMULST_OK;
+  return sl_dec_ffn_chain(h, ctx, x, wco_fm, bco, ln_g, ln_b, w1_fm, b1, w2_fm, b2, partial, sem, B, F);
+}

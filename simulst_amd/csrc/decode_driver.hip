@@ -570,6 +570,14 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   // LN2 + query projection inside the policy/cross-attention launch (few rows: one launch less on the dependent
   // chain) or as its own GEMM (many rows: no per-workgroup re-read of the projection weights)
   const bool fuse_q = split || B <= h->fuse_q_max_rows;
+  // row-local chains (dec_chain.hip) for co-scheduled batches: { out-proj + residual, LN + q-proj(s) } in one launch,
+  // { cross out-proj + residual, LN + fc1 + GELU, fc2 + residual } in another -- 5 launches per layer instead of 8-9
+  const bool chain = !split && !fuse_q && !h->force_unfused_decode && dd->ffn_partial && dd->ffn_sem &&
+                     sl_dec_chain_ok(h, dt, B, D, F, pk != 0);
+  if (chain) {                                   // tickets are left zero by every launch; a call aborted half-way must not poison the next
+    hipError_t e = hipMemsetAsync(dd->ffn_sem, 0, sizeof(int32_t) * ((B + 15) / 16), h->stream);
+    if (e != hipSuccess) { h->err = std::string("simulst_mma_decode: ticket reset: ") + hipGetErrorString(e); return (int)e; }
+  }
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_dec_layer& L = layers[l];
@@ -585,7 +593,8 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         if ((rc = lin(h, dt, B, 3 * D, D, dd->x, L.wqkv, L.bqkv, nullptr, dd->qkv, SIMULST_EPI_BIAS, L.ln1_g, L.ln1_b, pk))) return rc;
         if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
                                     dd->ctx, B, H, d, dd->cap, dt))) return rc;
-        if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
+        if (!chain)
+          if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
       }
       // (residual add of the head-split block +) LN2 + query projection(s) + policy + cross-attention in ONE launch:
       // each (head, utterance) workgroup normalises its residual row and projects its own 64 query channels
@@ -602,13 +611,23 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         // many rows: every (head, row) workgroup re-streaming its 32 KB of the query projection through L2 costs
         // more than one LN-prologue GEMM launch that reads the weights once per row tile
         const void* qsoft = L.c_wq_soft ? dd->q2 : dd->q;
-        if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq, L.c_bq, nullptr, dd->q, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b, pk))) return rc;
-        if (L.c_wq_soft)
-          if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq_soft, L.c_bq_soft, nullptr, dd->q2, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b, pk))) return rc;
+        if (chain) {
+          if ((rc = sl_dec_proj_chain(h, dd->ctx, dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, L.c_bq, dd->q, L.c_wq_soft,
+                                      L.c_bq_soft, dd->q2, B))) return rc;
+        } else {
+          if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq, L.c_bq, nullptr, dd->q, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b, pk))) return rc;
+          if (L.c_wq_soft)
+            if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq_soft, L.c_bq_soft, nullptr, dd->q2, SIMULST_EPI_BIAS, L.ln2_g, L.ln2_b, pk))) return rc;
+        }
         if ((rc = policy_cross(h, dd->q, qsoft, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
                                dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
                                dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, nullptr, nullptr,
                                nullptr, nullptr, nullptr, nullptr, nullptr, ctlp ? &ctl : nullptr, nullptr))) return rc;
+      }
+      if (chain && B <= h->dec_chain_ffn_max_rows) {
+        if ((rc = sl_dec_ffn_chain(h, dd->ctx, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2,
+                                   dd->ffn_partial, dd->ffn_sem, B, F))) return rc;
+        continue;
       }
       if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, xin, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
       if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b, pk))) return rc;

@@ -28,6 +28,19 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_SKINNY_MIN_BLOCKS_TALL")) h->skinny_min_blocks_tall = atoi(e);
   h->fuse_q_max_rows = 128;
   if (const char* e = getenv("SIMULST_FUSE_Q_MAX_ROWS")) h->fuse_q_max_rows = atoi(e);
+  h->dec_chain_on = true;
+  if (const char* e = getenv("SIMULST_DEC_CHAIN")) h->dec_chain_on = atoi(e) != 0;
+  h->dec_chain_min_rows = 129;
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_MIN_ROWS")) h->dec_chain_min_rows = atoi(e);
+  h->dec_chain_rt16_max_rows = 1024;
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_RT16_MAX_ROWS")) h->dec_chain_rt16_max_rows = atoi(e);
+  h->dec_chain_rt32_max_rows = 2048;
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_RT32_MAX_ROWS")) h->dec_chain_rt32_max_rows = atoi(e);
+  h->dec_chain_max_rows = 1 << 30;
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_MAX_ROWS")) h->dec_chain_max_rows = atoi(e);
+  h->dec_chain_ffn_max_rows = 0;        // measured: the feed-forward chain does not beat its three launches (dec_chain.hip)
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_FFN_MAX_ROWS")) h->dec_chain_ffn_max_rows = atoi(e);
+  h->dec_chain_lds_attr_set = false;
   h->graph_exec = nullptr;
   h->ctc_lds_attr_set = false;
   h->ffn_lds_attr_set = false;

@@ -207,6 +207,9 @@ class MMADecoder:
         # weights, so it loses as soon as independent work shares the chip (352 k vs 404 k with 3 streams,
         # 404 k vs 527 k at 128 rows) => off by default, SIMULST_HEAD_SPLIT=1 / .head_split = True turns it on.
         self.head_split = os.environ.get("SIMULST_HEAD_SPLIT", "0") == "1"
+        # row-local layer chains (csrc/dec_chain.hip) for co-scheduled bf16 batches: the library takes them from
+        # SIMULST_DEC_CHAIN_MIN_ROWS rows on when the slab workspace below is passed
+        self.layer_chains = os.environ.get("SIMULST_LAYER_CHAINS", "1") == "1"
         D, F, V = cfg.embed_dim, cfg.ffn_dim, cfg.vocab
         # decode-loop weights in MFMA-fragment order (1 KB contiguous per wave load) when the shapes allow
         self.fragment_major = D % 64 == 0 and F % 64 == 0 and V % 16 == 0 and cfg.head_dim % 16 == 0
@@ -441,12 +444,17 @@ class MMADecoder:
                      # head-split self-attention block workspace (simulst_decoder_desc.x_mid / partial_self)
                      "x_mid": torch.empty(B, D, device=dev, dtype=dt_),
                      "p_self": torch.empty(B, cfg.num_heads, D, device=dev, dtype=torch.float32)}
+            if self.layer_chains and dt_ == torch.bfloat16 and D == 256 and cfg.ffn_dim % 256 == 0:
+                # row-local layer chains (simulst_decoder_desc.ffn_partial / ffn_sem): fp32 slabs of the split feed-forward
+                st.ws["ffn_partial"] = torch.empty(cfg.ffn_dim // 256, B, D, device=dev, dtype=torch.float32)
+                st.ws["ffn_sem"] = torch.zeros((B + 15) // 16, device=dev, dtype=torch.int32)
         if getattr(st, "structs_fragment_major", None) != self.fragment_major:   # states are cached across calls
             st.layer_structs = self._layer_structs(st)
             st.structs_fragment_major = self.fragment_major
         ws = st.ws
         ensure_positions(self.w, st.cap + cfg.padding_idx + 2)
         split = self.head_split and self.fragment_major
+        chains = self.layer_chains and self.fragment_major and "ffn_partial" in ws
         out_proj = self.w.out_proj_packed if self.fragment_major else self.w.out_proj
         return _lib.DecoderDesc(B, D, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st.cap, st.S_cap,
                                 _lib.F32 if dt_ == torch.float32 else _lib.BF16, self.attn_enum, self.ratio_arg,
@@ -456,7 +464,9 @@ class MMADecoder:
                                 st.enc_len.data_ptr(), st.n_prev.data_ptr(), ws["x"].data_ptr(), ws["qkv"].data_ptr(),
                                 ws["ctx"].data_ptr(), ws["q"].data_ptr(), ws["q2"].data_ptr(), ws["hidden"].data_ptr(),
                                 ws["logits"].data_ptr(), ws["x_mid"].data_ptr() if split else None,
-                                ws["p_self"].data_ptr() if split else None, int(self.fragment_major))
+                                ws["p_self"].data_ptr() if split else None, int(self.fragment_major),
+                                ws["ffn_partial"].data_ptr() if chains else None,
+                                ws["ffn_sem"].data_ptr() if chains else None)
 
     def stream_steps(self, st: DecoderState, tokens: torch.Tensor, ctl, n_iter: int):
         """n_iter masked policy()/predict() rounds of a batch of streams (simulst_mma_stream_steps): rows read

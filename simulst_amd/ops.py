@@ -286,6 +286,33 @@ class Ops:
                      "simulst_decoder_cross_attention")
         return out, beta
 
+    def decoder_proj_chain(self, ctx, x, wo_fm, bo, ln, wq_fm, bq, q=None, wq2_fm=None, bq2=None, q2=None):
+        """x <- x + Wo ctx + bo (in place);  q = Wq LN(x) + bq  (and q2 with wq2_fm) in ONE launch
+        (simulst_decoder_proj_chain; bf16, D == 256, fragment-major weights)."""
+        B, D = x.shape
+        if q is None:
+            q = torch.empty_like(x)
+        if wq2_fm is not None and q2 is None:
+            q2 = torch.empty_like(x)
+        self.h.check(self.lib.simulst_decoder_proj_chain(self.h.ptr, _p(ctx), _p(x), _p(wo_fm), _p(bo), _p(ln[0]), _p(ln[1]),
+                                                         _p(wq_fm), _p(bq), _p(q), _p(wq2_fm), _p(bq2), _p(q2), B, D, dt(x)),
+                     "simulst_decoder_proj_chain")
+        return q, q2
+
+    def decoder_ffn_chain(self, ctx, x, wco_fm, bco, ln, w1_fm, b1, w2_fm, b2, partial=None, sem=None):
+        """x <- x' + W2 gelu(W1 LN(x') + b1) + b2 with x' = x + Wco ctx + bco, in ONE launch
+        (simulst_decoder_ffn_chain; bf16, D == 256, F % 256 == 0, fragment-major weights)."""
+        B, D = x.shape
+        F = w1_fm.shape[0]
+        if partial is None:
+            partial = torch.empty(F // 256, B, D, device=x.device, dtype=torch.float32)
+        if sem is None:
+            sem = torch.zeros((B + 15) // 16, device=x.device, dtype=torch.int32)
+        self.h.check(self.lib.simulst_decoder_ffn_chain(self.h.ptr, _p(ctx), _p(x), _p(wco_fm), _p(bco), _p(ln[0]), _p(ln[1]),
+                                                        _p(w1_fm), _p(b1), _p(w2_fm), _p(b2), _p(partial), _p(sem), B, D, F,
+                                                        dt(x)), "simulst_decoder_ffn_chain")
+        return x
+
     def policy_cross_attention(self, qm, qs, Kmono, Ksoft, V, head_step, *, H, ratio, attn_type, key_len,
                                tgt_idx=None, energy_bias=0.0, waitk_k=0, online=False, mass_preservation=True,
                                out=None):
