@@ -491,13 +491,22 @@ int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, c
  *                modules/monotonic_multihead_attention.py as run by models/mma_model.py:99-135
  *   ffn chain:   x' = bf16(x + Wco ctx + bco);  x <- bf16(x' + W2 gelu(W1 LN(x') + b1) + b2)
  *                = encoder_attn out_proj + residual, final_layer_norm, fc1, activation, fc2, residual of the same layer.
- *                partial: fp32 [F / 256][B][D] scratch; sem: (B + 15) / 16 int32, zero on entry, zero on return. */
+ *                partial: fp32 [F / 256][B][D] slabs (one per 256 hidden units).  x_mid == NULL: the last-arriving
+ *                workgroup of a row tile adds the slabs inside the launch (sem: (B + 15) / 16 int32, zero on entry, zero on
+ *                return).  x_mid != NULL: x' is written to x_mid, x is left alone and the slabs are added by the following
+ *                simulst_decoder_slab_sum_qkv (the form the decode loop uses: the launch boundary is the hand-off).
+ *   slab sum:    x <- bf16(x_mid + b2 + slab 0 + slab 1 + ...) (split order: deterministic);  with wqkv_fm != NULL also
+ *                qkv [B][3 D] <- Wqkv LN(x) + bqkv, the next layer's self_attn_layer_norm + q / k / v projections. */
 int simulst_decoder_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* wo_fm, const float* bo,
                                const float* ln_g, const float* ln_b, const void* wq_fm, const float* bq, void* q,
                                const void* wq2_fm, const float* bq2, void* q2, int32_t B, int32_t D, int32_t dtype);
 int simulst_decoder_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* wco_fm, const float* bco,
                               const float* ln_g, const float* ln_b, const void* w1_fm, const float* b1, const void* w2_fm,
-                              const float* b2, float* partial, int32_t* sem, int32_t B, int32_t D, int32_t F, int32_t dtype);
+                              const float* b2, float* partial, int32_t* sem, void* x_mid, int32_t B, int32_t D, int32_t F,
+                              int32_t dtype);
+int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2,
+                                 const float* ln_g, const float* ln_b, const void* wqkv_fm, const float* bqkv, void* qkv,
+                                 int32_t B, int32_t D, int32_t F, int32_t dtype);
 
 /* policy + cross-attention of one layer for one step in ONE launch (simulst_step_p_choose +
  * simulst_mma_step_search + simulst_decoder_cross_attention, same results). qm/qs: monotonic / soft

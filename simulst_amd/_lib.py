@@ -117,7 +117,8 @@ SIGNATURES = {
     "simulst_policy_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                        _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_decoder_proj_chain": [_vp] * 13 + [_i32, _i32, _i32],
-    "simulst_decoder_ffn_chain": [_vp] * 13 + [_i32, _i32, _i32, _i32],
+    "simulst_decoder_ffn_chain": [_vp] * 14 + [_i32, _i32, _i32, _i32],
+    "simulst_decoder_slab_sum_qkv": [_vp] * 10 + [_i32, _i32, _i32, _i32],
 }
 
 _lib = None

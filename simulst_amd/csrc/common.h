@@ -258,7 +258,9 @@ int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* W
                       void* q2, int B);
 int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
                      const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
-                     int32_t* sem, int B, int F);
+                     int32_t* sem, void* x_mid, int B, int F);
+int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
+                     const float* ln_b, const void* Wqkv, const float* bqkv, void* qkv, int B, int F);
 int sl_self_attention_fused(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* Wqkv,
                             const float* bqkv, const void* Wo, void* k_cache, void* v_cache, const int32_t* n_prev,
                             int np_uniform, float* partial, int32_t B, int32_t H, int32_t d, int32_t cap,

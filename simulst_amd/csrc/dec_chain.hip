@@ -60,30 +60,46 @@ __device__ __forceinline__ void lds_barrier() {
 // tiles (16 fragments = 64 VGPRs): two units live in registers at any time, the one being multiplied and the next one in
 // flight.  (Holding two whole blocks -- 256 VGPRs of weights -- made hipcc park fragments in AGPRs behind vmcnt(0) waits:
 // every load became a dependent round trip, 2.7 us per phase.)
-struct WUnit { uint4 f[2][NKS]; };
+struct WUnit { u32x4_t f[2][NKS]; };
 
 // fragments (tn, s0 + s) and (tn + 1, s0 + s), s < 8, of a fragment-major matrix with nksT k-steps per column tile
 __device__ __forceinline__ void load_unit(WUnit& u, const uint4* __restrict__ w, int tn, int nksT, int s0, int lane) {
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) u.f[c][s] = w[((long)(tn + c) * nksT + s0 + s) * 64 + lane];
+    for (int s = 0; s < NKS; ++s) u.f[c][s] = *reinterpret_cast<const u32x4_t*>(w + ((long)(tn + c) * nksT + s0 + s) * 64 + lane);
 }
 
 // acc[rt][C0 + c][e] += X[row 16 rt + lr][:] . W[col 16 (tn + c) + 4 lg + e][:]   (X rows from LDS, K = 256)
+//
+// The empty asm after every k-step keeps the step's operand fragments alive (and is ordered after its MFMAs through the
+// accumulators it names).  Without it hipcc (ROCm 7.2) places the destination of a v_mfma_f32_16x16x32_bf16 whose srcC dies
+// (or is the constant 0) on the registers of the instruction's OWN A or B operand -- "v_mfma_f32_16x16x32_bf16 v[20:23],
+// v[20:23], v[144:147], 0" -- and on MI355X workgroups built that way produced run-to-run different rows (slab rows off by
+// ~1e-2, other rows every launch; fewer overlaps, fewer such rows): the 8-pass instruction evidently still reads operands
+// after it has begun to write.  A value that is still live cannot share registers with a new one.
 template <int RTL, int C0>
 __device__ __forceinline__ void mma_unit(f32x4 (&acc)[RTL][4], const WUnit& u, const unsigned short* xs, int lr, int lg) {
 #pragma unroll
   for (int s = 0; s < NKS; ++s) {
-    uint4 xf[RTL];
+    u32x4_t xf[RTL];
 #pragma unroll
-    for (int rt = 0; rt < RTL; ++rt) xf[rt] = *reinterpret_cast<const uint4*>(xs + (rt * 16 + lr) * XS + 32 * s + 8 * lg);
+    for (int rt = 0; rt < RTL; ++rt) xf[rt] = *reinterpret_cast<const u32x4_t*>(xs + (rt * 16 + lr) * XS + 32 * s + 8 * lg);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int rt = 0; rt < RTL; ++rt)
-        acc[rt][C0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&u.f[c][s]),
-                                                                  *reinterpret_cast<const bf16x8_t*>(&xf[rt]), acc[rt][C0 + c], 0, 0, 0);
+        acc[rt][C0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, u.f[c][s]),
+                                                                  __builtin_bit_cast(bf16x8_t, xf[rt]), acc[rt][C0 + c], 0, 0, 0);
+    if constexpr (RTL == 1)
+      asm volatile("" :: "v"(u.f[0][s]), "v"(u.f[1][s]), "v"(xf[0]), "v"(acc[0][C0]), "v"(acc[0][C0 + 1]));
+    else if constexpr (RTL == 2)
+      asm volatile("" :: "v"(u.f[0][s]), "v"(u.f[1][s]), "v"(xf[0]), "v"(xf[1]), "v"(acc[0][C0]), "v"(acc[0][C0 + 1]),
+                   "v"(acc[1][C0]), "v"(acc[1][C0 + 1]));
+    else
+      asm volatile("" :: "v"(u.f[0][s]), "v"(u.f[1][s]), "v"(xf[0]), "v"(xf[1]), "v"(xf[2]), "v"(xf[3]), "v"(acc[0][C0]),
+                   "v"(acc[0][C0 + 1]), "v"(acc[1][C0]), "v"(acc[1][C0 + 1]), "v"(acc[2][C0]), "v"(acc[2][C0 + 1]),
+                   "v"(acc[3][C0]), "v"(acc[3][C0 + 1]));
   }
 }
 
@@ -139,6 +155,24 @@ __device__ __forceinline__ void ln_rows(const unsigned short* src, unsigned shor
         pack4((v[0] - mean) * rstd * g.x + b.x, (v[1] - mean) * rstd * g.y + b.y, (v[2] - mean) * rstd * g.z + b.z,
               (v[3] - mean) * rstd * g.w + b.w);
   }
+}
+
+// x row = bf16(x' + b2 + slab 0 + slab 1 + ...): the split-order sum of the feed-forward chain, columns 4 lane .. 4 lane + 3
+__device__ __forceinline__ uint2 add_slabs(const float (&r)[4], float4 b2, const float* __restrict__ partial, int splits, int M,
+                                           int g, int lane) {
+  float4 s = float4{b2.x + r[0], b2.y + r[1], b2.z + r[2], b2.w + r[3]};
+  for (int k0 = 0; k0 < splits; k0 += 8) {
+    float4 p[8];                                                   // 8 slab reads in flight (one dependent round trip,
+#pragma unroll                                                     //  not eight); out-of-range slots re-read the last slab
+    for (int j = 0; j < 8; ++j)
+      p[j] = *reinterpret_cast<const float4*>(partial + ((long)min(k0 + j, splits - 1) * M + g) * CD + 4 * lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float m = k0 + j < splits ? 1.f : 0.f;
+      s.x = fmaf(p[j].x, m, s.x); s.y = fmaf(p[j].y, m, s.y); s.z = fmaf(p[j].z, m, s.z); s.w = fmaf(p[j].w, m, s.w);
+    }
+  }
+  return pack4(s.x, s.y, s.z, s.w);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -236,12 +270,14 @@ __global__ __launch_bounds__(256, 1) void dec_proj_chain_kernel(
 // ---------------------------------------------------------------------------------------------------------------------
 // x <- x' + fc2(gelu(fc1(LN(x')))) + b2  with  x' = x + Wco . ctx + bco;   grid = row tiles x splits, split sp owns hidden
 // units [256 sp, 256 sp + 256).  partial: [splits][M][256] fp32 slabs; sem: one zeroed int per row tile (left zero).
-template <int RTL>
+// HANDOFF false: the kernel ends after the slab stores (split 0 has written x' to x); the slabs are added by the NEXT launch
+// (dec_qkv_chain_kernel), where the kernel boundary is the hand-off and every workgroup of the row tile reduces in parallel.
+template <int RTL, bool HANDOFF>
 __global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
     const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wco, const float* __restrict__ bco,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W1,
     const float* __restrict__ b1, const uint4* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ partial,
-    int* __restrict__ sem, int M, int F, int splits) {
+    int* __restrict__ sem, bf16* __restrict__ x_mid, int M, int F, int splits) {
   constexpr int RT = 16 * RTL;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];           // 2 * RT * XS + 8 elements: ONE LDS object
   unsigned short* bufA = lds;
@@ -289,9 +325,14 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
       float r[4];
       unpack4(res[rt][ct], r);
       const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
-      *reinterpret_cast<uint2*>(bufB + row * XS + nb + 16 * ct) =
-          pack4(acc[rt][ct][0] + bv.x + r[0], acc[rt][ct][1] + bv.y + r[1], acc[rt][ct][2] + bv.z + r[2],
-                acc[rt][ct][3] + bv.w + r[3]);
+      const uint2 o = pack4(acc[rt][ct][0] + bv.x + r[0], acc[rt][ct][1] + bv.y + r[1], acc[rt][ct][2] + bv.z + r[2],
+                            acc[rt][ct][3] + bv.w + r[3]);
+      *reinterpret_cast<uint2*>(bufB + row * XS + nb + 16 * ct) = o;
+      if constexpr (!HANDOFF) {
+        // x' leaves through split 0's workgroup; the other splits of the tile read x only in their prologue -- but they may
+        // not have run yet, so x' goes to the spare buffer and the next launch takes it from there
+        if (sp == 0 && m0 + row < M) *reinterpret_cast<uint2*>(x_mid + (long)(m0 + row) * CD + nb + 16 * ct) = o;
+      }
     }
   }
   lds_barrier();
@@ -333,6 +374,7 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
       *reinterpret_cast<float4*>(slab + (long)g * CD + nb + 16 * ct) =
           float4{acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]};
   }
+  if constexpr (!HANDOFF) return;
   // ---- hand-off: publish the slab, draw a ticket; the last arriver of the row tile reduces
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -358,23 +400,68 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
     if (g >= M) continue;
     float r[4];
     unpack4(*reinterpret_cast<const uint2*>(bufB + row * XS + 4 * lane), r);
-    const float4 bo4 = *reinterpret_cast<const float4*>(vec + 512 + 4 * lane);
-    float4 s = float4{bo4.x + r[0], bo4.y + r[1], bo4.z + r[2], bo4.w + r[3]};
-    for (int k0 = 0; k0 < splits; k0 += 8) {                       // fixed order: the sum does not depend on who is last
-      float4 p[8];                                                 // 8 slab reads in flight (one dependent round trip,
-#pragma unroll                                                     //  not eight); out-of-range slots re-read the last slab
-      for (int j = 0; j < 8; ++j)
-        p[j] = *reinterpret_cast<const float4*>(partial + ((long)min(k0 + j, splits - 1) * M + g) * CD + 4 * lane);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float m = k0 + j < splits ? 1.f : 0.f;
-        s.x = fmaf(p[j].x, m, s.x); s.y = fmaf(p[j].y, m, s.y); s.z = fmaf(p[j].z, m, s.z); s.w = fmaf(p[j].w, m, s.w);
-      }
-    }
-    *reinterpret_cast<uint2*>(x + (long)g * CD + 4 * lane) = pack4(s.x, s.y, s.z, s.w);
+    *reinterpret_cast<uint2*>(x + (long)g * CD + 4 * lane) =
+        add_slabs(r, *reinterpret_cast<const float4*>(vec + 512 + 4 * lane), partial, splits, M, g, lane);
   }
   PROBE_LAST(1);
   if (tid == 0) __hip_atomic_store(sem + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The launch after a feed-forward chain without hand-off:  x <- bf16(x' + b2 + slabs)  (x' from x_mid), then, unless
+// W == nullptr, qkv[:, 256 cb .. 256 cb + 255] = W LN(x) + b for column block cb = blockIdx.x % n_cb  (LN1 + QKV of the next
+// layer: n_cb = 3).  Every column block's workgroup adds the slabs of its row tile itself (parallel, no hand-off); block 0
+// writes x.  W == nullptr (after the last layer): grid = row tiles, reduction only.
+template <int RTL>
+__global__ __launch_bounds__(256, 1) void dec_qkv_chain_kernel(
+    const bf16* __restrict__ x_mid, bf16* __restrict__ x, const float* __restrict__ partial, const float* __restrict__ b2,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W, const float* __restrict__ bias,
+    bf16* __restrict__ out, int M, int splits, int n_cb) {
+  constexpr int RT = 16 * RTL;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // lds_bytes(RTL)
+  unsigned short* bufA = lds;
+  unsigned short* bufB = lds + RT * XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int cb = blockIdx.x % n_cb, m0 = (blockIdx.x / n_cb) * RT;
+  const int tw = 16 * cb + 4 * wave;
+  WUnit u0, u1;
+  if (W) { load_unit(u0, W, tw, NKS, 0, lane); load_unit(u1, W, tw + 2, NKS, 0, lane); }
+  float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS);     // [bias of this column block | gamma | beta] x 256
+  if (W) { vec[tid] = bias[256 * cb + tid]; vec[256 + tid] = ln_g[tid]; vec[512 + tid] = ln_b[tid]; }
+  const float4 b24 = *reinterpret_cast<const float4*>(b2 + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < 4 * RTL; ++i) {
+    const int row = wave + 4 * i, g = m0 + row;
+    uint2 o = make_uint2(0, 0);
+    if (g < M) {
+      float r[4];
+      unpack4(*reinterpret_cast<const uint2*>(x_mid + (long)g * CD + 4 * lane), r);
+      o = add_slabs(r, b24, partial, splits, M, g, lane);
+      if (cb == 0) *reinterpret_cast<uint2*>(x + (long)g * CD + 4 * lane) = o;
+    }
+    *reinterpret_cast<uint2*>(bufB + row * XS + 4 * lane) = o;
+  }
+  if (!W) return;
+  lds_barrier();
+  ln_rows<RTL>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 256 + 4 * lane),
+               *reinterpret_cast<const float4*>(vec + 512 + 4 * lane), wave, lane);
+  lds_barrier();
+  f32x4 acc[RTL][4];
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  const int nb = 64 * wave + 4 * lg;
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int g = m0 + rt * 16 + lr;
+    if (g >= M) continue;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
+      *reinterpret_cast<uint2*>(out + (long)g * (256 * n_cb) + 256 * cb + nb + 16 * ct) =
+          pack4(acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w);
+    }
+  }
 }
 
 }  // namespace
@@ -392,7 +479,11 @@ static int raise_lds_limits(simulst_handle* h) {
   if (h->dec_chain_lds_attr_set) return SIMULST_OK;
   hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
   if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
+    e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
   if (e != hipSuccess) { h->err = "simulst_mma_decode: cannot raise the dynamic LDS limit of the layer chains"; return (int)e; }
   h->dec_chain_lds_attr_set = true;
   return SIMULST_OK;
@@ -415,31 +506,34 @@ int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* W
 
 int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
                      const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
-                     int32_t* sem, int B, int F) {
+                     int32_t* sem, void* x_mid, int B, int F) {
   if (int rc = raise_lds_limits(h)) return rc;
   KTimer t(h, SIMULST_K_LINEAR_SKINNY);
   const int rtl = rtl_for(h, B), splits = F / 256;
-#define FC(R)                                                                                                          \
-  hipLaunchKernelGGL((dec_ffn_chain_kernel<R>), dim3(((B + 16 * R - 1) / (16 * R)) * splits), dim3(256), lds_bytes(R), h->stream, \
-                     (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,             \
-                     (const uint4*)W2, b2, partial, sem, B, F, splits)
-  if (rtl == 1) FC(1); else if (rtl == 2) FC(2); else FC(4);
+  // x_mid given: no in-launch hand-off -- x' goes to x_mid, the slabs are added by the next launch (sl_dec_qkv_chain)
+#define FC(R, HO)                                                                                                      \
+  hipLaunchKernelGGL((dec_ffn_chain_kernel<R, HO>), dim3(((B + 16 * R - 1) / (16 * R)) * splits), dim3(256), lds_bytes(R), \
+                     h->stream, (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,  \
+                     (const uint4*)W2, b2, partial, sem, (bf16*)x_mid, B, F, splits)
+  if (x_mid) { if (rtl == 1) FC(1, false); else if (rtl == 2) FC(2, false); else FC(4, false); }
+  else { if (rtl == 1) FC(1, true); else if (rtl == 2) FC(2, true); else FC(4, true); }
 #undef FC
-#ifdef SL_PROBE
-  {
-    static int calls = 0;
-    if ((++calls % 197) == 0) {
-      (void)hipStreamSynchronize(h->stream);
-      long t[32];
-      (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(sl_probe_chain), sizeof t);
-      fprintf(stderr, "[probe ffn chain] B=%d: ctx+Wco landed %.2f  mma0 %.2f  epi0+LN %.2f  mma1 %.2f  gelu %.2f  mma2 %.2f  slab stored %.2f  ticket %.2f | total %.2f us; last arriver of tile 1: reduce %.2f us, ends %.2f us after block 9 started\n",
-              B, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01,
-              (t[6] - t[5]) * 0.01, (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[8] - t[0]) * 0.01, (t[17] - t[16]) * 0.01,
-              (t[17] - t[0]) * 0.01);
-    }
-  }
-#endif
   return sl_launch_status(h, "simulst_mma_decode(feed-forward chain)");
+}
+
+// x <- x_mid + b2 + slabs; qkv = Wqkv LN(x) + bqkv (Wqkv == nullptr: the reduction only)
+int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
+                     const float* ln_b, const void* Wqkv, const float* bqkv, void* qkv, int B, int F) {
+  if (int rc = raise_lds_limits(h)) return rc;
+  KTimer t(h, SIMULST_K_LINEAR_SKINNY);
+  const int rtl = rtl_for(h, B), splits = F / 256, n_cb = Wqkv ? 3 : 1;
+#define QC(R)                                                                                                          \
+  hipLaunchKernelGGL((dec_qkv_chain_kernel<R>), dim3(((B + 16 * R - 1) / (16 * R)) * n_cb), dim3(256), lds_bytes(R),  \
+                     h->stream, (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wqkv, bqkv,       \
+                     (bf16*)qkv, B, splits, n_cb)
+  if (rtl == 1) QC(1); else if (rtl == 2) QC(2); else QC(4);
+#undef QC
+  return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + QKV chain)");
 }
 
 // C-ABI entry points of the two chains (the decode loop calls the internal forms above; these exist so that each chain
@@ -460,15 +554,30 @@ extern "C" int simulst_decoder_proj_chain(simulst_handle* h, const void* ctx, vo
 
 extern "C" int simulst_decoder_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* wco_fm, const float* bco,
                                          const float* ln_g, const float* ln_b, const void* w1_fm, const float* b1,
-                                         const void* w2_fm, const float* b2, float* partial, int32_t* sem, int32_t B,
-                                         int32_t D, int32_t F, int32_t dtype) {
+                                         const void* w2_fm, const float* b2, float* partial, int32_t* sem, void* x_mid,
+                                         int32_t B, int32_t D, int32_t F, int32_t dtype) {
   if (!h) return SIMULST_E_NULL;
   SL_CHECK_NULL(h, ctx); SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, wco_fm); SL_CHECK_NULL(h, bco); SL_CHECK_NULL(h, ln_g);
   SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, w1_fm); SL_CHECK_NULL(h, b1); SL_CHECK_NULL(h, w2_fm); SL_CHECK_NULL(h, b2);
-  SL_CHECK_NULL(h, partial); SL_CHECK_NULL(h, sem);
+  SL_CHECK_NULL(h, partial);
+  if (!x_mid) SL_CHECK_NULL(h, sem);
   SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_decoder_ffn_chain: bf16 only (fp32 keeps one launch per GEMM)");
   SL_REQUIRE(h, D == CD && B >= 0 && F >= 256 && F % 256 == 0 && F / 256 <= 32, SIMULST_E_SHAPE,
              "simulst_decoder_ffn_chain: D == 256, F a multiple of 256 up to 8192");
+  SL_REQUIRE(h, x_mid != x, SIMULST_E_ARG, "simulst_decoder_ffn_chain: x_mid must not alias x");
   if (B == 0) return SIMULST_OK;
-  return sl_dec_ffn_chain(h, ctx, x, wco_fm, bco, ln_g, ln_b, w1_fm, b1, w2_fm, b2, partial, sem, B, F);
+  return sl_dec_ffn_chain(h, ctx, x, wco_fm, bco, ln_g, ln_b, w1_fm, b1, w2_fm, b2, partial, sem, x_mid, B, F);
+}
+
+extern "C" int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid, void* x, const float* partial,
+                                            const float* b2, const float* ln_g, const float* ln_b, const void* wqkv_fm,
+                                            const float* bqkv, void* qkv, int32_t B, int32_t D, int32_t F, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, x_mid); SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, partial); SL_CHECK_NULL(h, b2);
+  if (wqkv_fm) { SL_CHECK_NULL(h, ln_g); SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, bqkv); SL_CHECK_NULL(h, qkv); }
+  SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_decoder_slab_sum_qkv: bf16 only");
+  SL_REQUIRE(h, D == CD && B >= 0 && F >= 256 && F % 256 == 0 && F / 256 <= 32, SIMULST_E_SHAPE,
+             "simulst_decoder_slab_sum_qkv: D == 256, F a multiple of 256 up to 8192");
+  if (B == 0) return SIMULST_OK;
+  return sl_dec_qkv_chain(h, x_mid, x, partial, b2, ln_g, ln_b, wqkv_fm, bqkv, qkv, B, F);
 }

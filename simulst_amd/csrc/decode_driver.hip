@@ -574,6 +574,7 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   // { cross out-proj + residual, LN + fc1 + GELU, fc2 + residual } in another -- 5 launches per layer instead of 8-9
   const bool chain = !split && !fuse_q && !h->force_unfused_decode && dd->ffn_partial && dd->ffn_sem &&
                      sl_dec_chain_ok(h, dt, B, D, F, pk != 0);
+  const bool chain_ffn = chain && B <= h->dec_chain_ffn_max_rows && dd->x_mid;
   if (chain) {                                   // tickets are left zero by every launch; a call aborted half-way must not poison the next
     hipError_t e = hipMemsetAsync(dd->ffn_sem, 0, sizeof(int32_t) * ((B + 15) / 16), h->stream);
     if (e != hipSuccess) { h->err = std::string("simulst_mma_decode: ticket reset: ") + hipGetErrorString(e); return (int)e; }
@@ -590,7 +591,12 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         hs.po = dd->partial_self; hs.bo = L.bo; hs.x_mid = dd->x_mid;
         xin = dd->x_mid;
       } else {
-        if ((rc = lin(h, dt, B, 3 * D, D, dd->x, L.wqkv, L.bqkv, nullptr, dd->qkv, SIMULST_EPI_BIAS, L.ln1_g, L.ln1_b, pk))) return rc;
+        if (chain_ffn && l > 0) {                // the previous layer's feed-forward slabs are added here, then LN1 + QKV
+          if ((rc = sl_dec_qkv_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[l - 1].b2, L.ln1_g, L.ln1_b, L.wqkv, L.bqkv,
+                                     dd->qkv, B, F))) return rc;
+        } else {
+          if ((rc = lin(h, dt, B, 3 * D, D, dd->x, L.wqkv, L.bqkv, nullptr, dd->qkv, SIMULST_EPI_BIAS, L.ln1_g, L.ln1_b, pk))) return rc;
+        }
         if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
                                     dd->ctx, B, H, d, dd->cap, dt))) return rc;
         if (!chain)
@@ -624,15 +630,18 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
                                dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, nullptr, nullptr,
                                nullptr, nullptr, nullptr, nullptr, nullptr, ctlp ? &ctl : nullptr, nullptr))) return rc;
       }
-      if (chain && B <= h->dec_chain_ffn_max_rows) {
+      if (chain_ffn) {
         if ((rc = sl_dec_ffn_chain(h, dd->ctx, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2,
-                                   dd->ffn_partial, dd->ffn_sem, B, F))) return rc;
+                                   dd->ffn_partial, dd->ffn_sem, dd->x_mid, B, F))) return rc;
         continue;
       }
       if ((rc = lin(h, dt, B, D, D, dd->ctx, L.c_wo, L.c_bo, xin, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
       if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b, pk))) return rc;
       if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
     }
+    if (chain_ffn)                               // the last layer's slabs
+      if ((rc = sl_dec_qkv_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[dd->n_layers - 1].b2, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr, B, F))) return rc;
     if ((rc = lin(h, dt, B, V, D, dd->x, dd->out_proj, nullptr, nullptr, dd->logits, SIMULST_EPI_BIAS_F32OUT, dd->ln_g,
                   dd->ln_b, pk))) return rc;
     {

@@ -38,7 +38,7 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_DEC_CHAIN_RT32_MAX_ROWS")) h->dec_chain_rt32_max_rows = atoi(e);
   h->dec_chain_max_rows = 1 << 30;
   if (const char* e = getenv("SIMULST_DEC_CHAIN_MAX_ROWS")) h->dec_chain_max_rows = atoi(e);
-  h->dec_chain_ffn_max_rows = 0;        // measured: the feed-forward chain does not beat its three launches (dec_chain.hip)
+  h->dec_chain_ffn_max_rows = 1024;     // measured (bench.py --steps 20): 448-row sequences +4 %, 640 +2 %, 1280 -2 %, 4096 -3 %
   if (const char* e = getenv("SIMULST_DEC_CHAIN_FFN_MAX_ROWS")) h->dec_chain_ffn_max_rows = atoi(e);
   h->dec_chain_lds_attr_set = false;
   h->graph_exec = nullptr;

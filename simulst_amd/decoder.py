@@ -463,7 +463,7 @@ class MMADecoder:
                                 self.w.pos.data_ptr(), self.w.ln_g.data_ptr(), self.w.ln_b.data_ptr(),
                                 st.enc_len.data_ptr(), st.n_prev.data_ptr(), ws["x"].data_ptr(), ws["qkv"].data_ptr(),
                                 ws["ctx"].data_ptr(), ws["q"].data_ptr(), ws["q2"].data_ptr(), ws["hidden"].data_ptr(),
-                                ws["logits"].data_ptr(), ws["x_mid"].data_ptr() if split else None,
+                                ws["logits"].data_ptr(), ws["x_mid"].data_ptr() if (split or chains) else None,
                                 ws["p_self"].data_ptr() if split else None, int(self.fragment_major),
                                 ws["ffn_partial"].data_ptr() if chains else None,
                                 ws["ffn_sem"].data_ptr() if chains else None)

@@ -299,19 +299,32 @@ class Ops:
                      "simulst_decoder_proj_chain")
         return q, q2
 
-    def decoder_ffn_chain(self, ctx, x, wco_fm, bco, ln, w1_fm, b1, w2_fm, b2, partial=None, sem=None):
+    def decoder_ffn_chain(self, ctx, x, wco_fm, bco, ln, w1_fm, b1, w2_fm, b2, partial=None, sem=None, x_mid=None):
         """x <- x' + W2 gelu(W1 LN(x') + b1) + b2 with x' = x + Wco ctx + bco, in ONE launch
-        (simulst_decoder_ffn_chain; bf16, D == 256, F % 256 == 0, fragment-major weights)."""
+        (simulst_decoder_ffn_chain; bf16, D == 256, F % 256 == 0, fragment-major weights).  With x_mid the launch stops
+        at the fp32 slabs (x' in x_mid, x untouched) and decoder_slab_sum_qkv finishes the sum."""
         B, D = x.shape
         F = w1_fm.shape[0]
         if partial is None:
             partial = torch.empty(F // 256, B, D, device=x.device, dtype=torch.float32)
-        if sem is None:
+        if sem is None and x_mid is None:
             sem = torch.zeros((B + 15) // 16, device=x.device, dtype=torch.int32)
         self.h.check(self.lib.simulst_decoder_ffn_chain(self.h.ptr, _p(ctx), _p(x), _p(wco_fm), _p(bco), _p(ln[0]), _p(ln[1]),
-                                                        _p(w1_fm), _p(b1), _p(w2_fm), _p(b2), _p(partial), _p(sem), B, D, F,
-                                                        dt(x)), "simulst_decoder_ffn_chain")
-        return x
+                                                        _p(w1_fm), _p(b1), _p(w2_fm), _p(b2), _p(partial), _p(sem),
+                                                        _p(x_mid), B, D, F, dt(x)), "simulst_decoder_ffn_chain")
+        return partial
+
+    def decoder_slab_sum_qkv(self, x_mid, x, partial, b2, ln=None, wqkv_fm=None, bqkv=None, qkv=None):
+        """x <- x_mid + b2 + sum of the slabs; with wqkv_fm also qkv = Wqkv LN(x) + bqkv (simulst_decoder_slab_sum_qkv)"""
+        B, D = x.shape
+        F = partial.shape[0] * 256
+        if wqkv_fm is not None and qkv is None:
+            qkv = torch.empty(B, 3 * D, device=x.device, dtype=x.dtype)
+        g, b = ln if ln is not None else (None, None)
+        self.h.check(self.lib.simulst_decoder_slab_sum_qkv(self.h.ptr, _p(x_mid), _p(x), _p(partial), _p(b2), _p(g), _p(b),
+                                                           _p(wqkv_fm), _p(bqkv), _p(qkv), B, D, F, dt(x)),
+                     "simulst_decoder_slab_sum_qkv")
+        return qkv
 
     def policy_cross_attention(self, qm, qs, Kmono, Ksoft, V, head_step, *, H, ratio, attn_type, key_len,
                                tgt_idx=None, energy_bias=0.0, waitk_k=0, online=False, mass_preservation=True,

@@ -89,6 +89,24 @@ def test_ffn_chain_vs_torch(ops, B, F):
         xd.copy_(cu(x))
         ops.decoder_ffn_chain(*args, partial=partial, sem=sem)
         assert torch.equal(xd, first)
+    # the two-launch form the decode loop uses: slabs + x' out of the first launch, the sum (+ the next layer's LayerNorm and
+    # q / k / v projections) in the second -- the same x bit for bit, qkv against the fp32 reference
+    Wqkv, bqkv = _bf(_rand((3 * D, D), g, D ** -0.5)), _rand((3 * D,), g, 0.1)
+    l1g, l1b = 1 + _rand((D,), g, 0.1), _rand((D,), g, 0.1)
+    for with_qkv in (True, False):
+        xd.copy_(cu(x))
+        x_mid = torch.empty_like(xd)
+        ops.decoder_ffn_chain(*args, partial=partial, x_mid=x_mid)
+        assert torch.equal(xd, cu(x))                      # untouched by the first launch
+        x2 = torch.full_like(xd, 7.0)
+        qkv = ops.decoder_slab_sum_qkv(x_mid, x2, partial, b2.cuda(), (l1g.cuda(), l1b.cuda()) if with_qkv else None,
+                                       pk(Wqkv) if with_qkv else None, bqkv.cuda() if with_qkv else None)
+        assert torch.equal(x2, first)
+        if with_qkv:
+            ref_qkv = _bf(_bf(_ln(first.float().cpu(), l1g, l1b)) @ Wqkv.T + bqkv)
+            torch.testing.assert_close(qkv.float().cpu(), ref_qkv, atol=0.06, rtol=0.02)
+        else:
+            assert qkv is None
 
 
 def test_chain_rejects_what_it_cannot_do(ops):
@@ -114,7 +132,7 @@ def test_decode_loop_with_chains_vs_one_launch_per_gemm(monkeypatch, attn, ffn):
     from simulst_amd.model import SimulSTModel
     from simulst_amd.ops import Ops
     from simulst_amd.weights import init_model
-    # the feed-forward chain is off by default (it does not beat its three launches); the handle reads the switch at creation
+    # the handle reads the switch at creation (default: feed-forward chain up to 1024 rows)
     monkeypatch.setenv("SIMULST_DEC_CHAIN_FFN_MAX_ROWS", "100000" if ffn else "0")
     ops = Ops()
     cfg = mma_model_s(encoder_layers=1, decoder_layers=3, simul_attn_type=attn, waitk_lagging=3)
