@@ -43,6 +43,29 @@ def test_full_size_batch_consistency_and_determinism(full_model):
     assert torch.isfinite(enc1.float()).all()
 
 
+def test_co_scheduled_rows_consistency_and_determinism(full_model):
+    """Seven stacked configs[1] batches in ONE launch sequence (448 rows: the row-local layer chains of csrc/dec_chain.hip are
+    on): copies of an utterance that sit in different row tiles / workgroups get bit-identical logits and tokens, and the
+    whole pass repeats bit for bit (the chains' first builds did not: DESIGN.md section 3, MFMA operand note)."""
+    cfg, w, model = full_model
+    g = torch.Generator().manual_seed(15)
+    base = torch.randn(24, 1000, 80, generator=g)                     # 24 distinct utterances; row i == row i + 24 k
+    fb = base.repeat(19, 1, 1)[:448].to(torch.bfloat16).cuda()
+    L = torch.full((448,), 1000, device="cuda")
+    runs = []
+    for _ in range(3):
+        toks, info = model.generate_offline(fb, L, n_steps=40, mask_eos=True)
+        runs.append((toks.clone(), info["state"].ws["logits"].clone(), info["encoder"]["encoder_out_btd"].clone()))
+    assert "ffn_partial" in info["state"].ws                          # the chain workspace was passed
+    for t, lg, enc in runs[1:]:
+        assert torch.equal(t, runs[0][0]) and torch.equal(lg, runs[0][1]) and torch.equal(enc, runs[0][2])
+    t, lg, enc = runs[0]
+    for r in range(24, 448):
+        assert torch.equal(lg[r], lg[r % 24]), r
+        assert torch.equal(t[r], t[r % 24]), r
+    assert torch.isfinite(lg).all()
+
+
 def test_full_size_ragged_rows_independent_of_batch_mates(full_model):
     """A ragged batch: every utterance's valid encoder rows and tokens equal what it gets alone (B = 1)."""
     cfg, w, model = full_model
