@@ -145,3 +145,36 @@ def test_batched_streaming_rows_equal_single_streams(ops, attn, kw, dtype):
             ref = oag.simulate_mma(w, ecfg, dcfg, fb[b])
             assert got[b]["actions"] == ref["actions"] and got[b]["tokens"] == ref["tokens"]
             assert got[b]["delays_ms"] == ref["delays_ms"]
+
+
+@pytest.mark.parametrize("attn,kw", [("waitk_fixed_pre_decision", dict(waitk_lagging=3)),
+                                     ("infinite_lookback_fixed_pre_decision", {})])
+def test_batched_streaming_160_rows_bf16_with_layer_chains(ops, attn, kw):
+    """160 simultaneous bf16 streams (more than 128 rows: the decode loop runs the row-local layer chains of
+    csrc/dec_chain.hip under the per-row READ / WRITE masks): the 20 copies of each of 8 utterances, which sit in different row
+    tiles, must act, write and time identically; and most rows must act as they do with one launch per GEMM."""
+    from simulst_amd.agent import BatchedStreamingAgent
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, simul_attn_type=attn, max_target_positions=40, **kw)
+    w = init_model(cfg, seed=4242)
+    if "waitk" not in attn:
+        for l in range(2):
+            w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 8
+    w["decoder.embed_tokens.weight"][cfg.eos] *= 1.5
+    model = SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=ops)
+    base = torch.randn(8, 560, 80, generator=torch.Generator().manual_seed(78))
+    fb = base.repeat(20, 1, 1)
+    got = BatchedStreamingAgent(model, steps_per_call=4).run_batch(fb)
+    assert len(got) == 160
+    for b in range(8, 160):
+        for k in ("actions", "tokens", "delays_ms"):
+            assert got[b][k] == got[b % 8][k], (attn, b, k)
+    ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 1)
+    try:
+        plain = BatchedStreamingAgent(model, steps_per_call=4).run_batch(fb[:8])
+    finally:
+        ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
+    same = sum(got[b]["actions"] == plain[b]["actions"] and got[b]["tokens"] == plain[b]["tokens"] for b in range(8))
+    assert same >= 6, same
