@@ -75,12 +75,12 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
   };
   // bias of a step's 4 column tiles, requested one step ahead like the weights (a load inside the epilogue would
   // expose its L2 latency once per step: probe, 1.0 of the 1.9 us of a GELU epilogue)
-  float bnext[4];
+  float4 bnext[4];
   auto bload = [&](int step) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = step * PB_N + j * 16 + lr;
-      bnext[j] = (bias && c < p.N) ? bias[c] : 0.f;
+      const int c = step * PB_N + j * 16 + 4 * lg;              // this lane's 4 consecutive columns of tile j (N % 16 == 0)
+      bnext[j] = (bias && c < p.N) ? *reinterpret_cast<const float4*>(bias + c) : float4{0.f, 0.f, 0.f, 0.f};
     }
   };
   wload(step0);
@@ -105,16 +105,39 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
   }
   PROBE(1);                                                     // A fragments arrived (+ LayerNorm)
   float* st = stage[wave];
+  // rows this lane finishes in the epilogue (row it * 8 + lane / 8 of the wave's 32): fixed for the whole sweep, so their
+  // batch / row split and the residual row pointers are computed once
+  int e_b[4], e_ii[4];
+  bool e_ok[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = m0 + wave * 32 + it * 8 + (lane >> 3);
+    e_ok[it] = r < p.M;
+    e_b[it] = e_ok[it] ? r / p.rpb : 0;
+    e_ii[it] = e_ok[it] ? r - e_b[it] * p.rpb : 0;
+  }
+  const bool r_fast = RES && ((p.r_rs | p.r_bs) & 7) == 0;
   for (int step = step0; step < n_steps; ++step) {
     __syncthreads();                                            // the previous step's fragment reads are done
 #pragma unroll
     for (int q = 0; q < 8; ++q) wl[q * 256 + tid] = wv[q];
     __syncthreads();
     if (step == step0) PROBE(2);                                // first weight block in LDS
-    float bcur[4];
+    float4 bcur[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bcur[j] = bnext[j];
     if (step + 1 < n_steps) { wload(step + 1); bload(step + 1); }
+    // residual row segments of this step, requested BEFORE the MFMAs (probe: inside the epilogue their round trip was
+    // exposed four times per step -- 4.6 of the 6 us of an out-proj step)
+    uint4 rpre[RES ? 4 : 1];
+    if constexpr (RES) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = step * PB_N + (lane & 7) * 8;
+        const bool ok = r_fast && e_ok[it] && c + 8 <= p.N && (EPI != SIMULST_EPI_EMF_OUT || e_ii[it] < p.n_main);
+        rpre[it] = ld16(R + (ok ? (long)e_b[it] * p.r_bs + (long)e_ii[it] * p.r_rs + c : 0));
+      }
+    }
     f32x4 acc[2][4];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -127,33 +150,33 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
         const uint4 wf = wl[(j * 8 + s) * 64 + lane];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&fa[m][s]),
-                                                             *reinterpret_cast<const bf16x8_t*>(&wf), acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&wf),
+                                                             *reinterpret_cast<const bf16x8_t*>(&fa[m][s]), acc[m][j], 0, 0, 0);
       }
     }
     if (step == step0) PROBE(3);                                // MFMAs of the first step issued
-    // ---- wave-private epilogue: acc[m][j][e] = C[32w + 16m + 4lg + e][64 step + 16j + lr]
+    // ---- wave-private epilogue.  The weights are the A operand of the MFMAs, so a lane holds 4 consecutive COLUMNS of one
+    //      row:  acc[m][j][e] = C[32w + 16m + lr][64 step + 16j + 4lg + e]  -- one 16-byte staging write per tile (the
+    //      first version had the activations as A and wrote 32 single floats per step)
     const int n0 = step * PB_N;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float bv = bcur[j];
+      const float4 bv = bcur[j];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          f32x2 v = f32x2{acc[m][j][e] + bv, acc[m][j][e + 1] + bv};
-          if constexpr (EPI == SIMULST_EPI_BIAS_GELU) v = gelu_fast2(v);
-          st[(m * 16 + lg * 4 + e) * SS + j * 16 + lr] = v.x;
-          st[(m * 16 + lg * 4 + e + 1) * SS + j * 16 + lr] = v.y;
-        }
+      for (int m = 0; m < 2; ++m) {
+        f32x2 v0 = f32x2{acc[m][j][0] + bv.x, acc[m][j][1] + bv.y};
+        f32x2 v1 = f32x2{acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
+        if constexpr (EPI == SIMULST_EPI_BIAS_GELU) { v0 = gelu_fast2(v0); v1 = gelu_fast2(v1); }
+        *reinterpret_cast<float4*>(&st[(m * 16 + lr) * SS + j * 16 + 4 * lg]) = float4{v0.x, v0.y, v1.x, v1.y};
+      }
     }
     // rows of the wave as 16-byte chunks: lane -> (row it*8 + lane/8, 8 columns at (lane%8)*8)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int rl = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
-      const int r = m0 + wave * 32 + rl, c = n0 + c8;
-      if (r >= p.M || c >= p.N) continue;
-      const int b = r / p.rpb, ii = r - b * p.rpb;
+      const int c = n0 + c8;
+      if (!e_ok[it] || c >= p.N) continue;
+      const int b = e_b[it], ii = e_ii[it];
       const float* fs = &st[rl * SS + c8];
       if constexpr (EPI == SIMULST_EPI_EMF_OUT) {
         if (ii >= p.n_main) {                                   // summary rows: tanh into the next layer's memory bank
@@ -180,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
       bf16* dst = C + c_index(p, b, ii, c);
       if constexpr (RES) {
         const bf16* rp = R + (long)b * p.r_bs + (long)ii * p.r_rs + c;
-        if (c + 8 <= p.N && ((p.r_rs | p.r_bs) & 7) == 0) {
-          const uint4 rv = *reinterpret_cast<const uint4*>(rp);
+        if (c + 8 <= p.N && r_fast) {
+          const uint4 rv = rpre[it];
           const unsigned int ru[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
