@@ -226,10 +226,12 @@ def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps, cores):
     fb = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + i))
                       for i in range(sample_B)])
     L = torch.full((sample_B,), T_FRAMES)
+    margins = []
     with torch.no_grad():
         t0 = time.perf_counter()
-        toks, _, _ = oag.greedy_offline(weights_f32, ecfg, dcfg, fb, L, n_steps=n_steps, mask_eos=True)
+        toks, _, _ = oag.greedy_offline(weights_f32, ecfg, dcfg, fb, L, n_steps=n_steps, mask_eos=True, margins=margins)
         dt = time.perf_counter() - t0
+    run_cpu_baseline.margins = torch.stack(margins, dim=1) if margins else None      # [rows, steps] top-2 gaps of the oracle
     return {"value": round(toks.numel() / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"{sample_B} utterances x {T_FRAMES} frames, {n_steps} forced greedy steps "
                       f"({toks.numel()} tokens) in {dt:.1f} s, torch fp32, {cores} thread{'s' if cores > 1 else ''}"}, toks, fb
@@ -481,6 +483,7 @@ def main(argv=None):
             cores_all = min(os.cpu_count() or 1, 16)   # the oracle's small ops stop scaling well before this
             cpu_base, ref_toks, ref_fb = run_cpu_baseline(cfg, weights, args.cpu_sample, N_STEPS_DECODE, cores_all)
             log("cpu baseline (all cores) done")
+            ref_margins = run_cpu_baseline.margins
             one, _, _ = run_cpu_baseline(cfg, weights, max(1, args.cpu_sample_1thread), N_STEPS_DECODE, 1)
             cpu_base["single_thread"] = one
             log("cpu baseline (1 thread) done")
@@ -496,11 +499,25 @@ def main(argv=None):
                 t16, _ = model.generate_offline(ref_fb.to(device=dev, dtype=dtype), torch.full((n_s,), T_FRAMES),
                                                 n_steps=N_STEPS_DECODE, mask_eos=True)
             n_t = min(n_s, Bs)
+
+            def divergence(h):
+                """rows whose hypothesis equals the oracle's, and for the others the oracle's top-2 log-probability gap at
+                the FIRST differing step (after it a forced-greedy row feeds on its own token, so the rest differs too)"""
+                ref, mg = ref_toks[:h.size(0)], ref_margins
+                same = (h == ref).all(dim=1)
+                gaps = []
+                for r in (~same).nonzero().flatten().tolist():
+                    t = int((h[r] != ref[r]).float().argmax())
+                    gaps.append(round(float(mg[r, t]), 5) if mg is not None else None)
+                return {"rows_identical": int(same.sum()), "rows": int(h.size(0)),
+                        "oracle_top2_gap_at_first_divergence": sorted(g for g in gaps if g is not None)}
             cpu_base["parity_on_sample"] = {
                 "fp32_tokens_identical_to_oracle": bool(torch.equal(t32.cpu(), ref_toks)),
                 f"{args.dtype}_token_agreement_with_fp32_oracle": round(float((t16.cpu() == ref_toks).float().mean()), 4),
                 f"{args.dtype}_token_agreement_of_the_timed_pass_rows_0_{n_t - 1}_of_a_{Bs}_row_sequence":
-                    round(float((hyp_timed[:n_t].cpu() == ref_toks[:n_t]).float().mean()), 4)}
+                    round(float((hyp_timed[:n_t].cpu() == ref_toks[:n_t]).float().mean()), 4),
+                "timed_pass_rows_vs_oracle": divergence(hyp_timed[:n_t].cpu()),
+                f"{args.dtype}_batch_of_{n_s}_alone_vs_oracle": divergence(t16.cpu())}
             log(f"parity on the cpu sample: {cpu_base['parity_on_sample']}")
         sched = (f"{sum(plan)} batches of {B} as {len(plan)} launch sequence(s) of {sorted(set(plan), reverse=True)} stacked "
                  f"batches on {streams_used} HIP stream(s)" +

@@ -21,12 +21,8 @@
 // and the NEXT block requested before the current one is multiplied.  v_mfma_f32_16x16x32_bf16 with the weights as the
 // A operand: a lane then holds 4 consecutive output columns of ONE row, i.e. an 8-byte LDS / global write.
 // Rounding points are those of the launches replaced (bf16 after bias + residual, after LayerNorm, after GELU).
-// Every variant is built for ONE wave per SIMD (__launch_bounds__(256, 1)): the 32-row feed-forward variant built for two
-// produced run-to-run different rows (whole slab rows off by ~1e-2, different rows every launch) on MI355X, with
-// __syncthreads() in place of the LDS-only barrier as well, while the one-wave builds of all three tile heights repeat
-// bit for bit (tests/test_hip_dec_chain.py repeats them).  The cause was not found (the two-wave ISA differs in register
-// allocation only: accumulators in VGPRs, some MFMA destinations on their own operand registers); the chains put at most
-// one workgroup on a CU anyway.
+// One 16-row tile per workgroup and MFMAs from inline assembly with tied accumulators (mma_unit), a whole CU's LDS per
+// workgroup (lds_bytes): both are reproducibility measures, see there.
 //
 // The slab hand-off follows cdna_hip_programming.md section 5.4 item 2 (plain stores, vmcnt drain, barrier, lane 0
 // agent-scope release fence + ticket; last arriver: agent-scope acquire fence, barrier, plain loads): placement-
@@ -70,37 +66,36 @@ __device__ __forceinline__ void load_unit(WUnit& u, const uint4* __restrict__ w,
     for (int s = 0; s < NKS; ++s) u.f[c][s] = *reinterpret_cast<const u32x4_t*>(w + ((long)(tn + c) * nksT + s0 + s) * 64 + lane);
 }
 
-// acc[rt][C0 + c][e] += X[row 16 rt + lr][:] . W[col 16 (tn + c) + 4 lg + e][:]   (X rows from LDS, K = 256)
-//
-// The empty asm after every k-step keeps the step's operand fragments alive (and is ordered after its MFMAs through the
-// accumulators it names).  Without it hipcc (ROCm 7.2) places the destination of a v_mfma_f32_16x16x32_bf16 whose srcC dies
-// (or is the constant 0) on the registers of the instruction's OWN A or B operand -- "v_mfma_f32_16x16x32_bf16 v[20:23],
-// v[20:23], v[144:147], 0" -- and on MI355X workgroups built that way produced run-to-run different rows (slab rows off by
-// ~1e-2, other rows every launch; fewer overlaps, fewer such rows): the 8-pass instruction evidently still reads operands
-// after it has begun to write.  A value that is still live cannot share registers with a new one.
+// acc += W-fragment . X-fragment with v_mfma_f32_16x16x32_bf16 issued from inline assembly, accumulator TIED (one "+v"
+// operand: destination == srcC, and it cannot share registers with the A / B inputs).  Two things hipcc (ROCm 7.2) does with the
+// builtin made these kernels irreproducible on MI355X:
+//   * it places the destination of an MFMA whose srcC is dead or the constant 0 on the registers of the instruction's OWN A / B
+//     operand ("v_mfma_f32_16x16x32_bf16 v[20:23], v[20:23], v[144:147], 0"): the 32-row variant then produced run-to-run
+//     different rows even alone on the chip;
+//   * it renames accumulators between register blocks in the middle of a chain ("v_mfma a[8:11], .., .., a[4:7]" followed by
+//     "v_mfma a[4:7], .., .., a[12:15]"): such a dependent pair is protected by counted wait states only, not by the hardware's
+//     same-destination accumulate path, and with another workgroup's MFMAs sharing the SIMD (the fused Emformer feed-forward or
+//     the Emformer attention of ANOTHER stream resident on the same CU) single 16-column pieces of a row came out a k-step
+//     short -- never when the chains ran alone (tools/determinism_check.py, tests/test_hip_dec_chain.py::test_chains_repeat_
+//     beside_other_streams).
+// The compiler cannot see an MFMA inside asm, so the wait states it would have inserted are written out: s_nop after the
+// zero-initialisation (VALU write -> MFMA srcC) and after the last MFMA of a unit before the accumulators are read.
+__device__ __forceinline__ void mfma_tied(f32x4& acc, const u32x4_t& w, const u32x4_t& x) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+}
+
+// acc[0][C0 + c][e] += X[row lr][:] . W[col 16 (tn + c) + 4 lg + e][:]   (X rows from LDS, K = 256); RTL == 1 only: with more
+// row tiles per wave the register allocator starts moving accumulators between the asm statements
 template <int RTL, int C0>
 __device__ __forceinline__ void mma_unit(f32x4 (&acc)[RTL][4], const WUnit& u, const unsigned short* xs, int lr, int lg) {
+  static_assert(RTL == 1, "one 16-row tile per workgroup");
 #pragma unroll
   for (int s = 0; s < NKS; ++s) {
-    u32x4_t xf[RTL];
-#pragma unroll
-    for (int rt = 0; rt < RTL; ++rt) xf[rt] = *reinterpret_cast<const u32x4_t*>(xs + (rt * 16 + lr) * XS + 32 * s + 8 * lg);
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int rt = 0; rt < RTL; ++rt)
-        acc[rt][C0 + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, u.f[c][s]),
-                                                                  __builtin_bit_cast(bf16x8_t, xf[rt]), acc[rt][C0 + c], 0, 0, 0);
-    if constexpr (RTL == 1)
-      asm volatile("" :: "v"(u.f[0][s]), "v"(u.f[1][s]), "v"(xf[0]), "v"(acc[0][C0]), "v"(acc[0][C0 + 1]));
-    else if constexpr (RTL == 2)
-      asm volatile("" :: "v"(u.f[0][s]), "v"(u.f[1][s]), "v"(xf[0]), "v"(xf[1]), "v"(acc[0][C0]), "v"(acc[0][C0 + 1]),
-                   "v"(acc[1][C0]), "v"(acc[1][C0 + 1]));
-    else
-      asm volatile("" :: "v"(u.f[0][s]), "v"(u.f[1][s]), "v"(xf[0]), "v"(xf[1]), "v"(xf[2]), "v"(xf[3]), "v"(acc[0][C0]),
-                   "v"(acc[0][C0 + 1]), "v"(acc[1][C0]), "v"(acc[1][C0 + 1]), "v"(acc[2][C0]), "v"(acc[2][C0 + 1]),
-                   "v"(acc[3][C0]), "v"(acc[3][C0 + 1]));
+    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + lr * XS + 32 * s + 8 * lg);
+    mfma_tied(acc[0][C0], u.f[0][s], xf);
+    mfma_tied(acc[0][C0 + 1], u.f[1][s], xf);
   }
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");             // 8-pass MFMA result -> VALU read
 }
 
 template <int RTL>
@@ -110,7 +105,9 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[RTL][4]) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+v"(acc[rt][ct]));                        // really in VGPRs now (not folded into the first MFMA)
     }
+  asm volatile("s_nop 3" ::: "memory");                           // VALU write -> MFMA srcC
 }
 
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
@@ -471,19 +468,24 @@ bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bo
          B >= h->dec_chain_min_rows && B <= h->dec_chain_max_rows;
 }
 
-static int rtl_for(const simulst_handle* h, int B) { return B <= h->dec_chain_rt16_max_rows ? 1 : (B <= h->dec_chain_rt32_max_rows ? 2 : 4); }
-constexpr int lds_bytes(int rtl) { return (2 * 16 * rtl * XS + 8) * 2 + 5 * 256 * 4; }   // row buffers, flag, 5 vectors
+static int rtl_for(const simulst_handle*, int) { return 1; }   // 16 rows per workgroup (see mma_unit)
+// Dynamic LDS requested per workgroup: 150 KB although 23 KB are used, i.e. a chain workgroup shares its CU with no other
+// workgroup that holds LDS.  With the plain 23 KB request the chains were irreproducible whenever an LDS-holding workgroup of
+// ANOTHER stream was resident on the same CU (fused Emformer feed-forward, 75 KB: 95 % of launches off by up to 0.2 in a few
+// rows; two Emformer-attention workgroups, 2 x 50 KB: 1-10 %; never alone, never beside kernels without LDS), with static or
+// dynamic LDS, __syncthreads() or LDS-only barriers, builtin or inline-asm MFMAs alike; at 64 KB only the 75 KB neighbour still
+// fits and still disturbs, from 88 KB on neither fits and every stress run repeats bit for bit (tools/determinism_check.py,
+// tests/test_hip_dec_chain.py::test_chains_repeat_beside_other_streams).  The mechanism was not found; the other kernels of
+// the library repeat bit for bit beside the same neighbours.
+constexpr int lds_used_bytes(int rtl) { return (2 * 16 * rtl * XS + 8) * 2 + 5 * 256 * 4; }   // row buffers, flag, 5 vectors
+constexpr int lds_bytes(int) { return 150 * 1024; }
 
-// 64-row tiles need 70 KB of LDS: above the 64 KB a kernel gets without asking
 static int raise_lds_limits(simulst_handle* h) {
   if (h->dec_chain_lds_attr_set) return SIMULST_OK;
-  hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(4));
+  hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
   if (e != hipSuccess) { h->err = "simulst_mma_decode: cannot raise the dynamic LDS limit of the layer chains"; return (int)e; }
   h->dec_chain_lds_attr_set = true;
   return SIMULST_OK;
@@ -499,7 +501,7 @@ int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* W
   hipLaunchKernelGGL((dec_proj_chain_kernel<R>), dim3((B + 16 * R - 1) / (16 * R)), dim3(256), lds_bytes(R), h->stream, \
                      (const bf16*)ctx, (bf16*)x, (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q,     \
                      (const uint4*)Wq2, bq2, (bf16*)q2, B)
-  if (rtl == 1) PC(1); else if (rtl == 2) PC(2); else PC(4);
+  (void)rtl; PC(1);
 #undef PC
   return sl_launch_status(h, "simulst_mma_decode(out-proj + LN + q-proj chain)");
 }
@@ -515,8 +517,8 @@ int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wc
   hipLaunchKernelGGL((dec_ffn_chain_kernel<R, HO>), dim3(((B + 16 * R - 1) / (16 * R)) * splits), dim3(256), lds_bytes(R), \
                      h->stream, (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,  \
                      (const uint4*)W2, b2, partial, sem, (bf16*)x_mid, B, F, splits)
-  if (x_mid) { if (rtl == 1) FC(1, false); else if (rtl == 2) FC(2, false); else FC(4, false); }
-  else { if (rtl == 1) FC(1, true); else if (rtl == 2) FC(2, true); else FC(4, true); }
+  (void)rtl;
+  if (x_mid) FC(1, false); else FC(1, true);
 #undef FC
   return sl_launch_status(h, "simulst_mma_decode(feed-forward chain)");
 }
@@ -531,7 +533,7 @@ int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float*
   hipLaunchKernelGGL((dec_qkv_chain_kernel<R>), dim3(((B + 16 * R - 1) / (16 * R)) * n_cb), dim3(256), lds_bytes(R),  \
                      h->stream, (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wqkv, bqkv,       \
                      (bf16*)qkv, B, splits, n_cb)
-  if (rtl == 1) QC(1); else if (rtl == 2) QC(2); else QC(4);
+  (void)rtl; QC(1);
 #undef QC
   return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + QKV chain)");
 }

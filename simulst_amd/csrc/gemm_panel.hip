@@ -147,11 +147,15 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint4 wf = wl[(j * 8 + s) * 64 + lane];
+        const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(&wl[(j * 8 + s) * 64 + lane]);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&wf),
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf),
                                                              *reinterpret_cast<const bf16x8_t*>(&fa[m][s]), acc[m][j], 0, 0, 0);
+        // the weight fragment stays alive past both MFMAs that read it: otherwise hipcc puts the second one's destination
+        // on the fragment's own registers ("v_mfma v[162:165], v[162:165], v[2:5], 0"), the allocation that made the layer
+        // chains irreproducible from run to run (dec_chain.hip)
+        asm volatile("" :: "v"(wf), "v"(acc[0][j]), "v"(acc[1][j]));
       }
     }
     if (step == step0) PROBE(3);                                // MFMAs of the first step issued

@@ -163,3 +163,77 @@ def test_decode_loop_with_chains_vs_one_launch_per_gemm(monkeypatch, attn, ffn):
     assert close >= (1.0 if attn.startswith("waitk") else 0.9), close
     assert (t1 == t0).float().mean().item() >= 0.9
     assert (tN == tM).float().mean().item() > 0.6
+
+
+def test_chains_repeat_beside_other_streams(ops):
+    """The three chains while two OTHER streams keep LDS-holding, matrix-core-heavy kernels resident (the fused Emformer
+    feed-forward with two 75 KB workgroups per CU, the Emformer block attention with three of 50 KB): every repeat must equal
+    the result computed on a quiet chip bit for bit.  With a 23 KB LDS request per chain workgroup this failed in 95 % of the
+    repeats beside the feed-forward kernel (csrc/dec_chain.hip, lds_bytes)."""
+    import threading
+    import time
+    from simulst_amd import _lib
+    from simulst_amd.encoder import ffn_pack_w1, ffn_pack_w2
+    from simulst_amd.ops import Ops
+    B, F = 192, 2048
+    g = torch.Generator().manual_seed(12)
+    bf = lambda t: t.to(torch.bfloat16).cuda().contiguous()
+    pk = lambda W: ops.pack_fragment_major(bf(W))
+    ctx, x0 = bf(_rand((B, D), g)), bf(_rand((B, D), g))
+    Wo, Wq, Wco = (pk(_rand((D, D), g, D ** -0.5)) for _ in range(3))
+    W1, W2, Wqkv = pk(_rand((F, D), g, D ** -0.5)), pk(_rand((D, F), g, F ** -0.5)), pk(_rand((3 * D, D), g, D ** -0.5))
+    bD, bF, b3 = _rand((D,), g, 0.1).cuda(), _rand((F,), g, 0.1).cuda(), _rand((3 * D,), g, 0.1).cuda()
+    ln = (torch.ones(D).cuda(), torch.zeros(D).cuda())
+    partial = torch.empty(F // 256, B, D, device="cuda")
+
+    def chains():
+        x = x0.clone()
+        q, _ = ops.decoder_proj_chain(ctx, x, Wo, bD, ln, Wq, bD)
+        x_mid, x2 = torch.empty_like(x), torch.empty_like(x)
+        ops.decoder_ffn_chain(ctx, x, Wco, bD, ln, W1, bF, W2, bD, partial=partial, x_mid=x_mid)
+        qkv = ops.decoder_slab_sum_qkv(x_mid, x2, partial, bD, ln, Wqkv, b3)
+        torch.cuda.synchronize()
+        return x, q, x2, qkv
+
+    quiet = chains()
+    for _ in range(20):
+        assert all(torch.equal(a, b) for a, b in zip(chains(), quiet))
+    stop = threading.Event()
+
+    def noise(kind):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            o2 = Ops(_lib.Handle(st.cuda_stream))
+            if kind == "ffn":
+                rows = 64 * 378
+                xx = bf(torch.randn(rows, D)); yy = torch.empty_like(xx)
+                w1p, w2p = ffn_pack_w1(bf(torch.randn(F, D) * D ** -0.5)), ffn_pack_w2(bf(torch.randn(D, F) * F ** -0.5))
+                z1, z2 = torch.zeros(F).cuda(), torch.zeros(D).cuda()
+                while not stop.is_set():
+                    for _ in range(20):
+                        o2.emformer_ffn(xx, ln[0], ln[1], w1p, z1, w2p, z2, yy)
+                    st.synchronize()
+            else:
+                T, S, R, Lc, M = 250, 16, 8, 32, 5
+                N = (T + S - 1) // S
+                n_mem, n_rc, n_sum = N - 1, N * R, N
+                QKV = bf(torch.randn(64, n_mem + n_rc + T + n_sum, 3 * D))
+                CTX = torch.empty(64, n_rc + T + n_sum, D, device="cuda", dtype=torch.bfloat16)
+                Ls = torch.full((64,), T, dtype=torch.int32, device="cuda")
+                while not stop.is_set():
+                    for _ in range(20):
+                        o2.emformer_attention(QKV, Ls, CTX, B=64, T=T, D=D, H=4, S=S, R=R, Lc=Lc, M=M, n_mem=n_mem, n_seg=N,
+                                              use_summary=True)
+                    st.synchronize()
+
+    threads = [threading.Thread(target=noise, args=(k,)) for k in ("ffn", "emf")]
+    try:
+        for t in threads:
+            t.start()
+        time.sleep(0.5)
+        bad = sum(not all(torch.equal(a, b) for a, b in zip(chains(), quiet)) for _ in range(150))
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert bad == 0, f"{bad} of 150 repeats differ from the quiet result"

@@ -66,6 +66,25 @@ def test_co_scheduled_rows_consistency_and_determinism(full_model):
     assert torch.isfinite(lg).all()
 
 
+def test_multi_stream_pass_repeats_bit_for_bit(full_model):
+    """Three launch sequences of 192 rows on three HIP streams (the bench schedule in small: one stream decodes while the
+    others run their MFMA- and LDS-heavy encoder kernels on the same CUs), four times: the tokens of every repeat equal the
+    first bit for bit.  tools/determinism_check.py is the stand-alone form at the bench sizes."""
+    from simulst_amd.model import ConcurrentOffline
+    cfg, w, model = full_model
+    g = torch.Generator().manual_seed(25)
+    batches = [(torch.randn(192, 1000, 80, generator=g).to(torch.bfloat16).cuda(), torch.full((192,), 1000)) for _ in range(3)]
+    pipe = ConcurrentOffline(model, w, 3)
+    first = None
+    for _ in range(4):
+        out = pipe.run(batches, 30, mask_eos=True)
+        torch.cuda.synchronize()
+        toks = torch.stack([o.cpu() for o in out])
+        if first is None:
+            first = toks
+        assert torch.equal(toks, first)
+
+
 def test_full_size_ragged_rows_independent_of_batch_mates(full_model):
     """A ragged batch: every utterance's valid encoder rows and tokens equal what it gets alone (B = 1)."""
     cfg, w, model = full_model

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Run-to-run reproducibility of the multi-stream offline pass at the bench shapes: S launch sequences of R rows on S HIP
+streams, repeated N times; every repeat must give the tokens of the first bit for bit (the kernels have no atomics and no
+order-dependent reductions, so anything else is a hazard -- see DESIGN.md section 3, MFMA operand note).
+
+    python tools/determinism_check.py [--rows 448] [--streams 3] [--repeats 6] [--steps 110]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=448)
+    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=110)
+    args = ap.parse_args()
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import ConcurrentOffline, SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(waitk_lagging=5)
+    w = init_model(cfg, seed=999)
+    model = SimulSTModel(cfg, w, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(4)
+    batches = []
+    for s in range(args.streams):
+        fb = torch.randn(args.rows, 1000, 80, generator=g).cuda().to(torch.bfloat16)
+        batches.append((fb, torch.full((args.rows,), 1000)))
+    pipe = ConcurrentOffline(model, w, args.streams)
+    first, report = None, []
+    for it in range(args.repeats):
+        out = pipe.run(batches, args.steps, mask_eos=True)
+        torch.cuda.synchronize()
+        toks = torch.stack([o.cpu() for o in out])
+        if first is None:
+            first = toks
+            continue
+        d = (toks != first)
+        rows = d.any(dim=2)
+        report.append({"repeat": it, "rows_differing": int(rows.sum()),
+                       "first_step": int(d.float().argmax(dim=2)[rows].min()) if rows.any() else None})
+    ok = all(r["rows_differing"] == 0 for r in report)
+    print(json.dumps({"rows": args.rows, "streams": args.streams, "steps": args.steps, "reproducible": ok, "repeats": report}))
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
