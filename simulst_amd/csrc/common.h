@@ -45,8 +45,6 @@ struct simulst_handle {
   // row-local chains of the decoder layer (dec_chain.hip) for co-scheduled bf16 batches
   bool dec_chain_on;
   int dec_chain_min_rows;      // rows from which the chains replace the per-GEMM launches (below: head-split block)
-  int dec_chain_rt16_max_rows; // rows up to which a workgroup owns 16 rows (more workgroups, shorter chains),
-  int dec_chain_rt32_max_rows; //   32 rows; above: 64
   int dec_chain_max_rows;      // rows above which the per-GEMM launches are kept
   int dec_chain_ffn_max_rows;  // rows up to which the feed-forward chain is used as well
   bool dec_chain_lds_attr_set;

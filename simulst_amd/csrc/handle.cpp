@@ -32,10 +32,6 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_DEC_CHAIN")) h->dec_chain_on = atoi(e) != 0;
   h->dec_chain_min_rows = 129;
   if (const char* e = getenv("SIMULST_DEC_CHAIN_MIN_ROWS")) h->dec_chain_min_rows = atoi(e);
-  h->dec_chain_rt16_max_rows = 1024;
-  if (const char* e = getenv("SIMULST_DEC_CHAIN_RT16_MAX_ROWS")) h->dec_chain_rt16_max_rows = atoi(e);
-  h->dec_chain_rt32_max_rows = 2048;
-  if (const char* e = getenv("SIMULST_DEC_CHAIN_RT32_MAX_ROWS")) h->dec_chain_rt32_max_rows = atoi(e);
   h->dec_chain_max_rows = 1 << 30;
   if (const char* e = getenv("SIMULST_DEC_CHAIN_MAX_ROWS")) h->dec_chain_max_rows = atoi(e);
   h->dec_chain_ffn_max_rows = 1024;     // measured (bench.py --steps 20): 448-row sequences +4 %, 640 +2 %, 1280 -2 %, 4096 -3 %

@@ -46,7 +46,7 @@ def test_full_size_batch_consistency_and_determinism(full_model):
 def test_co_scheduled_rows_consistency_and_determinism(full_model):
     """Seven stacked configs[1] batches in ONE launch sequence (448 rows: the row-local layer chains of csrc/dec_chain.hip are
     on): copies of an utterance that sit in different row tiles / workgroups get bit-identical logits and tokens, and the
-    whole pass repeats bit for bit (the chains' first builds did not: DESIGN.md section 3, MFMA operand note)."""
+    whole pass repeats bit for bit (the chains' first builds did not: DESIGN.md section 3, reproducibility note)."""
     cfg, w, model = full_model
     g = torch.Generator().manual_seed(15)
     base = torch.randn(24, 1000, 80, generator=g)                     # 24 distinct utterances; row i == row i + 24 k

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run-to-run reproducibility of the multi-stream offline pass at the bench shapes: S launch sequences of R rows on S HIP
 streams, repeated N times; every repeat must give the tokens of the first bit for bit (the kernels have no atomics and no
-order-dependent reductions, so anything else is a hazard -- see DESIGN.md section 3, MFMA operand note).
+order-dependent reductions, so anything else is a hazard -- see DESIGN.md section 3, reproducibility note).
 
     python tools/determinism_check.py [--rows 448] [--streams 3] [--repeats 6] [--steps 110]
 """

@@ -1,4 +1,4 @@
-TAG=r02_d
+TAG=r02_e
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -13,5 +13,5 @@ M=$(ls $O/pmc_mfma/*/*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$M" ] && python tools/pmc_classes.py mfma $M $O/pmc_mfma.json "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 64 --warmup 64 --concurrency 1 --no-pipeline --no-cpu-baseline --timed-only --min-warmup-seconds 0" > $O/pmc_mfma.txt
 rm -rf $O/pmc_mfma; find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete
 grep "timed region" $O/*.err; head -4 $O/pmc_mfma.txt
-python tools/kernel_bench.py emf_attn > $O/kernel_bench_emf_attn.json 2>/dev/null; python tools/kernel_bench.py self_attn > $O/kernel_bench_self_attn.json 2>/dev/null; python tools/kernel_bench.py dec_chain --utterances 448 1024 > $O/kernel_bench_dec_chain.json 2>/dev/null
-tail -1 $O/kernel_bench_dec_chain.json | cut -c1-600
+python tools/kernel_bench.py emf_attn > $O/kernel_bench_emf_attn.json 2>/dev/null; python tools/kernel_bench.py self_attn > $O/kernel_bench_self_attn.json 2>/dev/null; python tools/determinism_check.py > $O/determinism_check.json 2>/dev/null; python tools/determinism_check.py --rows 192 --steps 60 >> $O/determinism_check.json 2>/dev/null
+cat $O/determinism_check.json | cut -c1-120
