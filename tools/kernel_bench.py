@@ -76,7 +76,8 @@ def self_attn(args, ops):
 
 
 def dec_chain(args, ops):
-    """the two row-local chains of the decoder layer against the GEMM launches they replace"""
+    """the row-local chains of the decoder layer against the GEMM launches they replace (host-side launch cost included:
+    below ~10 us per call the numbers are bounded by the ctypes call rate, use rocprofv3 for kernel durations)"""
     from simulst_amd.ops import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES
     D, F = 256, 2048
     g = torch.Generator().manual_seed(0)
@@ -101,17 +102,22 @@ def dec_chain(args, ops):
             ops.linear(ctx, Wo_p, bD, epilogue=EPI_BIAS_RES, residual=x, out=x, w_fragment_major=True)
             ops.linear(x, Wq_p, bD, epilogue=EPI_BIAS, out=q, w_fragment_major=True, ln=ln)
 
-        def ffn_chain():
-            ops.decoder_ffn_chain(ctx, x, Wco_p, bD, ln, W1_p, bF, W2_p, bD, partial=partial, sem=sem)
+        x_mid, qkv = torch.empty_like(x), torch.empty(B, 3 * D, device="cuda", dtype=torch.bfloat16)
+        Wqkv_p, b3 = pk(mk(3 * D, D)), torch.zeros(3 * D).cuda()
 
-        def ffn_three():
+        def ffn_chain():          # the form the decode loop uses: slabs out of the first launch, summed by the next layer's LN + QKV
+            ops.decoder_ffn_chain(ctx, x, Wco_p, bD, ln, W1_p, bF, W2_p, bD, partial=partial, x_mid=x_mid)
+            ops.decoder_slab_sum_qkv(x_mid, x, partial, bD, ln, Wqkv_p, b3, qkv=qkv)
+
+        def ffn_three():          # cross out-proj, fc1 + GELU, fc2, and the next layer's LN + QKV: four launches
             ops.linear(ctx, Wco_p, bD, epilogue=EPI_BIAS_RES, residual=x, out=x, w_fragment_major=True)
             ops.linear(x, W1_p, bF, epilogue=EPI_BIAS_GELU, out=hid, w_fragment_major=True, ln=ln)
             ops.linear(hid, W2_p, bD, epilogue=EPI_BIAS_RES, residual=x, out=x, w_fragment_major=True)
+            ops.linear(x, Wqkv_p, b3, epilogue=EPI_BIAS, out=qkv, w_fragment_major=True, ln=ln)
 
         r = {}
-        for name, fn in (("proj_chain", proj_chain), ("proj_two_launches", proj_two), ("ffn_chain", ffn_chain),
-                         ("ffn_three_launches", ffn_three)):
+        for name, fn in (("proj_chain", proj_chain), ("proj_two_launches", proj_two), ("ffn_and_qkv_chains", ffn_chain),
+                         ("ffn_and_qkv_four_launches", ffn_three)):
             x.normal_()
             r[name + "_us"] = round(timeit(fn, 200), 2)
         out[str(B)] = r
