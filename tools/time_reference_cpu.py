@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--threads", type=int, nargs="+", default=[1, 8])
     ap.add_argument("--steps", type=int, default=110)
     ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--check-oracle", action="store_true",
+                    help="also run oracle/ (the CPU restatement the GPU tests are checked against) on the SAME weights and inputs "
+                         "and report the agreement: pins the oracle to the reference at FULL model size")
     args = ap.parse_args()
     if not os.path.isdir("/root/reference/codebase"):
         sys.exit("needs /root/reference (build container only)")
@@ -78,6 +81,21 @@ def main():
                 lp[:, D.eos()] = -float("inf")               # forced length, as in the bench
                 toks = torch.cat([toks, lp.argmax(-1, keepdim=True)], dim=1)
             t_dec = time.perf_counter() - t1
+        if args.check_oracle and nt == args.threads[0]:
+            from oracle import agent as oag
+            from oracle.configs import from_model_config
+            w = {"encoder." + k: v.detach() for k, v in enc.state_dict().items()}
+            w.update({"decoder." + k: v.detach() for k, v in dec.state_dict().items()})
+            ecfg, dcfg = from_model_config(cfg)
+            with torch.no_grad():
+                o_toks, _, o_enc = oag.greedy_offline(w, ecfg, dcfg, fb, L, n_steps=args.steps, mask_eos=True)
+            ref_enc = eo["encoder_out"][0]                       # [T', B, D]
+            print(json.dumps({"check": "oracle vs reference, same weights, full model size", "utterances": B, "frames": T,
+                              "steps": args.steps,
+                              "tokens_identical": bool(torch.equal(o_toks, toks[:, 1:])),
+                              "token_agreement": round(float((o_toks == toks[:, 1:]).float().mean()), 4),
+                              "encoder_out_max_abs_diff": float((o_enc["encoder_out"][0] - ref_enc).abs().max()),
+                              "encoder_out_max_abs": float(ref_enc.abs().max())}), flush=True)
         n_tok = B * args.steps
         print(json.dumps({"kind": "reference (encoder, attention policies and decoder control flow are the reference's files; "
                                   "fairseq layers underneath are tests/golden/fairseq_standin.py)",
