@@ -125,16 +125,42 @@ def dec_chain(args, ops):
     return out
 
 
+def cross_attn(args, ops):
+    """policy + cross-attention launch of the wait-k decoder (simulst_policy_cross_attention) at the configs[1] shape: 250 encoder
+    rows per utterance, 4 heads x 64, target index late enough that every key is visible (90 % of the 110 steps);
+    bytes = K and V rows read + q + context"""
+    from simulst_amd import _lib
+    D, H, d, S = 256, 4, 64, 250
+    out = {}
+    for B in args.utterances:
+        q = torch.randn(B, D, device="cuda").to(torch.bfloat16)
+        K = torch.randn(B, H, S, d, device="cuda").to(torch.bfloat16)
+        V = torch.randn(B, H, S, d, device="cuda").to(torch.bfloat16)
+        hs = torch.zeros(B * H, dtype=torch.int64, device="cuda")
+        kl = torch.full((B,), S, dtype=torch.int32, device="cuda")
+        tg = torch.full((B,), 60, dtype=torch.int32, device="cuda")
+        ctx = torch.empty(B, D, device="cuda", dtype=torch.bfloat16)
+
+        def run():
+            ops.policy_cross_attention(q, q, K, K, V, hs, H=H, ratio=8, attn_type=_lib.ATTN_ENUM["waitk"],
+                                       key_len=kl, tgt_idx=tg, waitk_k=5, out=ctx)
+        us = timeit(run, 50 if B >= 1024 else 200)
+        nbytes = B * (2 * S * D + 2 * D) * 2
+        out[str(B)] = {"us": round(us, 1), "GBps": round(nbytes / us / 1e3, 1), "bytes": nbytes}
+        print("cross_attn", B, out[str(B)], flush=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["emf_attn", "self_attn", "dec_chain"])
+    ap.add_argument("what", choices=["emf_attn", "self_attn", "dec_chain", "cross_attn"])
     ap.add_argument("--utterances", type=int, nargs="+", default=[448, 4096])
     ap.add_argument("--n-prev", type=int, nargs="+", default=[55, 109])
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
     from simulst_amd.ops import Ops
     ops = Ops()
-    res = {"emf_attn": emf_attn, "self_attn": self_attn, "dec_chain": dec_chain}[args.what](args, ops)
+    res = {"emf_attn": emf_attn, "self_attn": self_attn, "dec_chain": dec_chain, "cross_attn": cross_attn}[args.what](args, ops)
     print(json.dumps({"kernel": args.what, "tag": args.tag, "device": torch.cuda.get_device_name(0), "results": res}))
 
 
