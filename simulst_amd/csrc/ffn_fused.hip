@@ -25,7 +25,9 @@
 // emits the GELU as a block in front of the MFMAs, sched_group_barrier patterns did not change that, 3 % slower.  The GELU on
 // scalar fp32 instructions instead of the packed forms (-fno-slp-vectorize): 1 % faster at 4096 utterances, 9 % slower at 64;
 // __builtin_amdgcn_iglp_opt(0 / 1) (fragment reads four ahead of the MFMAs instead of two): 2-3 % slower -- the LDS read
-// latency is not what the remaining distance to the MFMA rate is made of.
+// latency is not what the remaining distance to the MFMA rate is made of.  Starting the wave in the odd slot of each SIMD
+// 40-160 s_sleep units late, so that the two waves of a SIMD are out of phase from the first chunk on: no change (775-807 TFLOP/s
+// in every setting): they drift apart by themselves.
 // Algorithmic work per launch: 4 * rows * D * F flop (two contractions), HBM bytes 2 * rows * D * 2 (x read for the
 // contraction, again for the residual: L2/MALL-hot) + rows * D * 2 written; weights 2 * D * F * 2 B from L2 per workgroup.
 #include "gemm_args.h"
