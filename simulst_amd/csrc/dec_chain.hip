@@ -469,16 +469,18 @@ bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bo
 }
 
 static int rtl_for(const simulst_handle*, int) { return 1; }   // 16 rows per workgroup (see mma_unit)
-// Dynamic LDS requested per workgroup: 150 KB although 23 KB are used, i.e. a chain workgroup shares its CU with no other
-// workgroup that holds LDS.  With the plain 23 KB request the chains were irreproducible whenever an LDS-holding workgroup of
-// ANOTHER stream was resident on the same CU (fused Emformer feed-forward, 75 KB: 95 % of launches off by up to 0.2 in a few
-// rows; two Emformer-attention workgroups, 2 x 50 KB: 1-10 %; never alone, never beside kernels without LDS), with static or
-// dynamic LDS, __syncthreads() or LDS-only barriers, builtin or inline-asm MFMAs alike; at 64 KB only the 75 KB neighbour still
-// fits and still disturbs, from 88 KB on neither fits and every stress run repeats bit for bit (tools/determinism_check.py,
-// tests/test_hip_dec_chain.py::test_chains_repeat_beside_other_streams).  The mechanism was not found; the other kernels of
-// the library repeat bit for bit beside the same neighbours.
+// Dynamic LDS requested per workgroup: ALL 160 KB of the CU although 23 KB are used, i.e. a chain workgroup shares its CU with
+// no other workgroup that holds LDS.  With the plain 23 KB request the chains were irreproducible whenever an LDS-holding,
+// matrix-core-heavy workgroup of ANOTHER stream was resident on the same CU (fused Emformer feed-forward, 75 KB: 95 % of launches
+// off by up to 0.2 in a few rows; two Emformer-attention workgroups, 2 x 50 KB: 1-10 %; never alone, never beside kernels without
+// LDS), with static or dynamic LDS, __syncthreads() or LDS-only barriers, builtin or inline-asm MFMAs alike.  Partial
+// reservations only move the problem: at 64 KB the 75 KB neighbour still fits and disturbs, at 88 KB neither of those two fits
+// but a 128 x 128 tile GEMM workgroup does (163 of 300 launches differ, and the 3-stream pipeline is irreproducible again).
+// With the whole LDS every stress run repeats bit for bit (tools/determinism_check.py, tests/test_hip_dec_chain.py::
+// test_chains_repeat_beside_other_streams) at 2 % of the multi-stream throughput.  The mechanism was not found; the other
+// kernels of the library repeat bit for bit beside the same neighbours.
 constexpr int lds_used_bytes(int rtl) { return (2 * 16 * rtl * XS + 8) * 2 + 5 * 256 * 4; }   // row buffers, flag, 5 vectors
-constexpr int lds_bytes(int) { return 150 * 1024; }
+constexpr int lds_bytes(int) { return 160 * 1024; }
 
 static int raise_lds_limits(simulst_handle* h) {
   if (h->dec_chain_lds_attr_set) return SIMULST_OK;

@@ -166,10 +166,11 @@ def test_decode_loop_with_chains_vs_one_launch_per_gemm(monkeypatch, attn, ffn):
 
 
 def test_chains_repeat_beside_other_streams(ops):
-    """The three chains while two OTHER streams keep LDS-holding, matrix-core-heavy kernels resident (the fused Emformer
-    feed-forward with two 75 KB workgroups per CU, the Emformer block attention with three of 50 KB): every repeat must equal
-    the result computed on a quiet chip bit for bit.  With a 23 KB LDS request per chain workgroup this failed in 95 % of the
-    repeats beside the feed-forward kernel (csrc/dec_chain.hip, lds_bytes)."""
+    """The three chains while three OTHER streams keep LDS-holding, matrix-core-heavy kernels resident (the fused Emformer
+    feed-forward with two 75 KB workgroups per CU, the Emformer block attention with three of 50 KB, the 128 x 128 tile GEMM):
+    every repeat must equal the result computed on a quiet chip bit for bit.  With a 23 KB LDS request per chain workgroup this
+    failed in 95 % of the repeats beside the feed-forward kernel, with 88 KB in half of them beside the tile GEMM
+    (csrc/dec_chain.hip, lds_bytes)."""
     import threading
     import time
     from simulst_amd import _lib
@@ -213,6 +214,13 @@ def test_chains_repeat_beside_other_streams(ops):
                     for _ in range(20):
                         o2.emformer_ffn(xx, ln[0], ln[1], w1p, z1, w2p, z2, yy)
                     st.synchronize()
+            elif kind == "gemm":                          # 128 x 128 tile GEMM (the subsampler's shape)
+                xa = bf(torch.randn(64 * 500, 512)); Wn = bf(torch.randn(512, 512) * 512 ** -0.5)
+                bb, oo = torch.zeros(512).cuda(), torch.empty(64 * 500, 512, device="cuda", dtype=torch.bfloat16)
+                while not stop.is_set():
+                    for _ in range(30):
+                        o2.linear(xa, Wn, bb, out=oo)
+                    st.synchronize()
             else:
                 T, S, R, Lc, M = 250, 16, 8, 32, 5
                 N = (T + S - 1) // S
@@ -226,7 +234,7 @@ def test_chains_repeat_beside_other_streams(ops):
                                               use_summary=True)
                     st.synchronize()
 
-    threads = [threading.Thread(target=noise, args=(k,)) for k in ("ffn", "emf")]
+    threads = [threading.Thread(target=noise, args=(k,)) for k in ("ffn", "emf", "gemm")]
     try:
         for t in threads:
             t.start()
