@@ -93,6 +93,24 @@ int simulst_debug_ffn_variant(simulst_handle* h, int variant);
  * workspace is supplied (A/B parity of the two paths) */
 int simulst_debug_force_unfused_decode(simulst_handle* h, int on);
 
+/* Reproducibility investigation of the row-local layer chains (tools/chain_race_probe.py):
+ * simulst_debug_chain_lds_bytes sets the dynamic LDS a chain workgroup REQUESTS (0 = default; the kernels use 23 KB, a larger
+ * request only keeps other LDS-holding workgroups off the compute unit).  simulst_debug_chain_probe runs the projection chain
+ * (simulst_decoder_proj_chain without the second query projection) in a form that also writes, after its last contraction,
+ * every value that crossed an LDS hand-off inside the launch to dbg (simulst_debug_chain_probe_bytes(B) bytes; layout in
+ * csrc/dec_chain.hip); variant 0 is the production instruction sequence, 1-3 are timing variants of its barriers / LDS writes. */
+int simulst_debug_chain_lds_bytes(simulst_handle* h, int32_t bytes);
+/* how the chains' MFMAs get their activation fragments from LDS: 0 one ds_read_b128 at a time into ONE register quad (the round-2
+ * form), 1 all eight reads of a contraction first into distinct quads (default), 2 as 0 with 16 wait states behind every MFMA pair */
+int simulst_debug_chain_xmode(simulst_handle* h, int32_t mode);
+/* dbg != NULL: every simulst_decoder_proj_chain launch of this handle ends by copying its two LDS row buffers (rows entering the
+ * LayerNorm, rows leaving it; 16 x 256 bf16 each per 16-row workgroup) to dbg [ceil(B / 16)][2][16][256]; NULL switches it off */
+int simulst_debug_chain_tail(simulst_handle* h, void* dbg);
+int64_t simulst_debug_chain_probe_bytes(int32_t B);
+int simulst_debug_chain_probe(simulst_handle* h, const void* ctx, void* x, const void* wo_fm, const float* bo,
+                              const float* ln_g, const float* ln_b, const void* wq_fm, const float* bq, void* q,
+                              int32_t B, int32_t variant, void* dbg);
+
 /* ---- dense contraction ----------------------------------------------------------
  * C[r, :] = epi(A[r, :] . W^T) for logical rows r = b * rows_per_batch + i.
  * A row address  = A + b*a_batch_stride + i*a_row_stride (elements), K contiguous;
@@ -447,12 +465,13 @@ typedef struct {
                                                     fragment-major order of simulst_linear_desc.w_fragment_major
                                                     (E stays row-major: it is read by row); required by the
                                                     head-split block */
-  /* optional workspace of the row-local layer chains (both non-NULL, bf16, D == 256, F % 256 == 0, fragment-major
+  /* optional workspace of the row-local layer chains (ffn_partial and x_mid non-NULL, bf16, D == 256, F % 256 == 0, fragment-major
    * weights, more than 128 rows): { out-proj + residual, LN + q-proj } become one launch and { cross out-proj +
    * residual, LN + fc1 + GELU, fc2 + residual } another, the hidden units split over F / 256 workgroups per row tile
    * whose fp32 slabs the last-arriving workgroup adds in split order (deterministic).  NULL: one launch per GEMM. */
   float* ffn_partial;                            /* [F / 256][B][D] */
-  int32_t* ffn_sem;                              /* [(B + 15) / 16] zero-initialised tickets (left zero by every call) */
+  int32_t* ffn_sem;                              /* unused by the decode loop (it runs the feed-forward chain without the in-launch
+                                                    hand-off); may be NULL.  simulst_decoder_ffn_chain(x_mid = NULL) takes its own */
 } simulst_decoder_desc;
 
 /* tokens_io [B] int64: in = newest token of [eos]+hyp, out = last token picked.

@@ -79,6 +79,11 @@ SIGNATURES = {
     "simulst_debug_force_valu_attention": [_vp, C.c_int],
     "simulst_debug_force_unfused_decode": [_vp, C.c_int],
     "simulst_debug_ffn_variant": [_vp, C.c_int],
+    "simulst_debug_chain_lds_bytes": [_vp, _i32],
+    "simulst_debug_chain_xmode": [_vp, _i32],
+    "simulst_debug_chain_tail": [_vp, _vp],
+    "simulst_debug_chain_probe_bytes": [_i32],
+    "simulst_debug_chain_probe": [_vp] * 10 + [_i32, _i32, _vp],
     "simulst_pack_fragment_major": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
@@ -138,7 +143,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name == "simulst_last_error"
-                      else C.c_int64 if name == "simulst_ctc_best_alignment_scratch_bytes" else C.c_int)
+                      else C.c_int64 if name in ("simulst_ctc_best_alignment_scratch_bytes", "simulst_debug_chain_probe_bytes")
+                      else C.c_int)
     _lib = lib
     return lib
 

@@ -41,6 +41,7 @@ struct simulst_handle {
   uint64_t graph_key;
   bool ffn_lds_attr_set;       // simulst_emformer_ffn did the same for the fused feed-forward kernel
   int ffn_variant;             // simulst_debug_ffn_variant (timing ablations of the fused feed-forward launch)
+  bool conv_pos_lds_attr_set;  // simulst_conv_pos raised its kernels' dynamic-LDS limit through this handle
   bool ctc_lds_attr_set;       // simulst_ctc_best_alignment raised its kernel's dynamic-LDS limit through this handle
   // row-local chains of the decoder layer (dec_chain.hip) for co-scheduled bf16 batches
   bool dec_chain_on;
@@ -48,6 +49,10 @@ struct simulst_handle {
   int dec_chain_max_rows;      // rows above which the per-GEMM launches are kept
   int dec_chain_ffn_max_rows;  // rows up to which the feed-forward chain is used as well
   bool dec_chain_lds_attr_set;
+  int dec_chain_lds_bytes;     // dynamic LDS requested per chain workgroup (0: the default, dec_chain.hip lds_request)
+  bool dec_chain_probe_attr_set;
+  void* dec_chain_tail;        // investigation: the projection chain dumps its two LDS row buffers here at its end (null: off)
+  int dec_chain_xmode;         // how the chains' MFMAs get their activation fragments (dec_chain.hip mma_unit)
 };
 
 #define SL_CHECK_NULL(h, p)                                   \

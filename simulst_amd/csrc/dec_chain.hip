@@ -85,15 +85,31 @@ __device__ __forceinline__ void mfma_tied(f32x4& acc, const u32x4_t& w, const u3
 }
 
 // acc[0][C0 + c][e] += X[row lr][:] . W[col 16 (tn + c) + 4 lg + e][:]   (X rows from LDS, K = 256); RTL == 1 only: with more
-// row tiles per wave the register allocator starts moving accumulators between the asm statements
-template <int RTL, int C0>
+// row tiles per wave the register allocator starts moving accumulators between the asm statements.
+// XM = how the 8 activation fragments of the row tile reach the MFMAs (simulst_debug_chain_xmode):
+//   bit 0 clear  one at a time: ds_read_b128, wait, two MFMAs, next ds_read_b128 -- hipcc gives every read the SAME register
+//                quad, i.e. each read is issued right behind the two MFMAs that consume that quad as their B operand
+//   bit 0 set    all 8 reads issued first into 8 distinct quads (32 VGPRs), then the 16 MFMAs
+//   bit 1        selects the wave reduction of ln_rows (see there)
+template <int RTL, int C0, int XM>
 __device__ __forceinline__ void mma_unit(f32x4 (&acc)[RTL][4], const WUnit& u, const unsigned short* xs, int lr, int lg) {
   static_assert(RTL == 1, "one 16-row tile per workgroup");
+  if constexpr ((XM & 1) != 0) {
+    u32x4_t xf[NKS];
 #pragma unroll
-  for (int s = 0; s < NKS; ++s) {
-    const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + lr * XS + 32 * s + 8 * lg);
-    mfma_tied(acc[0][C0], u.f[0][s], xf);
-    mfma_tied(acc[0][C0 + 1], u.f[1][s], xf);
+    for (int s = 0; s < NKS; ++s) xf[s] = *reinterpret_cast<const u32x4_t*>(xs + lr * XS + 32 * s + 8 * lg);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      mfma_tied(acc[0][C0], u.f[0][s], xf[s]);
+      mfma_tied(acc[0][C0 + 1], u.f[1][s], xf[s]);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const u32x4_t xf = *reinterpret_cast<const u32x4_t*>(xs + lr * XS + 32 * s + 8 * lg);
+      mfma_tied(acc[0][C0], u.f[0][s], xf);
+      mfma_tied(acc[0][C0 + 1], u.f[1][s], xf);
+    }
   }
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");             // 8-pass MFMA result -> VALU read
 }
@@ -133,9 +149,14 @@ __device__ __forceinline__ void rows_to_lds(const bf16* __restrict__ src, unsign
   }
 }
 
+// sum over the 64 lanes on the DPP data path (row shifts / row broadcasts, then lane 63 to every lane through an SGPR): no
+// ds_bpermute, i.e. nothing of the reduction goes through the LDS crossbar
+__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_last(wave_scan_incl_dpp(v)); }
+
 // LayerNorm of the tile's rows, src -> dst (both LDS, bf16), wave w takes rows w, w + 4, ...; one-pass moments in fp32 as
-// in the LayerNorm prologue of the GEMM kernels this chain replaces (gemm_mid.hip)
-template <int RTL>
+// in the LayerNorm prologue of the GEMM kernels this chain replaces (gemm_mid.hip).  XM bit 1: the two wave reductions on
+// the DPP path (wave_sum_dpp) instead of the ds_bpermute butterfly (wave_sum)
+template <int RTL, int XM>
 __device__ __forceinline__ void ln_rows(const unsigned short* src, unsigned short* dst, float4 g, float4 b, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4 * RTL; ++i) {
@@ -144,8 +165,8 @@ __device__ __forceinline__ void ln_rows(const unsigned short* src, unsigned shor
     unpack4(*reinterpret_cast<const uint2*>(src + row * XS + 4 * lane), v);
     float s1 = (v[0] + v[1]) + (v[2] + v[3]);
     float s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
+    if constexpr ((XM & 2) != 0) { s1 = wave_sum_dpp(s1); s2 = wave_sum_dpp(s2); }
+    else { s1 = wave_sum(s1); s2 = wave_sum(s2); }
     const float mean = s1 * (1.0f / CD);
     const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / CD) - mean * mean, 0.f) + 1e-5f);
     *reinterpret_cast<uint2*>(dst + row * XS + 4 * lane) =
@@ -174,12 +195,12 @@ __device__ __forceinline__ uint2 add_slabs(const float (&r)[4], float4 b2, const
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ctx [M][256] --Wo, bo, + x--> x (in place) --LN--> --Wq, bq--> q   (--Wq2, bq2--> q2 when Wq2 != nullptr)
-template <int RTL>
-__global__ __launch_bounds__(256, 1) void dec_proj_chain_kernel(
+template <int RTL, int XM>
+__global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
     const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ Wq,
     const float* __restrict__ bq, bf16* __restrict__ q, const uint4* __restrict__ Wq2, const float* __restrict__ bq2,
-    bf16* __restrict__ q2, int M) {
+    bf16* __restrict__ q2, int M, unsigned short* __restrict__ dbg) {
   constexpr int RT = 16 * RTL;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // 2 * RT * XS elements
   unsigned short* bufA = lds;
@@ -208,9 +229,9 @@ __global__ __launch_bounds__(256, 1) void dec_proj_chain_kernel(
   lds_barrier();
   f32x4 acc[RTL][4];
   zero_acc<RTL>(acc);
-  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
   load_unit(u0, Wq, tw, NKS, 0, lane);                   // next block's first unit lands while this block finishes
-  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
   load_unit(u1, Wq, tw + 2, NKS, 0, lane);
 #pragma unroll
   for (int rt = 0; rt < RTL; ++rt) {
@@ -227,13 +248,13 @@ __global__ __launch_bounds__(256, 1) void dec_proj_chain_kernel(
     }
   }
   lds_barrier();                                       // x rows complete in bufB; every wave is past its reads of bufA
-  ln_rows<RTL>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
+  ln_rows<RTL, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
                *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane), wave, lane);
   lds_barrier();
   zero_acc<RTL>(acc);
-  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
   if (Wq2) load_unit(u0, Wq2, tw, NKS, 0, lane);
-  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
   if (Wq2) load_unit(u1, Wq2, tw + 2, NKS, 0, lane);
 #pragma unroll
   for (int rt = 0; rt < RTL; ++rt) {
@@ -248,8 +269,8 @@ __global__ __launch_bounds__(256, 1) void dec_proj_chain_kernel(
   }
   if (Wq2) {
     zero_acc<RTL>(acc);
-    mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
-    mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+    mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
+    mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
 #pragma unroll
     for (int rt = 0; rt < RTL; ++rt) {
       const int g = m0 + rt * 16 + lr;
@@ -262,6 +283,15 @@ __global__ __launch_bounds__(256, 1) void dec_proj_chain_kernel(
       }
     }
   }
+  if (dbg) {   // investigation tail (simulst_debug_chain_tail): what the two row buffers hold when the kernel ends
+    unsigned short* Dg = dbg + (long)blockIdx.x * (2 * RT * CD);
+#pragma unroll
+    for (int i = 0; i < 4 * RTL; ++i) {
+      const int row = wave + 4 * i;
+      *reinterpret_cast<uint2*>(Dg + row * CD + 4 * lane) = *reinterpret_cast<const uint2*>(bufB + row * XS + 4 * lane);
+      *reinterpret_cast<uint2*>(Dg + RT * CD + row * CD + 4 * lane) = *reinterpret_cast<const uint2*>(bufA + row * XS + 4 * lane);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -269,8 +299,8 @@ __global__ __launch_bounds__(256, 1) void dec_proj_chain_kernel(
 // units [256 sp, 256 sp + 256).  partial: [splits][M][256] fp32 slabs; sem: one zeroed int per row tile (left zero).
 // HANDOFF false: the kernel ends after the slab stores (split 0 has written x' to x); the slabs are added by the NEXT launch
 // (dec_qkv_chain_kernel), where the kernel boundary is the hand-off and every workgroup of the row tile reduces in parallel.
-template <int RTL, bool HANDOFF>
-__global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
+template <int RTL, bool HANDOFF, int XM>
+__global__ __launch_bounds__(256, 2) void dec_ffn_chain_kernel(
     const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wco, const float* __restrict__ bco,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W1,
     const float* __restrict__ b1, const uint4* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ partial,
@@ -308,9 +338,9 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
   PROBE(1);
   f32x4 acc[RTL][4];
   zero_acc<RTL>(acc);
-  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
   load_unit(u0, W1, 16 * sp + tw, NKS, 0, lane);         // fc1 rows (hidden units) of this split, this wave's 64
-  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
   load_unit(u1, W1, 16 * sp + tw + 2, NKS, 0, lane);
   PROBE(2);
   // x' = bf16(x + Wco . ctx + bco) -> bufB (kept to the end: the residual of the reduction)
@@ -333,14 +363,14 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
     }
   }
   lds_barrier();
-  ln_rows<RTL>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
+  ln_rows<RTL, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
                *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane), wave, lane);
   lds_barrier();
   PROBE(3);
   zero_acc<RTL>(acc);
-  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
   load_unit(u0, W2, tw, nks2, NKS * sp, lane);           // fc2 columns of this wave, k-steps (hidden units) of this split
-  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
   load_unit(u1, W2, tw + 2, nks2, NKS * sp, lane);
   PROBE(4);
   lds_barrier();                                               // every wave is done reading LN(x') from bufA
@@ -358,8 +388,8 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
   lds_barrier();
   PROBE(5);
   zero_acc<RTL>(acc);
-  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
-  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
   PROBE(6);
   float* slab = partial + (long)sp * M * CD;
 #pragma unroll
@@ -409,8 +439,8 @@ __global__ __launch_bounds__(256, 1) void dec_ffn_chain_kernel(
 // W == nullptr, qkv[:, 256 cb .. 256 cb + 255] = W LN(x) + b for column block cb = blockIdx.x % n_cb  (LN1 + QKV of the next
 // layer: n_cb = 3).  Every column block's workgroup adds the slabs of its row tile itself (parallel, no hand-off); block 0
 // writes x.  W == nullptr (after the last layer): grid = row tiles, reduction only.
-template <int RTL>
-__global__ __launch_bounds__(256, 1) void dec_qkv_chain_kernel(
+template <int RTL, int XM>
+__global__ __launch_bounds__(256, 2) void dec_qkv_chain_kernel(
     const bf16* __restrict__ x_mid, bf16* __restrict__ x, const float* __restrict__ partial, const float* __restrict__ b2,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W, const float* __restrict__ bias,
     bf16* __restrict__ out, int M, int splits, int n_cb) {
@@ -440,13 +470,13 @@ __global__ __launch_bounds__(256, 1) void dec_qkv_chain_kernel(
   }
   if (!W) return;
   lds_barrier();
-  ln_rows<RTL>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 256 + 4 * lane),
+  ln_rows<RTL, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 256 + 4 * lane),
                *reinterpret_cast<const float4*>(vec + 512 + 4 * lane), wave, lane);
   lds_barrier();
   f32x4 acc[RTL][4];
   zero_acc<RTL>(acc);
-  mma_unit<RTL, 0>(acc, u0, bufA, lr, lg);
-  mma_unit<RTL, 2>(acc, u1, bufA, lr, lg);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
   const int nb = 64 * wave + 4 * lg;
 #pragma unroll
   for (int rt = 0; rt < RTL; ++rt) {
@@ -461,6 +491,152 @@ __global__ __launch_bounds__(256, 1) void dec_qkv_chain_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// PROBE form of dec_proj_chain_kernel (Wq2 == nullptr) for tools/chain_race_probe.py: the same instruction sequence, with every
+// value that crosses an LDS hand-off kept in registers and written to a debug buffer AFTER the last contraction, so that a
+// launch whose q differs from the quiet result can be localised: which hand-off delivered something else than was written.
+//   per workgroup (unsigned shorts):  d  [16][256] LayerNorm input as its reader got it (hand-off 1: epilogue ds_write_b64 ->
+//                                        barrier -> ds_read_b64 of another wave)
+//                                     a  [16][256] LayerNorm output as written
+//                                     b  [16][256] the same rows read back from LDS at the end of the kernel
+//                                     c0 / c1 [4 waves][8 k-steps][64 lanes][8] the fragments the two MFMA units of the q
+//                                        projection actually consumed (hand-off 2: ds_write_b64 -> barrier -> ds_read_b128)
+//                                     ms [16][64][2] fp32 mean / rstd per lane (the wave reduction)
+// VAR: 0 the production sequence; 1 s_sleep between the lgkmcnt wait and s_barrier; 2 s_sleep after s_barrier;
+//      3 LayerNorm output written by ds_write_b64 from inline assembly (the accidental cure recorded in DESIGN.md section 3)
+constexpr int PROBE_WG = 3 * 16 * CD + 2 * 4 * NKS * 64 * 8 + 16 * 64 * 2 * 2;   // unsigned shorts per workgroup
+
+template <int VAR>
+__device__ __forceinline__ void probe_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (VAR == 1) asm volatile("s_sleep 2" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if constexpr (VAR == 2) asm volatile("s_sleep 2" ::: "memory");
+  asm volatile("" ::: "memory");
+}
+
+template <int C0>
+__device__ __forceinline__ void mma_unit_keep(f32x4 (&acc)[1][4], const WUnit& u, const unsigned short* xs, int lr, int lg,
+                                              u32x4_t (&keep)[NKS]) {
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    keep[s] = *reinterpret_cast<const u32x4_t*>(xs + lr * XS + 32 * s + 8 * lg);
+    mfma_tied(acc[0][C0], u.f[0][s], keep[s]);
+    mfma_tied(acc[0][C0 + 1], u.f[1][s], keep[s]);
+  }
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void dec_proj_chain_probe_kernel(
+    const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ Wq,
+    const float* __restrict__ bq, bf16* __restrict__ q, int M, unsigned short* __restrict__ dbg) {
+  constexpr int RT = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* bufA = lds;
+  unsigned short* bufB = lds + RT * XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * RT;
+  const int tw = 4 * wave;
+  WUnit u0, u1;
+  load_unit(u0, Wo, tw, NKS, 0, lane);
+  rows_to_lds<1>(ctx, bufA, m0, M, tid);
+  load_unit(u1, Wo, tw + 2, NKS, 0, lane);
+  const int nb = 64 * wave + 4 * lg;
+  float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS);
+  vec[tid] = bo[tid]; vec[256 + tid] = bq[tid]; vec[512 + tid] = 0.f;
+  vec[768 + tid] = ln_g[tid]; vec[1024 + tid] = ln_b[tid];
+  uint2 res[4];
+  {
+    const int g = m0 + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) res[ct] = *reinterpret_cast<const uint2*>(x + (long)(g < M ? g : 0) * CD + nb + 16 * ct);
+  }
+  probe_barrier<VAR>();
+  f32x4 acc[1][4];
+  zero_acc<1>(acc);
+  mma_unit<1, 0, 0>(acc, u0, bufA, lr, lg);
+  load_unit(u0, Wq, tw, NKS, 0, lane);
+  mma_unit<1, 2, 0>(acc, u1, bufA, lr, lg);
+  load_unit(u1, Wq, tw + 2, NKS, 0, lane);
+  {
+    const int row = lr, g = m0 + row;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float r[4];
+      unpack4(res[ct], r);
+      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
+      const uint2 o = pack4(acc[0][ct][0] + bv.x + r[0], acc[0][ct][1] + bv.y + r[1], acc[0][ct][2] + bv.z + r[2],
+                            acc[0][ct][3] + bv.w + r[3]);
+      *reinterpret_cast<uint2*>(bufB + row * XS + nb + 16 * ct) = o;
+      if (g < M) *reinterpret_cast<uint2*>(x + (long)g * CD + nb + 16 * ct) = o;
+    }
+  }
+  probe_barrier<VAR>();
+  uint2 din[4], aout[4];
+  float mk[4], rk[4];
+  {
+    const float4 g4 = *reinterpret_cast<const float4*>(vec + 768 + 4 * lane);
+    const float4 b4 = *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave + 4 * i;
+      float v[4];
+      din[i] = *reinterpret_cast<const uint2*>(bufB + row * XS + 4 * lane);
+      unpack4(din[i], v);
+      float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+      float s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      const float mean = s1 * (1.0f / CD);
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / CD) - mean * mean, 0.f) + 1e-5f);
+      mk[i] = mean; rk[i] = rstd;
+      aout[i] = pack4((v[0] - mean) * rstd * g4.x + b4.x, (v[1] - mean) * rstd * g4.y + b4.y,
+                      (v[2] - mean) * rstd * g4.z + b4.z, (v[3] - mean) * rstd * g4.w + b4.w);
+      if constexpr (VAR == 3) {
+        const unsigned a32 = (unsigned)(size_t)(bufA + row * XS + 4 * lane);
+        asm volatile("ds_write_b64 %0, %1" :: "v"(a32), "v"(aout[i]) : "memory");
+      } else {
+        *reinterpret_cast<uint2*>(bufA + row * XS + 4 * lane) = aout[i];
+      }
+    }
+  }
+  probe_barrier<VAR>();
+  u32x4_t k0[NKS], k1[NKS];
+  zero_acc<1>(acc);
+  mma_unit_keep<0>(acc, u0, bufA, lr, lg, k0);
+  mma_unit_keep<2>(acc, u1, bufA, lr, lg, k1);
+  {
+    const int g = m0 + lr;
+    if (g < M) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float4 bv = *reinterpret_cast<const float4*>(vec + 256 + nb + 16 * ct);
+        *reinterpret_cast<uint2*>(q + (long)g * CD + nb + 16 * ct) =
+            pack4(acc[0][ct][0] + bv.x, acc[0][ct][1] + bv.y, acc[0][ct][2] + bv.z, acc[0][ct][3] + bv.w);
+      }
+    }
+  }
+  // ---- dumps (nothing above this line differs from the production kernel except the registers kept alive)
+  unsigned short* Dg = dbg + (long)blockIdx.x * PROBE_WG;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave + 4 * i;
+    *reinterpret_cast<uint2*>(Dg + row * CD + 4 * lane) = din[i];
+    *reinterpret_cast<uint2*>(Dg + 16 * CD + row * CD + 4 * lane) = aout[i];
+    *reinterpret_cast<uint2*>(Dg + 32 * CD + row * CD + 4 * lane) = *reinterpret_cast<const uint2*>(bufA + row * XS + 4 * lane);
+    float* ms = reinterpret_cast<float*>(Dg + 48 * CD + 2 * 4 * NKS * 64 * 8);
+    ms[(row * 64 + lane) * 2] = mk[i];
+    ms[(row * 64 + lane) * 2 + 1] = rk[i];
+  }
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    *reinterpret_cast<u32x4_t*>(Dg + 48 * CD + ((wave * NKS + s) * 64 + lane) * 8) = k0[s];
+    *reinterpret_cast<u32x4_t*>(Dg + 48 * CD + 4 * NKS * 64 * 8 + ((wave * NKS + s) * 64 + lane) * 8) = k1[s];
+  }
+}
+
 }  // namespace
 
 bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bool packed) {
@@ -468,7 +644,6 @@ bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bo
          B >= h->dec_chain_min_rows && B <= h->dec_chain_max_rows;
 }
 
-static int rtl_for(const simulst_handle*, int) { return 1; }   // 16 rows per workgroup (see mma_unit)
 // Dynamic LDS requested per workgroup: ALL 160 KB of the CU although 23 KB are used, i.e. a chain workgroup shares its CU with
 // no other workgroup that holds LDS.  With the plain 23 KB request the chains were irreproducible whenever an LDS-holding,
 // matrix-core-heavy workgroup of ANOTHER stream was resident on the same CU (fused Emformer feed-forward, 75 KB: 95 % of launches
@@ -480,30 +655,46 @@ static int rtl_for(const simulst_handle*, int) { return 1; }   // 16 rows per wo
 // test_chains_repeat_beside_other_streams) at 2 % of the multi-stream throughput.  The mechanism was not found; the other
 // kernels of the library repeat bit for bit beside the same neighbours.
 constexpr int lds_used_bytes(int rtl) { return (2 * 16 * rtl * XS + 8) * 2 + 5 * 256 * 4; }   // row buffers, flag, 5 vectors
-constexpr int lds_bytes(int) { return 160 * 1024; }
+constexpr int LDS_WHOLE_CU = 160 * 1024;
+
+static int lds_request(const simulst_handle* h) {
+  const int want = h->dec_chain_lds_bytes > 0 ? h->dec_chain_lds_bytes : lds_used_bytes(1);     // default: what the kernels use
+  return want < lds_used_bytes(1) ? lds_used_bytes(1) : (want > LDS_WHOLE_CU ? LDS_WHOLE_CU : want);
+}
+
+template <int XM>
+static hipError_t raise_lds_limits_mode() {
+  hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, true, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, false, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+  return e;
+}
 
 static int raise_lds_limits(simulst_handle* h) {
   if (h->dec_chain_lds_attr_set) return SIMULST_OK;
-  hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+  hipError_t e = raise_lds_limits_mode<0>();
+  if (e == hipSuccess) e = raise_lds_limits_mode<1>();
+  if (e == hipSuccess) e = raise_lds_limits_mode<2>();
+  if (e == hipSuccess) e = raise_lds_limits_mode<3>();
   if (e != hipSuccess) { h->err = "simulst_mma_decode: cannot raise the dynamic LDS limit of the layer chains"; return (int)e; }
   h->dec_chain_lds_attr_set = true;
   return SIMULST_OK;
 }
+
+// the fragment-read mode of the handle (mma_unit) selects the instantiation
+#define SL_XMODE(h, CALL) do { switch ((h)->dec_chain_xmode) { case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; default: CALL(3); break; } } while (0)
 
 int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* Wo, const float* bo, const float* ln_g,
                       const float* ln_b, const void* Wq, const float* bq, void* q, const void* Wq2, const float* bq2,
                       void* q2, int B) {
   if (int rc = raise_lds_limits(h)) return rc;
   KTimer t(h, SIMULST_K_LINEAR_SKINNY);
-  const int rtl = rtl_for(h, B);
-#define PC(R)                                                                                                          \
-  hipLaunchKernelGGL((dec_proj_chain_kernel<R>), dim3((B + 16 * R - 1) / (16 * R)), dim3(256), lds_bytes(R), h->stream, \
+#define PC(XM)                                                                                                         \
+  hipLaunchKernelGGL((dec_proj_chain_kernel<1, XM>), dim3((B + 15) / 16), dim3(256), lds_request(h), h->stream,        \
                      (const bf16*)ctx, (bf16*)x, (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q,     \
-                     (const uint4*)Wq2, bq2, (bf16*)q2, B)
-  (void)rtl; PC(1);
+                     (const uint4*)Wq2, bq2, (bf16*)q2, B, (unsigned short*)h->dec_chain_tail)
+  SL_XMODE(h, PC);
 #undef PC
   return sl_launch_status(h, "simulst_mma_decode(out-proj + LN + q-proj chain)");
 }
@@ -513,14 +704,17 @@ int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wc
                      int32_t* sem, void* x_mid, int B, int F) {
   if (int rc = raise_lds_limits(h)) return rc;
   KTimer t(h, SIMULST_K_LINEAR_SKINNY);
-  const int rtl = rtl_for(h, B), splits = F / 256;
+  const int splits = F / 256;
   // x_mid given: no in-launch hand-off -- x' goes to x_mid, the slabs are added by the next launch (sl_dec_qkv_chain)
-#define FC(R, HO)                                                                                                      \
-  hipLaunchKernelGGL((dec_ffn_chain_kernel<R, HO>), dim3(((B + 16 * R - 1) / (16 * R)) * splits), dim3(256), lds_bytes(R), \
+#define FC(HO, XM)                                                                                                     \
+  hipLaunchKernelGGL((dec_ffn_chain_kernel<1, HO, XM>), dim3(((B + 15) / 16) * splits), dim3(256), lds_request(h),     \
                      h->stream, (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,  \
                      (const uint4*)W2, b2, partial, sem, (bf16*)x_mid, B, F, splits)
-  (void)rtl;
-  if (x_mid) FC(1, false); else FC(1, true);
+#define FC0(XM) FC(false, XM)
+#define FC1(XM) FC(true, XM)
+  if (x_mid) SL_XMODE(h, FC0); else SL_XMODE(h, FC1);
+#undef FC0
+#undef FC1
 #undef FC
   return sl_launch_status(h, "simulst_mma_decode(feed-forward chain)");
 }
@@ -530,12 +724,12 @@ int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float*
                      const float* ln_b, const void* Wqkv, const float* bqkv, void* qkv, int B, int F) {
   if (int rc = raise_lds_limits(h)) return rc;
   KTimer t(h, SIMULST_K_LINEAR_SKINNY);
-  const int rtl = rtl_for(h, B), splits = F / 256, n_cb = Wqkv ? 3 : 1;
-#define QC(R)                                                                                                          \
-  hipLaunchKernelGGL((dec_qkv_chain_kernel<R>), dim3(((B + 16 * R - 1) / (16 * R)) * n_cb), dim3(256), lds_bytes(R),  \
+  const int splits = F / 256, n_cb = Wqkv ? 3 : 1;
+#define QC(XM)                                                                                                         \
+  hipLaunchKernelGGL((dec_qkv_chain_kernel<1, XM>), dim3(((B + 15) / 16) * n_cb), dim3(256), lds_request(h),           \
                      h->stream, (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wqkv, bqkv,       \
                      (bf16*)qkv, B, splits, n_cb)
-  (void)rtl; QC(1);
+  SL_XMODE(h, QC);
 #undef QC
   return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + QKV chain)");
 }
@@ -584,4 +778,51 @@ extern "C" int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid
              "simulst_decoder_slab_sum_qkv: D == 256, F a multiple of 256 up to 8192");
   if (B == 0) return SIMULST_OK;
   return sl_dec_qkv_chain(h, x_mid, x, partial, b2, ln_g, ln_b, wqkv_fm, bqkv, qkv, B, F);
+}
+
+// ---- debug hooks of the reproducibility investigation (tools/chain_race_probe.py) ----------------
+extern "C" int simulst_debug_chain_lds_bytes(simulst_handle* h, int32_t bytes) {
+  if (!h) return SIMULST_E_NULL;
+  SL_REQUIRE(h, bytes >= 0 && bytes <= LDS_WHOLE_CU, SIMULST_E_ARG, "simulst_debug_chain_lds_bytes: 0 (default) .. 163840");
+  h->dec_chain_lds_bytes = bytes;
+  return SIMULST_OK;
+}
+
+extern "C" int simulst_debug_chain_xmode(simulst_handle* h, int32_t mode) {
+  if (!h) return SIMULST_E_NULL;
+  SL_REQUIRE(h, mode >= 0 && mode <= 3, SIMULST_E_ARG, "simulst_debug_chain_xmode: 0 .. 3");
+  h->dec_chain_xmode = mode;
+  return SIMULST_OK;
+}
+
+extern "C" int simulst_debug_chain_tail(simulst_handle* h, void* dbg) {
+  if (!h) return SIMULST_E_NULL;
+  h->dec_chain_tail = dbg;
+  return SIMULST_OK;
+}
+
+extern "C" int64_t simulst_debug_chain_probe_bytes(int32_t B) { return (int64_t)((B + 15) / 16) * PROBE_WG * 2; }
+
+extern "C" int simulst_debug_chain_probe(simulst_handle* h, const void* ctx, void* x, const void* wo_fm, const float* bo,
+                                         const float* ln_g, const float* ln_b, const void* wq_fm, const float* bq, void* q,
+                                         int32_t B, int32_t variant, void* dbg) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, ctx); SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, wo_fm); SL_CHECK_NULL(h, bo); SL_CHECK_NULL(h, ln_g);
+  SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, wq_fm); SL_CHECK_NULL(h, bq); SL_CHECK_NULL(h, q); SL_CHECK_NULL(h, dbg);
+  SL_REQUIRE(h, B > 0 && variant >= 0 && variant <= 3, SIMULST_E_ARG, "simulst_debug_chain_probe: variant 0..3");
+  if (!h->dec_chain_probe_attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_probe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_proj_chain_probe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_proj_chain_probe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_proj_chain_probe_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+    if (e != hipSuccess) { h->err = "simulst_debug_chain_probe: cannot raise the dynamic LDS limit"; return (int)e; }
+    h->dec_chain_probe_attr_set = true;
+  }
+#define PK(V)                                                                                                          \
+  hipLaunchKernelGGL((dec_proj_chain_probe_kernel<V>), dim3((B + 15) / 16), dim3(256), lds_request(h), h->stream,      \
+                     (const bf16*)ctx, (bf16*)x, (const uint4*)wo_fm, bo, ln_g, ln_b, (const uint4*)wq_fm, bq, (bf16*)q, \
+                     B, (unsigned short*)dbg)
+  switch (variant) { case 0: PK(0); break; case 1: PK(1); break; case 2: PK(2); break; default: PK(3); break; }
+#undef PK
+  return sl_launch_status(h, "simulst_debug_chain_probe");
 }

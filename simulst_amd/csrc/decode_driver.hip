@@ -572,13 +572,11 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   const bool fuse_q = split || B <= h->fuse_q_max_rows;
   // row-local chains (dec_chain.hip) for co-scheduled batches: { out-proj + residual, LN + q-proj(s) } in one launch,
   // { cross out-proj + residual, LN + fc1 + GELU, fc2 + residual } in another -- 5 launches per layer instead of 8-9
-  const bool chain = !split && !fuse_q && !h->force_unfused_decode && dd->ffn_partial && dd->ffn_sem &&
+  // (the feed-forward chain is always launched in its hand-off-free form here -- x_mid given, slabs added by the next layer's
+  //  LN + QKV launch -- so the ticket array dd->ffn_sem of the in-launch hand-off is not needed and not touched)
+  const bool chain = !split && !fuse_q && !h->force_unfused_decode && dd->ffn_partial &&
                      sl_dec_chain_ok(h, dt, B, D, F, pk != 0);
   const bool chain_ffn = chain && B <= h->dec_chain_ffn_max_rows && dd->x_mid;
-  if (chain) {                                   // tickets are left zero by every launch; a call aborted half-way must not poison the next
-    hipError_t e = hipMemsetAsync(dd->ffn_sem, 0, sizeof(int32_t) * ((B + 15) / 16), h->stream);
-    if (e != hipSuccess) { h->err = std::string("simulst_mma_decode: ticket reset: ") + hipGetErrorString(e); return (int)e; }
-  }
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_dec_layer& L = layers[l];

@@ -37,8 +37,15 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->dec_chain_ffn_max_rows = 1024;     // measured (bench.py --steps 20): 448-row sequences +4 %, 640 +2 %, 1280 -2 %, 4096 -3 %
   if (const char* e = getenv("SIMULST_DEC_CHAIN_FFN_MAX_ROWS")) h->dec_chain_ffn_max_rows = atoi(e);
   h->dec_chain_lds_attr_set = false;
+  h->dec_chain_probe_attr_set = false;
+  h->dec_chain_lds_bytes = 0;
+  h->dec_chain_xmode = 3;      // fragments hoisted + LayerNorm reductions on the DPP path: 1.378 -> 1.401 M tokens/s in the driver form
+  h->dec_chain_tail = nullptr;
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_XMODE")) h->dec_chain_xmode = atoi(e);
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_LDS_BYTES")) h->dec_chain_lds_bytes = atoi(e);
   h->graph_exec = nullptr;
   h->ctc_lds_attr_set = false;
+  h->conv_pos_lds_attr_set = false;
   h->ffn_lds_attr_set = false;
   h->ffn_variant = 0;
   h->graph_key = 0;

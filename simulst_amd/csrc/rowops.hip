@@ -411,9 +411,13 @@ extern "C" int simulst_conv_pos(simulst_handle* h, const void* x, const void* hi
   if (B <= 0 || T_ <= 0) return SIMULST_OK;
   KTimer t(h, SIMULST_K_CONV_POS);
   dim3 grid((T_ + 63) / 64, groups, B);
+  if (lds > 48 * 1024 && !h->conv_pos_lds_attr_set) {      // once per handle, like the other kernels with large dynamic LDS
+    hipError_t e = hipFuncSetAttribute((const void*)conv_pos_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_pos_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { h->err = std::string("simulst_conv_pos: cannot raise the dynamic LDS limit: ") + hipGetErrorString(e); return (int)e; }
+    h->conv_pos_lds_attr_set = true;
+  }
   DT_SWITCH(dtype, {
-    if (lds > 48 * 1024)     // idempotent host-side attribute; no process-global "already done" flag
-      (void)hipFuncSetAttribute((const void*)conv_pos_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(conv_pos_kernel<T>, grid, dim3(256), lds, h->stream, (const T*)x, (const T*)hist,
                        (const T*)W, bias, lengths, (T*)y, T_, D, cpg, k);
   });

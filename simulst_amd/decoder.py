@@ -445,9 +445,8 @@ class MMADecoder:
                      "x_mid": torch.empty(B, D, device=dev, dtype=dt_),
                      "p_self": torch.empty(B, cfg.num_heads, D, device=dev, dtype=torch.float32)}
             if self.layer_chains and dt_ == torch.bfloat16 and D == 256 and cfg.ffn_dim % 256 == 0:
-                # row-local layer chains (simulst_decoder_desc.ffn_partial / ffn_sem): fp32 slabs of the split feed-forward
+                # row-local layer chains (simulst_decoder_desc.ffn_partial): fp32 slabs of the split feed-forward
                 st.ws["ffn_partial"] = torch.empty(cfg.ffn_dim // 256, B, D, device=dev, dtype=torch.float32)
-                st.ws["ffn_sem"] = torch.zeros((B + 15) // 16, device=dev, dtype=torch.int32)
         if getattr(st, "structs_fragment_major", None) != self.fragment_major:   # states are cached across calls
             st.layer_structs = self._layer_structs(st)
             st.structs_fragment_major = self.fragment_major
@@ -466,7 +465,7 @@ class MMADecoder:
                                 ws["logits"].data_ptr(), ws["x_mid"].data_ptr() if (split or chains) else None,
                                 ws["p_self"].data_ptr() if split else None, int(self.fragment_major),
                                 ws["ffn_partial"].data_ptr() if chains else None,
-                                ws["ffn_sem"].data_ptr() if chains else None)
+                                None)
 
     def stream_steps(self, st: DecoderState, tokens: torch.Tensor, ctl, n_iter: int):
         """n_iter masked policy()/predict() rounds of a batch of streams (simulst_mma_stream_steps): rows read

@@ -166,11 +166,15 @@ def test_decode_loop_with_chains_vs_one_launch_per_gemm(monkeypatch, attn, ffn):
 
 
 def test_chains_repeat_beside_other_streams(ops):
-    """The three chains while three OTHER streams keep LDS-holding, matrix-core-heavy kernels resident (the fused Emformer
-    feed-forward with two 75 KB workgroups per CU, the Emformer block attention with three of 50 KB, the 128 x 128 tile GEMM):
-    every repeat must equal the result computed on a quiet chip bit for bit.  With a 23 KB LDS request per chain workgroup this
-    failed in 95 % of the repeats beside the feed-forward kernel, with 88 KB in half of them beside the tile GEMM
-    (csrc/dec_chain.hip, lds_bytes)."""
+    """The three chains while four OTHER streams keep matrix-core-heavy kernels resident on the same compute units (the fused
+    Emformer feed-forward with two 75 KB workgroups per CU, the Emformer block attention with three of 50 KB, the 128 x 128 tile
+    GEMM, and a decode-step GEMM that uses the matrix cores WITHOUT holding LDS): every repeat must equal the result computed on a
+    quiet chip bit for bit.  The chain workgroups request only the 23 KB of LDS they use, so they DO share compute units with
+    those neighbours.  Round 2's build failed this in 85-95 % of the repeats beside the feed-forward kernel: hipcc's SLP
+    vectoriser had fused the LayerNorm arithmetic into packed fp32 instructions with an op_sel source swizzle, which returned
+    x - 0 for x - mean in lanes 48-63 beside such a neighbour (tools/chain_race_probe.py,
+    profiles/r03_chain_race_root_cause.json); csrc/dec_chain.hip is now compiled without that vectoriser and
+    tests/test_isa_guards.py refuses the instruction form anywhere in the library."""
     import threading
     import time
     from simulst_amd import _lib
@@ -214,6 +218,13 @@ def test_chains_repeat_beside_other_streams(ops):
                     for _ in range(20):
                         o2.emformer_ffn(xx, ln[0], ln[1], w1p, z1, w2p, z2, yy)
                     st.synchronize()
+            elif kind == "skinny":                        # matrix cores without LDS: the decode-step GEMM
+                xa = bf(torch.randn(128, 256)); Wn = o2.pack_fragment_major(bf(torch.randn(2048, 256) * 256 ** -0.5))
+                bb = torch.zeros(2048).cuda()
+                while not stop.is_set():
+                    for _ in range(50):
+                        o2.linear(xa, Wn, bb, w_fragment_major=True)
+                    st.synchronize()
             elif kind == "gemm":                          # 128 x 128 tile GEMM (the subsampler's shape)
                 xa = bf(torch.randn(64 * 500, 512)); Wn = bf(torch.randn(512, 512) * 512 ** -0.5)
                 bb, oo = torch.zeros(512).cuda(), torch.empty(64 * 500, 512, device="cuda", dtype=torch.bfloat16)
@@ -234,7 +245,7 @@ def test_chains_repeat_beside_other_streams(ops):
                                               use_summary=True)
                     st.synchronize()
 
-    threads = [threading.Thread(target=noise, args=(k,)) for k in ("ffn", "emf", "gemm")]
+    threads = [threading.Thread(target=noise, args=(k,)) for k in ("ffn", "emf", "gemm", "skinny")]
     try:
         for t in threads:
             t.start()

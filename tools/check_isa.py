@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Build-time ISA guards of libsimulst_hip.so (run by tests/test_isa_guards.py on the CPU side).
+
+1. NO packed fp32 instruction with an op_sel source swizzle anywhere in the library.  hipcc's SLP vectoriser produces them
+   from scalar code (x - mean for two elements becomes `v_pk_add_f32 d, x, m op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]`); in the
+   decoder's layer chains they returned x - 0 in lanes 48-63 whenever a matrix-core-heavy workgroup of another stream shared
+   the SIMD -- the run-to-run differences of round 2 (tools/chain_race_probe.py reproduces them from a
+   library built with `make CHAINFLAGS=-fslp-vectorize`).  Packed fp32 WITHOUT op_sel (op_sel_hi broadcasts included) is
+   what every other kernel of the library uses, thousands of them, and all of those repeat bit for bit.
+2. The layer chains (csrc/dec_chain.hip) issue v_mfma_f32_16x16x32_bf16 from inline assembly, invisible to hipcc's hazard
+   recogniser and register allocator: between the first MFMA on an accumulator and the `s_nop 15` that closes the unit nothing
+   but MFMAs may touch an accumulator register.
+
+    python tools/check_isa.py [path/to/libsimulst_hip.so]        # exit status 1 on a violation
+"""
+import glob
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+SWIZZLED = re.compile(r"\bv_pk_(add|mul|fma)_f32\b.*\bop_sel:\[")
+
+
+def regs(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def disassemble(so_path):
+    """-> {kernel symbol: [instruction, ...]} of every gfx950 code object inside the shared library"""
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "lib.so")
+        shutil.copy(so_path, so)
+        subprocess.run([OBJDUMP, "--offloading", so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for co in sorted(glob.glob(so + ".*gfx950")):
+            txt = subprocess.run([OBJDUMP, "-d", co], check=True, capture_output=True, text=True).stdout
+            cur = None
+            for line in txt.split("\n"):
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+                if m:
+                    cur = out.setdefault(m.group(1), [])
+                    continue
+                if cur is not None and line.startswith("\t"):
+                    cur.append(line.split("//")[0].strip())
+    return out
+
+
+def check_swizzles(kernels):
+    bad = []
+    for name, body in kernels.items():
+        n = sum(1 for ins in body if SWIZZLED.search(ins))
+        if n:
+            bad.append((name, n, next(ins for ins in body if SWIZZLED.search(ins))))
+    return bad
+
+
+def check_chain_accumulators(body):
+    """chain kernels: nothing but MFMAs touches an accumulator between the first MFMA of a unit and its closing s_nop 15"""
+    out, i = [], 0
+    while i < len(body):
+        if body[i].startswith("v_mfma"):
+            accs, j = set(), i
+            while j < len(body) and not body[j].startswith("s_nop 15"):
+                op, _, rest = body[j].partition(" ")
+                ops = [t.strip() for t in rest.split(",")] if rest else []
+                if op.startswith("v_mfma"):
+                    accs |= regs(ops[0])
+                elif ops and not op.startswith("s_"):
+                    touched = set().union(*[regs(t.split(" ")[0]) for t in ops])
+                    if touched & accs:
+                        out.append(f"'{body[j]}' touches an accumulator inside an MFMA chain")
+                j += 1
+            if j >= len(body):
+                out.append("MFMA chain without the closing s_nop 15")
+            i = j
+        i += 1
+    return out
+
+
+def main():
+    so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "simulst_amd", "libsimulst_hip.so")
+    kernels = disassemble(so)
+    if not kernels:
+        print("no gfx950 kernels found in", so, file=sys.stderr)
+        return 2
+    rc = 0
+    n_pk = sum(1 for b in kernels.values() for ins in b if re.match(r"v_pk_(add|mul|fma)_f32\b", ins))
+    bad = check_swizzles(kernels)
+    print(f"{len(kernels)} kernels, {n_pk} packed fp32 instructions, {sum(n for _, n, _ in bad)} with an op_sel source swizzle")
+    for name, n, ex in bad:
+        print(f"  SWIZZLED packed fp32 in {name}: {n}, e.g. '{ex}'")
+        rc = 1
+    chains = {k: b for k, b in kernels.items() if re.search(r"dec_(proj|ffn|qkv)_chain_kernel", k)}
+    if not chains:
+        print("the layer-chain kernels are missing from the library", file=sys.stderr)
+        return 2
+    for name, body in sorted(chains.items()):
+        v = check_chain_accumulators(body)
+        n_mfma = sum(1 for ins in body if ins.startswith("v_mfma"))
+        print(f"  {name[:70]}: {n_mfma} MFMAs, {len(v)} accumulator finding(s)")
+        for msg in v[:3]:
+            print("     ", msg)
+        rc = rc or (1 if v else 0)
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())
