@@ -501,6 +501,75 @@ typedef struct {
 int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,
                              int64_t* tokens_io, const simulst_stream_ctl* ctl, int32_t n_iter);
 
+
+/* ---- whole CIF decode steps on the device --------------------------------------------
+ * The position-synchronous decoder of models/cif_transformer.py:579-724 (CIFDecoder.extract_features_scriptable / forward with
+ * incremental_state) for a batch, n_steps target positions with no host round trip -- the loop eval/generate.py:187-209 runs
+ * through SequenceGenerator and, with n_steps == 1, one policy()/predict() pair of agents/cif_agent.py:368-436.  At position u
+ * (= tokens in [eos] + hypothesis) row b looks at integrated vector cif[b][min(cif_len[b], u) - 1] (:622-628); its decoder layer is
+ * fairseq's with FakeCrossAttn out_proj(gelu(q_proj(LN x) + k_proj(c))) in place of attention (:340-362); the EOS logit gets
+ * max(0, u - cif_len[b]) * overshoot_weight (:716-722).  k_proj(c) is projected ONCE per integrated vector by the caller
+ * (Kc = simulst_linear over the new slots, bias included) and gathered per step.  Same workspace / weight-order conventions as
+ * simulst_decoder_desc. */
+typedef struct {
+  const void* wqkv; const float* bqkv;           /* self-attention [3D][D] (q|k|v) */
+  const void* wo; const float* bo;
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+  const void* c_wq;                              /* FakeCrossAttn.q_proj [D][D] (no bias, models/cif_transformer.py:344) */
+  const void* c_wo; const float* c_bo;           /* FakeCrossAttn.out_proj */
+  const void* fc1; const float* b1; const void* fc2; const float* b2;
+  void *k_cache, *v_cache;                       /* [B][H][cap][d] */
+  const void* Kc;                                /* [B][n_cap][D] = k_proj(cif_out) + bias of this layer, row-major */
+} simulst_cif_dec_layer;
+
+typedef struct {
+  int32_t B, D, H, F, V, n_layers, cap, n_cap, dtype;
+  int32_t pad_idx, eos_idx;
+  int32_t highway;                               /* --cif-highway: logits = E^T (LN(x) + c) (models/cif_transformer.py:681-682) */
+  int32_t n_prev_uniform;                        /* >= 0: every row has written exactly this many tokens; -1: use n_prev[] */
+  float embed_scale, overshoot_weight;
+  const void* E; const void* out_proj; const float* pos_table; const float *ln_g, *ln_b;
+  const int32_t* cif_len;                        /* [B] integrated vectors available per row */
+  const void* cif;                               /* [B][n_cap][D] the vectors themselves (highway only, else may be NULL) */
+  int32_t* n_prev;                               /* [B] in/out: tokens written so far */
+  void *x, *qkv, *ctx, *q, *hidden;              /* workspace: [B][D], [B][3D], [B][D], [B][D], [B][F] */
+  float* logits;                                 /* workspace [B][V] */
+  void* kk;                                      /* workspace [n_layers][B][D]: the gathered Kc rows of the current step */
+  void* cif_t;                                   /* workspace [B][D] (highway only) */
+  float* eos_bias;                               /* workspace [B] */
+  void* x_mid; float* ffn_partial;               /* optional: row-local layer chains, as in simulst_decoder_desc */
+  int32_t weights_fragment_major;
+} simulst_cif_decoder_desc;
+
+/* tokens_io [B]: in = newest token of [eos] + hyp, out = last token picked; out_tokens [n_steps][B].  pad is never picked; EOS is
+ * masked when mask_eos != 0 or while n_prev == 0 (SequenceGenerator min_len = 1). */
+int simulst_cif_decode(simulst_handle* h, const simulst_cif_decoder_desc* d, const simulst_cif_dec_layer* layers,
+                       int64_t* tokens_io, int64_t* out_tokens, int32_t n_steps, int32_t mask_eos);
+
+/* BATCHED STREAMING CIF decode (no counterpart in the reference: CIFLayer.infer raises for B > 1, models/cif_transformer.py:199-200):
+ * n_iter policy()/predict() rounds for every row.  A row WRITES in a round iff it is not done and (cif_len > n_prev or its source has
+ * ended) -- the complement of the agent's READ condition (agents/cif_agent.py:385-389) -- committing the plain argmax
+ * (agents/cif_agent.py:414-436) to hyp with the stamp cur_ms; it is done on EOS or when it holds more than max_len_now tokens.
+ * Rows that cannot write are left untouched; the host feeds the next chunk (simulst_cif_stream_append + Kc projection) and calls again. */
+typedef struct {
+  const uint8_t* online;  /* [B] row's source has not ended */
+  uint8_t* done;          /* [B] in/out */
+  int32_t* delays_ms;     /* [B][cap] or NULL */
+  int64_t* hyp;           /* [B][cap] committed tokens */
+  int32_t cap, cur_ms, max_len_now;
+} simulst_cif_stream_ctl;
+
+int simulst_cif_stream_steps(simulst_handle* h, const simulst_cif_decoder_desc* d, const simulst_cif_dec_layer* layers,
+                             int64_t* tokens_io, const simulst_cif_stream_ctl* ctl, int32_t n_iter);
+
+/* Bookkeeping of a BATCHED CIFLayer.infer call (models/cif_transformer.py:235-255): of the n[b] slots simulst_cif_integrate produced
+ * for this chunk (out [B][T_cap][D], tail_w [B]) all but the last -- the un-fired tail, withheld unless finish -- are appended to the
+ * row's accumulated vectors acc [B][n_cap][D] at acc_len[b] (updated); the tail is carried as prev_weight[b] = tail_w[b],
+ * prev_feat[b] = out[b][n[b] - 1] / beta (:239-251) to be put in front of the next chunk by the caller. */
+int simulst_cif_stream_append(simulst_handle* h, const void* out, const int32_t* n, const float* tail_w, void* acc,
+                              int32_t* acc_len, void* prev_feat, float* prev_weight, int32_t B, int32_t T_cap, int32_t n_cap,
+                              int32_t D, float beta, int32_t finish, int32_t dtype);
+
 /* Row-local chains of the decoder layer for co-scheduled batches (bf16, D == 256, fragment-major weights); the decode
  * loop uses them from 129 rows on when simulst_decoder_desc.ffn_partial / ffn_sem are given.  Same rounding points as the
  * launches they replace (bf16 after bias + residual, after LayerNorm, after GELU).

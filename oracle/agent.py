@@ -215,3 +215,43 @@ def greedy_offline(w, ecfg, dcfg, src_tokens, src_lengths, n_steps=None, mask_eo
         if bool(done.all()):
             break
     return toks[:, 1:], lengths, enc
+
+
+def greedy_offline_cif(w, ecfg, dcfg, beta, src_tokens, src_lengths, n_steps=None, mask_eos=False, max_len_a=0.1,
+                       max_len_b=10, overshoot_weight=1.0, margins=None):
+    """Offline batched greedy decode of the CIF model: eval/generate.py:187-209 -> task.inference_step ->
+    SequenceGenerator(beam=1) restated as in ``greedy_offline``: CIFEncoder.forward once (Emformer + CIFLayer.forward,
+    models/cif_transformer.py:141-186,289-296), then CIFDecoder.forward per target position (:579-724) with the EOS overshoot
+    bias (default overshoot_weight 1.0, :701).  Returns tokens [B, n], lengths [B], encoder dict (with cif_out / cif_lengths)."""
+    B = src_tokens.size(0)
+    enc = em.encoder_forward(w, "encoder", ecfg, src_tokens, src_lengths)
+    pad = enc["encoder_padding_mask"][0]
+    c = cifm.cif_layer_forward(w, "encoder.cif_layer", beta, enc["encoder_out"][0], pad if pad.any() else None)
+    enc_in = {"cif_out": c["cif_out"], "cif_lengths": c["cif_lengths"]}
+    enc.update(enc_in)
+    if n_steps is None:
+        n_steps = int(max_len_a * src_tokens.size(1) + max_len_b)
+    st = dec.new_decoder_state(dcfg)
+    toks = torch.full((B, 1), dcfg.eos, dtype=torch.long)
+    done = torch.zeros(B, dtype=torch.bool)
+    lengths = torch.zeros(B, dtype=torch.long)
+    for step in range(n_steps):
+        logits, _ = dec.cif_decoder_step(w, "decoder", dcfg, toks, enc_in, st, overshoot_weight)
+        lp = torch.log_softmax(logits[:, -1].float(), dim=-1)
+        lp[:, dcfg.padding_idx] = -float("inf")
+        if mask_eos or step == 0:
+            lp[:, dcfg.eos] = -float("inf")
+        if not mask_eos and step == n_steps - 1:
+            lp[:, :dcfg.eos] = -float("inf")
+            lp[:, dcfg.eos + 1:] = -float("inf")
+        nxt = lp.argmax(dim=-1)
+        if margins is not None:
+            top2 = lp.topk(2, dim=-1).values
+            margins.append(top2[:, 0] - top2[:, 1])
+        nxt = torch.where(done, torch.full_like(nxt, dcfg.eos), nxt)
+        lengths += (~done).long()
+        done = done | (nxt == dcfg.eos)
+        toks = torch.cat([toks, nxt.unsqueeze(1)], dim=1)
+        if bool(done.all()):
+            break
+    return toks[:, 1:], lengths, enc

@@ -60,6 +60,25 @@ class DecoderDesc(C.Structure):
                                           "ctx", "q", "q2", "hidden", "logits", "x_mid", "partial_self")] + \
                [("weights_fragment_major", C.c_int32), ("ffn_partial", C.c_void_p), ("ffn_sem", C.c_void_p)]
 
+class CifDecLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b",
+                                          "c_wq", "c_wo", "c_bo", "fc1", "b1", "fc2", "b2", "k_cache", "v_cache", "Kc")]
+
+
+class CifDecoderDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "D", "H", "F", "V", "n_layers", "cap", "n_cap", "dtype", "pad_idx", "eos_idx",
+                                         "highway", "n_prev_uniform")] + \
+               [("embed_scale", C.c_float), ("overshoot_weight", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("E", "out_proj", "pos_table", "ln_g", "ln_b", "cif_len", "cif", "n_prev", "x", "qkv",
+                                          "ctx", "q", "hidden", "logits", "kk", "cif_t", "eos_bias", "x_mid", "ffn_partial")] + \
+               [("weights_fragment_major", C.c_int32)]
+
+
+class CifStreamCtl(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("online", "done", "delays_ms", "hyp")] + \
+               [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now")]
+
+
 class StreamCtl(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("active", "read_flag", "online", "done", "delays_ms", "hyp")] + \
                [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now")]
@@ -121,6 +140,9 @@ SIGNATURES = {
     "simulst_mma_stream_steps": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, C.POINTER(StreamCtl), _i32],
     "simulst_policy_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                        _i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "simulst_cif_decode": [_vp, C.POINTER(CifDecoderDesc), C.POINTER(CifDecLayer), _vp, _vp, _i32, _i32],
+    "simulst_cif_stream_steps": [_vp, C.POINTER(CifDecoderDesc), C.POINTER(CifDecLayer), _vp, C.POINTER(CifStreamCtl), _i32],
+    "simulst_cif_stream_append": [_vp] * 8 + [_i32, _i32, _i32, _i32, C.c_float, _i32, _i32],
     "simulst_decoder_proj_chain": [_vp] * 13 + [_i32, _i32, _i32],
     "simulst_decoder_ffn_chain": [_vp] * 14 + [_i32, _i32, _i32, _i32],
     "simulst_decoder_slab_sum_qkv": [_vp] * 10 + [_i32, _i32, _i32, _i32],

@@ -97,6 +97,40 @@ class CIFLayer:
                 "delays": [delays], "alpha_sum": [asum], "tail_weights": [tail_w], "cif_out_btd": feats}
 
 
+    # ---- batched streaming (no counterpart in the reference: CIFLayer.infer raises for B > 1, :199-200) -------------------
+    def new_batched_state(self, B: int, D: int, n_cap: int):
+        """per-row carry and accumulated integrated vectors of B lockstep streams, all on the device"""
+        dev = self.device
+        return {"conv_hist": torch.zeros(B, self.k - 1, D, device=dev, dtype=self.dtype), "first": True,
+                "prev_feat": torch.zeros(B, 1, D, device=dev, dtype=self.dtype),
+                "prev_weight": torch.zeros(B, 1, device=dev, dtype=torch.float32),
+                "cif": torch.zeros(B, n_cap, D, device=dev, dtype=self.dtype), "n_cap": n_cap,
+                "cif_len": torch.zeros(B, device=dev, dtype=torch.int32)}
+
+    def infer_batched(self, x_btd: torch.Tensor, st: dict, finish: bool = False):
+        """CIFLayer.infer for B rows that receive the same number of new encoder frames (lockstep sources): per row exactly
+        the B == 1 arithmetic -- weights of the new frames, the carried (weight, feature / beta) pseudo-frame in front
+        (:217-226), one integrate-and-fire scan, the un-fired tail withheld and carried unless ``finish`` (:235-255).  The new
+        vectors are appended to st["cif"] at st["cif_len"] on the device (simulst_cif_stream_append); nothing is read back."""
+        B, T, D = x_btd.shape
+        if T > 0:
+            alpha = self._alpha(x_btd, st["conv_hist"])
+            st["conv_hist"] = torch.cat([st["conv_hist"], x_btd], dim=1)[:, -(self.k - 1):].contiguous()
+        else:
+            alpha = torch.zeros(B, 0, device=self.device, dtype=torch.float32)
+        x = x_btd
+        if not st["first"]:
+            alpha = torch.cat([st["prev_weight"], alpha], dim=1).contiguous()
+            x = torch.cat([st["prev_feat"], x], dim=1).contiguous()
+        st["first"] = False
+        if x.size(1) == 0:
+            return
+        out, n, _, tail_w, _ = self.ops.cif_integrate(x.contiguous(), alpha, beta=self.beta,
+                                                      tail_thres=self.tail_thres if finish else 0.0)
+        self.ops.cif_stream_append(out, n, tail_w, st["cif"], st["cif_len"], st["prev_feat"], st["prev_weight"],
+                                   beta=self.beta, finish=finish)
+
+
 class CIFEncoder(S2TEmformerEncoder):
     """models/cif_transformer.py:264-321."""
 
@@ -134,9 +168,143 @@ class CIFDecoder:
         self.dictionary = _Dictionary(cfg)
         self.layers = [SimpleNamespace(index=l, encoder_attn=SimpleNamespace()) for l in range(cfg.decoder_layers)]
 
+        D, F, V = cfg.embed_dim, cfg.ffn_dim, cfg.vocab
+        self.fragment_major = D % 64 == 0 and F % 64 == 0 and V % 16 == 0 and cfg.head_dim % 16 == 0
+        import os
+        self.layer_chains = os.environ.get("SIMULST_LAYER_CHAINS", "1") == "1"
+        self._pack_all()
+
+    def _pack_all(self):
+        """decode-loop weight matrices in MFMA-fragment order (simulst_linear_desc.w_fragment_major), made once"""
+        w = self.w
+        w.packed, w.out_proj_packed, w.kc_packed = None, None, {}
+        if self.fragment_major:
+            names = ["wqkv", "wo", "c_wq", "c_wo", "fc1", "fc2"]
+            w.packed = [{n: self.ops.pack_fragment_major(L[n]) for n in names} for L in w.layers]
+            w.out_proj_packed = self.ops.pack_fragment_major(w.out_proj)
+        if self.dtype == torch.bfloat16 and self.cfg.embed_dim <= 256 and self.cfg.embed_dim % 64 == 0:
+            for L in w.layers:                      # the row-panel kernel's form of k_proj (thousands of integrated vectors)
+                w.kc_packed[L["c_wk"].data_ptr()] = self.ops.pack_fragment_major(L["c_wk"])
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     def clear_cache(self, incremental_state, end_id=None):
         """a discarded prediction needs no rollback: forward() takes the written-token count from prev_output_tokens"""
         return None
+
+    # ------------------------------------------------------------------ device-resident loop (simulst_cif_decode)
+    def new_device_state(self, B: int, cap: int, n_cap: int):
+        cfg, dev, dt_ = self.cfg, self.device, self.dtype
+        H, d, D, Ld = cfg.num_heads, cfg.head_dim, cfg.embed_dim, cfg.decoder_layers
+        from .decoder import ensure_positions
+        ensure_positions(self.w, cap + cfg.padding_idx + 2)
+        st = {"B": B, "cap": cap, "n_cap": n_cap,
+              "k": [torch.zeros(B, H, cap, d, device=dev, dtype=dt_) for _ in range(Ld)],
+              "v": [torch.zeros(B, H, cap, d, device=dev, dtype=dt_) for _ in range(Ld)],
+              "Kc": [torch.zeros(B, n_cap, D, device=dev, dtype=dt_) for _ in range(Ld)],
+              "n_prev": torch.zeros(B, device=dev, dtype=torch.int32), "n_prev_host": 0, "lockstep": True,
+              "cif": None, "cif_len": None, "tok": torch.empty(B, device=dev, dtype=torch.int64),
+              "ws": {"x": torch.empty(B, D, device=dev, dtype=dt_), "qkv": torch.empty(B, 3 * D, device=dev, dtype=dt_),
+                     "ctx": torch.empty(B, D, device=dev, dtype=dt_), "q": torch.empty(B, D, device=dev, dtype=dt_),
+                     "hidden": torch.empty(B, cfg.ffn_dim, device=dev, dtype=dt_),
+                     "logits": torch.empty(B, cfg.vocab, device=dev, dtype=torch.float32),
+                     "kk": torch.empty(Ld, B, D, device=dev, dtype=dt_), "cif_t": torch.empty(B, D, device=dev, dtype=dt_),
+                     "eos_bias": torch.zeros(B, device=dev, dtype=torch.float32),
+                     "x_mid": torch.empty(B, D, device=dev, dtype=dt_)}}
+        if self.layer_chains and dt_ == torch.bfloat16 and D == 256 and cfg.ffn_dim % 256 == 0 and self.fragment_major:
+            st["ws"]["ffn_partial"] = torch.empty(cfg.ffn_dim // 256, B, D, device=dev, dtype=torch.float32)
+        arr = (_lib.CifDecLayer * Ld)()
+        for l, L in enumerate(self.w.layers):
+            a, P = arr[l], (self.w.packed[l] if self.fragment_major else L)
+            for n in ("bqkv", "bo", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b", "c_bo", "b1", "b2"):
+                setattr(a, n, L[n].data_ptr())
+            for n in ("wqkv", "wo", "c_wq", "c_wo", "fc1", "fc2"):
+                setattr(a, n, P[n].data_ptr())
+            a.k_cache, a.v_cache, a.Kc = st["k"][l].data_ptr(), st["v"][l].data_ptr(), st["Kc"][l].data_ptr()
+        st["layer_structs"] = arr
+        return st
+
+    def project_cif(self, st, cif: torch.Tensor, lo: int, hi: int):
+        """Kc_l[:, lo:hi] = k_proj_l(cif[:, lo:hi]) + bias for every layer: FakeCrossAttn's key projection (:358), done once per
+        integrated vector instead of once per target position.  cif [B, n_cap, D] is kept as the state's vector buffer."""
+        ops, D = self.ops, self.cfg.embed_dim
+        st["cif"] = cif
+        n = hi - lo
+        if n <= 0:
+            return
+        B, n_cap = cif.size(0), cif.size(1)
+        assert n_cap == st["n_cap"] and cif.is_contiguous()
+        for l, L in enumerate(self.w.layers):
+            Wt, fm = L["c_wk"], False
+            if B * n >= 4096 and Wt.data_ptr() in self.w.kc_packed:
+                Wt, fm = self.w.kc_packed[Wt.data_ptr()], True
+            ops.linear_raw(cif[:, lo:], Wt, L["c_bk"], st["Kc"][l][:, lo:], M_batches=B, rows_per_batch=n, N=D, K=D,
+                           a_bs=n_cap * D, a_rs=D, c_bs=n_cap * D, c_rs=D, epilogue=EPI_BIAS, w_fragment_major=fm)
+
+    def _desc(self, st, np_uniform: int, overshoot_weight: float):
+        cfg, ws = self.cfg, st["ws"]
+        from .decoder import ensure_positions
+        ensure_positions(self.w, st["cap"] + cfg.padding_idx + 2)
+        out_proj = self.w.out_proj_packed if self.fragment_major else self.w.out_proj
+        chains = "ffn_partial" in ws
+        return _lib.CifDecoderDesc(st["B"], cfg.embed_dim, cfg.num_heads, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, st["cap"],
+                                   st["n_cap"], _lib.F32 if self.dtype == torch.float32 else _lib.BF16, cfg.padding_idx, cfg.eos,
+                                   int(cfg.cif_highway), np_uniform, self.embed_scale, float(overshoot_weight),
+                                   self.w.E.data_ptr(), out_proj.data_ptr(), self.w.pos.data_ptr(), self.w.ln_g.data_ptr(),
+                                   self.w.ln_b.data_ptr(), st["cif_len"].data_ptr(), st["cif"].data_ptr(), st["n_prev"].data_ptr(),
+                                   ws["x"].data_ptr(), ws["qkv"].data_ptr(), ws["ctx"].data_ptr(), ws["q"].data_ptr(),
+                                   ws["hidden"].data_ptr(), ws["logits"].data_ptr(), ws["kk"].data_ptr(), ws["cif_t"].data_ptr(),
+                                   ws["eos_bias"].data_ptr(), ws["x_mid"].data_ptr() if chains else None,
+                                   ws["ffn_partial"].data_ptr() if chains else None, int(self.fragment_major))
+
+    def decode_steps(self, st, n_steps: int, mask_eos: bool, overshoot_weight: float = 1.0):
+        """n_steps target positions of every row on the device (simulst_cif_decode); st["tok"] holds the newest token of
+        [eos] + hyp and is updated in place.  Returns tokens [n_steps, B]."""
+        import ctypes as C
+        assert st["n_prev_host"] + n_steps < st["cap"], "decoder state capacity exceeded"
+        d = self._desc(st, st["n_prev_host"] if st["lockstep"] else -1, overshoot_weight)
+        out = torch.empty(n_steps, st["B"], device=self.device, dtype=torch.int64)
+        self.ops.h.check(self.ops.lib.simulst_cif_decode(self.ops.h.ptr, C.byref(d), st["layer_structs"], st["tok"].data_ptr(),
+                                                         out.data_ptr(), n_steps, int(mask_eos)), "simulst_cif_decode")
+        st["n_prev_host"] += n_steps
+        return out
+
+    def stream_steps(self, st, ctl, n_iter: int, overshoot_weight: float = 1.0):
+        """n_iter masked policy()/predict() rounds of a batch of streams (simulst_cif_stream_steps)"""
+        import ctypes as C
+        d = self._desc(st, -1, overshoot_weight)
+        self.ops.h.check(self.ops.lib.simulst_cif_stream_steps(self.ops.h.ptr, C.byref(d), st["layer_structs"],
+                                                               st["tok"].data_ptr(), C.byref(ctl), n_iter),
+                         "simulst_cif_stream_steps")
+
+    def greedy_offline(self, cif_btd: torch.Tensor, cif_len: torch.Tensor, n_steps: int, mask_eos: bool = True,
+                       overshoot_weight: float = 1.0, fused: bool = True):
+        """Batched greedy decode over the integrated vectors of a finished source (eval/generate.py:187-209 through
+        SequenceGenerator, beam 1).  cif_btd [B, n, D] (rows beyond cif_len unused), cif_len [B].  Returns tokens [B, n_steps]."""
+        B, n, D = cif_btd.shape
+        key = (B, n_steps + 2, n)
+        if not hasattr(self, "_offline_states"):
+            self._offline_states = {}
+        st = self._offline_states.get(key)
+        if st is None:
+            st = self._offline_states[key] = self.new_device_state(B, cap=key[1], n_cap=n)
+        st["n_prev"].zero_()
+        st["n_prev_host"], st["lockstep"] = 0, True
+        st["cif_len"] = cif_len.to(device=self.device, dtype=torch.int32).contiguous()
+        self.project_cif(st, cif_btd.contiguous(), 0, n)
+        st["tok"].fill_(self.cfg.eos)
+        if fused:
+            return self.decode_steps(st, n_steps, mask_eos, overshoot_weight).t().contiguous()
+        # per-op launches from the host (reference-shaped control flow; parity tests)
+        hst = self.new_state(B, cap=n_steps + 2)
+        out = torch.empty(n_steps, B, device=self.device, dtype=torch.int64)
+        toks = st["tok"]
+        for s_ in range(n_steps):
+            logits, overshoot = self.step(hst, toks, cif_btd, st["cif_len"], overshoot_weight)
+            toks = self.ops.greedy_argmax(logits, pad_idx=self.cfg.padding_idx, eos_idx=self.cfg.eos,
+                                          mask_eos=mask_eos or s_ == 0, eos_bias=overshoot.contiguous(), out=out[s_])
+            self.commit(hst)
+        return out.t().contiguous()
 
     def max_positions(self):
         return self.cfg.max_target_positions
@@ -231,6 +399,17 @@ class CIFTransformerModel(FairseqModelSurface):
     def max_decoder_positions(self):
         return self.cfg.max_target_positions
 
+    def generate_offline(self, src_tokens, src_lengths, n_steps=None, mask_eos=False, overshoot_weight=1.0, fused=True):
+        """task.inference_step with beam 1 for the CIF model (eval/generate.py:200-209; exp/infer_st.yaml:2-5): encoder +
+        integrate-and-fire once, then the position-synchronous greedy loop on the device.  Returns tokens [B, n] and the
+        encoder dict."""
+        enc = self.encoder.forward(src_tokens, src_lengths)
+        if n_steps is None:
+            n_steps = int(0.1 * src_tokens.size(1) + 10)
+        toks = self.decoder.greedy_offline(enc["cif_out_btd"], enc["cif_lengths"][0], n_steps, mask_eos, overshoot_weight,
+                                           fused=fused)
+        return toks, {"encoder": enc}
+
 
 class CIFAgent:
     """agents/cif_agent.py: READ while cif_lengths <= len(hyp) and the source has not ended (:385-389),
@@ -300,6 +479,86 @@ class CIFAgent:
                 break
         return {"tokens": list(states.target), "delays_ms": delays, "actions": "".join(actions),
                 "AL": average_lagging(delays, src.total_ms()), "n_cif": states.cif_len}
+
+
+class BatchedCIFStreamingAgent(CIFAgent):
+    """B simultaneous CIF streams through ONE encoder / decoder batch, every row taking its own READ / WRITE decisions (the
+    reference streams one utterance per process: CIFLayer.infer raises for B > 1, models/cif_transformer.py:199-200).  Sources
+    advance in lockstep; after each chunk every row writes while it holds more integrated vectors than tokens (the complement
+    of the agent's READ condition, agents/cif_agent.py:385-389) -- masked position-synchronous steps on the device
+    (simulst_cif_stream_steps).  A row's decisions depend only on its own state and on the source released so far, so its
+    tokens, delays and action string are those of ``CIFAgent.run_utterance`` on that utterance alone
+    (tests/test_hip_cif_decode.py)."""
+
+    def run_batch(self, fbank: torch.Tensor):
+        """fbank [B, T, 80] (equal lengths).  One record per row, same keys as run_utterance."""
+        from .latency import average_lagging
+        model, dec, enc = self.model, self.model.decoder, self.model.encoder
+        cfg, dev = model.cfg, model.device
+        B, T = fbank.size(0), fbank.size(1)
+        fbank = fbank.to(dev)
+        cap = int(self.max_len(T)) + 4
+        n_cap = int((T // enc.stride + 2 * self.right_context + 8) / enc.cif_layer.beta) + 4
+        st = dec.new_device_state(B, cap=cap, n_cap=n_cap)
+        st["lockstep"] = False
+        cst = enc.cif_layer.new_batched_state(B, cfg.embed_dim, n_cap)
+        st["cif_len"] = cst["cif_len"]
+        u8 = dict(device=dev, dtype=torch.uint8)
+        online, done = torch.ones(B, **u8), torch.zeros(B, **u8)
+        hyp = torch.zeros(B, cap, device=dev, dtype=torch.int64)
+        delays = torch.zeros(B, cap, device=dev, dtype=torch.int32)
+        st["tok"].fill_(cfg.eos)
+        enc_state = {}
+        src = FrameSource(fbank[0])
+        actions = [[] for _ in range(B)]
+        n_written = [0] * B
+        cif_len_h = [0] * B
+        last_update = 0
+        expected = (self.segment_length + self.right_context) * self.stride_ms // 10
+        alive = list(range(B))
+        while alive:
+            # ---- READ phase: every unfinished stream takes the next chunk (agents/cif_agent.py:296-346)
+            for b in alive:
+                actions[b].append("R")
+            if src.finished:
+                raise RuntimeError("READ after source finished")
+            src.read(expected)
+            finish = (src.pos - last_update) < expected or src.finished
+            out = S2TEmformerEncoder.infer(enc, fbank[:, :src.pos], torch.full((B,), src.pos), enc_state, finish=finish)
+            enc.cif_layer.infer_batched(out["encoder_out_btd"].contiguous(), cst, finish)
+            last_update = src.pos
+            expected = self.segment_length * self.stride_ms // 10
+            new_len = cst["cif_len"].tolist()                      # one read-back per chunk: loop control + projection window
+            lo, hi = min(cif_len_h), max(new_len)
+            cif_len_h = new_len
+            dec.project_cif(st, cst["cif"], lo, hi)
+            # ---- WRITE phase: masked steps until no row can write any more
+            online.fill_(0 if src.finished else 1)
+            ctl = _lib.CifStreamCtl(online.data_ptr(), done.data_ptr(), delays.data_ptr(), hyp.data_ptr(), cap,
+                                    src.elapsed_ms(), int(self.max_len(src.pos)))
+            while True:
+                if src.finished:
+                    n_iter = 8                                     # rows write until EOS / the length cap
+                else:
+                    n_iter = max([cif_len_h[b] - n_written[b] for b in alive] + [0])
+                if n_iter > 0:
+                    dec.stream_steps(st, ctl, n_iter, self.overshoot_weight)
+                n_prev = st["n_prev"].tolist()
+                done_h = done.tolist()
+                for b in alive:
+                    actions[b].extend("W" * (n_prev[b] - n_written[b]))
+                    n_written[b] = n_prev[b]
+                alive = [b for b in alive if not done_h[b]]
+                if not src.finished or not alive:
+                    break
+        hyp_h, delays_h = hyp.tolist(), delays.tolist()
+        recs = []
+        for b in range(B):
+            n = n_written[b]
+            d = [int(x) for x in delays_h[b][:n]]
+            recs.append({"tokens": hyp_h[b][:n], "delays_ms": d, "actions": "".join(actions[b]),
+                         "AL": average_lagging(d, src.total_ms()), "n_cif": cif_len_h[b]})
+        return recs
 
 
 @register_model_architecture("cif_transformer", "cif_transformer_s")

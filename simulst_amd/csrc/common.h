@@ -258,7 +258,7 @@ static inline bool sl_self_attention_fused_ok(int H, int d, int cap) {
 bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bool packed);
 int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* Wo, const float* bo, const float* ln_g,
                       const float* ln_b, const void* Wq, const float* bq, void* q, const void* Wq2, const float* bq2,
-                      void* q2, int B);
+                      void* q2, int B, const void* kk_gelu = nullptr);
 int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
                      const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
                      int32_t* sem, void* x_mid, int B, int F);

@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
     const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ Wq,
     const float* __restrict__ bq, bf16* __restrict__ q, const uint4* __restrict__ Wq2, const float* __restrict__ bq2,
-    bf16* __restrict__ q2, int M, unsigned short* __restrict__ dbg) {
+    bf16* __restrict__ q2, int M, unsigned short* __restrict__ dbg, const bf16* __restrict__ kk) {
+  // kk != nullptr (CIF decoder, models/cif_transformer.py:357-362): q = gelu(Wq LN(x) + bq + kk) with kk [M][256] the k_proj of the
+  // integrated vector each row looks at -- FakeCrossAttn's activation(q_proj(query) + k_proj(key)); Wq2 is unused then
   constexpr int RT = 16 * RTL;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // 2 * RT * XS elements
   unsigned short* bufA = lds;
@@ -216,15 +218,17 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
   // in LDS (registers are for the weight units)
   const int nb = 64 * wave + 4 * lg;
   float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS);     // [bo | bq | bq2 | gamma | beta] x 256
-  vec[tid] = bo[tid]; vec[256 + tid] = bq[tid]; vec[512 + tid] = Wq2 ? bq2[tid] : 0.f;
+  vec[tid] = bo[tid]; vec[256 + tid] = bq ? bq[tid] : 0.f; vec[512 + tid] = Wq2 ? bq2[tid] : 0.f;
   vec[768 + tid] = ln_g[tid]; vec[1024 + tid] = ln_b[tid];
-  uint2 res[RTL][4];
+  uint2 res[RTL][4], res2[RTL][4];
 #pragma unroll
   for (int rt = 0; rt < RTL; ++rt) {
     const int g = m0 + rt * 16 + lr;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < 4; ++ct) {
       res[rt][ct] = *reinterpret_cast<const uint2*>(x + (long)(g < M ? g : 0) * CD + nb + 16 * ct);
+      res2[rt][ct] = kk ? *reinterpret_cast<const uint2*>(kk + (long)(g < M ? g : 0) * CD + nb + 16 * ct) : make_uint2(0, 0);
+    }
   }
   lds_barrier();
   f32x4 acc[RTL][4];
@@ -263,8 +267,16 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       const float4 bv = *reinterpret_cast<const float4*>(vec + 256 + nb + 16 * ct);
-      *reinterpret_cast<uint2*>(q + (long)g * CD + nb + 16 * ct) =
-          pack4(acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w);
+      if (kk) {
+        float r[4];
+        unpack4(res2[rt][ct], r);
+        const f32x2 h0 = gelu_fast2(f32x2{acc[rt][ct][0] + bv.x + r[0], acc[rt][ct][1] + bv.y + r[1]});
+        const f32x2 h1 = gelu_fast2(f32x2{acc[rt][ct][2] + bv.z + r[2], acc[rt][ct][3] + bv.w + r[3]});
+        *reinterpret_cast<uint2*>(q + (long)g * CD + nb + 16 * ct) = pack4(h0.x, h0.y, h1.x, h1.y);
+      } else {
+        *reinterpret_cast<uint2*>(q + (long)g * CD + nb + 16 * ct) =
+            pack4(acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w);
+      }
     }
   }
   if (Wq2) {
@@ -687,13 +699,13 @@ static int raise_lds_limits(simulst_handle* h) {
 
 int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* Wo, const float* bo, const float* ln_g,
                       const float* ln_b, const void* Wq, const float* bq, void* q, const void* Wq2, const float* bq2,
-                      void* q2, int B) {
+                      void* q2, int B, const void* kk_gelu) {
   if (int rc = raise_lds_limits(h)) return rc;
   KTimer t(h, SIMULST_K_LINEAR_SKINNY);
 #define PC(XM)                                                                                                         \
   hipLaunchKernelGGL((dec_proj_chain_kernel<1, XM>), dim3((B + 15) / 16), dim3(256), lds_request(h), h->stream,        \
                      (const bf16*)ctx, (bf16*)x, (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q,     \
-                     (const uint4*)Wq2, bq2, (bf16*)q2, B, (unsigned short*)h->dec_chain_tail)
+                     (const uint4*)Wq2, bq2, (bf16*)q2, B, (unsigned short*)h->dec_chain_tail, (const bf16*)kk_gelu)
   SL_XMODE(h, PC);
 #undef PC
   return sl_launch_status(h, "simulst_mma_decode(out-proj + LN + q-proj chain)");
@@ -747,7 +759,7 @@ extern "C" int simulst_decoder_proj_chain(simulst_handle* h, const void* ctx, vo
   SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_decoder_proj_chain: bf16 only (fp32 keeps one launch per GEMM)");
   SL_REQUIRE(h, D == CD && B >= 0, SIMULST_E_SHAPE, "simulst_decoder_proj_chain: D == 256");
   if (B == 0) return SIMULST_OK;
-  return sl_dec_proj_chain(h, ctx, x, wo_fm, bo, ln_g, ln_b, wq_fm, bq, q, wq2_fm, bq2, q2, B);
+  return sl_dec_proj_chain(h, ctx, x, wo_fm, bo, ln_g, ln_b, wq_fm, bq, q, wq2_fm, bq2, q2, B, nullptr);
 }
 
 extern "C" int simulst_decoder_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* wco_fm, const float* bco,

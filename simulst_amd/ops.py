@@ -243,6 +243,15 @@ class Ops:
                                                     float(beta), float(tail_thres), dt(x)), "simulst_cif_integrate")
         return out, cif_len, delays, tail_w, alpha_sum
 
+    def cif_stream_append(self, out, n, tail_w, acc, acc_len, prev_feat, prev_weight, *, beta, finish):
+        """bookkeeping of a batched CIFLayer.infer call (simulst_cif_stream_append): append all but the withheld tail slot of
+        every row to its accumulated vectors, carry the tail"""
+        _chk_contig(out, acc, prev_feat)
+        B, T_cap, D = out.shape
+        self.h.check(self.lib.simulst_cif_stream_append(self.h.ptr, _p(out), _p(n), _p(tail_w), _p(acc), _p(acc_len),
+                                                        _p(prev_feat), _p(prev_weight), B, T_cap, acc.shape[1], D,
+                                                        float(beta), int(finish), dt(out)), "simulst_cif_stream_append")
+
     def cif_alpha_head(self, hidden, gamma, beta_ln, w, bias):
         _chk_contig(hidden, w)
         D = hidden.shape[-1]
