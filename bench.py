@@ -29,6 +29,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                     sample of the same workload: all cores, and one thread (the reference's own eval setting,
                     eval/1-simuleval.sh:65,78-82)
   configs1_one_batch_of_64_alone -- BASELINE.json configs[1] read literally: one batch of 64 alone on the GPU
+  configs2_mma_hard, configs3_cif -- (one GPU) BASELINE.json configs[2] / configs[3] on the same 64 x 1000-frame batches: decoded
+                    tokens/s offline (the timed plan's schedule) AND through the batched streaming agent, the Average Lagging of
+                    the streamed run, identity of tokens / READ-WRITE actions / delays with the CPU oracle on a sample, and the
+                    config's own roofline (path byte model + dominant kernel class)
 """
 import argparse
 import json
@@ -46,9 +50,11 @@ if ROOT not in sys.path:
 # execute concurrently on this stack (tools/microbench_streams.hip); 8 lets 3-4 independent decode chains overlap.
 # Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-PMC_COUNTERS_FILE = "r01_n_counters.json"      # per kernel: HBM GB/s + MFMA utilisation from the same passes
-ENCODER_TRAFFIC_FILE = "r02_encoder_traffic.json"   # tools/encoder_traffic.py: PMC passes of one encoder pass
-PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py
+# HBM traffic of the dominant kernels from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest round first
+ENCODER_TRAFFIC_FILES = ["r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
+CROSS_ATTN_TRAFFIC_FILES = ["r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
+PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # all classes of one launch sequence (round 1), tools/pmc_summary.py
+L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
 
 B_PER_GPU, T_FRAMES, N_STEPS_DECODE, WAITK = 64, 1000, 110, 5
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
@@ -81,6 +87,10 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="replay the decode step as a hipGraph (measured neutral on MI355X: the step is bound by "
                          "kernel bodies, not by launch cost)")
+    ap.add_argument("--passes", type=int, default=3,
+                    help="timed passes of the K-step plan; value = the MEDIAN pass, all of them are reported")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[2] / configs[3] legs")
+    ap.add_argument("--extra-rows", type=int, default=448, help="rows of the batched streaming runs of the extra legs")
     ap.add_argument("--cpu-sample", type=int, default=64)
     ap.add_argument("--cpu-sample-1thread", type=int, default=4,
                     help="utterances of the one-thread CPU baseline sample (the oracle at one thread is ~8x slower)")
@@ -128,12 +138,14 @@ def model_param_bytes(cfg, esz):
     return enc * esz, dec * esz
 
 
-def path_bytes_per_token(cfg, B, T, U, esz, waitk):
+def path_bytes_per_token(cfg, B, T, U, esz, waitk, kind="waitk"):
     """Algorithmic HBM bytes per decoded token of the whole path, the byte model of SURVEY.md 8(d): per batch of B
     utterances the encoder weights once and the decoder weights once per step; per utterance fbank (fp32 source),
     one read + write of the encoder activations per layer, the cross-attention K/V rows each step may look at,
     the self-attention cache rows, and the K/V projections written once.  2.135 MB/token at B=64, T=1000, U=110,
-    wait-k 5, bf16."""
+    wait-k 5, bf16.  kind: 'waitk' (soft attention over the (t + k) * ratio visible frames), 'hard' (MMA-hard: the pooled
+    monotonic keys of every step + ONE value row, SURVEY 8(d) "~0 for hard-aligned one-hot gather"), 'cif' (no source attention:
+    the integrated vectors and their key projections written once, one projected row gathered per step and layer)."""
     D, Ld = cfg.embed_dim, cfg.decoder_layers
     T1 = (T - 1) // 2 + 1
     Te = (T1 - 1) // 2 + 1
@@ -141,9 +153,18 @@ def path_bytes_per_token(cfg, B, T, U, esz, waitk):
     enc_w, dec_w = model_param_bytes(cfg, esz)
     per_utt = T * cfg.input_feat * 4
     per_utt += cfg.encoder_layers * 2 * (N * cfg.R + Te) * D * esz
-    per_utt += Ld * 2 * D * esz * sum(min((t + waitk) * cfg.pre_decision_ratio, Te) for t in range(U))
+    if kind == "waitk":
+        per_utt += Ld * 2 * D * esz * sum(min((t + waitk) * cfg.pre_decision_ratio, Te) for t in range(U))
+        per_utt += Ld * 2 * Te * D * esz                       # K / V projections written once
+    elif kind == "hard":
+        P = max(1, Te // max(cfg.pre_decision_ratio, 1))
+        per_utt += Ld * U * (P + 1) * D * esz                  # pooled monotonic keys + the one value row per step
+        per_utt += Ld * 2 * Te * D * esz
+    else:                                                      # cif: ~Te / 2 integrated vectors at alpha ~ 0.5
+        n_cif = Te // 2
+        per_utt += 2 * Te * D * esz + n_cif * D * esz          # CIF layer: frames read (conv + scan), vectors written
+        per_utt += Ld * (n_cif * D * esz + U * D * esz)        # key projections written once, one row gathered per step
     per_utt += Ld * 2 * D * esz * sum(u + 1 for u in range(U))
-    per_utt += Ld * 2 * Te * D * esz
     return (enc_w + dec_w * U + B * per_utt) / (B * U)
 
 
@@ -166,9 +187,11 @@ def algorithmic_work(cfg, B, T, U):
     return fl, dict(T1=T1, Te=Te, N=N, rows_x=rows_x, rows_z=rows_z, rows_c=rows_c)
 
 
-def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name):
+def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="waitk"):
     """Roofline entry of one kernel class of a launch sequence of Bs rows: algorithmic bytes (HBM-bound classes) or
-    flops (the encoder-side contractions) of the class per sequence / its device time."""
+    flops (the encoder-side contractions) of the class per sequence / its device time.  The decode-step GEMM groups are
+    scored against the L2 delivery rate: their operands (a layer's weights, a few hundred KB of activations) live in the
+    XCDs' L2s, what bounds them is operand delivery per workgroup and the dependent round trip, not HBM."""
     esz = 2 if dtype_name == "bf16" else 4
     D, F, V, Ld, U = cfg.embed_dim, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, N_STEPS_DECODE
     if ms <= 0 or n_launch <= 0:
@@ -182,20 +205,37 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name):
                 "frac": round(ach / peak, 5), "traffic": None, "launches_per_sequence": n_launch,
                 "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_flop_per_launch": round(flops / n_launch)}
     if name in ("linear_skinny", "linear_tile64"):
-        # decode-step contractions: arithmetic intensity = rows flop/byte of weight, left of the ridge (312 flop/B) up
-        # to a few hundred rows => HBM/L2 bound.  Algorithmic bytes per launch = weights N*K + activations in + out.
+        # decode-step contractions (and the row-local chains, timed under linear_skinny).  Bytes DELIVERED from L2 per
+        # launch: every row tile of rt rows (16: wave-per-tile GEMMs and chains, 64: the 64 x 64 tile kernel) pulls the
+        # [N][K] weights once, plus activations in and out.
+        rt = 64 if name == "linear_tile64" else 16
+        tiles = -(-Bs // rt)
+
         def gb(n, k):
-            return (n * k + Bs * k + Bs * n) * esz
+            return (tiles * n * k + Bs * k + Bs * n) * esz
         wide = Ld * (gb(3 * D, D) + gb(F, D)) + gb(V, D)          # N >= 512: QKV, fc1, vocabulary projection
         narrow = Ld * (3 * gb(D, D) + gb(D, F))                    # out-proj x2, q-proj, fc2
         tile64 = Bs >= 256
         byts = U * ((wide if tile64 else 0) if name == "linear_tile64" else (narrow if tile64 else wide + narrow))
+        if byts <= 0:
+            return None
+        ach = byts / (ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "l2", "achieved": round(ach, 2), "peak": L2_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / L2_PEAK_GBS, 5), "traffic": None, "launches_per_sequence": n_launch,
+                "avg_launch_us": round(ms * 1e3 / n_launch, 3), "delivered_bytes_per_launch": round(byts / n_launch),
+                "model": f"operand bytes delivered from L2: weights once per {rt}-row tile + activations; peak = 34.5 TB/s aggregate "
+                         "L2 (MI355X_MICROARCH.md); a dependent launch cannot finish under ~3 us (one operand round trip + one store)"}
     elif name == "emformer_attention":
         byts = cfg.encoder_layers * Bs * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
     elif name == "decoder_cross_attention":
-        # wait-k: target t reads min((t + k) * ratio, Te) key and value rows of D channels
-        rows = sum(min((t + WAITK) * cfg.pre_decision_ratio, dims["Te"]) for t in range(U))
-        byts = Ld * Bs * (2 * rows * D + 2 * U * D) * esz
+        if kind == "hard":
+            # MMA-hard: the policy looks at every pooled monotonic key (here: the Te cached frames it pools), the value
+            # aggregation is one row
+            byts = Ld * Bs * U * (dims["Te"] * D + 3 * D) * esz
+        else:
+            # wait-k: target t reads min((t + k) * ratio, Te) key and value rows of D channels
+            rows = sum(min((t + WAITK) * cfg.pre_decision_ratio, dims["Te"]) for t in range(U))
+            byts = Ld * Bs * (2 * rows * D + 2 * U * D) * esz
     elif name == "decoder_self_attention":
         byts = Ld * Bs * sum((2 * (u + 1) * D + 4 * D) for u in range(U)) * esz
     elif name == "layernorm":
@@ -235,6 +275,182 @@ def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps, cores):
     return {"value": round(toks.numel() / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"{sample_B} utterances x {T_FRAMES} frames, {n_steps} forced greedy steps "
                       f"({toks.numel()} tokens) in {dt:.1f} s, torch fp32, {cores} thread{'s' if cores > 1 else ''}"}, toks, fb
+
+
+def extra_config_legs(args, dev, dtype, fb_all, plan, B):
+    """BASELINE.json configs[2] (MMA-hard) and configs[3] (CIF) on the bench's own batches (64 x 1000 frames each), one GPU:
+      offline            the timed plan's schedule (same launch-sequence sizes and streams), 110 forced greedy steps per row --
+                         eval/generate.py:187-209 semantics; median of --passes passes
+      batched streaming  --extra-rows simultaneous streams through the batched agents (agent.BatchedStreamingAgent,
+                         cif.BatchedCIFStreamingAgent: per-row READ / WRITE on the device), --max-len-a 0.1 --max-len-b 10
+                         (agents/default_agent.py:120-123 flags; the reference default 1.0 / 0 lets a random-init model write
+                         1000 tokens per utterance); tokens/s = committed tokens / wall time, mean Average Lagging of the rows
+      parity             fp32 HIP == CPU oracle on a sample (offline: 8 utterances' tokens; streaming: 2 utterances' READ / WRITE
+                         strings, tokens and delays => Average Lagging), and the agreement of the timed bf16 runs' first rows
+      roofline           the config's path byte model (SURVEY 8(d) style) + the dominant kernel class of an instrumented replay
+    Random-init weights do not make a policy move: like tools/config_parity.py the EOS row of the tied embedding is zeroed
+    (hypotheses run to their cap), the MMA query projections are scaled x 8 (heads advance at different rates) and the CIF
+    weight predictor is biased so that it fires (~74 integrated vectors per 1000 frames); oracle and HIP path get the same tensors."""
+    import torch
+    from oracle import agent as oag
+    from oracle.configs import from_model_config
+    from simulst_amd import _lib
+    from simulst_amd.agent import BatchedStreamingAgent
+    from simulst_amd.cif import BatchedCIFStreamingAgent, CIFTransformerModel
+    from simulst_amd.config import cif_transformer_s, mma_model_s
+    from simulst_amd.model import ConcurrentOffline, SimulSTModel
+    from simulst_amd.weights import init_model
+    U, esz = N_STEPS_DECODE, (2 if dtype == torch.bfloat16 else 4)
+    dtn = "bf16" if dtype == torch.bfloat16 else "f32"
+    rows_s = min(args.extra_rows, fb_all.size(0))
+    n_off, n_str = 8, 2
+    fb_cpu = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + i)) for i in range(n_off)])
+    g_max = max(plan)
+    out = {}
+    for key in ("configs2_mma_hard", "configs3_cif"):
+        t_leg = time.perf_counter()
+        cif = key == "configs3_cif"
+        if cif:
+            cfg = cif_transformer_s(cif_beta=1.0)
+            w = init_model(cfg, seed=999)
+            w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
+            w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.5
+            kind, workload = "cif", "configs[3]: cif_transformer_s (beta 1.0, cif_conv_kernel 3)"
+        else:
+            cfg = mma_model_s(simul_attn_type="hard_aligned_fixed_pre_decision", fixed_pre_decision_ratio=8, mass_preservation=True)
+            w = init_model(cfg, seed=999)
+            for l in range(cfg.decoder_layers):
+                k = f"decoder.layers.{l}.encoder_attn.q_proj.weight"
+                w[k] = w[k] * 8
+            kind, workload = "hard", "configs[2]: mma_model_s, hard_aligned_fixed_pre_decision ratio 8, mass preservation"
+        w["decoder.embed_tokens.weight"][cfg.eos] = 0
+        ecfg, dcfg = from_model_config(cfg)
+        Model = CIFTransformerModel if cif else SimulSTModel
+        model = Model(cfg, w, device=dev, dtype=dtype)
+        factory = (lambda ops: CIFTransformerModel(cfg, w, device=dev, dtype=dtype, ops=ops)) if cif else None
+        pipe = ConcurrentOffline(model, w, args.concurrency, factory=factory) if args.concurrency > 1 else None
+
+        def seqs():
+            o, r0 = [], 0
+            for g in plan:
+                o.append((fb_all[r0:r0 + B * g], torch.full((B * g,), T_FRAMES, device=dev)))
+                r0 += B * g
+            return o
+
+        def run_offline():
+            if pipe is None:
+                return torch.cat([model.generate_offline(f_, l_, n_steps=U, mask_eos=True)[0].clone() for f_, l_ in seqs()], 0)
+            return torch.cat(pipe.run(seqs(), U, mask_eos=True), 0)
+        with torch.no_grad():
+            for _ in range(2):
+                run_offline()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(max(1, args.passes)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                hyp = run_offline()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            n_tok = hyp.size(0) * U
+            offline = {"tokens_per_s": round(n_tok / sorted(ts)[len(ts) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts],
+                       "tokens_per_pass": n_tok, "plan_batches_per_sequence": plan, "streams": min(args.concurrency, len(plan)),
+                       "decode_steps": U, "semantics": "offline batched, EOS masked (eval/generate.py:187-209)"}
+            # ---- batched streaming
+            agent = (BatchedCIFStreamingAgent(model, max_len_a=0.1, max_len_b=10) if cif
+                     else BatchedStreamingAgent(model, max_len_a=0.1, max_len_b=10, steps_per_call=8))
+            fbs = fb_all[:rows_s]
+            agent.run_batch(fbs)
+            torch.cuda.synchronize()
+            ts, recs = [], None
+            for _ in range(max(1, args.passes)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                recs = agent.run_batch(fbs)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            n_st = sum(len(r["tokens"]) for r in recs)
+            streaming = {"tokens_per_s": round(n_st / sorted(ts)[len(ts) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts],
+                         "rows": rows_s, "tokens_per_pass": n_st, "average_lagging_ms_mean": round(sum(r["AL"] for r in recs) / rows_s, 2),
+                         "reads_per_row": recs[0]["actions"].count("R"), "max_len": "0.1 * frames + 10 tokens",
+                         "semantics": "every row takes its own READ / WRITE decisions on the device; chunk schedule 96 then 64 frames "
+                                      "(agents/default_agent.py:367,407)"}
+            # ---- instrumented replay of one launch sequence of the plan: the dominant class and its roofline entry
+            Bs = B * g_max
+            fseq, lseq = fb_all[:Bs], torch.full((Bs,), T_FRAMES, device=dev)
+            h = model.ops.h
+            model.generate_offline(fseq, lseq, n_steps=U, mask_eos=True)
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            model.generate_offline(fseq, lseq, n_steps=U, mask_eos=True)
+            torch.cuda.synchronize()
+            plain_s = time.perf_counter() - tp0
+            h.timer_reset(); h.timer_enable(-1, True)
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            model.generate_offline(fseq, lseq, n_steps=U, mask_eos=True)
+            torch.cuda.synchronize()
+            replay_s = time.perf_counter() - tr0
+            h.timer_enable(-1, False)
+            raw = {_lib.KERNEL_CLASS_NAMES[c]: h.timer_read(c) for c in range(_lib.K_COUNT)}
+            n_launch = sum(v[1] for v in raw.values())
+            ovh = max(0.0, (replay_s - plain_s) * 1e3 / max(n_launch, 1))
+            per_class = {k: (max(0.0, v[0] - ovh * v[1]), v[1]) for k, v in raw.items()}
+            fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, U)
+            entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, dtn, kind=kind) for k, v in per_class.items()}
+            entries = {k: e for k, e in entries.items() if e is not None}
+            dom = max(entries, key=lambda k: per_class[k][0] / {"linear_skinny": 4, "linear_tile64": 3}.get(k, 1))
+            bpt = path_bytes_per_token(cfg, B, T_FRAMES, U, esz, 0, kind=kind)
+            roof = dict(entries[dom])
+            roof["path_hbm_model"] = {"bytes_per_token": round(bpt), "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / bpt),
+                                      "frac_offline": round(offline["tokens_per_s"] / (HBM_PEAK_GBS * 1e9 / bpt), 5),
+                                      "definition": "the byte model of SURVEY.md 8(d) with this config's source attention: " +
+                                                    ("pooled monotonic keys + one value row per step" if kind == "hard" else
+                                                     "integrated vectors and their key projections written once, one row gathered per step")}
+            roof["one_sequence_alone"] = {"rows": Bs, "ms": round(plain_s * 1e3, 3), "tokens_per_s": round(Bs * U / plain_s, 1)}
+            roof["class_ms_per_sequence"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
+            roof["launches_per_sequence_all_classes"] = n_launch
+            # ---- parity on a sample against the CPU oracle
+            m32 = Model(cfg, w, device=dev, dtype=torch.float32)
+            L8 = torch.full((n_off,), T_FRAMES)
+            margins = []
+            if cif:
+                ref, _, _ = oag.greedy_offline_cif(w, ecfg, dcfg, cfg.cif_beta, fb_cpu, L8, n_steps=U, mask_eos=True, margins=margins)
+            else:
+                ref, _, _ = oag.greedy_offline(w, ecfg, dcfg, fb_cpu, L8, n_steps=U, mask_eos=True, margins=margins)
+            mg = torch.stack(margins, 1)
+            t32 = m32.generate_offline(fb_cpu.to(dev), L8, n_steps=U, mask_eos=True)[0].cpu()
+            h16 = hyp[:n_off].cpu()
+            gaps = []
+            for r in range(n_off):
+                if not torch.equal(h16[r], ref[r]):
+                    gaps.append(round(float(mg[r, int((h16[r] != ref[r]).float().argmax())]), 5))
+            ag32 = (BatchedCIFStreamingAgent(m32, max_len_a=0.1, max_len_b=10) if cif
+                    else BatchedStreamingAgent(m32, max_len_a=0.1, max_len_b=10, steps_per_call=8))
+            got32 = ag32.run_batch(fb_cpu[:n_str].to(dev))
+            same32, same16 = [], []
+            for i in range(n_str):
+                rs = (oag.simulate_cif(w, ecfg, dcfg, cfg.cif_beta, fb_cpu[i], max_len_a=0.1, max_len_b=10) if cif
+                      else oag.simulate_mma(w, ecfg, dcfg, fb_cpu[i], max_len_a=0.1, max_len_b=10))
+                same32.append(all(got32[i][k] == rs[k] for k in ("actions", "tokens", "delays_ms", "AL")))
+                same16.append({"actions_identical": recs[i]["actions"] == rs["actions"],
+                               "token_agreement": round(sum(a == b for a, b in zip(recs[i]["tokens"], rs["tokens"])) /
+                                                        max(len(rs["tokens"]), 1), 4),
+                               "AL_ms": [round(recs[i]["AL"], 2), round(rs["AL"], 2)]})
+            parity = {"offline_fp32_tokens_identical_to_oracle": bool(torch.equal(t32, ref)), "offline_sample_utterances": n_off,
+                      f"offline_{dtn}_timed_rows_identical_to_oracle": int(sum(torch.equal(h16[r], ref[r]) for r in range(n_off))),
+                      f"offline_{dtn}_oracle_top2_gap_at_first_divergence": sorted(gaps),
+                      "streaming_fp32_actions_tokens_delays_AL_identical_to_oracle": all(same32), "streaming_sample_utterances": n_str,
+                      f"streaming_{dtn}_timed_rows_vs_oracle": same16}
+        out[key] = {"workload": workload + f"; 64 x {T_FRAMES}-frame batches, {dtn}", "offline": offline,
+                    "batched_streaming": streaming, "parity_on_sample": parity, "roofline": roof,
+                    "seconds_spent": round(time.perf_counter() - t_leg, 1)}
+        log(f"{key}: offline {offline['tokens_per_s']:.0f} tokens/s, batched streaming {streaming['tokens_per_s']:.0f} tokens/s "
+            f"(AL {streaming['average_lagging_ms_mean']} ms), parity {parity['offline_fp32_tokens_identical_to_oracle']} / "
+            f"{parity['streaming_fp32_actions_tokens_delays_AL_identical_to_oracle']}")
+        del pipe, model, m32
+        torch.cuda.empty_cache()
+    return out
 
 
 _T0 = time.perf_counter()
@@ -325,14 +541,28 @@ def main(argv=None):
     plan = plan_launch_sequences(args.steps, G, args.concurrency, min_per_sequence=args.min_per_sequence)
     g_max = max(plan) if plan else 1
     streams_used = min(args.concurrency, len(plan)) if args.concurrency > 1 else 1
-    # synthetic fbank, seed 999 + global utterance id, resident in HBM before the clock starts: g_max batches of B
-    fb_all = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + rank * B * g_max + i))
-                          for i in range(B * g_max)]).to(device=dev, dtype=dtype)
-    L_all = torch.full((B * g_max,), T_FRAMES, device=dev)
+    # synthetic fbank resident in HBM before the clock starts, one DISTINCT utterance per decoded row (B * sum(plan) of them):
+    # the first batch of every rank on the CPU generator of SURVEY.md 8(d) (seed 999 + utterance id: the utterances the
+    # cpu_baseline sample and the parity checks decode), the rest in one draw on the device generator (seed 999 + rank)
+    n_utt = B * max(sum(plan), 1)
+    head = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + rank * n_utt + i))
+                        for i in range(B)]).to(device=dev, dtype=dtype)
+    fb_all = torch.empty(n_utt, T_FRAMES, 80, device=dev, dtype=dtype)
+    fb_all[:B] = head
+    if n_utt > B:
+        gdev = torch.Generator(device=dev).manual_seed(999 + rank)
+        for i0 in range(B, n_utt, 4096):               # in slices: the fp32 draw of 24 576 utterances would be 7.9 GB at once
+            i1 = min(n_utt, i0 + 4096)
+            fb_all[i0:i1] = torch.randn(i1 - i0, T_FRAMES, 80, device=dev, generator=gdev).to(dtype)
+    L_all = torch.full((n_utt,), T_FRAMES, device=dev)
     fb, L = fb_all[:B], L_all[:B]              # one batch (configs[1] read literally)
 
     def sequences(p):
-        return [(fb_all[:B * g], L_all[:B * g]) for g in p]
+        out, r0 = [], 0
+        for g in p:                            # every launch sequence decodes its own utterances
+            out.append((fb_all[r0:r0 + B * g], L_all[r0:r0 + B * g]))
+            r0 += B * g
+        return out
 
     pipe = None
     if args.concurrency > 1:
@@ -366,23 +596,29 @@ def main(argv=None):
             warm_done += sum(plan)
         torch.cuda.synchronize()
         log(f"warm-up: {warm_done} steps (asked for {args.warmup}) as the timed plan's launch sequences")
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        hyp_timed = run_plan(plan)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        # EXACTLY K steps per timed pass, bracketed by barrier + synchronize on both sides, MAX over ranks; --passes such
+        # passes, the MEDIAN one is `value` (a single 0.1 s pass is at the mercy of one scheduling hiccup), all are reported
+        pass_s = []
+        for _ in range(max(1, args.passes)):
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hyp_timed = run_plan(plan)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            pass_s.append(el)
+    elapsed = sorted(pass_s)[len(pass_s) // 2]
     tokens_per_step = B * N_STEPS_DECODE * world
     value = tokens_per_step * args.steps / elapsed
     assert hyp_timed.shape[0] == B * args.steps * world, "the timed region did not decode every batch"
-    log(f"timed region: {elapsed:.3f} s for {args.steps} steps -> {value:.0f} tokens/s")
+    log(f"timed passes of {args.steps} steps: {[round(x * 1e3, 2) for x in pass_s]} ms -> median {value:.0f} tokens/s")
 
     roofline, cpu_base = None, None
     if args.timed_only:
@@ -450,14 +686,29 @@ def main(argv=None):
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this command at 4096 rows per sequence; profiles/*_pmc_traffic.json says how it was corrected): scaled by rows,
         # and only attached when this run's dtype is the recorded one
+        def first_profile(names):
+            for n in names:
+                pth = os.path.join(ROOT, "profiles", n)
+                if os.path.exists(pth):
+                    return n, json.load(open(pth))
+            raise OSError("no committed PMC file")
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
             rec_rows = pmc.get("rows_per_sequence", 1536)
             for e in [roofline] + ([roofline["other_bound_class"]] if other else []):
+                if e["kernel"] == "decoder_cross_attention" and args.dtype == "bf16":
+                    # the dominant kernel: counter bytes / algorithmic bytes of the newest committed FETCH_SIZE / WRITE_SIZE
+                    # passes of that kernel alone, applied to this run's algorithmic bytes per launch
+                    nm, ca = first_profile(CROSS_ATTN_TRAFFIC_FILES)
+                    rec = next(v for k, v in ca.items() if k.startswith("policy_cross_attn_kernel"))
+                    e["traffic"] = round(e["algorithmic_bytes_per_launch"] * rec["ratio"])
+                    e["traffic_source"] = (f"profiles/{nm}: HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) / algorithmic "
+                                           f"bytes = {rec['ratio']} at {rec['rows']} rows, applied to this launch's algorithmic bytes")
+                    continue
                 if e["kernel"] == "linear" and args.dtype == "bf16":
                     # the encoder contractions changed in round 2 (fused feed-forward block): their HBM bytes come from the
                     # FETCH_SIZE / WRITE_SIZE passes of one encoder pass (tools/encoder_traffic.py)
-                    enc = json.load(open(os.path.join(ROOT, "profiles", ENCODER_TRAFFIC_FILE)))
+                    ENCODER_TRAFFIC_FILE, enc = first_profile(ENCODER_TRAFFIC_FILES)
                     gemm = sum(v["hbm_bytes_per_pass"] for k, v in enc["per_kernel"].items()
                                if k.startswith(("ffn_fused_kernel", "panel_kernel", "linear_kernel")))
                     e["traffic"] = round(gemm / enc["utterances"] * Bs / e["launches_per_sequence"])
@@ -479,6 +730,10 @@ def main(argv=None):
         roofline["rows_per_sequence"] = Bs
         roofline["class_ms_per_sequence"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
         roofline["launches_per_sequence_all_classes"] = n_launch
+        extra = {}
+        if world == 1 and not args.no_extra_configs:
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
+            extra = extra_config_legs(args, dev, dtype, fb_all, plan, B)
         if world == 1 and not args.no_cpu_baseline:
             cores_all = min(os.cpu_count() or 1, 16)   # the oracle's small ops stop scaling well before this
             cpu_base, ref_toks, ref_fb = run_cpu_baseline(cfg, weights, args.cpu_sample, N_STEPS_DECODE, cores_all)
@@ -486,6 +741,9 @@ def main(argv=None):
             ref_margins = run_cpu_baseline.margins
             one, _, _ = run_cpu_baseline(cfg, weights, max(1, args.cpu_sample_1thread), N_STEPS_DECODE, 1)
             cpu_base["single_thread"] = one
+            cpu_base["reference_itself"] = ("kind 'port' = the oracle restatement; the reference's OWN encoder / decoder files were timed "
+                                            "in the build container only (the GPU box has no /root/reference): 76-328 tokens/s where the port "
+                                            "runs 88-429 on the same 8 cores, profiles/r02_reference_cpu_timing.json")
             log("cpu baseline (1 thread) done")
             # the checker's other job: the HIP path on the SAME sample against the oracle's tokens -- fp32 must be
             # identical (the bit-exact claim of the wait-k path), the bf16 run of the bench reports its agreement,
@@ -527,13 +785,21 @@ def main(argv=None):
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-            "data": "synthetic N(0,1) fbank seed 999+utt_id; random-init weights seed 999",
+            "data": "synthetic N(0,1) fbank, one distinct utterance per decoded row (first batch: CPU generator seed 999 + utt_id, "
+                    "the rest one device-generator draw seed 999 + rank); random-init weights seed 999",
+            "timed_passes": {"n": len(pass_s), "ms": [round(x * 1e3, 3) for x in pass_s],
+                             "tokens_per_s_min_median_max": [round(tokens_per_step * args.steps / max(pass_s), 1), round(value, 1),
+                                                             round(tokens_per_step * args.steps / min(pass_s), 1)],
+                             "value_is": "the median pass; each pass = exactly K steps between barrier + synchronize"},
             "config": {"workload": "configs[1]: Emformer enc (12L) + wait-k=5 dec (6L), 80x1000 fbank, "
                                    "batch 64/GPU, 110 forced greedy steps",
                        "batch_per_gpu": B, "frames": T_FRAMES, "decode_steps": N_STEPS_DECODE,
                        "tokens_per_step": tokens_per_step, "sharding": f"utterance-sharded x{world}",
                        "plan_batches_per_sequence": plan, "co_scheduled_batches": g_max, "streams": streams_used,
-                       "rows_per_sequence": Bs, "warmup_steps_executed": warm_done, "schedule": sched},
+                       "rows_per_sequence": Bs, "warmup_steps_executed": warm_done,
+                       "warmup_note": "the warm-up repeats the timed plan's own launch sequences until W steps AND "
+                                      f"{args.min_warmup_seconds} s have passed (a cold MI355X ramps its clocks for ~0.5 s)",
+                       "schedule": sched},
             "configs1_one_batch_of_64_alone": {"tokens_per_s": round(B * N_STEPS_DECODE / serial_s, 1),
                                                "ms_per_batch": round(serial_s * 1e3, 3),
                                                "frac_of_path_hbm_roofline":
@@ -542,6 +808,7 @@ def main(argv=None):
                                    "ms_per_sequence": round(group_s * 1e3, 3)},
             "roofline": roofline, "cpu_baseline": cpu_base,
         }
+        out.update(extra)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

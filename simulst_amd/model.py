@@ -234,7 +234,7 @@ class ConcurrentOffline:
     generate_offline; replicas share the device weights and own their stream, handle and decoder state."""
 
     def __init__(self, model: SimulSTModel, weights, concurrency: int = 4, graph: bool = False,
-                 stagger_encoders: bool = False):
+                 stagger_encoders: bool = False, factory=None):
         """stagger_encoders chains the encoder passes of the streams on the device (each waits for the previous
         stream's). Measured on MI355X it is SLOWER than letting them run side by side (20-step form 1.235 M vs
         1.290 M tokens/s, 384-step form 1.757 M vs 1.786 M): the side-by-side encoders already share the MFMA pipes
@@ -252,8 +252,10 @@ class ConcurrentOffline:
                 ops = Ops(_lib.Handle(st.cuda_stream))
                 if graph:
                     ops.h.graph_enable(True)
-                self.models.append(SimulSTModel(model.cfg, weights, device=dev, dtype=model.dtype, ops=ops,
-                                                share_with=model))
+                # factory(ops): replicas of another model class with a generate_offline method (the CIF model: its replicas
+                # hold their own 58 MB of device weights)
+                self.models.append(factory(ops) if factory is not None else
+                                   SimulSTModel(model.cfg, weights, device=dev, dtype=model.dtype, ops=ops, share_with=model))
             self.streams.append(st)
 
     def _generate(self, c, src_tokens, src_lengths, n_steps, mask_eos):
