@@ -437,6 +437,9 @@ typedef struct {
   uint8_t* head_read;                            /* [B*H] out */
   const void *Kmono, *Ksoft, *V;                 /* [B][H][S_cap][head_dim] (head-major) cached projections of the
                                                     encoder states: a head's key rows are contiguous 128-byte lines */
+  const float* Kpool;                            /* optional [B][H][P_cap][head_dim] fp32: the pooled monotonic keys of every
+                                                    COMPLETE pre-decision window (simulst_pool_keys, 'average' pooling), read
+                                                    by the policy instead of the window's frames; NULL: pooled per step */
 } simulst_dec_layer;
 
 typedef struct {
@@ -470,6 +473,7 @@ typedef struct {
    * residual, LN + fc1 + GELU, fc2 + residual } another, the hidden units split over F / 256 workgroups per row tile
    * whose fp32 slabs the last-arriving workgroup adds in split order (deterministic).  NULL: one launch per GEMM. */
   float* ffn_partial;                            /* [F / 256][B][D] */
+  int32_t P_cap;                                 /* pooled positions per row of simulst_dec_layer.Kpool (0 when no layer has one) */
   int32_t* ffn_sem;                              /* unused by the decode loop (it runs the feed-forward chain without the in-launch
                                                     hand-off); may be NULL.  simulst_decoder_ffn_chain(x_mid = NULL) takes its own */
 } simulst_decoder_desc;
@@ -595,6 +599,14 @@ int simulst_decoder_ffn_chain(simulst_handle* h, const void* ctx, void* x, const
 int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2,
                                  const float* ln_g, const float* ln_b, const void* wqkv_fm, const float* bqkv, void* qkv,
                                  int32_t B, int32_t D, int32_t F, int32_t dtype);
+
+/* Pooled monotonic keys for fixed pre-decision with 'average' pooling (modules/fixed_pre_decision.py:23-29,104-110): for the
+ * windows j in [j_lo, j_hi) that are complete for row b ((j + 1) * ratio <= key_len[b]), Kpool[b][h][j][:] = mean of frames
+ * [j * ratio, (j + 1) * ratio) of Kmono [B][H][S_cap][head_dim] -- the sum in frame order divided by ratio, exactly what the policy
+ * computes from the frames at every step when no cache is given.  Called once per batch of new encoder frames; a window that is
+ * still incomplete (only the first one while key_len < ratio, :123-131) is pooled from its frames by the policy as before. */
+int simulst_pool_keys(simulst_handle* h, const void* Kmono, float* Kpool, const int32_t* key_len, int32_t B, int32_t H, int32_t d,
+                      int32_t S_cap, int32_t P_cap, int32_t ratio, int32_t j_lo, int32_t j_hi, int32_t dtype);
 
 /* policy + cross-attention of one layer for one step in ONE launch (simulst_step_p_choose +
  * simulst_mma_step_search + simulst_decoder_cross_attention, same results). qm/qs: monotonic / soft

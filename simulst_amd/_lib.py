@@ -48,7 +48,7 @@ class DecLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g",
                                           "ln3_b", "c_wq", "c_bq", "c_wq_soft", "c_bq_soft", "c_wo", "c_bo", "fc1",
                                           "b1", "fc2", "b2")] + [("energy_bias", C.c_float)] + \
-               [(n, C.c_void_p) for n in ("k_cache", "v_cache", "head_step", "head_read", "Kmono", "Ksoft", "V")]
+               [(n, C.c_void_p) for n in ("k_cache", "v_cache", "head_step", "head_read", "Kmono", "Ksoft", "V", "Kpool")]
 
 
 class DecoderDesc(C.Structure):
@@ -58,7 +58,7 @@ class DecoderDesc(C.Structure):
                [("embed_scale", C.c_float)] + \
                [(n, C.c_void_p) for n in ("E", "out_proj", "pos_table", "ln_g", "ln_b", "enc_len", "n_prev", "x", "qkv",
                                           "ctx", "q", "q2", "hidden", "logits", "x_mid", "partial_self")] + \
-               [("weights_fragment_major", C.c_int32), ("ffn_partial", C.c_void_p), ("ffn_sem", C.c_void_p)]
+               [("weights_fragment_major", C.c_int32), ("ffn_partial", C.c_void_p), ("P_cap", C.c_int32), ("ffn_sem", C.c_void_p)]
 
 class CifDecLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b",
@@ -138,6 +138,7 @@ SIGNATURES = {
     "simulst_greedy_argmax": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
     "simulst_mma_decode": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, _vp, _i32, _i32],
     "simulst_mma_stream_steps": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, C.POINTER(StreamCtl), _i32],
+    "simulst_pool_keys": [_vp, _vp, _vp, _vp] + [_i32] * 9,
     "simulst_policy_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                        _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_cif_decode": [_vp, C.POINTER(CifDecoderDesc), C.POINTER(CifDecLayer), _vp, _vp, _i32, _i32],

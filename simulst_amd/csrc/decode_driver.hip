@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
     const float* __restrict__ bqs, StreamCtl ctl,
     // head-split self-attention block (decode_fused.hip): the residual row is xres + bo + sum_h po[b][h][:] (that
     // block's per-head output-projection partials, added in head order), written once to x_mid
-    const float* __restrict__ po, const float* __restrict__ bo, T* __restrict__ x_mid, int w_packed) {
+    const float* __restrict__ po, const float* __restrict__ bo, T* __restrict__ x_mid, int w_packed,
+    // cached pooled monotonic keys [B][H][P_cap][d] fp32 (simulst_pool_keys): the mean of every COMPLETE pre-decision window,
+    // computed once when its last frame arrives instead of from the window's frames at every step (nullptr: from the frames)
+    const float* __restrict__ Kpool, int P_cap) {
   constexpr int W = VL<T>::W;
   if (ctl.active) {   // row parked / finished, or an EARLIER layer asked for source (heads of one layer all run)
     const unsigned char rf = ctl.read_flag[blockIdx.y];
@@ -222,6 +225,14 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
       int f0, f1;
       pooled_frames(j, len, ratio, pool_last, f0, f1);
       float en = 0.f;
+      if (Kpool && !pool_last && f1 - f0 == ratio && j < P_cap) {
+        // same operations in the same order as the loop below (sum of the window's frames, / ratio, one fma per channel)
+        const float* kp = Kpool + ((long)r * P_cap + j) * d;
+        for (int c = 0; c < d; c += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(kp + c);
+          en = fmaf(v.x, q_s[c], en); en = fmaf(v.y, q_s[c + 1], en); en = fmaf(v.z, q_s[c + 2], en); en = fmaf(v.w, q_s[c + 3], en);
+        }
+      } else
       for (int c = 0; c < d; c += W) {
         float accv[W];
 #pragma unroll
@@ -403,7 +414,7 @@ int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int64_t* head_step, uint8_t* head_read, void* ctx, int B, int H, int d, int S_cap, int ratio,
                         int attn_type, int waitk_k, int online, int mass_pres, int n_hint, const void* xres,
                         const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
-                        const float* bqs, const StreamCtl& ctl, const HeadSplit& hs) {
+                        const float* bqs, const StreamCtl& ctl, const HeadSplit& hs, const float* kpool, int P_cap) {
   const size_t lds = (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
 #define PC_LAUNCH_Q(NP, FQ)                                                                                            \
@@ -411,7 +422,7 @@ int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                      (const T*)qs, (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx,            \
                      (long*)head_step, head_read, (T*)ctx, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_pres,   \
                      n_hint, (const T*)xres, ln_g, ln_b, (const T*)Wqm, bqm, (const T*)Wqs, bqs, ctl, hs.po, hs.bo,     \
-                     (T*)hs.x_mid, hs.w_packed)
+                     (T*)hs.x_mid, hs.w_packed, kpool, P_cap)
 #define PC_LAUNCH(NP) do { if (xres) PC_LAUNCH_Q(NP, true); else PC_LAUNCH_Q(NP, false); } while (0)
   SL_DISPATCH_NP(attn::lanes_per_row<T>(d), PC_LAUNCH)
 #undef PC_LAUNCH
@@ -428,7 +439,8 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int32_t mass_preservation, int32_t dtype, int32_t n_hint, const void* xres = nullptr,
                         const float* ln_g = nullptr, const float* ln_b = nullptr, const void* Wqm = nullptr,
                         const float* bqm = nullptr, const void* Wqs = nullptr, const float* bqs = nullptr,
-                        const StreamCtl* ctl = nullptr, const HeadSplit* hs = nullptr);
+                        const StreamCtl* ctl = nullptr, const HeadSplit* hs = nullptr, const float* kpool = nullptr,
+                        int P_cap = 0);
 
 extern "C" int simulst_policy_cross_attention(simulst_handle* h, const void* qm, const void* qs, const void* Kmono,
                                               const void* Ksoft, const void* Vc, float energy_bias,
@@ -446,7 +458,7 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int32_t S_cap, int32_t ratio, int32_t attn_type, int32_t waitk_k, int32_t online,
                         int32_t mass_preservation, int32_t dtype, int32_t n_hint, const void* xres,
                         const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
-                        const float* bqs, const StreamCtl* ctlp, const HeadSplit* hsp) {
+                        const float* bqs, const StreamCtl* ctlp, const HeadSplit* hsp, const float* kpool, int P_cap) {
   if (!h) return SIMULST_E_NULL;
   StreamCtl ctl = {};
   if (ctlp) ctl = *ctlp;
@@ -473,10 +485,43 @@ static int policy_cross(simulst_handle* h, const void* qm, const void* qs, const
   if (dtype == SIMULST_F32)
     return launch_policy_cross<float>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
                                       ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint,
-                                      xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl, hs);
+                                      xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl, hs, kpool, P_cap);
   return launch_policy_cross<bf16>(h, qm, qs, Kmono, Ksoft, Vc, energy_bias, key_len, tgt_idx, head_step, head_read,
                                    ctx, B, H, d, S_cap, ratio, attn_type, waitk_k, online, mass_preservation, n_hint,
-                                   xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl, hs);
+                                   xres, ln_g, ln_b, Wqm, bqm, Wqs, bqs, ctl, hs, kpool, P_cap);
+}
+
+
+// pooled monotonic keys of the windows [j_lo, j_hi) that are complete for a row (fixed pre-decision, 'average' pooling,
+// modules/fixed_pre_decision.py:23-29,104-110): Kpool[b][h][j][c] = (sum over the window's ratio frames, in frame order) / ratio
+template <typename T>
+__global__ void pool_keys_kernel(const T* __restrict__ Km, float* __restrict__ Kpool, const int* __restrict__ key_len, int H, int d,
+                                 int S_cap, int P_cap, int ratio, int j_lo) {
+  const int j = j_lo + blockIdx.x, r = blockIdx.y, b = r / H, c = threadIdx.x;
+  const int len = key_len ? key_len[b] : S_cap;
+  if (c >= d || j >= P_cap || (j + 1) * ratio > len) return;
+  const T* k = Km + ((long)r * S_cap + (long)j * ratio) * d + c;
+  float acc = 0.f;
+  for (int f = 0; f < ratio; ++f) acc += to_f32(k[(long)f * d]);
+  Kpool[((long)r * P_cap + j) * d + c] = acc / (float)ratio;
+}
+
+extern "C" int simulst_pool_keys(simulst_handle* h, const void* Kmono, float* Kpool, const int32_t* key_len, int32_t B, int32_t H,
+                                 int32_t d, int32_t S_cap, int32_t P_cap, int32_t ratio, int32_t j_lo, int32_t j_hi, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, Kmono); SL_CHECK_NULL(h, Kpool);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_pool_keys: dtype");
+  SL_REQUIRE(h, B >= 0 && H > 0 && d > 0 && d <= 256 && S_cap > 0 && P_cap > 0 && ratio > 0 && j_lo >= 0, SIMULST_E_SHAPE,
+             "simulst_pool_keys: shape (average pooling only: ratio > 0)");
+  if (j_hi > P_cap) j_hi = P_cap;
+  if (B == 0 || j_hi <= j_lo) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_MISC);
+  const dim3 grid(j_hi - j_lo, B * H), block(d <= 64 ? 64 : 256);
+  if (dtype == SIMULST_F32)
+    hipLaunchKernelGGL(pool_keys_kernel<float>, grid, block, 0, h->stream, (const float*)Kmono, Kpool, key_len, H, d, S_cap, P_cap, ratio, j_lo);
+  else
+    hipLaunchKernelGGL(pool_keys_kernel<bf16>, grid, block, 0, h->stream, (const bf16*)Kmono, Kpool, key_len, H, d, S_cap, P_cap, ratio, j_lo);
+  return sl_launch_status(h, "simulst_pool_keys");
 }
 
 static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const simulst_dec_layer* layers,
@@ -610,7 +655,8 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         if ((rc = policy_cross(h, nullptr, nullptr, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
                                dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
                                dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, dd->x, L.ln2_g,
-                               L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft, ctlp ? &ctl : nullptr, &hs))) return rc;
+                               L.ln2_b, L.c_wq, L.c_bq, L.c_wq_soft, L.c_bq_soft, ctlp ? &ctl : nullptr, &hs, L.Kpool,
+                               dd->P_cap))) return rc;
       } else {
         // many rows: every (head, row) workgroup re-streaming its 32 KB of the query projection through L2 costs
         // more than one LN-prologue GEMM launch that reads the weights once per row tile
@@ -626,7 +672,7 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         if ((rc = policy_cross(h, dd->q, qsoft, L.Kmono, L.Ksoft ? L.Ksoft : L.Kmono, L.V, L.energy_bias, dd->enc_len,
                                dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, d, dd->S_cap, dd->ratio,
                                dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, nullptr, nullptr,
-                               nullptr, nullptr, nullptr, nullptr, nullptr, ctlp ? &ctl : nullptr, nullptr))) return rc;
+                               nullptr, nullptr, nullptr, nullptr, nullptr, ctlp ? &ctl : nullptr, nullptr, L.Kpool, dd->P_cap))) return rc;
       }
       if (chain_ffn) {
         if ((rc = sl_dec_ffn_chain(h, dd->ctx, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2,

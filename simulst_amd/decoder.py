@@ -112,6 +112,10 @@ class DecoderState:
         self.Kmono = [torch.zeros(B, H, S_cap, d, device=device, dtype=dtype) for _ in range(Ld)]
         self.Ksoft = None
         self.V = [torch.zeros(B, H, S_cap, d, device=device, dtype=dtype) for _ in range(Ld)]
+        # pooled monotonic keys of the complete pre-decision windows (simulst_pool_keys), [B, H, P_cap, d] fp32 per layer;
+        # allocated by MMADecoder.new_state for learned policies with 'average' pooling
+        self.Kpool = None
+        self.P_cap = 0
         self.enc_len = torch.zeros(B, device=device, dtype=torch.int32)
         self.enc_len_bh = torch.zeros(B * H, device=device, dtype=torch.int32)
         self.enc_rows = 0                    # rows of the source already projected (lockstep)
@@ -134,6 +138,9 @@ class DecoderState:
             self.Kmono, self.V = regrow(self.Kmono, S_cap), regrow(self.V, S_cap)
             if self.Ksoft is not None:
                 self.Ksoft = regrow(self.Ksoft, S_cap)
+            if self.Kpool is not None:
+                self.P_cap = S_cap // self._pool_ratio + 1
+                self.Kpool = regrow(self.Kpool, self.P_cap)
             self.S_cap = S_cap
         for a in ("ws", "layer_structs", "structs_fragment_major"):     # device-loop descriptors hold raw pointers
             if hasattr(self, a):
@@ -196,6 +203,10 @@ class MMADecoder:
         self.ops = ops or Ops()
         self.w = shared_weights if shared_weights is not None else DecoderWeights(weights, cfg, self.device, dtype, prefix)
         self.attn_enum = _lib.ATTN_ENUM[cfg.attn_type]
+        # learned policies with 'average' fixed pre-decision: the pooled monotonic keys of complete windows are cached when the
+        # frames arrive (simulst_pool_keys) instead of being pooled from the frames at every decode step
+        self.pool_cache = (cfg.attn_type != "waitk" and cfg.pre_decision_ratio > 1 and cfg.fixed_pre_decision_type == "average"
+                           and os.environ.get("SIMULST_POOL_CACHE", "1") == "1")
         self.soft = cfg.attn_type != "hard_aligned"
         self.separate_soft = cfg.attn_type in ("infinite_lookback", "chunkwise")
         self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(cfg.embed_dim)
@@ -233,6 +244,11 @@ class MMADecoder:
         if self.separate_soft:
             st.Ksoft = [torch.zeros(B, self.cfg.num_heads, S_cap, self.cfg.head_dim, device=self.device, dtype=self.dtype)
                         for _ in range(self.cfg.decoder_layers)]
+        if self.pool_cache:
+            st._pool_ratio = self.cfg.pre_decision_ratio
+            st.P_cap = S_cap // st._pool_ratio + 1
+            st.Kpool = [torch.zeros(B, self.cfg.num_heads, st.P_cap, self.cfg.head_dim, device=self.device, dtype=torch.float32)
+                        for _ in range(self.cfg.decoder_layers)]
         return st
 
     # ------------------------------------------------------------------ source side
@@ -262,6 +278,10 @@ class MMADecoder:
         st.enc_rows = r0 + n
         st.enc_len = enc_len.to(device=self.device, dtype=torch.int32)
         st.enc_len_bh = st.enc_len.repeat_interleave(cfg.num_heads).contiguous()
+        if st.Kpool is not None and n > 0:
+            ratio = cfg.pre_decision_ratio
+            for l in range(cfg.decoder_layers):               # windows the new frames may have completed
+                ops.pool_keys(st.Kmono[l], st.Kpool[l], st.enc_len, ratio=ratio, j_lo=r0 // ratio, j_hi=(r0 + n) // ratio)
 
     # ------------------------------------------------------------------ one decode step
     def step(self, st: DecoderState, last_tokens: torch.Tensor, stop_on_read: bool = False):
@@ -412,6 +432,7 @@ class MMADecoder:
             a.head_step, a.head_read = st.head_step[l].data_ptr(), st.head_read[l].data_ptr()
             a.Kmono, a.V = st.Kmono[l].data_ptr(), st.V[l].data_ptr()
             a.Ksoft = st.Ksoft[l].data_ptr() if self.separate_soft else None
+            a.Kpool = st.Kpool[l].data_ptr() if st.Kpool is not None else None
         return arr
 
     def decode_steps(self, st: DecoderState, last_tokens: torch.Tensor, n_steps: int, mask_eos: bool):
@@ -464,7 +485,7 @@ class MMADecoder:
                                 ws["ctx"].data_ptr(), ws["q"].data_ptr(), ws["q2"].data_ptr(), ws["hidden"].data_ptr(),
                                 ws["logits"].data_ptr(), ws["x_mid"].data_ptr() if (split or chains) else None,
                                 ws["p_self"].data_ptr() if split else None, int(self.fragment_major),
-                                ws["ffn_partial"].data_ptr() if chains else None,
+                                ws["ffn_partial"].data_ptr() if chains else None, st.P_cap if st.Kpool is not None else 0,
                                 None)
 
     def stream_steps(self, st: DecoderState, tokens: torch.Tensor, ctl, n_iter: int):

@@ -243,6 +243,13 @@ class Ops:
                                                     float(beta), float(tail_thres), dt(x)), "simulst_cif_integrate")
         return out, cif_len, delays, tail_w, alpha_sum
 
+    def pool_keys(self, Kmono, Kpool, key_len, *, ratio, j_lo, j_hi):
+        """pooled monotonic keys of the complete pre-decision windows [j_lo, j_hi) (simulst_pool_keys); Kmono [B, H, S_cap, d],
+        Kpool [B, H, P_cap, d] fp32"""
+        B, H, S_cap, d = Kmono.shape
+        self.h.check(self.lib.simulst_pool_keys(self.h.ptr, _p(Kmono), _p(Kpool), _p(key_len), B, H, d, S_cap, Kpool.shape[2],
+                                                int(ratio), int(j_lo), int(j_hi), dt(Kmono)), "simulst_pool_keys")
+
     def cif_stream_append(self, out, n, tail_w, acc, acc_len, prev_feat, prev_weight, *, beta, finish):
         """bookkeeping of a batched CIFLayer.infer call (simulst_cif_stream_append): append all but the withheld tail slot of
         every row to its accumulated vectors, carry the tail"""

@@ -279,3 +279,37 @@ def test_force_unfused_hook(ops):
         ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
     assert torch.equal(t_split, t_seven)
 
+
+
+@pytest.mark.parametrize("attn", ["hard_aligned_fixed_pre_decision", "infinite_lookback_fixed_pre_decision"])
+def test_pooled_key_cache_equals_pooling_per_step(ops, attn):
+    """simulst_pool_keys: the pooled monotonic keys cached as the source grows (appends of 6, 5, 13, 1 and 30 rows: windows
+    complete across append boundaries, ragged rows, one row still shorter than a window) give bit-identical logits, tokens
+    and head steps to pooling the window's frames at every step (modules/fixed_pre_decision.py:97-131)."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.decoder import MMADecoder
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=1, decoder_layers=2, simul_attn_type=attn, fixed_pre_decision_ratio=8)
+    w = init_model(cfg, seed=7)
+    for l in range(2):
+        w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 6
+    enc = torch.randn(3, 55, cfg.embed_dim, generator=torch.Generator().manual_seed(2)).cuda()
+    lens = [55, 41, 5]
+    outs = []
+    for cache in (True, False):
+        dec = MMADecoder(cfg, w, dtype=torch.float32, ops=ops)
+        dec.pool_cache = cache
+        st = dec.new_state(3, cap=32, S_cap=64)
+        assert (st.Kpool is not None) == cache
+        st.lockstep, st.online = True, False
+        toks = torch.full((3,), cfg.eos, device="cuda", dtype=torch.int64)
+        r0, got = 0, []
+        for n in (6, 5, 13, 1, 30):
+            dec.append_encoder_out(st, enc[:, r0:r0 + n], torch.tensor([min(L, r0 + n) for L in lens]))
+            r0 += n
+            got.append(dec.decode_steps(st, toks, 3, mask_eos=True).clone())
+            got.append(st.ws["logits"].clone())
+            got.extend(h.clone() for h in st.head_step)
+        outs.append(got)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
