@@ -150,10 +150,17 @@ def _make_unpickler():
     import pickle
 
     class TolerantUnpickler(pickle.Unpickler):
+        # classes that may be absent on the inference box and are only DATA here (configs, enums, dictionaries); anything else
+        # that cannot be imported is an error, not something to load as an inert shell
+        SHELL_PREFIXES = ("omegaconf", "fairseq", "argparse", "examples.", "codebase", "hydra", "typing", "enum", "collections")
+
         def find_class(self, module, name):
             try:
                 return super().find_class(module, name)
             except Exception:
+                if not module.startswith(self.SHELL_PREFIXES):
+                    raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}, which is neither importable nor one of the "
+                                                 f"configuration classes read as plain data ({', '.join(self.SHELL_PREFIXES)})")
                 return type(name, (_Shell,), {"__module__": module})
 
     class _Mod:                      # what torch.load wants from a pickle_module
@@ -198,7 +205,19 @@ def read_checkpoint(path: str) -> Dict:
     else:
         raise ValueError(f"{path}: checkpoint carries neither 'cfg' nor 'args'")
     if "arch" not in model_args and "_name" in model_args:
-        model_args["arch"] = model_args["_name"]
+        # hydra configs carry the MODEL name in `_name` ('mma_model'), not the architecture ('mma_model_s'): take the one
+        # architecture registered for that model, or say what is missing
+        from . import cif, model  # noqa: F401  (register the models and archs)
+        from .registry import ARCH_REGISTRY
+        name = model_args["_name"]
+        if name in ARCH_REGISTRY:
+            model_args["arch"] = name
+        else:
+            archs = sorted(a for a, (m, _) in ARCH_REGISTRY.items() if m == name)
+            if len(archs) != 1:
+                raise ValueError(f"{path}: the checkpoint names model {name!r} but no architecture; registered architectures of "
+                                 f"that model: {archs} -- pass arg_overrides={{'arch': ...}}")
+            model_args["arch"] = archs[0]
     return {"cfg": {"model": model_args, "task": task_args}, "model": state["model"]}
 
 

@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.simulst_version() >= 100
 
 
+def test_library_exports_nothing_but_the_declared_abi():
+    """the dynamic symbol table holds exactly the simulst_* entry points of the header: internal sl_* C++ helpers are hidden
+    (csrc/exports.map)"""
+    import subprocess
+    so = os.path.join(ROOT, "simulst_amd", "libsimulst_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == header_functions(), set(exported) ^ set(header_functions())
+
+
 def test_null_handle_and_null_pointer_statuses():
     from simulst_amd import _lib
     lib = _lib.load()

@@ -158,8 +158,10 @@ def test_read_checkpoint_layouts(tmp_path):
            "for k, v in d.items()}; self._metadata = None\n")
     exec(src, fake.__dict__)
     for c in (fake.Node, fake.DictConfig):
-        c.__module__ = "fake_omegaconf"
-    sys.modules["fake_omegaconf"] = fake
+        c.__module__ = "omegaconf.dictconfig"
+    sys.modules["omegaconf.dictconfig"] = fake
+    parent_was = sys.modules.get("omegaconf")
+    sys.modules["omegaconf"] = types.ModuleType("omegaconf")
     try:
         cfgobj = fake.DictConfig({"model": fake.DictConfig({"_name": "mma_model_s", "waitk_lagging": 9,
                                                             "conv_kernel_sizes": "5,5"}),
@@ -167,7 +169,10 @@ def test_read_checkpoint_layouts(tmp_path):
         p3 = str(tmp_path / "omega.pt")
         torch.save({"cfg": cfgobj, "model": w}, p3)
     finally:
-        del sys.modules["fake_omegaconf"]
+        del sys.modules["omegaconf.dictconfig"]
+        del sys.modules["omegaconf"]
+        if parent_was is not None:
+            sys.modules["omegaconf"] = parent_was
     st = ck.read_checkpoint(p3)
     assert st["cfg"]["model"] == {"_name": "mma_model_s", "waitk_lagging": 9, "conv_kernel_sizes": "5,5",
                                   "arch": "mma_model_s"}
@@ -175,7 +180,24 @@ def test_read_checkpoint_layouts(tmp_path):
     with pytest.raises(ValueError, match="not a fairseq checkpoint"):
         torch.save({"weights": w}, str(tmp_path / "bad.pt"))
         ck.read_checkpoint(str(tmp_path / "bad.pt"))
-    assert pickle  # (imported for symmetry with the loader's module use)
+    # `_name` holding the MODEL name (hydra layout): the one architecture registered for it is taken
+    p4 = str(tmp_path / "hydra_name.pt")
+    torch.save({"cfg": {"model": {"_name": "mma_model", "waitk_lagging": 4}, "task": {}}, "model": w}, p4)
+    assert ck.read_checkpoint(p4)["cfg"]["model"]["arch"] == "mma_model_s"
+    torch.save({"cfg": {"model": {"_name": "no_such_model"}, "task": {}}, "model": w}, p4)
+    with pytest.raises(ValueError, match="no architecture"):
+        ck.read_checkpoint(p4)
+    # a pickle that refers to an un-importable class OUTSIDE the configuration namespaces fails loudly instead of loading as a shell
+    evil = types.ModuleType("somewhere_else")
+    exec("class Thing:\n    pass\n", evil.__dict__)
+    evil.Thing.__module__ = "somewhere_else"
+    sys.modules["somewhere_else"] = evil
+    try:
+        torch.save({"cfg": {"model": {"arch": "mma_model_s"}, "task": {}}, "model": w, "extra_state": evil.Thing()}, p4)
+    finally:
+        del sys.modules["somewhere_else"]
+    with pytest.raises(pickle.UnpicklingError, match="somewhere_else"):
+        ck.read_checkpoint(p4)
 
 
 def test_load_dictionary(tmp_path):
