@@ -342,6 +342,19 @@ int simulst_step_p_choose(simulst_handle* h, const void* q, const void* Kmono, f
                           int32_t ratio, int32_t incremental, int32_t attn_type, int32_t waitk_k,
                           const int32_t* tgt_idx, int32_t online, int32_t dtype);
 
+/* The same step probabilities with the reference's PADDED-BATCH pooling (modules/fixed_pre_decision.py:104-131), for learned
+ * policies: Kmono holds the projections of ALL S_pad rows of the padded encoder output of every utterance (rows beyond
+ * key_len[b] included); the S_pad rows are pooled, floor-trimmed (`incremental`) and cropped as one tensor, so the window that
+ * straddles the end of a shorter utterance averages valid and padded rows, and a pooled position j > 0 whose window holds more
+ * than pad_threshold (--fixed-pre-decision-pad-threshold, default 0.3) padding is masked (p = 0, :112-121); p [B*H][S_cap] is
+ * written for columns < S_pad.  At INFERENCE (incremental) the two forms agree on every column < key_len[b] -- the straddling
+ * window's value lands on frame (j + 1) * ratio - 1 >= key_len[b], beyond the forced stop -- which is why the decode loop keeps the
+ * per-utterance form; in a training-mode forward (incremental == 0) they differ at column key_len[b] - 1. */
+int simulst_step_p_choose_padded(simulst_handle* h, const void* q, const void* Kmono, float energy_bias,
+                                 const int32_t* key_len, float* p, int32_t B, int32_t S_pad, int32_t S_cap, int32_t H,
+                                 int32_t d, int32_t ratio, int32_t incremental, int32_t attn_type, float pad_threshold,
+                                 int32_t dtype);
+
 /* ---- CIF integrate-and-fire -------------------------------------------------------
  * x [B][S][C], alpha [B][S] fp32 -> out [B][T_cap][C] (zero beyond cif_len), cif_len [B] int32,
  * delays [B][T_cap] fp32, tail_w [B] fp32, alpha_sum [B] fp32.  One wavefront prefix-sum of

@@ -138,6 +138,7 @@ SIGNATURES = {
     "simulst_greedy_argmax": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32],
     "simulst_mma_decode": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, _vp, _i32, _i32],
     "simulst_mma_stream_steps": [_vp, C.POINTER(DecoderDesc), C.POINTER(DecLayer), _vp, C.POINTER(StreamCtl), _i32],
+    "simulst_step_p_choose_padded": [_vp, _vp, _vp, _f32, _vp, _vp] + [_i32] * 8 + [_f32, _i32],
     "simulst_pool_keys": [_vp, _vp, _vp, _vp] + [_i32] * 9,
     "simulst_policy_cross_attention": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32,
                                        _i32, _i32, _i32, _i32, _i32, _i32, _i32],

@@ -305,13 +305,19 @@ __global__ __launch_bounds__(256) void step_p_choose_kernel(const T* __restrict_
                                                             float energy_bias, const int* __restrict__ key_len,
                                                             float* __restrict__ p, int S_cap, int H, int d,
                                                             int ratio, int incremental, int attn_type, int waitk_k,
-                                                            const int* __restrict__ tgt_idx, int online) {
+                                                            const int* __restrict__ tgt_idx, int online, int S_pad,
+                                                            float pad_thr) {
+  // S_pad > 0: the reference's PADDED-BATCH pooling (modules/fixed_pre_decision.py:104-131): the key tensor of S_pad rows is
+  // pooled, trimmed and cropped as a whole -- rows of a shorter utterance beyond key_len[b] (the projections of the padded
+  // encoder states) take part in the window that straddles its end -- and a pooled position j > 0 whose window holds more
+  // than pad_thr padding is masked (p = 0).  S_pad == 0: every utterance by its own length (the B == 1 result).
   extern __shared__ float sm[];
   const bool pool_last = ratio < 0;                          // sign of ratio = pooling type (common.h)
   ratio = ratio < 0 ? -ratio : ratio;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int D = H * d;
-  const int len = key_len ? key_len[b] : S_cap;
+  const int len_b = key_len ? key_len[b] : S_cap;
+  const int len = S_pad > 0 ? S_pad : len_b;
   float* pp = sm + wave * S_cap;                             // pooled probabilities of this wave's head
   for (int h = wave; h < H; h += 4) {
     float* pr = p + ((long)b * H + h) * S_cap;
@@ -331,7 +337,12 @@ __global__ __launch_bounds__(256) void step_p_choose_kernel(const T* __restrict_
           for (int f = f0; f < f1; ++f) acc += to_f32(Km[(((long)b * H + h) * S_cap + f) * d + lane]);
         acc = acc / (float)(f1 - f0) * qv;
         const float en = wave_sum(acc) + energy_bias;
-        if (lane == 0) pp[j] = 1.0f / (1.0f + expf(-en));
+        bool masked = false;
+        if (S_pad > 0 && j > 0) {                              // pooled padding mask, threshold, first position never masked
+          const int n_pad = f1 - max(f0, min(f1, len_b));
+          masked = (float)n_pad / (float)(f1 - f0) > pad_thr;
+        }
+        if (lane == 0) pp[j] = masked ? 0.f : 1.0f / (1.0f + expf(-en));
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -611,12 +622,37 @@ extern "C" int simulst_step_p_choose(simulst_handle* h, const void* q, const voi
   if (dtype == SIMULST_F32)
     hipLaunchKernelGGL(step_p_choose_kernel<float>, dim3(B), dim3(256), lds, h->stream, (const float*)q,
                        (const float*)Kmono, energy_bias, key_len, p, S_cap, H, d, ratio, incremental, attn_type,
-                       waitk_k, tgt_idx, online);
+                       waitk_k, tgt_idx, online, 0, 0.f);
   else
     hipLaunchKernelGGL(step_p_choose_kernel<bf16>, dim3(B), dim3(256), lds, h->stream, (const bf16*)q,
                        (const bf16*)Kmono, energy_bias, key_len, p, S_cap, H, d, ratio, incremental, attn_type,
-                       waitk_k, tgt_idx, online);
+                       waitk_k, tgt_idx, online, 0, 0.f);
   return sl_launch_status(h, "simulst_step_p_choose");
+}
+
+extern "C" int simulst_step_p_choose_padded(simulst_handle* h, const void* q, const void* Kmono, float energy_bias,
+                                            const int32_t* key_len, float* p, int32_t B, int32_t S_pad, int32_t S_cap,
+                                            int32_t H, int32_t d, int32_t ratio, int32_t incremental, int32_t attn_type,
+                                            float pad_threshold, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, p); SL_CHECK_NULL(h, q); SL_CHECK_NULL(h, Kmono); SL_CHECK_NULL(h, key_len);
+  SL_REQUIRE(h, dtype == SIMULST_F32 || dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_step_p_choose_padded: dtype");
+  SL_REQUIRE(h, attn_type == SIMULST_ATTN_HARD || attn_type == SIMULST_ATTN_INFINITE_LOOKBACK || attn_type == SIMULST_ATTN_CHUNKWISE,
+             SIMULST_E_ARG, "simulst_step_p_choose_padded: learned policies only (wait-k has no energies to pool)");
+  SL_REQUIRE(h, ratio != 0 && S_cap > 0 && S_pad > 0 && S_pad <= S_cap && H > 0 && d > 0 && d <= 64 && S_cap <= 4096, SIMULST_E_SHAPE,
+             "simulst_step_p_choose_padded: shape (0 < S_pad <= S_cap <= 4096, head_dim <= 64)");
+  if (B <= 0) return SIMULST_OK;
+  const size_t lds = (size_t)4 * S_cap * sizeof(float);
+  KTimer t(h, SIMULST_K_SCAN);
+  if (dtype == SIMULST_F32)
+    hipLaunchKernelGGL(step_p_choose_kernel<float>, dim3(B), dim3(256), lds, h->stream, (const float*)q,
+                       (const float*)Kmono, energy_bias, key_len, p, S_cap, H, d, ratio, incremental, attn_type, 1, nullptr, 0,
+                       S_pad, pad_threshold);
+  else
+    hipLaunchKernelGGL(step_p_choose_kernel<bf16>, dim3(B), dim3(256), lds, h->stream, (const bf16*)q,
+                       (const bf16*)Kmono, energy_bias, key_len, p, S_cap, H, d, ratio, incremental, attn_type, 1, nullptr, 0,
+                       S_pad, pad_threshold);
+  return sl_launch_status(h, "simulst_step_p_choose_padded");
 }
 
 extern "C" int simulst_cif_integrate(simulst_handle* h, const void* x, const float* alpha, const int32_t* src_len,

@@ -228,6 +228,17 @@ class Ops:
                      "simulst_step_p_choose")
         return p
 
+    def step_p_choose_padded(self, q, Kmono, p, key_len, *, S_pad, ratio, incremental, attn_type, energy_bias=0.0,
+                             pad_threshold=0.3):
+        """step probabilities with the reference's padded-batch pooling and its pad-threshold mask
+        (simulst_step_p_choose_padded; modules/fixed_pre_decision.py:104-131).  Kmono [B, H, S_cap, d] must hold the
+        projections of all S_pad rows of the padded encoder output."""
+        B, H, S_cap, d = Kmono.shape
+        self.h.check(self.lib.simulst_step_p_choose_padded(self.h.ptr, _p(q), _p(Kmono), float(energy_bias), _p(key_len), _p(p), B,
+                                                           int(S_pad), S_cap, H, d, int(ratio), int(incremental), attn_type,
+                                                           float(pad_threshold), dt(Kmono)), "simulst_step_p_choose_padded")
+        return p
+
     def cif_integrate(self, x, alpha, *, beta, tail_thres, src_len=None, T_cap=None):
         _chk_contig(x, alpha)
         B, S, Cc = x.shape

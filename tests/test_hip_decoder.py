@@ -313,3 +313,35 @@ def test_pooled_key_cache_equals_pooling_per_step(ops, attn):
         outs.append(got)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("attn", ["hard_aligned_fixed_pre_decision", "infinite_lookback_fixed_pre_decision"])
+def test_ragged_offline_batch_equals_the_references_padded_batch_decoding(ops, attn):
+    """SURVEY 8(a) c4 settled with a number: the oracle decodes a ragged batch the reference's way (eval/generate.py: ONE padded
+    key tensor, pooled as a whole, pooled pad mask with threshold 0.3, modules/fixed_pre_decision.py:104-131), the HIP decode loop
+    pools every utterance by its own length.  At inference the two can only differ on columns >= key_len[b] (the straddling
+    window's probability lands on frame (j + 1) * ratio - 1), which the forced stop at key_len[b] - 1 hides: 0 of 12 hypotheses
+    differ, with learned policies that do move (query projections x 8) and lengths at, below and between multiples of ratio * 4."""
+    from oracle import agent as oag
+    from oracle.configs import from_model_config
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=3, simul_attn_type=attn, fixed_pre_decision_ratio=8)
+    w = init_model(cfg, seed=21)
+    for l in range(3):
+        w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 8
+    w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(5)) * cfg.embed_dim ** -0.5
+    ecfg, dcfg = from_model_config(cfg)
+    L = torch.tensor([512, 511, 480, 449, 417, 400, 352, 321, 290, 257, 224, 130])      # encoder frames 128 ... 33
+    fb = torch.randn(len(L), 512, 80, generator=torch.Generator().manual_seed(8))
+    for b in range(len(L)):
+        fb[b, L[b]:] = 0
+    n_steps = 30
+    with torch.no_grad():
+        ref, _, _ = oag.greedy_offline(w, ecfg, dcfg, fb, L, n_steps=n_steps, mask_eos=True)
+        toks, info = SimulSTModel(cfg, w, dtype=torch.float32, ops=ops).generate_offline(fb.cuda(), L, n_steps=n_steps, mask_eos=True)
+    differing = int((toks.cpu() != ref).any(dim=1).sum())
+    assert differing == 0, differing
+    steps = torch.stack([h.cpu() for h in info["state"].head_step])
+    assert len(torch.unique(steps)) > 6, "the policies did not move"

@@ -855,3 +855,52 @@ def test_g19_pre_decision_last_vs_golden(ops, name, ratio):
                 read = bool(a[pre + ".head_read"].any())
                 if not (online and read):
                     tgt += 1
+
+
+@pytest.mark.parametrize("incremental", [True, False])
+@pytest.mark.parametrize("ptype", ["average", "last"])
+def test_step_p_choose_padded_batch_vs_oracle(ops, incremental, ptype):
+    """the reference's padded-batch pooling with the 0.3 pad-threshold mask (modules/fixed_pre_decision.py:104-131)
+    -- simulst_step_p_choose_padded against the oracle's p_choose on a ragged batch (lengths below, at and between multiples of
+    the ratio, one row shorter than a window), every column of the padded tensor; and the claim the decode loop rests on: at
+    inference the per-utterance form (simulst_step_p_choose) equals it on every column < key_len[b]."""
+    from oracle import monotonic as mono
+    from simulst_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    D, H, r = 64, 2, 8
+    d = D // H
+    lens = [41, 40, 33, 27, 16, 9, 5]
+    B, S_pad = len(lens), 41
+    key = torch.randn(S_pad, B, D, generator=g)                 # padded rows carry values too (encoder states of the padding)
+    query = torch.randn(1, B, D, generator=g)
+    w = {"a.q_proj.weight": torch.randn(D, D, generator=g) * 0.3, "a.q_proj.bias": torch.randn(D, generator=g) * 0.1,
+         "a.k_proj.weight": torch.randn(D, D, generator=g) * 0.3, "a.k_proj.bias": torch.randn(D, generator=g) * 0.1}
+    cfg = mono.AttnCfg(attn_type="hard_aligned", num_heads=H, pre_decision_ratio=r, pre_decision_type=ptype,
+                       pre_decision_pad_threshold=0.3)
+    pad = torch.arange(S_pad).view(1, -1) >= torch.tensor(lens).view(-1, 1)
+    pad_bh = torch.repeat_interleave(pad, H, 0)
+    ref = mono.p_choose(w, "a", cfg, query, key, pad_bh, {}, incremental).squeeze(1)          # [B*H, S_pad]
+    S_cap = 48
+    q = torch.nn.functional.linear(query[0], w["a.q_proj.weight"], w["a.q_proj.bias"]).cuda()
+    K = torch.nn.functional.linear(key, w["a.k_proj.weight"], w["a.k_proj.bias"])              # [S_pad, B, D]
+    Km = torch.zeros(B, H, S_cap, d)
+    Km[:, :, :S_pad] = K.view(S_pad, B, H, d).permute(1, 2, 0, 3)
+    Km = Km.cuda().contiguous()
+    kl = torch.tensor(lens, dtype=torch.int32).cuda()
+    ratio_arg = -r if ptype == "last" else r
+    p = torch.zeros(B * H, S_cap, device="cuda")
+    ops.step_p_choose_padded(q, Km, p, kl, S_pad=S_pad, ratio=ratio_arg, incremental=incremental, attn_type=_lib.ATTN_HARD)
+    torch.testing.assert_close(p[:, :S_pad].cpu(), ref, atol=2e-5, rtol=1e-4)
+    p1 = torch.zeros(B * H, S_cap, device="cuda")
+    ops.step_p_choose(q, Km, p1, B=B, S_cap=S_cap, H=H, d=d, ratio=ratio_arg, incremental=incremental, attn_type=_lib.ATTN_HARD,
+                      key_len=kl)
+    differing = 0
+    for b, L in enumerate(lens):
+        for hh in range(H):
+            a, c = p[b * H + hh, :L].cpu(), p1[b * H + hh, :L].cpu()
+            if incremental and L >= r:
+                # inference: the decisions of a row only see columns < key_len[b]; both forms put the same values there
+                torch.testing.assert_close(a, c, atol=2e-5, rtol=1e-4)
+            differing += int(not torch.allclose(a, c, atol=2e-5, rtol=1e-4))
+    if not incremental and ptype == "average":
+        assert differing > 0          # training-mode forward: the partial last window lands on column key_len - 1 only per utterance
