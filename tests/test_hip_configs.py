@@ -110,10 +110,13 @@ def _parity_args(**kw):
     return SimpleNamespace(**base)
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture()
 def parity_tool():
+    """tools/config_parity.py as a module, with the oracle's thread count bounded: torch's default is one thread per host core
+    (256 on the GPU box), which makes the oracle's many small CPU ops ~20 x slower than 16 threads do"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import config_parity
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     return config_parity
 
 
@@ -138,6 +141,100 @@ def test_config4_cif_full_depth_streaming_utterance(parity_tool):
         res = parity_tool.run_cif(_parity_args())
     for beta in ("beta_1.0", "beta_0.926"):
         assert all(r["identical"] for r in res[beta]["utterances"]), res[beta]["utterances"]
+
+
+# ---- the configs at the sizes BASELINE.json / SURVEY.md 8(d) state: all 8 utterances (312 .. 1534 frames), hypotheses to their
+#      cap min(T, 1024) tokens (agents/default_agent.py:173-174; the EOS row of the tied random embedding is zeroed, so random-init
+#      hypotheses do run to the cap: 6 128 tokens per MMA policy), B = 1 through the agent AND as one batch through the batched
+#      agents.  The oracle side runs on 16 host threads (parity_tool fixture).
+def test_config1_waitk3_all_eight_utterances_to_the_cap(parity_tool):
+    """configs[0] at its stated size: wait-k=3, 8 utterances, B = 1 streaming to min(T, 1024) tokens + 8 x 640 batched"""
+    with torch.no_grad():
+        res = parity_tool.run_mma(_parity_args(max_tokens=1024, utterances=8, batched=True), "waitk_fixed_pre_decision", 3)
+    assert len(res["utterances"]) == 8 and all(r["identical"] for r in res["utterances"])
+    assert [r["tokens"] for r in res["utterances"]] == [313, 499, 641, 778, 846, 1001, 1025, 1025]
+    assert res["hip_batched_streaming_8x640"]["rows_identical_to_b1_and_oracle"]
+
+
+def test_config3_mma_hard_all_eight_utterances_to_the_cap(parity_tool):
+    """configs[2] at its stated size: MMA-hard, 8 utterances B = 1 to the cap, and batched (rows take different decisions)"""
+    with torch.no_grad():
+        res = parity_tool.run_mma(_parity_args(max_tokens=1024, utterances=8, batched=True), "hard_aligned_fixed_pre_decision", 0)
+    assert len(res["utterances"]) == 8 and all(r["identical"] for r in res["utterances"])
+    assert sum(r["tokens"] for r in res["utterances"]) > 4000
+    b = res["hip_batched_streaming_8x640"]
+    assert b["rows_identical_to_b1_and_oracle"] and b["distinct_action_strings"] > 1
+
+
+def test_config4_cif_all_eight_utterances(parity_tool):
+    """configs[3] at its stated size: cif_transformer_s, beta 1.0 and 0.926, 8 utterances B = 1 to EOS (the overshoot bias ends a
+    hypothesis a few positions after its last integrated vector, models/cif_transformer.py:716-722), and 8 x 640 batched through
+    the device-side CIF streaming loop"""
+    with torch.no_grad():
+        res = parity_tool.run_cif(_parity_args(max_tokens=1024, utterances=8, batched=True))
+    for beta in ("beta_1.0", "beta_0.926"):
+        assert len(res[beta]["utterances"]) == 8 and all(r["identical"] for r in res[beta]["utterances"]), res[beta]["utterances"]
+        assert res[beta]["hip_batched_streaming_8x640"]["rows_identical_to_b1_and_oracle"]
+
+
+def test_config5_full_rank_shard_of_the_40k_set():
+    """configs[4] at its stated size: rank 3 of 8 of the 40 000-utterance log-normal set = 5 000 utterances, decoded in ragged
+    launch sequences of up to 1024 neighbours in length on three streams (bf16, wait-k 3), every hypothesis checked for the
+    properties the reference's generator guarantees (eval/generate.py:187-209, exp/infer_st.yaml:3-5): one hypothesis per
+    utterance of the shard, length = its own cap int(0.1 T + 10) or its first EOS, no padding symbol, EOS only at the end."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import ConcurrentOffline, SimulSTModel
+    from simulst_amd.offline_eval import decode_batch, make_batch, max_steps, plan_shard, synthetic_lengths, trim_hypotheses
+    from simulst_amd.sharding import shard_utterances
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=3)
+    w = init_model(cfg, seed=999)
+    lengths = synthetic_lengths(40000)
+    world, rank = 8, 3
+    seqs = plan_shard(lengths, world, rank, max_rows=1024, streams=3)
+    mine = sorted(i for s_ in seqs for i in s_)
+    assert mine == sorted(shard_utterances(lengths, world, rank)) and len(mine) == 5000
+    # the 8 shards partition the set
+    allu = sorted(i for r in range(world) for i in shard_utterances(lengths, world, r))
+    assert allu == list(range(40000))
+    g = torch.Generator(device="cuda").manual_seed(999 + rank)
+
+    def fbank_dev(i, T):                       # device-side synthetic features: 5 000 utterances are 1.4 GB of fp32 on the host
+        return torch.randn(T, 80, device="cuda", generator=g)
+    model = SimulSTModel(cfg, w, dtype=torch.bfloat16)
+    pool = ConcurrentOffline(model, w, 3)
+    batches = []
+    for idx in seqs:
+        L = torch.tensor([lengths[i] for i in idx])
+        Tpad = (int(L.max()) + 255) // 256 * 256
+        fb = torch.zeros(len(idx), Tpad, 80, device="cuda", dtype=torch.bfloat16)
+        for r, i in enumerate(idx):
+            fb[r, :lengths[i]] = fbank_dev(i, lengths[i]).to(torch.bfloat16)
+        batches.append((fb, L.cuda(), L, max_steps(int(L.max())), Tpad))
+    outs = [None] * len(batches)
+
+    def worker(c):
+        with torch.no_grad(), torch.cuda.stream(pool.streams[c]):
+            for bi in range(c, len(batches), 3):
+                outs[bi] = decode_batch(pool.models[c], batches[bi])
+    import threading
+    th = [threading.Thread(target=worker, args=(c,)) for c in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    n_tok, seen = 0, set()
+    for idx, b, toks in zip(seqs, batches, outs):
+        n = trim_hypotheses(toks, b[2], cfg.eos)
+        toks = toks.cpu()
+        for r, i in enumerate(idx):
+            h = toks[r, :int(n[r])].tolist()
+            assert i not in seen
+            seen.add(i)
+            assert 1 <= len(h) <= max_steps(lengths[i])
+            assert cfg.eos not in h[:-1] and (h[-1] == cfg.eos or len(h) == max_steps(lengths[i]))
+            assert cfg.padding_idx not in h
+            n_tok += len(h)
+    assert seen == set(mine) and n_tok > 400000
 
 
 def test_config5_one_ranks_shard(cfg_w):

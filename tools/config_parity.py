@@ -130,7 +130,26 @@ def run_cif(args):
             t2 = time.perf_counter(); got = agent.run_utterance(fbd); torch.cuda.synchronize(); t3 = time.perf_counter()
             n_tok += compare(rows, T, ref, got, ("n_cif",), strict=False)
             t_cpu, t_gpu = t_cpu + t1 - t0, t_gpu + t3 - t2
-        out[f"beta_{beta}"] = {"utterances": rows,
+        batched = None
+        if args.batched:
+            # batched streaming: 8 streams of EQUAL length (the first 640 frames of 8 different utterances) in ONE batch through
+            # simulst_cif_stream_steps / simulst_cif_stream_append, against the B = 1 agent and the oracle
+            from simulst_amd.cif import BatchedCIFStreamingAgent
+            Tb = 640
+            fbs = torch.stack([fbank_of(100 + u, Tb) for u in range(8)])
+            singles = [agent.run_utterance(fbs[b].cuda()) for b in range(8)]
+            torch.cuda.synchronize(); tb0 = time.perf_counter()
+            got_b = BatchedCIFStreamingAgent(model, overshoot_weight=1.0).run_batch(fbs)
+            torch.cuda.synchronize(); tb1 = time.perf_counter()
+            keys = ("actions", "tokens", "delays_ms", "AL", "n_cif")
+            same = all(got_b[b][k] == singles[b][k] for b in range(8) for k in keys)
+            ref0 = oag.simulate_cif(w, ecfg, dcfg, beta, fbs[0])
+            same = same and all(got_b[0][k] == ref0[k] for k in keys)
+            assert same
+            batched = {"rows_identical_to_b1_and_oracle": same, "seconds": round(tb1 - tb0, 2),
+                       "distinct_action_strings": len({g["actions"] for g in got_b}),
+                       "tokens_per_s": round(sum(len(g["tokens"]) for g in got_b) / (tb1 - tb0), 1)}
+        out[f"beta_{beta}"] = {"utterances": rows, "hip_batched_streaming_8x640": batched,
                                "oracle_cpu": {"seconds": round(t_cpu, 2), "tokens_per_s": round(n_tok / max(t_cpu, 1e-9), 1), "threads": args.threads},
                                "hip_b1_streaming": {"seconds": round(t_gpu, 2), "tokens_per_s": round(n_tok / max(t_gpu, 1e-9), 1)}}
     return out
@@ -147,7 +166,7 @@ def main():
                     help="with --config 3: another monotonic attention type, e.g. infinite_lookback_fixed_pre_decision")
     args = ap.parse_args()
     if args.batched is None:
-        args.batched = args.config == 3
+        args.batched = args.config in (3, 4)
     torch.set_num_threads(args.threads)
     with torch.no_grad():
         if args.config == 1:
