@@ -298,8 +298,12 @@ class ConcurrentOffline:
             t.start()
         for t in threads:
             t.join()
+        # the join is on the HOST: a `cur.wait_stream(st)` here would park a barrier packet in the caller's stream while the
+        # worker streams are still running, and that waiting queue counts against the FOUR hardware queues the device keeps
+        # active at once -- with four worker streams it made all of them run one after the other (0.91 M instead of 1.50 M
+        # tokens/s at 4 x 6 batches; a rocprofv3 run of the same command did overlap them: DESIGN.md section 3, schedules)
         for st in self.streams:
-            cur.wait_stream(st)
+            st.synchronize()
         if errs:
             raise errs[0]
         return out
