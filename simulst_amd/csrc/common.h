@@ -40,6 +40,7 @@ struct simulst_handle {
   hipGraphExec_t graph_exec;
   uint64_t graph_key;
   bool ffn_lds_attr_set;       // simulst_emformer_ffn did the same for the fused feed-forward kernel
+  bool ea_general_only;        // SIMULST_EA_GENERAL=1: expected alignment through the chunked log-space kernel for every S (A/B measurements)
   int ffn_variant;             // simulst_debug_ffn_variant (timing ablations of the fused feed-forward launch)
   bool conv_pos_lds_attr_set;  // simulst_conv_pos raised its kernels' dynamic-LDS limit through this handle
   bool ctc_lds_attr_set;       // simulst_ctc_best_alignment raised its kernel's dynamic-LDS limit through this handle

@@ -48,6 +48,8 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->conv_pos_lds_attr_set = false;
   h->ffn_lds_attr_set = false;
   h->ffn_variant = 0;
+  h->ea_general_only = false;
+  if (const char* e = getenv("SIMULST_EA_GENERAL")) h->ea_general_only = atoi(e) != 0;
   h->graph_key = 0;
   for (int i = 0; i < SIMULST_K_COUNT; ++i) { h->timer_on[i] = false; h->timer_ms[i] = 0.0; h->timer_n[i] = 0; }
   *out = h;

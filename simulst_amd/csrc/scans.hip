@@ -54,6 +54,35 @@ __global__ __launch_bounds__(256) void step_search_kernel(const float* __restric
   }
 }
 
+// wavefront scans on the DPP data path used by the expected-alignment kernels: the additive one over the whole wave or over two
+// independent 32-lane halves, and the multiplicative one (identity 1.0 for lanes without a source)
+__device__ __forceinline__ float wave_scan_incl_dpp_seg(float v, bool full_wave) {
+#define SL_DPP_ADD(ctrl, row_mask, bound)                                                                              \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, bound))
+  SL_DPP_ADD(0x111, 0xf, true);
+  SL_DPP_ADD(0x112, 0xf, true);
+  SL_DPP_ADD(0x114, 0xf, true);
+  SL_DPP_ADD(0x118, 0xf, true);
+  SL_DPP_ADD(0x142, 0xa, false);
+  if (full_wave) SL_DPP_ADD(0x143, 0xc, false);
+#undef SL_DPP_ADD
+  return v;
+}
+__device__ __forceinline__ float wave_scan_incl_dpp_mul(float v, bool full_wave) {
+  // invalid source lanes (shifted in / masked rows) keep `old` = 1.0f: the identity of the product
+#define SL_DPP_MUL(ctrl, row_mask)                                                                                     \
+  v *= __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+  SL_DPP_MUL(0x111, 0xf);
+  SL_DPP_MUL(0x112, 0xf);
+  SL_DPP_MUL(0x114, 0xf);
+  SL_DPP_MUL(0x118, 0xf);
+  SL_DPP_MUL(0x142, 0xa);
+  if (full_wave) SL_DPP_MUL(0x143, 0xc);
+#undef SL_DPP_MUL
+  return v;
+}
+
+
 // ---- expected alignment (utils/monotonic_attention.py:12-76) ----------------------------
 // one wave per row bh; sequential over targets, two wavefront scans over the source per target.
 // The recurrence is a chain of (target, 64-wide chunk) steps whose only global input, p, does not depend on it: the p
@@ -71,7 +100,7 @@ __global__ __launch_bounds__(256) void expected_alignment_kernel(const float* __
   float* prev = sm + wave * S;                   // alpha_{i-1}
   const int len = key_len ? key_len[r] : S;
   for (int s = lane; s < S; s += 64) prev[s] = (s == 0) ? 1.f : 0.f;
-  const float lead = logf(1.0f + eps);           // the prepended 1 also passes through log(. + eps)
+  const float lead = 1.0f + eps;                 // the prepended 1 also passes through (. + eps)
   const int n_chunks = (S + 63) / 64;
   const long total = (long)U * n_chunks;
   const float* prow = p + (long)r * U * S;
@@ -100,12 +129,16 @@ __global__ __launch_bounds__(256) void expected_alignment_kernel(const float* __
       q[j] = load_next();
       const int s = k * 64 + lane;
       const bool in = s < S;
-      float lg = in ? logf(1.0f - pv + eps) : 0.f;
-      float incl = wave_scan_incl_dpp(lg);
-      float cp = expf(carry_log + incl - lg);    // exclusive cumprod of (1 - p)
-      carry_log += wave_last(incl);
+      // exclusive cumprod of (1 - p + eps) as a multiplicative wavefront scan (exp(cumsum(log x)) of utils/functions.py:20-66 up
+      // to fp32 rounding; both underflow at the same point): no transcendental round trips inside the recurrence
+      const float x = in ? (1.0f - pv + eps) : 1.0f;
+      const float incl = wave_scan_incl_dpp_mul(x, true);
+      float excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, incl), 0x138, 0xf, 0xf, false));
+      if (lane == 0) excl = 1.0f;
+      const float cp = carry_log * excl;          // carry_log holds the running PRODUCT (the name is the log-space version's)
+      carry_log *= wave_last(incl);
       float cpc = fminf(fmaxf(cp, eps), 1.0f);
-      float term = in ? prev[s] / cpc : 0.f;
+      float term = in ? prev[s] * __builtin_amdgcn_rcpf(cpc) : 0.f;
       float tin = wave_scan_incl_dpp(term);
       float a = pv * cp * (carry_sum + tin);
       carry_sum += wave_last(tin);
@@ -122,6 +155,144 @@ __global__ __launch_bounds__(256) void expected_alignment_kernel(const float* __
         carry_sum = 0.f;
         __builtin_amdgcn_wave_barrier();
       }
+    }
+  }
+}
+
+// ---- the same recurrence for sources of at most 64 frames (one chunk: the pooled source of a fixed-pre-decision model,
+// 32 positions at the configs[1] shape): no carries between chunks, alpha_{i-1} stays in a register, and the exclusive cumprod
+// of (1 - p + eps) is a MULTIPLICATIVE wavefront scan -- exp(cumsum(log x)) of utils/functions.py:20-66 is prod x up to fp32
+// rounding (both underflow at the same point), and it takes two transcendental round trips out of every step of a chain that is
+// 110 targets long.  HALF: S <= 32, TWO rows per wave (lanes 0-31 and 32-63 run independent 32-lane scans: the row_bcast:31 step
+// of the DPP scan is skipped) -- with one row per wave half of every wave idles at S = 32.
+// ---- sources of 65 .. 512 positions: ONE pair of wavefront scans per target instead of one pair per 64-wide chunk.  A lane owns
+// EL consecutive positions (a serial scan of EL values in registers), the wave scans the 64 lane totals, alpha_{i-1} stays in
+// registers.  The chunked kernel walks ceil(S / 64) dependent scan pairs per target (S = 250: 440 dependent steps for 110 targets).
+template <int EL>
+__global__ __launch_bounds__(256) void expected_alignment_wide_kernel(const float* __restrict__ p, float* __restrict__ alpha,
+                                                                      const int* __restrict__ key_len, int BH, int U, int S,
+                                                                      float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= BH) return;
+  const int len = key_len ? key_len[r] : S;
+  const int s0 = lane * EL;
+  bool in[EL], ld[EL];
+#pragma unroll
+  for (int e = 0; e < EL; ++e) { in[e] = s0 + e < S; ld[e] = in[e] && s0 + e < len; }
+  const float* pp = p + (long)r * U * S;
+  float* ap = alpha + (long)r * U * S;
+  int off[EL];                                    // positions beyond the source read element 0 (never stored)
+#pragma unroll
+  for (int e = 0; e < EL; ++e) off[e] = in[e] ? s0 + e : 0;
+  float q[2][EL];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < EL; ++e) q[j][e] = pp[(long)(j < U ? j : 0) * S + off[e]];
+  float prev[EL];
+#pragma unroll
+  for (int e = 0; e < EL; ++e) prev[e] = (s0 + e == 0) ? 1.f : 0.f;
+  const float lead = 1.0f + eps;
+  for (int i = 0; i < U; ++i) {
+    float pv[EL];
+    const int slot = i & 1;
+#pragma unroll
+    for (int e = 0; e < EL; ++e) pv[e] = ld[e] ? (slot ? q[1][e] : q[0][e]) : 0.f;
+    if (i + 2 < U) {
+      const float* pn = pp + (long)(i + 2) * S;
+#pragma unroll
+      for (int e = 0; e < EL; ++e) { const float v = pn[off[e]]; if (slot) q[1][e] = v; else q[0][e] = v; }
+    }
+    float l[EL];                                   // inclusive products inside the lane
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      const float x = in[e] ? (1.0f - pv[e] + eps) : 1.0f;
+      l[e] = e == 0 ? x : l[e - 1] * x;
+    }
+    const float incl = wave_scan_incl_dpp_mul(l[EL - 1], true);
+    float excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, incl), 0x138, 0xf, 0xf, false));
+    if (lane == 0) excl = 1.0f;
+    const float base = lead * excl;
+    float cp[EL], t[EL];
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      cp[e] = e == 0 ? base : base * l[e - 1];
+      const float cpc = fminf(fmaxf(cp[e], eps), 1.0f);
+      const float term = in[e] ? prev[e] * __builtin_amdgcn_rcpf(cpc) : 0.f;
+      t[e] = e == 0 ? term : t[e - 1] + term;
+    }
+    const float tin = wave_scan_incl_dpp(t[EL - 1]);
+    // sum of the lanes below: the inclusive scan SHIFTED by one lane (0 into lane 0), not `tin - own total` -- the terms grow
+    // along the source as the cumprod shrinks, so a lane's own total can dwarf its prefix and the subtraction cancels
+    const float before = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tin), 0x138, 0xf, 0xf, true));
+#pragma unroll
+    for (int e = 0; e < EL; ++e) {
+      const float a = fminf(fmaxf(pv[e] * cp[e] * (before + t[e]), 0.f), 1.f);
+      if (in[e]) ap[(long)i * S + s0 + e] = a;
+      prev[e] = a;
+    }
+  }
+}
+
+// one target of the recurrence for a lane (single chunk): p value in, alpha out; `prev` = alpha of the previous target
+template <bool HALF>
+__device__ __forceinline__ float ea_small_step(float pv, float prev, bool in, int s, float eps, float lead) {
+  const float x = in ? (1.0f - pv + eps) : 1.0f;
+  const float incl = wave_scan_incl_dpp_mul(x, !HALF);
+  // exclusive product: the inclusive one of the lane below (wave_shr:1), 1 at the head of a segment
+  float excl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x3f800000, __builtin_bit_cast(int, incl), 0x138, 0xf, 0xf, false));
+  if (s == 0) excl = 1.0f;
+  const float cp = lead * excl;
+  const float cpc = fminf(fmaxf(cp, eps), 1.0f);
+  const float term = in ? prev * __builtin_amdgcn_rcpf(cpc) : 0.f;
+  const float tin = wave_scan_incl_dpp_seg(term, !HALF);
+  return fminf(fmaxf(pv * cp * tin, 0.f), 1.f);
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void expected_alignment_small_kernel(const float* __restrict__ p, float* __restrict__ alpha,
+                                                                       const int* __restrict__ key_len, int BH, int U, int S,
+                                                                       float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RPW = HALF ? 2 : 1, SEG = HALF ? 32 : 64;
+  const int s = lane & (SEG - 1);
+  const int r = (blockIdx.x * 4 + wave) * RPW + (HALF ? (lane >> 5) : 0);
+  const bool row_ok = r < BH;
+  const int len = row_ok ? (key_len ? key_len[r] : S) : 0;
+  const bool in = row_ok && s < S;
+  const bool ld = in && s < len;
+  // lanes without a source position read (and never store) element 0 of a valid row: no divergent branch around the loads
+  const float* pp = p + (long)(row_ok ? r : 0) * U * S + (in ? s : 0);
+  float* ap = alpha + (long)(row_ok ? r : 0) * U * S + (in ? s : 0);
+  float q[EA_PF];
+#pragma unroll
+  for (int j = 0; j < EA_PF; ++j) q[j] = pp[(long)(j < U ? j : 0) * S];
+  const float* pn = pp + (long)EA_PF * S;          // next value to request
+  float prev = (s == 0) ? 1.f : 0.f;
+  const float lead = 1.0f + eps;
+  int i = 0;
+  for (; i + 2 * EA_PF <= U; i += EA_PF) {         // full groups whose prefetch stays inside the row
+#pragma unroll
+    for (int j = 0; j < EA_PF; ++j) {
+      const float pv = ld ? q[j] : 0.f;
+      q[j] = *pn;
+      pn += S;
+      prev = ea_small_step<HALF>(pv, prev, in, s, eps, lead);
+      if (in) *ap = prev;
+      ap += S;
+    }
+  }
+  for (; i < U; i += EA_PF) {                      // the last one or two groups: prefetch guarded
+#pragma unroll
+    for (int j = 0; j < EA_PF; ++j) {
+      if (i + j >= U) break;
+      const float pv = ld ? q[j] : 0.f;
+      if (i + j + EA_PF < U) q[j] = *pn;
+      pn += S;
+      prev = ea_small_step<HALF>(pv, prev, in, s, eps, lead);
+      if (in) *ap = prev;
+      ap += S;
     }
   }
 }
@@ -556,8 +727,17 @@ extern "C" int simulst_expected_alignment(simulst_handle* h, const float* p, flo
              "simulst_expected_alignment: shape (S <= 4096)");
   if (BH == 0 || U == 0) return SIMULST_OK;
   KTimer t(h, SIMULST_K_SCAN);
-  hipLaunchKernelGGL(expected_alignment_kernel, dim3((BH + 3) / 4), dim3(256), 4 * S * sizeof(float), h->stream, p,
-                     alpha, key_len, BH, U, S, eps);
+  if (S <= 32 && !h->ea_general_only)           // two rows per wave, register-resident recurrence, product scan
+    hipLaunchKernelGGL(expected_alignment_small_kernel<true>, dim3((BH + 7) / 8), dim3(256), 0, h->stream, p, alpha, key_len, BH, U, S, eps);
+  else if (S <= 64 && !h->ea_general_only)
+    hipLaunchKernelGGL(expected_alignment_small_kernel<false>, dim3((BH + 3) / 4), dim3(256), 0, h->stream, p, alpha, key_len, BH, U, S, eps);
+  else if (S <= 256 && !h->ea_general_only)     // one scan pair per target, 4 positions per lane
+    hipLaunchKernelGGL(expected_alignment_wide_kernel<4>, dim3((BH + 3) / 4), dim3(256), 0, h->stream, p, alpha, key_len, BH, U, S, eps);
+  else if (S <= 512 && !h->ea_general_only)
+    hipLaunchKernelGGL(expected_alignment_wide_kernel<8>, dim3((BH + 3) / 4), dim3(256), 0, h->stream, p, alpha, key_len, BH, U, S, eps);
+  else
+    hipLaunchKernelGGL(expected_alignment_kernel, dim3((BH + 3) / 4), dim3(256), 4 * S * sizeof(float), h->stream, p,
+                       alpha, key_len, BH, U, S, eps);
   return sl_launch_status(h, "simulst_expected_alignment");
 }
 

@@ -904,3 +904,33 @@ def test_step_p_choose_padded_batch_vs_oracle(ops, incremental, ptype):
             differing += int(not torch.allclose(a, c, atol=2e-5, rtol=1e-4))
     if not incremental and ptype == "average":
         assert differing > 0          # training-mode forward: the partial last window lands on column key_len - 1 only per utterance
+
+
+@pytest.mark.parametrize("S", [7, 32, 33, 64, 65, 250, 256, 300, 512])
+def test_expected_alignment_small_source_kernels(ops, S):
+    """sources of at most 64 positions (one chunk) take the register-resident kernel with the multiplicative scan, two rows per
+    wave up to 32 positions; 65 .. 512 positions the kernel with 4 / 8 positions per lane (one scan pair per target): against the oracle (utils/monotonic_attention.py:12-76 restated) with ragged key lengths and an odd
+    number of rows, and against the chunked log-space kernel (SIMULST_EA_GENERAL=1)"""
+    import os
+    from oracle import monotonic as omo
+    from simulst_amd import _lib
+    from simulst_amd.ops import Ops
+    g = torch.Generator().manual_seed(S)
+    BH, U = 37, 23
+    p = torch.sigmoid(torch.randn(BH, U, S, generator=g) * 2)
+    kl = torch.randint(1, S + 1, (BH,), generator=g, dtype=torch.int32)
+    kl[0], kl[1] = S, 1
+    pad = torch.arange(S).view(1, -1) >= kl.view(-1, 1)
+    ref = omo.expected_alignment_from_p_choose(p, pad, 1e-6)
+    got = ops.expected_alignment(p.cuda(), kl.cuda(), 1e-6).cpu()
+    valid = (~pad).unsqueeze(1).expand_as(ref)
+    torch.testing.assert_close(got[valid], ref[valid], atol=1e-5, rtol=1e-3)
+    os.environ["SIMULST_EA_GENERAL"] = "1"
+    try:
+        gen = Ops(_lib.Handle()).expected_alignment(p.cuda(), kl.cuda(), 1e-6).cpu()
+    finally:
+        del os.environ["SIMULST_EA_GENERAL"]
+    torch.testing.assert_close(got[valid], gen[valid], atol=5e-6, rtol=1e-3)
+    # no padding mask at all
+    torch.testing.assert_close(ops.expected_alignment(p.cuda(), None, 1e-6).cpu(), omo.expected_alignment_from_p_choose(p, None, 1e-6),
+                               atol=1e-5, rtol=1e-3)
