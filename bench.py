@@ -29,6 +29,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                     sample of the same workload: all cores, and one thread (the reference's own eval setting,
                     eval/1-simuleval.sh:65,78-82)
   configs1_one_batch_of_64_alone -- BASELINE.json configs[1] read literally: one batch of 64 alone on the GPU
+  configs1_batched_streaming -- (one GPU) configs[1] in its batched-streaming semantics: --extra-rows wait-k
+                    streams through agent.BatchedStreamingAgent, tokens/s + Average Lagging + identity with the CPU oracle on a sample
   configs2_mma_hard, configs3_cif -- (one GPU) BASELINE.json configs[2] / configs[3] on the same 64 x 1000-frame batches: decoded
                     tokens/s offline (the timed plan's schedule) AND through the batched streaming agent, the Average Lagging of
                     the streamed run, identity of tokens / READ-WRITE actions / delays with the CPU oracle on a sample, and the
@@ -89,7 +91,7 @@ def parse_args(argv=None):
                          "kernel bodies, not by launch cost)")
     ap.add_argument("--passes", type=int, default=3,
                     help="timed passes of the K-step plan; value = the MEDIAN pass, all of them are reported")
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[2] / configs[3] legs")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] streaming / configs[2] / configs[3] legs")
     ap.add_argument("--extra-rows", type=int, default=448, help="rows of the batched streaming runs of the extra legs")
     ap.add_argument("--cpu-sample", type=int, default=64)
     ap.add_argument("--cpu-sample-1thread", type=int, default=4,
@@ -307,10 +309,14 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
     fb_cpu = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + i)) for i in range(n_off)])
     g_max = max(plan)
     out = {}
-    for key in ("configs2_mma_hard", "configs3_cif"):
+    for key in ("configs1_batched_streaming", "configs2_mma_hard", "configs3_cif"):
         t_leg = time.perf_counter()
-        cif = key == "configs3_cif"
-        if cif:
+        cif, waitk = key == "configs3_cif", key == "configs1_batched_streaming"
+        if waitk:
+            cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=WAITK, fixed_pre_decision_ratio=8)
+            w = init_model(cfg, seed=999)
+            kind, workload = "waitk", f"configs[1], batched-streaming semantics: mma_model_s, waitk_fixed_pre_decision k = {WAITK} ratio 8"
+        elif cif:
             cfg = cif_transformer_s(cif_beta=1.0)
             w = init_model(cfg, seed=999)
             w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
@@ -342,18 +348,18 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                 return torch.cat([model.generate_offline(f_, l_, n_steps=U, mask_eos=True)[0].clone() for f_, l_ in seqs()], 0)
             return torch.cat(pipe.run(seqs(), U, mask_eos=True), 0)
         with torch.no_grad():
-            for _ in range(2):
+            for _ in range(0 if waitk else 2):
                 run_offline()
             torch.cuda.synchronize()
             ts = []
-            for _ in range(max(1, args.passes)):
+            for _ in range(0 if waitk else max(1, args.passes)):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 hyp = run_offline()
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
-            n_tok = hyp.size(0) * U
-            offline = {"tokens_per_s": round(n_tok / sorted(ts)[len(ts) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts],
+            n_tok = 0 if waitk else hyp.size(0) * U
+            offline = None if waitk else {"tokens_per_s": round(n_tok / sorted(ts)[len(ts) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts],
                        "tokens_per_pass": n_tok, "plan_batches_per_sequence": plan, "streams": min(args.concurrency, len(plan)),
                        "decode_steps": U, "semantics": "offline batched, EOS masked (eval/generate.py:187-209)"}
             # ---- batched streaming
@@ -375,58 +381,62 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                          "reads_per_row": recs[0]["actions"].count("R"), "max_len": "0.1 * frames + 10 tokens",
                          "semantics": "every row takes its own READ / WRITE decisions on the device; chunk schedule 96 then 64 frames "
                                       "(agents/default_agent.py:367,407)"}
-            # ---- instrumented replay of one launch sequence of the plan: the dominant class and its roofline entry
-            Bs = B * g_max
-            fseq, lseq = fb_all[:Bs], torch.full((Bs,), T_FRAMES, device=dev)
-            h = model.ops.h
-            plain_s = float("inf")
-            for rep in range(4):                                   # two warm-ups (this shape's state and allocator pool), best of two
+            roof = None
+            if not waitk:
+                # ---- instrumented replay of one launch sequence of the plan: the dominant class and its roofline entry
+                Bs = B * g_max
+                fseq, lseq = fb_all[:Bs], torch.full((Bs,), T_FRAMES, device=dev)
+                h = model.ops.h
+                plain_s = float("inf")
+                for rep in range(4):                                   # two warm-ups (this shape's state and allocator pool), best of two
+                    torch.cuda.synchronize()
+                    tp0 = time.perf_counter()
+                    model.generate_offline(fseq, lseq, n_steps=U, mask_eos=True)
+                    torch.cuda.synchronize()
+                    if rep >= 2:
+                        plain_s = min(plain_s, time.perf_counter() - tp0)
+                h.timer_reset(); h.timer_enable(-1, True)
                 torch.cuda.synchronize()
-                tp0 = time.perf_counter()
+                tr0 = time.perf_counter()
                 model.generate_offline(fseq, lseq, n_steps=U, mask_eos=True)
                 torch.cuda.synchronize()
-                if rep >= 2:
-                    plain_s = min(plain_s, time.perf_counter() - tp0)
-            h.timer_reset(); h.timer_enable(-1, True)
-            torch.cuda.synchronize()
-            tr0 = time.perf_counter()
-            model.generate_offline(fseq, lseq, n_steps=U, mask_eos=True)
-            torch.cuda.synchronize()
-            replay_s = time.perf_counter() - tr0
-            h.timer_enable(-1, False)
-            raw = {_lib.KERNEL_CLASS_NAMES[c]: h.timer_read(c) for c in range(_lib.K_COUNT)}
-            n_launch = sum(v[1] for v in raw.values())
-            ovh = max(0.0, (replay_s - plain_s) * 1e3 / max(n_launch, 1))
-            per_class = {k: (max(0.0, v[0] - ovh * v[1]), v[1]) for k, v in raw.items()}
-            fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, U)
-            entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, dtn, kind=kind) for k, v in per_class.items()}
-            entries = {k: e for k, e in entries.items() if e is not None}
-            dom = max(entries, key=lambda k: per_class[k][0] / {"linear_skinny": 4, "linear_tile64": 3}.get(k, 1))
-            bpt = path_bytes_per_token(cfg, B, T_FRAMES, U, esz, 0, kind=kind)
-            roof = dict(entries[dom])
-            roof["path_hbm_model"] = {"bytes_per_token": round(bpt), "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / bpt),
-                                      "frac_offline": round(offline["tokens_per_s"] / (HBM_PEAK_GBS * 1e9 / bpt), 5),
-                                      "definition": "the byte model of SURVEY.md 8(d) with this config's source attention: " +
-                                                    ("pooled monotonic keys + one value row per step" if kind == "hard" else
-                                                     "integrated vectors and their key projections written once, one row gathered per step")}
-            roof["one_sequence_alone"] = {"rows": Bs, "ms": round(plain_s * 1e3, 3), "tokens_per_s": round(Bs * U / plain_s, 1)}
-            roof["class_ms_per_sequence"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
-            roof["launches_per_sequence_all_classes"] = n_launch
+                replay_s = time.perf_counter() - tr0
+                h.timer_enable(-1, False)
+                raw = {_lib.KERNEL_CLASS_NAMES[c]: h.timer_read(c) for c in range(_lib.K_COUNT)}
+                n_launch = sum(v[1] for v in raw.values())
+                ovh = max(0.0, (replay_s - plain_s) * 1e3 / max(n_launch, 1))
+                per_class = {k: (max(0.0, v[0] - ovh * v[1]), v[1]) for k, v in raw.items()}
+                fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, U)
+                entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, dtn, kind=kind) for k, v in per_class.items()}
+                entries = {k: e for k, e in entries.items() if e is not None}
+                dom = max(entries, key=lambda k: per_class[k][0] / {"linear_skinny": 4, "linear_tile64": 3}.get(k, 1))
+                bpt = path_bytes_per_token(cfg, B, T_FRAMES, U, esz, 0, kind=kind)
+                roof = dict(entries[dom])
+                roof["path_hbm_model"] = {"bytes_per_token": round(bpt), "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / bpt),
+                                          "frac_offline": round(offline["tokens_per_s"] / (HBM_PEAK_GBS * 1e9 / bpt), 5),
+                                          "definition": "the byte model of SURVEY.md 8(d) with this config's source attention: " +
+                                                        ("pooled monotonic keys + one value row per step" if kind == "hard" else
+                                                         "integrated vectors and their key projections written once, one row gathered per step")}
+                roof["one_sequence_alone"] = {"rows": Bs, "ms": round(plain_s * 1e3, 3), "tokens_per_s": round(Bs * U / plain_s, 1)}
+                roof["class_ms_per_sequence"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
+                roof["launches_per_sequence_all_classes"] = n_launch
             # ---- parity on a sample against the CPU oracle
             m32 = Model(cfg, w, device=dev, dtype=torch.float32)
-            L8 = torch.full((n_off,), T_FRAMES)
-            margins = []
-            if cif:
-                ref, _, _ = oag.greedy_offline_cif(w, ecfg, dcfg, cfg.cif_beta, fb_cpu, L8, n_steps=U, mask_eos=True, margins=margins)
-            else:
-                ref, _, _ = oag.greedy_offline(w, ecfg, dcfg, fb_cpu, L8, n_steps=U, mask_eos=True, margins=margins)
-            mg = torch.stack(margins, 1)
-            t32 = m32.generate_offline(fb_cpu.to(dev), L8, n_steps=U, mask_eos=True)[0].cpu()
-            h16 = hyp[:n_off].cpu()
+            ref = t32 = h16 = None
             gaps = []
-            for r in range(n_off):
-                if not torch.equal(h16[r], ref[r]):
-                    gaps.append(round(float(mg[r, int((h16[r] != ref[r]).float().argmax())]), 5))
+            if not waitk:
+                L8 = torch.full((n_off,), T_FRAMES)
+                margins = []
+                if cif:
+                    ref, _, _ = oag.greedy_offline_cif(w, ecfg, dcfg, cfg.cif_beta, fb_cpu, L8, n_steps=U, mask_eos=True, margins=margins)
+                else:
+                    ref, _, _ = oag.greedy_offline(w, ecfg, dcfg, fb_cpu, L8, n_steps=U, mask_eos=True, margins=margins)
+                mg = torch.stack(margins, 1)
+                t32 = m32.generate_offline(fb_cpu.to(dev), L8, n_steps=U, mask_eos=True)[0].cpu()
+                h16 = hyp[:n_off].cpu()
+                for r in range(n_off):
+                    if not torch.equal(h16[r], ref[r]):
+                        gaps.append(round(float(mg[r, int((h16[r] != ref[r]).float().argmax())]), 5))
             ag32 = (BatchedCIFStreamingAgent(m32, max_len_a=0.1, max_len_b=10) if cif
                     else BatchedStreamingAgent(m32, max_len_a=0.1, max_len_b=10, steps_per_call=8))
             got32 = ag32.run_batch(fb_cpu[:n_str].to(dev))
@@ -439,16 +449,19 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                                "token_agreement": round(sum(a == b for a, b in zip(recs[i]["tokens"], rs["tokens"])) /
                                                         max(len(rs["tokens"]), 1), 4),
                                "AL_ms": [round(recs[i]["AL"], 2), round(rs["AL"], 2)]})
-            parity = {"offline_fp32_tokens_identical_to_oracle": bool(torch.equal(t32, ref)), "offline_sample_utterances": n_off,
-                      f"offline_{dtn}_timed_rows_identical_to_oracle": int(sum(torch.equal(h16[r], ref[r]) for r in range(n_off))),
-                      f"offline_{dtn}_oracle_top2_gap_at_first_divergence": sorted(gaps),
-                      "streaming_fp32_actions_tokens_delays_AL_identical_to_oracle": all(same32), "streaming_sample_utterances": n_str,
+            parity = {"streaming_fp32_actions_tokens_delays_AL_identical_to_oracle": all(same32), "streaming_sample_utterances": n_str,
                       f"streaming_{dtn}_timed_rows_vs_oracle": same16}
-        out[key] = {"workload": workload + f"; 64 x {T_FRAMES}-frame batches, {dtn}", "offline": offline,
-                    "batched_streaming": streaming, "parity_on_sample": parity, "roofline": roof,
-                    "seconds_spent": round(time.perf_counter() - t_leg, 1)}
-        log(f"{key}: offline {offline['tokens_per_s']:.0f} tokens/s, batched streaming {streaming['tokens_per_s']:.0f} tokens/s "
-            f"(AL {streaming['average_lagging_ms_mean']} ms), parity {parity['offline_fp32_tokens_identical_to_oracle']} / "
+            if not waitk:
+                parity.update({"offline_fp32_tokens_identical_to_oracle": bool(torch.equal(t32, ref)), "offline_sample_utterances": n_off,
+                               f"offline_{dtn}_timed_rows_identical_to_oracle": int(sum(torch.equal(h16[r], ref[r]) for r in range(n_off))),
+                               f"offline_{dtn}_oracle_top2_gap_at_first_divergence": sorted(gaps)})
+        out[key] = {"workload": workload + f"; {T_FRAMES}-frame utterances, {dtn}", "batched_streaming": streaming,
+                    "parity_on_sample": parity, "seconds_spent": round(time.perf_counter() - t_leg, 1)}
+        if not waitk:
+            out[key].update({"offline": offline, "roofline": roof})
+        log(f"{key}: " + ("" if waitk else f"offline {offline['tokens_per_s']:.0f} tokens/s, ") +
+            f"batched streaming {streaming['tokens_per_s']:.0f} tokens/s (AL {streaming['average_lagging_ms_mean']} ms), parity " +
+            ("" if waitk else f"{parity['offline_fp32_tokens_identical_to_oracle']} / ") +
             f"{parity['streaming_fp32_actions_tokens_delays_AL_identical_to_oracle']}")
         del pipe, model, m32
         torch.cuda.empty_cache()

@@ -504,15 +504,32 @@ int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc* d, const s
  * advanced -- else the greedy token (plain argmax, agents/default_agent.py:415-424) is committed to hyp, stamped
  * with cur_ms, and the row finishes on EOS or when it holds more than max_len_now tokens
  * (agents/default_agent.py:268-271).  The host re-activates parked rows after feeding the next source chunk.
- * Device arrays of length B unless noted; dd->n_prev_uniform must be -1. */
+ * Device arrays of length B unless noted; dd->n_prev_uniform must be -1.
+ *
+ * SELF-PACED ROWS (sched_rows != NULL; evaluation of a streaming policy over sources that are already on the device, the way
+ * SimulEval feeds an agent from a file: agents/default_agent.py:303-342,364-412).  The caller has pushed EVERY chunk through the
+ * streaming encoder and appended it to the cached keys / values, and hands over the chunk schedule: after chunk c the row holds
+ * sched_rows[c] encoder rows, sched_ms[c] milliseconds of source and may hold sched_max_len[c] tokens.  A row that asks for source
+ * is not parked: the commit takes the next chunk for it (chunk_idx[b] += 1, enc_len[b] = sched_rows[chunk_idx[b]],
+ * online[b] = chunk is not the last) and the row tries the same target position again in the next round, so rows advance through
+ * their sources independently of each other with no host round trip -- at most cap + n_chunks rounds per row.  cur_ms and
+ * max_len_now are then read from the schedule at the row's chunk.  A row's READ / WRITE sequence, tokens and delays are those of
+ * the parked form (tests/test_hip_streaming.py); the READs are recovered from tok_chunk. */
 typedef struct {
   uint8_t* active;        /* in/out */
   uint8_t* read_flag;     /* scratch, zero before the first call */
-  const uint8_t* online;  /* row's source has not ended */
+  uint8_t* online;        /* row's source has not ended (written by the commit for self-paced rows) */
   uint8_t* done;          /* out: hypothesis finished */
   int32_t* delays_ms;     /* [B][cap] or NULL */
   int64_t* hyp;           /* [B][cap] committed tokens */
   int32_t cap, cur_ms, max_len_now;
+  int32_t n_chunks;               /* self-paced rows: length of the schedule */
+  const int32_t* sched_rows;      /* [n_chunks] or NULL (parked form) */
+  const int32_t* sched_ms;        /* [n_chunks] */
+  const int32_t* sched_max_len;   /* [n_chunks] */
+  int32_t* chunk_idx;             /* [B] in/out: the chunk each row has read up to (0 at the start) */
+  int32_t* enc_len;               /* [B] in/out: simulst_decoder_desc.enc_len, advanced with the row's chunk */
+  int32_t* tok_chunk;             /* [B][cap] out or NULL: chunk index at which each token was committed */
 } simulst_stream_ctl;
 
 int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,

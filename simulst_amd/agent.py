@@ -167,8 +167,113 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
         super().__init__(model, max_len_a, max_len_b, force_finish=False)
         self.steps_per_call = steps_per_call
 
-    def run_batch(self, fbank: torch.Tensor):
-        """fbank [B, T, 80] (equal lengths).  Returns one record per row, same keys as run_utterance."""
+    def run_batch(self, fbank: torch.Tensor, self_paced: bool = False, encoder: str = "chunked"):
+        """fbank [B, T, 80] (equal lengths).  Returns one record per row, same keys as run_utterance.
+
+        self_paced=False: the microphone form described above (one host round trip per chunk and per batch of masked steps).
+        self_paced=True: the evaluation form (SimulEval feeding agents from files, agents/default_agent.py:303-342): every chunk
+        goes through the streaming encoder first, then ONE device loop decodes, each row taking its next chunk by itself when its
+        policy says READ (simulst_stream_ctl, self-paced rows) -- at most cap + n_chunks steps instead of the sum over chunks of the
+        slowest row's steps.  Same records: a row's decisions depend only on its own state and the source released to it.
+        encoder="offline" (self-paced only): the encoder states come from ONE offline forward over the whole source instead of
+        the chunk-by-chunk ``infer`` calls -- the two agree to rounding (the reference's own check, agents/default_agent.py:438-476,
+        atol = rtol = 1e-3; tests/test_hip_properties.py::test_full_size_streaming_equals_offline_fp32), the rows released per
+        chunk are those of the streaming schedule (``stream_row_schedule``); decisions can differ from the chunked run only where
+        that rounding flips one."""
+        if self_paced:
+            return self._run_batch_self_paced(fbank, encoder)
+        if encoder != "chunked":
+            raise ValueError("the lockstep form streams through encoder.infer; encoder='offline' needs self_paced=True")
+        return self._run_batch_lockstep(fbank)
+
+    def _chunk_positions(self, T: int):
+        """Source frames offered after each READ (agents/default_agent.py:367,407: first segment + right context, then segments)."""
+        pos, out = 0, []
+        expected = (self.segment_length + self.right_context) * self.stride_ms // SHIFT_SIZE
+        while pos < T:
+            pos = min(pos + expected, T)
+            out.append(pos)
+            expected = self.segment_length * self.stride_ms // SHIFT_SIZE
+        return out
+
+    def _run_batch_self_paced(self, fbank: torch.Tensor, encoder: str = "chunked"):
+        from . import _lib
+        from .latency import average_lagging
+        model, dec, enc = self.model, self.model.decoder, self.model.encoder
+        cfg, dev = model.cfg, model.device
+        B, T = fbank.size(0), fbank.size(1)
+        fbank = fbank.to(dev)
+        if encoder not in ("chunked", "offline"):
+            raise ValueError(f"encoder={encoder!r}: 'chunked' or 'offline'")
+        cap = int(self.max_len(T)) + 4
+        positions = self._chunk_positions(T)
+        plan_rows = enc.stream_row_schedule(positions)
+        st = dec.new_state(B, cap=cap, S_cap=max(plan_rows[-1], 1))
+        st.lockstep = False
+        src = FrameSource(fbank[0])
+        rows, ms, mlen = [], [], []
+        if encoder == "offline":
+            out = enc.forward(fbank, torch.full((B,), T, device=dev))["encoder_out_btd"]
+            if out.size(1) != plan_rows[-1]:
+                raise RuntimeError(f"offline encoder returned {out.size(1)} rows, the streaming schedule releases {plan_rows[-1]}")
+            dec.append_encoder_out(st, out, torch.full((B,), out.size(1)))
+            for pos in positions:
+                src.read(pos - src.pos)
+                ms.append(src.elapsed_ms()); mlen.append(int(self.max_len(src.pos)))
+            rows = list(plan_rows)
+        else:
+            # every chunk through the streaming encoder (the launches of the microphone form, minus its host round trips)
+            enc_state = {}
+            for i, pos in enumerate(positions):
+                src.read(pos - src.pos)
+                out = enc.infer(fbank[:, :src.pos], torch.full((B,), src.pos), enc_state, finish=i == len(positions) - 1)
+                new = out["encoder_out_btd"]
+                dec.append_encoder_out(st, new, torch.full((B,), st.enc_rows + new.size(1)))
+                rows.append(st.enc_rows); ms.append(src.elapsed_ms()); mlen.append(int(self.max_len(src.pos)))
+            if rows != list(plan_rows):
+                raise RuntimeError(f"streaming encoder released {rows}, stream_row_schedule predicted {plan_rows}")
+        n_chunks = len(rows)
+        i32 = dict(device=dev, dtype=torch.int32)
+        sched = torch.tensor([rows, ms, mlen], **i32)
+        st.enc_len = torch.full((B,), rows[0], **i32)
+        st.enc_len_bh = st.enc_len.repeat_interleave(cfg.num_heads).contiguous()
+        u8 = dict(device=dev, dtype=torch.uint8)
+        active, read_flag, done = torch.ones(B, **u8), torch.zeros(B, **u8), torch.zeros(B, **u8)
+        online = torch.full((B,), 1 if n_chunks > 1 else 0, **u8)
+        hyp = torch.zeros(B, cap, device=dev, dtype=torch.int64)
+        delays, tok_chunk = torch.zeros(B, cap, **i32), torch.zeros(B, cap, **i32)
+        chunk_idx = torch.zeros(B, **i32)
+        tokens = torch.full((B,), cfg.eos, device=dev, dtype=torch.int64)
+        ctl = _lib.StreamCtl(active.data_ptr(), read_flag.data_ptr(), online.data_ptr(), done.data_ptr(), delays.data_ptr(),
+                             hyp.data_ptr(), cap, 0, 0, n_chunks, sched[0].data_ptr(), sched[1].data_ptr(), sched[2].data_ptr(),
+                             chunk_idx.data_ptr(), st.enc_len.data_ptr(), tok_chunk.data_ptr())
+        # ---- one device loop; a row needs at most (tokens it may hold + 1) + (n_chunks - 1) rounds
+        bound = mlen[-1] + 1 + n_chunks
+        n_run = 0
+        while True:                                        # rows that meet EOS early end the loop before the bound
+            n = max(1, min(bound - n_run, 32))
+            dec.stream_steps(st, tokens, ctl, n)
+            n_run += n
+            if not bool(active.any().item()):
+                break
+            if n_run >= bound:
+                raise RuntimeError("self-paced rows still active after cap + n_chunks rounds")
+        n_prev, ci_h = st.n_prev.tolist(), chunk_idx.tolist()
+        hyp_h, delays_h, tc_h = hyp.tolist(), delays.tolist(), tok_chunk.tolist()
+        recs = []
+        for b in range(B):
+            n = min(n_prev[b], cap)
+            acts, k = [], 0
+            for c in range(ci_h[b] + 1):                   # "R" for every chunk the row took, then the tokens written at it
+                acts.append("R")
+                while k < n and tc_h[b][k] == c:
+                    acts.append("W"); k += 1
+            d = [int(x) for x in delays_h[b][:n]]
+            recs.append({"tokens": hyp_h[b][:n], "delays_ms": d, "actions": "".join(acts),
+                         "AL": average_lagging(d, src.total_ms()), "n_enc": rows[ci_h[b]]})
+        return recs
+
+    def _run_batch_lockstep(self, fbank: torch.Tensor):
         import ctypes as C
         from . import _lib
         from .latency import average_lagging
@@ -177,7 +282,8 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
         B, T = fbank.size(0), fbank.size(1)
         fbank = fbank.to(dev)
         cap = int(self.max_len(T)) + 4
-        s_cap = T // enc.stride + 2 * self.right_context + 8
+        # exactly the rows the schedule releases: up to 256 keys the policy / cross-attention kernel keeps its single-latency form
+        s_cap = max(enc.stream_row_schedule(self._chunk_positions(T))[-1], 1)
         st = dec.new_state(B, cap=cap, S_cap=s_cap)
         st.lockstep = False
         u8 = dict(device=dev, dtype=torch.uint8)
@@ -212,7 +318,7 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
             active.copy_(1 - done)
             ctl = _lib.StreamCtl(active.data_ptr(), read_flag.data_ptr(), online.data_ptr(), done.data_ptr(),
                                  delays.data_ptr(), hyp.data_ptr(), cap, src.elapsed_ms(),
-                                 int(self.max_len(src.pos)))
+                                 int(self.max_len(src.pos)), 0, None, None, None, None, None, None)
             while True:
                 dec.stream_steps(st, tokens, ctl, self.steps_per_call)
                 if not bool(active.any().item()):

@@ -24,12 +24,16 @@ using attn::VL;
 struct StreamCtl {
   unsigned char* active;
   unsigned char* read_flag;
-  const unsigned char* online;
+  unsigned char* online;
   unsigned char* done;
   int* delays;          // [B][cap] source milliseconds at commit, may be null
   long* hyp;            // [B][cap] committed tokens
   int cap, cur_ms, max_len_now;
   int layer;            // 1-based id of the launching layer: read_flag holds the id of the layer that fired
+  // self-paced rows (sched_rows != nullptr, simulst_stream_ctl in the header): the chunk schedule and each row's place in it
+  const int* sched_rows; const int* sched_ms; const int* sched_max_len;
+  int* chunk_idx; int* enc_len; int* tok_chunk;
+  int n_chunks;
 };
 
 // head-split projections around the policy kernel (all null: separate GEMM launches do the projections)
@@ -353,17 +357,27 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
     if (streaming) {
       const bool act = ctl.active[b] != 0, rd = ctl.read_flag[b] != 0;
       int tok_next = (int)tokens[b], np_next = np;
+      const int ci = ctl.sched_rows ? ctl.chunk_idx[b] : 0;
+      const int cur_ms = ctl.sched_rows ? ctl.sched_ms[ci] : ctl.cur_ms;
+      const int max_len_now = ctl.sched_rows ? ctl.sched_max_len[ci] : ctl.max_len_now;
       if (act && !rd) {                                   // WRITE: commit, stamp, maybe finish
         if (np < ctl.cap) {
           ctl.hyp[(long)b * ctl.cap + np] = bi;
-          if (ctl.delays) ctl.delays[(long)b * ctl.cap + np] = ctl.cur_ms;
+          if (ctl.delays) ctl.delays[(long)b * ctl.cap + np] = cur_ms;
+          if (ctl.tok_chunk) ctl.tok_chunk[(long)b * ctl.cap + np] = ci;
         }
         tok_next = bi; np_next = np + 1;
         tokens[b] = bi;
         n_prev[b] = np_next;
-        if (bi == eos_idx || np_next > ctl.max_len_now) { ctl.done[b] = 1; ctl.active[b] = 0; }
+        if (bi == eos_idx || np_next > max_len_now) { ctl.done[b] = 1; ctl.active[b] = 0; }
       } else if (act && rd) {
-        ctl.active[b] = 0;                                // READ: wait for the next source chunk
+        if (ctl.sched_rows && ci + 1 < ctl.n_chunks) {    // READ, self-paced: the row takes its next chunk and tries again
+          ctl.chunk_idx[b] = ci + 1;
+          ctl.enc_len[b] = ctl.sched_rows[ci + 1];
+          ctl.online[b] = ci + 2 < ctl.n_chunks;
+        } else {
+          ctl.active[b] = 0;                              // READ: wait for the next source chunk
+        }
       }
       ctl.read_flag[b] = 0;
       s_tok = tok_next;
@@ -716,5 +730,12 @@ extern "C" int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder
   ctl.active = c->active; ctl.read_flag = c->read_flag; ctl.online = c->online; ctl.done = c->done;
   ctl.delays = c->delays_ms; ctl.hyp = (long*)c->hyp; ctl.cap = c->cap; ctl.cur_ms = c->cur_ms;
   ctl.max_len_now = c->max_len_now;
+  ctl.sched_rows = c->sched_rows; ctl.sched_ms = c->sched_ms; ctl.sched_max_len = c->sched_max_len;
+  ctl.chunk_idx = c->chunk_idx; ctl.enc_len = c->enc_len; ctl.tok_chunk = c->tok_chunk; ctl.n_chunks = c->n_chunks;
+  if (c->sched_rows) {
+    SL_CHECK_NULL(h, c->sched_ms); SL_CHECK_NULL(h, c->sched_max_len); SL_CHECK_NULL(h, c->chunk_idx); SL_CHECK_NULL(h, c->enc_len);
+    SL_REQUIRE(h, c->n_chunks > 0, SIMULST_E_SHAPE, "simulst_mma_stream_steps: n_chunks");
+    SL_REQUIRE(h, dd && c->enc_len == dd->enc_len, SIMULST_E_SHAPE, "simulst_mma_stream_steps: ctl.enc_len must be the descriptor's enc_len");
+  }
   return run_decode(h, dd, layers, tokens_io, nullptr, n_iter, 0, true, true, &ctl);
 }

@@ -402,6 +402,41 @@ class S2TEmformerEncoder:
         Yall = ops.layernorm(X, W.final_g, W.final_b)
         return Yall[:, R:]
 
+    def stream_row_schedule(self, frame_counts):
+        """Encoder rows released by ``infer`` after each call of a streaming schedule, computed from the arithmetic of
+        ``infer`` alone (subsampler caches of k - 1 frames, the carried look-ahead rows, one segment per call, the flush):
+        frame_counts = total source frames offered at each call, the last call with finish=True.  Returns the cumulative row
+        counts; tests/test_hip_streaming.py checks them against the rows the streaming encoder really returns."""
+        cfg = self.cfg
+        S, R = cfg.S, cfg.R
+        caches = [k - 1 for (_, _, k) in self.w.conv]
+        prev, carry, total, out = 0, None, 0, []
+        for i, pos in enumerate(frame_counts):
+            finish = i == len(frame_counts) - 1
+            n = pos - prev
+            prev = pos
+            if n > 0:
+                for j, (_, _, k) in enumerate(self.w.conv):
+                    t = caches[j] + n
+                    n = max((t - k) // 2 + 1, 0)
+                    caches[j] = k - 1
+            rows_in = n
+            x = rows_in + (R if finish else 0)
+            block = rows_in
+            if carry is not None:
+                block, x = rows_in + carry, x + carry
+            new_carry, carry_len = max(x - S, 0), 0
+            if block > S:
+                carry_len, x = block - S, min(x, S + R)
+            if x > R:
+                total += x - R
+            carry = new_carry
+            if finish and carry_len > 0:
+                assert 0 < carry - R <= S
+                total += carry - R
+            out.append(total)
+        return out
+
     def infer(self, src_tokens: torch.Tensor, src_lengths: torch.Tensor, incremental_state: dict, finish=False):
         """S2TEmformerEncoder.infer (models/s2t_emformer.py:199-278). src_tokens holds ALL frames so far
         [B,T,80]; the reference asserts B == 1 (:200) -- here a batch of streams advancing in lockstep

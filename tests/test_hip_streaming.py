@@ -135,6 +135,16 @@ def test_batched_streaming_rows_equal_single_streams(ops, attn, kw, dtype):
             assert got[b]["tokens"] == refs[b]["tokens"], (attn, b, spc)
             assert got[b]["delays_ms"] == refs[b]["delays_ms"]
             assert got[b]["AL"] == refs[b]["AL"]
+    # self-paced rows (the evaluation form: whole source encoded first, ONE device loop, a row takes its next chunk by itself)
+    paced = BatchedStreamingAgent(model).run_batch(fb, self_paced=True)
+    for b in range(B):
+        for k in ("actions", "tokens", "delays_ms", "AL"):
+            assert paced[b][k] == refs[b][k], (attn, b, k, "self-paced")
+    # ... and with the encoder states of ONE offline forward (equal to the chunked ones to rounding): a flipped decision is
+    # possible only at a near-tie
+    off = BatchedStreamingAgent(model).run_batch(fb, self_paced=True, encoder="offline")
+    same = sum(all(off[b][k] == refs[b][k] for k in ("actions", "tokens", "delays_ms")) for b in range(B))
+    assert same >= (B if dtype == torch.float32 else B - 2), (attn, dtype, same)
     if "waitk" not in attn:
         assert len({r["actions"] for r in refs}) > 1, "test needs rows that diverge"
     if dtype == torch.float32:
@@ -178,3 +188,32 @@ def test_batched_streaming_160_rows_bf16_with_layer_chains(ops, attn, kw):
         ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
     same = sum(got[b]["actions"] == plain[b]["actions"] and got[b]["tokens"] == plain[b]["tokens"] for b in range(8))
     assert same >= 6, same
+    # the same 160 streams as self-paced rows: every row as in the lockstep run (same kernels, same row tiles)
+    paced = BatchedStreamingAgent(model).run_batch(fb, self_paced=True)
+    for b in range(160):
+        for k in ("actions", "tokens", "delays_ms", "AL"):
+            assert paced[b][k] == got[b][k], (attn, b, k)
+
+
+@pytest.mark.parametrize("T", [40, 96, 100, 160, 161, 250, 560, 1000, 1003, 1534])
+def test_stream_row_schedule_predicts_the_streaming_encoder(ops, T):
+    """encoder.stream_row_schedule (integer arithmetic only) == the rows encoder.infer really releases after every READ of the
+    agent's chunk schedule, and its total == the offline forward's row count (what the self-paced agent relies on)."""
+    from simulst_amd.agent import BatchedStreamingAgent
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=1, decoder_layers=1, simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=3)
+    model = SimulSTModel(cfg, init_model(cfg, seed=5), dtype=torch.float32, ops=ops)
+    agent = BatchedStreamingAgent(model)
+    positions = agent._chunk_positions(T)
+    plan = model.encoder.stream_row_schedule(positions)
+    fb = torch.randn(2, T, 80, generator=torch.Generator().manual_seed(T)).cuda()
+    inc, total, got = {}, 0, []
+    for i, pos in enumerate(positions):
+        out = model.encoder.infer(fb[:, :pos], torch.full((2,), pos), inc, finish=i == len(positions) - 1)
+        total += out["encoder_out_btd"].size(1)
+        got.append(total)
+    assert got == plan, (T, got, plan)
+    off = model.encoder.forward(fb, torch.full((2,), T, device="cuda"))["encoder_out_btd"]
+    assert off.size(1) == plan[-1]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One batched streaming run of configs[2] (MMA-hard) or configs[3] (CIF) for rocprofv3 --kernel-trace --stats:
+"""One batched streaming run of configs[1] (wait-k 5), configs[2] (MMA-hard) or configs[3] (CIF) for rocprofv3 --kernel-trace --stats:
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stream -- python3 tools/profile_streaming.py --config 2 --rows 448"""
 import argparse
 import os
@@ -13,9 +13,11 @@ import torch  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3])
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--rows", type=int, default=448)
     ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--steps-per-call", type=int, default=8)
+    ap.add_argument("--self-paced", action="store_true", help="evaluation form: rows take their chunks themselves (MMA / wait-k)")
     args = ap.parse_args()
     from simulst_amd.agent import BatchedStreamingAgent
     from simulst_amd.cif import BatchedCIFStreamingAgent, CIFTransformerModel
@@ -30,19 +32,25 @@ def main():
         w["encoder.cif_layer.alpha_proj.4.bias"] -= 1.5
         w["decoder.embed_tokens.weight"][cfg.eos] = 0
         agent = BatchedCIFStreamingAgent(CIFTransformerModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10)
+    elif args.config == 1:
+        cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=5, fixed_pre_decision_ratio=8)
+        w = init_model(cfg, seed=999)
+        w["decoder.embed_tokens.weight"][cfg.eos] = 0
+        agent = BatchedStreamingAgent(SimulSTModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10, steps_per_call=args.steps_per_call)
     else:
         cfg = mma_model_s(simul_attn_type="hard_aligned_fixed_pre_decision", fixed_pre_decision_ratio=8, mass_preservation=True)
         w = init_model(cfg, seed=999)
         for l in range(cfg.decoder_layers):
             w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] *= 8
         w["decoder.embed_tokens.weight"][cfg.eos] = 0
-        agent = BatchedStreamingAgent(SimulSTModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10, steps_per_call=8)
+        agent = BatchedStreamingAgent(SimulSTModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10, steps_per_call=args.steps_per_call)
     fb = torch.randn(args.rows, 1000, 80, device="cuda", generator=torch.Generator(device="cuda").manual_seed(999)).to(torch.bfloat16)
-    agent.run_batch(fb)
+    kw = dict(self_paced=True) if args.self_paced else {}
+    agent.run_batch(fb, **kw)
     torch.cuda.synchronize()
     for _ in range(args.repeats):
         t0 = time.perf_counter()
-        recs = agent.run_batch(fb)
+        recs = agent.run_batch(fb, **kw)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         n = sum(len(r["tokens"]) for r in recs)
