@@ -584,13 +584,27 @@ int simulst_cif_decode(simulst_handle* h, const simulst_cif_decoder_desc* d, con
  * n_iter policy()/predict() rounds for every row.  A row WRITES in a round iff it is not done and (cif_len > n_prev or its source has
  * ended) -- the complement of the agent's READ condition (agents/cif_agent.py:385-389) -- committing the plain argmax
  * (agents/cif_agent.py:414-436) to hyp with the stamp cur_ms; it is done on EOS or when it holds more than max_len_now tokens.
- * Rows that cannot write are left untouched; the host feeds the next chunk (simulst_cif_stream_append + Kc projection) and calls again. */
+ * Rows that cannot write are left untouched; the host feeds the next chunk (simulst_cif_stream_append + Kc projection) and calls again.
+ *
+ * SELF-PACED ROWS (sched_cif_len != NULL; evaluation over sources already on the device, as for simulst_stream_ctl): every chunk has
+ * been encoded, integrated and its vectors projected; sched_cif_len[c][b] is the number of integrated vectors row b holds after chunk
+ * c, sched_ms / sched_max_len the source time and the length cap after chunk c.  A row that would READ takes chunks by itself inside
+ * the commit -- as many as it needs, since this policy's READ does not depend on the decoder -- so every round of an unfinished row
+ * is a WRITE and a row needs at most cap rounds.  chunk_idx [B] (zero at the start), cif_len (the descriptor's array) and online are
+ * advanced by the commit; tok_chunk records the chunk of every token (from which the READs are recovered). */
 typedef struct {
-  const uint8_t* online;  /* [B] row's source has not ended */
+  uint8_t* online;        /* [B] row's source has not ended (written by the commit for self-paced rows) */
   uint8_t* done;          /* [B] in/out */
   int32_t* delays_ms;     /* [B][cap] or NULL */
   int64_t* hyp;           /* [B][cap] committed tokens */
   int32_t cap, cur_ms, max_len_now;
+  int32_t n_chunks;               /* self-paced rows: length of the schedule */
+  const int32_t* sched_cif_len;   /* [n_chunks][B] or NULL (parked form) */
+  const int32_t* sched_ms;        /* [n_chunks] */
+  const int32_t* sched_max_len;   /* [n_chunks] */
+  int32_t* chunk_idx;             /* [B] in/out */
+  int32_t* cif_len;               /* [B] in/out: simulst_cif_decoder_desc.cif_len */
+  int32_t* tok_chunk;             /* [B][cap] out or NULL */
 } simulst_cif_stream_ctl;
 
 int simulst_cif_stream_steps(simulst_handle* h, const simulst_cif_decoder_desc* d, const simulst_cif_dec_layer* layers,

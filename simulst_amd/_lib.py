@@ -76,7 +76,8 @@ class CifDecoderDesc(C.Structure):
 
 class CifStreamCtl(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("online", "done", "delays_ms", "hyp")] + \
-               [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now")]
+               [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now", "n_chunks")] + \
+               [(n, C.c_void_p) for n in ("sched_cif_len", "sched_ms", "sched_max_len", "chunk_idx", "cif_len", "tok_chunk")]
 
 
 class StreamCtl(C.Structure):

@@ -490,8 +490,98 @@ class BatchedCIFStreamingAgent(CIFAgent):
     tokens, delays and action string are those of ``CIFAgent.run_utterance`` on that utterance alone
     (tests/test_hip_cif_decode.py)."""
 
-    def run_batch(self, fbank: torch.Tensor):
-        """fbank [B, T, 80] (equal lengths).  One record per row, same keys as run_utterance."""
+    def run_batch(self, fbank: torch.Tensor, self_paced: bool = False, encoder: str = "chunked"):
+        """fbank [B, T, 80] (equal lengths).  One record per row, same keys as run_utterance.
+
+        self_paced=True: the evaluation form (agent.BatchedStreamingAgent.run_batch): every chunk is encoded and integrated first,
+        then ONE device loop decodes; a row that would READ takes its next chunks inside the commit (this policy's READ does not
+        look at the decoder, so it costs no decoder step) -- at most cap rounds.  encoder="offline": the encoder states of one
+        offline forward, cut at the rows the streaming schedule releases, go through the same chunk-by-chunk CIF integration."""
+        if self_paced:
+            return self._run_batch_self_paced(fbank, encoder)
+        if encoder != "chunked":
+            raise ValueError("the lockstep form streams through encoder.infer; encoder='offline' needs self_paced=True")
+        return self._run_batch_lockstep(fbank)
+
+    def _run_batch_self_paced(self, fbank: torch.Tensor, encoder: str):
+        from .latency import average_lagging
+        if encoder not in ("chunked", "offline"):
+            raise ValueError(f"encoder={encoder!r}: 'chunked' or 'offline'")
+        model, dec, enc = self.model, self.model.decoder, self.model.encoder
+        cfg, dev = model.cfg, model.device
+        B, T = fbank.size(0), fbank.size(1)
+        fbank = fbank.to(dev)
+        cap = int(self.max_len(T)) + 4
+        first = (self.segment_length + self.right_context) * self.stride_ms // 10
+        nxt = self.segment_length * self.stride_ms // 10
+        positions, pos = [], 0
+        while pos < T:
+            pos = min(pos + (nxt if positions else first), T)
+            positions.append(pos)
+        plan_rows = enc.stream_row_schedule(positions)
+        n_cap = int((plan_rows[-1] + 1) / enc.cif_layer.beta) + 4
+        st = dec.new_device_state(B, cap=cap, n_cap=n_cap)
+        st["lockstep"] = False
+        cst = enc.cif_layer.new_batched_state(B, cfg.embed_dim, n_cap)
+        src = FrameSource(fbank[0])
+        off = None
+        if encoder == "offline":
+            off = S2TEmformerEncoder.forward(enc, fbank, torch.full((B,), T, device=dev))["encoder_out_btd"]
+            if off.size(1) != plan_rows[-1]:
+                raise RuntimeError(f"offline encoder returned {off.size(1)} rows, the streaming schedule releases {plan_rows[-1]}")
+        enc_state, table, ms, mlen, r0 = {}, [], [], [], 0
+        for i, pos in enumerate(positions):
+            src.read(pos - src.pos)
+            finish = i == len(positions) - 1
+            if off is None:
+                out = S2TEmformerEncoder.infer(enc, fbank[:, :pos], torch.full((B,), pos), enc_state, finish=finish)["encoder_out_btd"]
+                if r0 + out.size(1) != plan_rows[i]:
+                    raise RuntimeError(f"streaming encoder released {r0 + out.size(1)} rows after chunk {i}, predicted {plan_rows[i]}")
+            else:
+                out = off[:, r0:plan_rows[i]]
+            r0 = plan_rows[i]
+            enc.cif_layer.infer_batched(out.contiguous(), cst, finish)
+            table.append(cst["cif_len"].clone())
+            ms.append(src.elapsed_ms()); mlen.append(int(self.max_len(src.pos)))
+        n_chunks = len(positions)
+        i32 = dict(device=dev, dtype=torch.int32)
+        sched_len = torch.stack(table, 0).contiguous()
+        dec.project_cif(st, cst["cif"], 0, min(n_cap, int(sched_len[-1].max().item())))
+        sched = torch.tensor([ms, mlen], **i32)
+        st["cif_len"] = sched_len[0].clone()
+        u8 = dict(device=dev, dtype=torch.uint8)
+        online, done = torch.full((B,), 1 if n_chunks > 1 else 0, **u8), torch.zeros(B, **u8)
+        hyp = torch.zeros(B, cap, device=dev, dtype=torch.int64)
+        delays, tok_chunk, chunk_idx = torch.zeros(B, cap, **i32), torch.zeros(B, cap, **i32), torch.zeros(B, **i32)
+        st["tok"].fill_(cfg.eos)
+        ctl = _lib.CifStreamCtl(online.data_ptr(), done.data_ptr(), delays.data_ptr(), hyp.data_ptr(), cap, 0, 0, n_chunks,
+                                sched_len.data_ptr(), sched[0].data_ptr(), sched[1].data_ptr(), chunk_idx.data_ptr(),
+                                st["cif_len"].data_ptr(), tok_chunk.data_ptr())
+        bound, n_run = mlen[-1] + 2, 0
+        while True:                                        # every round of an unfinished row is a WRITE
+            n = max(1, min(bound - n_run, 32))
+            dec.stream_steps(st, ctl, n, self.overshoot_weight)
+            n_run += n
+            if bool(done.all().item()):
+                break
+            if n_run >= bound:
+                raise RuntimeError("self-paced CIF rows unfinished after cap rounds")
+        n_prev, ci_h, clen_h = st["n_prev"].tolist(), chunk_idx.tolist(), st["cif_len"].tolist()
+        hyp_h, delays_h, tc_h = hyp.tolist(), delays.tolist(), tok_chunk.tolist()
+        recs = []
+        for b in range(B):
+            n = min(n_prev[b], cap)
+            acts, k = [], 0
+            for c in range(ci_h[b] + 1):
+                acts.append("R")
+                while k < n and tc_h[b][k] == c:
+                    acts.append("W"); k += 1
+            d = [int(x) for x in delays_h[b][:n]]
+            recs.append({"tokens": hyp_h[b][:n], "delays_ms": d, "actions": "".join(acts),
+                         "AL": average_lagging(d, src.total_ms()), "n_cif": clen_h[b]})
+        return recs
+
+    def _run_batch_lockstep(self, fbank: torch.Tensor):
         from .latency import average_lagging
         model, dec, enc = self.model, self.model.decoder, self.model.encoder
         cfg, dev = model.cfg, model.device
@@ -535,7 +625,7 @@ class BatchedCIFStreamingAgent(CIFAgent):
             # ---- WRITE phase: masked steps until no row can write any more
             online.fill_(0 if src.finished else 1)
             ctl = _lib.CifStreamCtl(online.data_ptr(), done.data_ptr(), delays.data_ptr(), hyp.data_ptr(), cap,
-                                    src.elapsed_ms(), int(self.max_len(src.pos)))
+                                    src.elapsed_ms(), int(self.max_len(src.pos)), 0, None, None, None, None, None, None)
             while True:
                 if src.finished:
                     n_iter = 8                                     # rows write until EOS / the length cap

@@ -23,12 +23,19 @@ struct KcPtrs { const void* p[CIF_MAX_LAYERS]; };
 // models/cif_transformer.py:199-200).  A row writes while it holds more integrated vectors than tokens or its source has
 // ended (agents/cif_agent.py:385-389: READ iff cif_len <= len(hyp) and not finish_read); it finishes on EOS or when it holds
 // more than max_len_now tokens (agents/cif_agent.py units_to_segment).  All null for lockstep offline decode.
+//
+// Self-paced rows (sched_cif_len != nullptr; simulst_cif_stream_ctl in the header): the whole source has been integrated, the
+// schedule says how many integrated vectors a row holds after each chunk, and a row that would READ takes chunks by itself --
+// as many as it needs: this policy's READ does not depend on the decoder, so it costs no decoder step at all.
 struct CifCtl {
-  const unsigned char* online;
+  unsigned char* online;
   unsigned char* done;
   int* delays;
   long* hyp;
   int cap, cur_ms, max_len_now;
+  const int* sched_cif_len; const int* sched_ms; const int* sched_max_len;   // [n_chunks][B], [n_chunks], [n_chunks]
+  int* chunk_idx; int* cif_len; int* tok_chunk;
+  int n_chunks;
 };
 
 // logits == nullptr: no pick -- the step-0 form (embedding of tokens[b] at position n_prev[b] + this step's gather).
@@ -46,11 +53,21 @@ __global__ __launch_bounds__(256) void cif_commit_kernel(const float* __restrict
                                                          float scale, float overshoot_w, CifCtl ctl) {
   __shared__ float sv[4];
   __shared__ int si[4];
-  __shared__ int s_tok, s_np;
+  __shared__ int s_tok, s_np, s_clen;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int np = n_prev[b];
-  const int clen = cif_len[b];
   const bool streaming = ctl.done != nullptr;
+  const bool paced = ctl.sched_cif_len != nullptr;
+  // self-paced rows: thread 0 may move the row to a later chunk below; everything after the barrier reads s_clen
+  int clen = (paced && tid != 0) ? 0 : cif_len[b];
+  int ci = (paced && tid == 0) ? ctl.chunk_idx[b] : 0;
+  auto take_chunks = [&](int np_next) {                    // thread 0: READ until a vector is waiting or the source has ended
+    if (paced && !ctl.done[b]) {
+      while (clen <= np_next && ci + 1 < ctl.n_chunks) { ++ci; clen = ctl.sched_cif_len[(long)ci * B_ + b]; }
+      ctl.chunk_idx[b] = ci; ctl.cif_len[b] = clen; ctl.online[b] = ci + 1 < ctl.n_chunks;
+    }
+    s_clen = clen;
+  };
   if (logits) {
     const float* row = logits + (long)b * V;
     const bool no_eos = !streaming && (mask_eos || np == 0);
@@ -81,12 +98,13 @@ __global__ __launch_bounds__(256) void cif_commit_kernel(const float* __restrict
         if (writes) {
           if (np < ctl.cap) {
             ctl.hyp[(long)b * ctl.cap + np] = bi;
-            if (ctl.delays) ctl.delays[(long)b * ctl.cap + np] = ctl.cur_ms;
+            if (ctl.delays) ctl.delays[(long)b * ctl.cap + np] = paced ? ctl.sched_ms[ci] : ctl.cur_ms;
+            if (ctl.tok_chunk) ctl.tok_chunk[(long)b * ctl.cap + np] = ci;
           }
           tok_next = bi; np_next = np + 1;
           tokens[b] = bi;
           n_prev[b] = np_next;
-          if (bi == eos_idx || np_next > ctl.max_len_now) ctl.done[b] = 1;
+          if (bi == eos_idx || np_next > (paced ? ctl.sched_max_len[ci] : ctl.max_len_now)) ctl.done[b] = 1;
         }
       } else {
         tokens[b] = bi;
@@ -95,11 +113,14 @@ __global__ __launch_bounds__(256) void cif_commit_kernel(const float* __restrict
         n_prev[b] = np_next;
       }
       s_tok = tok_next; s_np = np_next;
+      take_chunks(np_next);
     }
   } else if (tid == 0) {
     s_tok = (int)tokens[b]; s_np = np;
+    take_chunks(np);
   }
   __syncthreads();
+  clen = s_clen;
   const long tok = s_tok;
   const int npn = s_np;
   const long pr = pad_idx + 1 + npn;                         // position row of the next input token
@@ -271,6 +292,13 @@ extern "C" int simulst_cif_stream_steps(simulst_handle* h, const simulst_cif_dec
   CifCtl ctl;
   ctl.online = c->online; ctl.done = c->done; ctl.delays = c->delays_ms; ctl.hyp = (long*)c->hyp; ctl.cap = c->cap;
   ctl.cur_ms = c->cur_ms; ctl.max_len_now = c->max_len_now;
+  ctl.sched_cif_len = c->sched_cif_len; ctl.sched_ms = c->sched_ms; ctl.sched_max_len = c->sched_max_len;
+  ctl.chunk_idx = c->chunk_idx; ctl.cif_len = c->cif_len; ctl.tok_chunk = c->tok_chunk; ctl.n_chunks = c->n_chunks;
+  if (c->sched_cif_len) {
+    SL_CHECK_NULL(h, c->sched_ms); SL_CHECK_NULL(h, c->sched_max_len); SL_CHECK_NULL(h, c->chunk_idx); SL_CHECK_NULL(h, c->cif_len);
+    SL_REQUIRE(h, c->n_chunks > 0, SIMULST_E_SHAPE, "simulst_cif_stream_steps: n_chunks");
+    SL_REQUIRE(h, c->cif_len == dd->cif_len, SIMULST_E_SHAPE, "simulst_cif_stream_steps: ctl.cif_len must be the descriptor's cif_len");
+  }
   return run_cif(h, dd, layers, tokens_io, nullptr, n_iter, 0, ctl);
 }
 

@@ -121,8 +121,17 @@ def test_batched_streaming_rows_identical_to_single_stream_and_oracle(beta):
             for k in ("actions", "tokens", "delays_ms", "AL", "n_cif"):
                 assert recs[b][k] == ref[k], (b, k, recs[b][k], ref[k])
         single = CIFAgent(model).run_utterance(fb[2].cuda())
+        # self-paced rows (whole source integrated first, one device loop, READs taken inside the commit): the same records
+        paced = BatchedCIFStreamingAgent(model).run_batch(fb, self_paced=True)
+        # ... and from the encoder states of one offline forward (equal to rounding)
+        off = BatchedCIFStreamingAgent(model).run_batch(fb, self_paced=True, encoder="offline")
     for k in ("actions", "tokens", "delays_ms", "AL", "n_cif"):
         assert recs[2][k] == single[k]
+    for b in range(6):
+        for k in ("actions", "tokens", "delays_ms", "AL", "n_cif"):
+            assert paced[b][k] == recs[b][k], (b, k, "self-paced")
+    same = sum(all(off[b][k] == recs[b][k] for k in ("actions", "tokens", "delays_ms")) for b in range(6))
+    assert same >= 5, same
     assert len({tuple(r["tokens"]) for r in recs}) > 1
 
 

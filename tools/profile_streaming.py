@@ -17,7 +17,8 @@ def main():
     ap.add_argument("--rows", type=int, default=448)
     ap.add_argument("--repeats", type=int, default=2)
     ap.add_argument("--steps-per-call", type=int, default=8)
-    ap.add_argument("--self-paced", action="store_true", help="evaluation form: rows take their chunks themselves (MMA / wait-k)")
+    ap.add_argument("--encoder", default="chunked", choices=["chunked", "offline"])
+    ap.add_argument("--self-paced", action="store_true", help="evaluation form: rows take their chunks themselves")
     args = ap.parse_args()
     from simulst_amd.agent import BatchedStreamingAgent
     from simulst_amd.cif import BatchedCIFStreamingAgent, CIFTransformerModel
@@ -45,7 +46,7 @@ def main():
         w["decoder.embed_tokens.weight"][cfg.eos] = 0
         agent = BatchedStreamingAgent(SimulSTModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10, steps_per_call=args.steps_per_call)
     fb = torch.randn(args.rows, 1000, 80, device="cuda", generator=torch.Generator(device="cuda").manual_seed(999)).to(torch.bfloat16)
-    kw = dict(self_paced=True) if args.self_paced else {}
+    kw = dict(self_paced=True, encoder=args.encoder) if args.self_paced else {}
     agent.run_batch(fb, **kw)
     torch.cuda.synchronize()
     for _ in range(args.repeats):
