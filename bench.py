@@ -362,25 +362,43 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             offline = None if waitk else {"tokens_per_s": round(n_tok / sorted(ts)[len(ts) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts],
                        "tokens_per_pass": n_tok, "plan_batches_per_sequence": plan, "streams": min(args.concurrency, len(plan)),
                        "decode_steps": U, "semantics": "offline batched, EOS masked (eval/generate.py:187-209)"}
-            # ---- batched streaming
+            # ---- batched streaming: the microphone form (sources advance in lockstep, one host round trip per chunk) and the
+            #      evaluation form (self-paced rows: whole source encoded first, one device loop), the latter also with the
+            #      encoder states of one offline forward
             agent = (BatchedCIFStreamingAgent(model, max_len_a=0.1, max_len_b=10) if cif
                      else BatchedStreamingAgent(model, max_len_a=0.1, max_len_b=10, steps_per_call=8))
             fbs = fb_all[:rows_s]
-            agent.run_batch(fbs)
-            torch.cuda.synchronize()
-            ts, recs = [], None
-            for _ in range(max(1, args.passes)):
+
+            def timed_stream(**kw):
+                agent.run_batch(fbs, **kw)
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                recs = agent.run_batch(fbs)
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            n_st = sum(len(r["tokens"]) for r in recs)
-            streaming = {"tokens_per_s": round(n_st / sorted(ts)[len(ts) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts],
-                         "rows": rows_s, "tokens_per_pass": n_st, "average_lagging_ms_mean": round(sum(r["AL"] for r in recs) / rows_s, 2),
-                         "reads_per_row": recs[0]["actions"].count("R"), "max_len": "0.1 * frames + 10 tokens",
-                         "semantics": "every row takes its own READ / WRITE decisions on the device; chunk schedule 96 then 64 frames "
-                                      "(agents/default_agent.py:367,407)"}
+                ts_, recs_ = [], None
+                for _ in range(max(1, args.passes)):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    recs_ = agent.run_batch(fbs, **kw)
+                    torch.cuda.synchronize()
+                    ts_.append(time.perf_counter() - t0)
+                n_ = sum(len(r["tokens"]) for r in recs_)
+                return recs_, {"tokens_per_s": round(n_ / sorted(ts_)[len(ts_) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts_],
+                               "tokens_per_pass": n_, "average_lagging_ms_mean": round(sum(r["AL"] for r in recs_) / rows_s, 2)}
+            recs, lock = timed_stream()
+            recs_p, paced = timed_stream(self_paced=True)
+            recs_o, paced_off = timed_stream(self_paced=True, encoder="offline")
+            keys3 = ("actions", "tokens", "delays_ms")
+            paced["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_p, recs))
+            paced_off["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_o, recs))
+            paced_off["note"] = ("encoder states from ONE offline forward, cut at the rows the streaming schedule releases: equal to the "
+                                 "chunked states to rounding (agents/default_agent.py:438-476), so a decision can flip at a near-tie")
+            streaming = dict(lock)
+            streaming.update({"rows": rows_s, "reads_per_row": recs[0]["actions"].count("R"), "max_len": "0.1 * frames + 10 tokens",
+                              "semantics": "every row takes its own READ / WRITE decisions on the device; chunk schedule 96 then 64 frames "
+                                           "(agents/default_agent.py:367,407); sources advance in lockstep, the host feeds one chunk at a time",
+                              "evaluation_form_self_paced_rows": paced, "evaluation_form_offline_encoder_states": paced_off,
+                              "evaluation_form": "sources already on the device (SimulEval reading files): every chunk encoded first, then "
+                                                 "one device loop in which a row takes its next chunk itself when its policy says READ "
+                                                 "(simulst_stream_ctl / simulst_cif_stream_ctl schedules); same READ / WRITE strings, "
+                                                 "tokens and delays per row"})
             roof = None
             if not waitk:
                 # ---- instrumented replay of one launch sequence of the plan: the dominant class and its roofline entry
@@ -460,7 +478,8 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
         if not waitk:
             out[key].update({"offline": offline, "roofline": roof})
         log(f"{key}: " + ("" if waitk else f"offline {offline['tokens_per_s']:.0f} tokens/s, ") +
-            f"batched streaming {streaming['tokens_per_s']:.0f} tokens/s (AL {streaming['average_lagging_ms_mean']} ms), parity " +
+            f"batched streaming {streaming['tokens_per_s']:.0f} tokens/s (AL {streaming['average_lagging_ms_mean']} ms; self-paced "
+            f"{paced['tokens_per_s']:.0f}, with offline encoder states {paced_off['tokens_per_s']:.0f}), parity " +
             ("" if waitk else f"{parity['offline_fp32_tokens_identical_to_oracle']} / ") +
             f"{parity['streaming_fp32_actions_tokens_delays_AL_identical_to_oracle']}")
         del pipe, model, m32

@@ -508,9 +508,10 @@ int simulst_mma_decode(simulst_handle* h, const simulst_decoder_desc* d, const s
  *
  * SELF-PACED ROWS (sched_rows != NULL; evaluation of a streaming policy over sources that are already on the device, the way
  * SimulEval feeds an agent from a file: agents/default_agent.py:303-342,364-412).  The caller has pushed EVERY chunk through the
- * streaming encoder and appended it to the cached keys / values, and hands over the chunk schedule: after chunk c the row holds
- * sched_rows[c] encoder rows, sched_ms[c] milliseconds of source and may hold sched_max_len[c] tokens.  A row that asks for source
- * is not parked: the commit takes the next chunk for it (chunk_idx[b] += 1, enc_len[b] = sched_rows[chunk_idx[b]],
+ * streaming encoder and appended it to the cached keys / values, and hands over every row's chunk schedule: after its chunk c row b
+ * holds sched_rows[b][c] encoder rows, sched_ms[b][c] milliseconds of source and may hold sched_max_len[b][c] tokens; its source has
+ * row_chunks[b] chunks (sources of different lengths ride in one batch).  A row that asks for source
+ * is not parked: the commit takes the next chunk for it (chunk_idx[b] += 1, enc_len[b] = sched_rows[b][chunk_idx[b]],
  * online[b] = chunk is not the last) and the row tries the same target position again in the next round, so rows advance through
  * their sources independently of each other with no host round trip -- at most cap + n_chunks rounds per row.  cur_ms and
  * max_len_now are then read from the schedule at the row's chunk.  A row's READ / WRITE sequence, tokens and delays are those of
@@ -523,13 +524,14 @@ typedef struct {
   int32_t* delays_ms;     /* [B][cap] or NULL */
   int64_t* hyp;           /* [B][cap] committed tokens */
   int32_t cap, cur_ms, max_len_now;
-  int32_t n_chunks;               /* self-paced rows: length of the schedule */
-  const int32_t* sched_rows;      /* [n_chunks] or NULL (parked form) */
-  const int32_t* sched_ms;        /* [n_chunks] */
-  const int32_t* sched_max_len;   /* [n_chunks] */
+  int32_t n_chunks;               /* self-paced rows: width of the schedule tables (the longest source's chunks) */
+  const int32_t* sched_rows;      /* [B][n_chunks] or NULL (parked form) */
+  const int32_t* sched_ms;        /* [B][n_chunks] */
+  const int32_t* sched_max_len;   /* [B][n_chunks] */
   int32_t* chunk_idx;             /* [B] in/out: the chunk each row has read up to (0 at the start) */
   int32_t* enc_len;               /* [B] in/out: simulst_decoder_desc.enc_len, advanced with the row's chunk */
   int32_t* tok_chunk;             /* [B][cap] out or NULL: chunk index at which each token was committed */
+  const int32_t* row_chunks;      /* [B] chunks of each row's source, or NULL: n_chunks for every row */
 } simulst_stream_ctl;
 
 int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,
@@ -587,8 +589,8 @@ int simulst_cif_decode(simulst_handle* h, const simulst_cif_decoder_desc* d, con
  * Rows that cannot write are left untouched; the host feeds the next chunk (simulst_cif_stream_append + Kc projection) and calls again.
  *
  * SELF-PACED ROWS (sched_cif_len != NULL; evaluation over sources already on the device, as for simulst_stream_ctl): every chunk has
- * been encoded, integrated and its vectors projected; sched_cif_len[c][b] is the number of integrated vectors row b holds after chunk
- * c, sched_ms / sched_max_len the source time and the length cap after chunk c.  A row that would READ takes chunks by itself inside
+ * been encoded, integrated and its vectors projected; sched_cif_len[b][c] is the number of integrated vectors row b holds after its
+ * chunk c, sched_ms[b][c] / sched_max_len[b][c] the source time and the length cap there, row_chunks[b] the chunks of its source.  A row that would READ takes chunks by itself inside
  * the commit -- as many as it needs, since this policy's READ does not depend on the decoder -- so every round of an unfinished row
  * is a WRITE and a row needs at most cap rounds.  chunk_idx [B] (zero at the start), cif_len (the descriptor's array) and online are
  * advanced by the commit; tok_chunk records the chunk of every token (from which the READs are recovered). */
@@ -598,13 +600,14 @@ typedef struct {
   int32_t* delays_ms;     /* [B][cap] or NULL */
   int64_t* hyp;           /* [B][cap] committed tokens */
   int32_t cap, cur_ms, max_len_now;
-  int32_t n_chunks;               /* self-paced rows: length of the schedule */
-  const int32_t* sched_cif_len;   /* [n_chunks][B] or NULL (parked form) */
-  const int32_t* sched_ms;        /* [n_chunks] */
-  const int32_t* sched_max_len;   /* [n_chunks] */
+  int32_t n_chunks;               /* self-paced rows: width of the schedule tables */
+  const int32_t* sched_cif_len;   /* [B][n_chunks] or NULL (parked form) */
+  const int32_t* sched_ms;        /* [B][n_chunks] */
+  const int32_t* sched_max_len;   /* [B][n_chunks] */
   int32_t* chunk_idx;             /* [B] in/out */
   int32_t* cif_len;               /* [B] in/out: simulst_cif_decoder_desc.cif_len */
   int32_t* tok_chunk;             /* [B][cap] out or NULL */
+  const int32_t* row_chunks;      /* [B] or NULL */
 } simulst_cif_stream_ctl;
 
 int simulst_cif_stream_steps(simulst_handle* h, const simulst_cif_decoder_desc* d, const simulst_cif_dec_layer* layers,

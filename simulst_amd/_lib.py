@@ -77,13 +77,13 @@ class CifDecoderDesc(C.Structure):
 class CifStreamCtl(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("online", "done", "delays_ms", "hyp")] + \
                [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now", "n_chunks")] + \
-               [(n, C.c_void_p) for n in ("sched_cif_len", "sched_ms", "sched_max_len", "chunk_idx", "cif_len", "tok_chunk")]
+               [(n, C.c_void_p) for n in ("sched_cif_len", "sched_ms", "sched_max_len", "chunk_idx", "cif_len", "tok_chunk", "row_chunks")]
 
 
 class StreamCtl(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("active", "read_flag", "online", "done", "delays_ms", "hyp")] + \
                [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now", "n_chunks")] + \
-               [(n, C.c_void_p) for n in ("sched_rows", "sched_ms", "sched_max_len", "chunk_idx", "enc_len", "tok_chunk")]
+               [(n, C.c_void_p) for n in ("sched_rows", "sched_ms", "sched_max_len", "chunk_idx", "enc_len", "tok_chunk", "row_chunks")]
 
 
 # name -> argtypes (restype is int unless noted); mirrors include/simulst_hip.h one to one

@@ -167,7 +167,7 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
         super().__init__(model, max_len_a, max_len_b, force_finish=False)
         self.steps_per_call = steps_per_call
 
-    def run_batch(self, fbank: torch.Tensor, self_paced: bool = False, encoder: str = "chunked"):
+    def run_batch(self, fbank: torch.Tensor, self_paced: bool = False, encoder: str = "chunked", lengths=None):
         """fbank [B, T, 80] (equal lengths).  Returns one record per row, same keys as run_utterance.
 
         self_paced=False: the microphone form described above (one host round trip per chunk and per batch of masked steps).
@@ -179,9 +179,12 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
         the chunk-by-chunk ``infer`` calls -- the two agree to rounding (the reference's own check, agents/default_agent.py:438-476,
         atol = rtol = 1e-3; tests/test_hip_properties.py::test_full_size_streaming_equals_offline_fp32), the rows released per
         chunk are those of the streaming schedule (``stream_row_schedule``); decisions can differ from the chunked run only where
-        that rounding flips one."""
+        that rounding flips one.  With it the sources may have different lengths (``lengths`` [B] frame counts, fbank padded): every
+        row follows the chunk schedule of its own length."""
         if self_paced:
-            return self._run_batch_self_paced(fbank, encoder)
+            return self._run_batch_self_paced(fbank, encoder, lengths)
+        if lengths is not None and len({int(x) for x in lengths}) > 1:
+            raise ValueError("sources of different lengths need self_paced=True, encoder='offline'")
         if encoder != "chunked":
             raise ValueError("the lockstep form streams through encoder.infer; encoder='offline' needs self_paced=True")
         return self._run_batch_lockstep(fbank)
@@ -196,7 +199,7 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
             expected = self.segment_length * self.stride_ms // SHIFT_SIZE
         return out
 
-    def _run_batch_self_paced(self, fbank: torch.Tensor, encoder: str = "chunked"):
+    def _run_batch_self_paced(self, fbank: torch.Tensor, encoder: str = "chunked", lengths=None):
         from . import _lib
         from .latency import average_lagging
         model, dec, enc = self.model, self.model.decoder, self.model.encoder
@@ -205,50 +208,55 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
         fbank = fbank.to(dev)
         if encoder not in ("chunked", "offline"):
             raise ValueError(f"encoder={encoder!r}: 'chunked' or 'offline'")
-        cap = int(self.max_len(T)) + 4
-        positions = self._chunk_positions(T)
-        plan_rows = enc.stream_row_schedule(positions)
-        st = dec.new_state(B, cap=cap, S_cap=max(plan_rows[-1], 1))
+        Ls = [T] * B if lengths is None else [int(x) for x in lengths]
+        if len(Ls) != B or min(Ls) <= 0 or max(Ls) > T:
+            raise ValueError("lengths: one positive frame count per row, at most fbank.size(1)")
+        if len(set(Ls)) > 1 and encoder != "offline":
+            raise ValueError("sources of different lengths need encoder='offline' (encoder.infer advances its rows in lockstep)")
+        # ---- every row's schedule: frames offered after each READ, encoder rows released, source time, length cap
+        per_T = {}
+        for t in set(Ls):
+            positions = self._chunk_positions(t)
+            per_T[t] = (positions, enc.stream_row_schedule(positions),
+                        [p * SHIFT_SIZE + (WINDOW_SIZE - SHIFT_SIZE) for p in positions], [int(self.max_len(p)) for p in positions])
+        n_chunks = max(len(v[0]) for v in per_T.values())
+        pad = lambda v: list(v) + [v[-1]] * (n_chunks - len(v))
+        i32 = dict(device=dev, dtype=torch.int32)
+        sched = torch.tensor([[pad(per_T[t][k]) for t in Ls] for k in (1, 2, 3)], **i32)      # [3][B][n_chunks]
+        row_chunks = torch.tensor([len(per_T[t][0]) for t in Ls], **i32)
+        rows_total = [per_T[t][1][-1] for t in Ls]
+        cap = int(self.max_len(max(Ls))) + 4
+        st = dec.new_state(B, cap=cap, S_cap=max(max(rows_total), 1))
         st.lockstep = False
-        src = FrameSource(fbank[0])
-        rows, ms, mlen = [], [], []
         if encoder == "offline":
-            out = enc.forward(fbank, torch.full((B,), T, device=dev))["encoder_out_btd"]
-            if out.size(1) != plan_rows[-1]:
-                raise RuntimeError(f"offline encoder returned {out.size(1)} rows, the streaming schedule releases {plan_rows[-1]}")
-            dec.append_encoder_out(st, out, torch.full((B,), out.size(1)))
-            for pos in positions:
-                src.read(pos - src.pos)
-                ms.append(src.elapsed_ms()); mlen.append(int(self.max_len(src.pos)))
-            rows = list(plan_rows)
+            e = enc.forward(fbank, torch.tensor(Ls, device=dev))
+            out = e["encoder_out_btd"]
+            if e["encoder_lengths"].tolist() != rows_total:
+                raise RuntimeError("offline encoder lengths differ from the rows the streaming schedule releases")
+            dec.append_encoder_out(st, out, e["encoder_lengths"])
         else:
             # every chunk through the streaming encoder (the launches of the microphone form, minus its host round trips)
-            enc_state = {}
+            enc_state, positions, rows = {}, per_T[T][0], []
             for i, pos in enumerate(positions):
-                src.read(pos - src.pos)
-                out = enc.infer(fbank[:, :src.pos], torch.full((B,), src.pos), enc_state, finish=i == len(positions) - 1)
-                new = out["encoder_out_btd"]
+                new = enc.infer(fbank[:, :pos], torch.full((B,), pos), enc_state, finish=i == len(positions) - 1)["encoder_out_btd"]
                 dec.append_encoder_out(st, new, torch.full((B,), st.enc_rows + new.size(1)))
-                rows.append(st.enc_rows); ms.append(src.elapsed_ms()); mlen.append(int(self.max_len(src.pos)))
-            if rows != list(plan_rows):
-                raise RuntimeError(f"streaming encoder released {rows}, stream_row_schedule predicted {plan_rows}")
-        n_chunks = len(rows)
-        i32 = dict(device=dev, dtype=torch.int32)
-        sched = torch.tensor([rows, ms, mlen], **i32)
-        st.enc_len = torch.full((B,), rows[0], **i32)
+                rows.append(st.enc_rows)
+            if rows != list(per_T[T][1]):
+                raise RuntimeError(f"streaming encoder released {rows}, stream_row_schedule predicted {per_T[T][1]}")
+        st.enc_len = sched[0, :, 0].contiguous()
         st.enc_len_bh = st.enc_len.repeat_interleave(cfg.num_heads).contiguous()
         u8 = dict(device=dev, dtype=torch.uint8)
         active, read_flag, done = torch.ones(B, **u8), torch.zeros(B, **u8), torch.zeros(B, **u8)
-        online = torch.full((B,), 1 if n_chunks > 1 else 0, **u8)
+        online = (row_chunks > 1).to(torch.uint8)
         hyp = torch.zeros(B, cap, device=dev, dtype=torch.int64)
         delays, tok_chunk = torch.zeros(B, cap, **i32), torch.zeros(B, cap, **i32)
         chunk_idx = torch.zeros(B, **i32)
         tokens = torch.full((B,), cfg.eos, device=dev, dtype=torch.int64)
         ctl = _lib.StreamCtl(active.data_ptr(), read_flag.data_ptr(), online.data_ptr(), done.data_ptr(), delays.data_ptr(),
                              hyp.data_ptr(), cap, 0, 0, n_chunks, sched[0].data_ptr(), sched[1].data_ptr(), sched[2].data_ptr(),
-                             chunk_idx.data_ptr(), st.enc_len.data_ptr(), tok_chunk.data_ptr())
-        # ---- one device loop; a row needs at most (tokens it may hold + 1) + (n_chunks - 1) rounds
-        bound = mlen[-1] + 1 + n_chunks
+                             chunk_idx.data_ptr(), st.enc_len.data_ptr(), tok_chunk.data_ptr(), row_chunks.data_ptr())
+        # ---- one device loop; a row needs at most (tokens it may hold + 1) + (its chunks - 1) rounds
+        bound = max(per_T[t][3][-1] + 1 + len(per_T[t][0]) for t in set(Ls))
         n_run = 0
         while True:                                        # rows that meet EOS early end the loop before the bound
             n = max(1, min(bound - n_run, 32))
@@ -270,7 +278,8 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
                     acts.append("W"); k += 1
             d = [int(x) for x in delays_h[b][:n]]
             recs.append({"tokens": hyp_h[b][:n], "delays_ms": d, "actions": "".join(acts),
-                         "AL": average_lagging(d, src.total_ms()), "n_enc": rows[ci_h[b]]})
+                         "AL": average_lagging(d, Ls[b] * SHIFT_SIZE + (WINDOW_SIZE - SHIFT_SIZE)),
+                         "n_enc": per_T[Ls[b]][1][ci_h[b]]})
         return recs
 
     def _run_batch_lockstep(self, fbank: torch.Tensor):
@@ -318,7 +327,7 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
             active.copy_(1 - done)
             ctl = _lib.StreamCtl(active.data_ptr(), read_flag.data_ptr(), online.data_ptr(), done.data_ptr(),
                                  delays.data_ptr(), hyp.data_ptr(), cap, src.elapsed_ms(),
-                                 int(self.max_len(src.pos)), 0, None, None, None, None, None, None)
+                                 int(self.max_len(src.pos)), 0, None, None, None, None, None, None, None)
             while True:
                 dec.stream_steps(st, tokens, ctl, self.steps_per_call)
                 if not bool(active.any().item()):

@@ -545,10 +545,10 @@ class BatchedCIFStreamingAgent(CIFAgent):
             ms.append(src.elapsed_ms()); mlen.append(int(self.max_len(src.pos)))
         n_chunks = len(positions)
         i32 = dict(device=dev, dtype=torch.int32)
-        sched_len = torch.stack(table, 0).contiguous()
-        dec.project_cif(st, cst["cif"], 0, min(n_cap, int(sched_len[-1].max().item())))
-        sched = torch.tensor([ms, mlen], **i32)
-        st["cif_len"] = sched_len[0].clone()
+        sched_len = torch.stack(table, 1).contiguous()                            # [B][n_chunks]
+        dec.project_cif(st, cst["cif"], 0, min(n_cap, int(sched_len[:, -1].max().item())))
+        sched = torch.tensor([[ms] * B, [mlen] * B], **i32)                       # [2][B][n_chunks]
+        st["cif_len"] = sched_len[:, 0].clone()
         u8 = dict(device=dev, dtype=torch.uint8)
         online, done = torch.full((B,), 1 if n_chunks > 1 else 0, **u8), torch.zeros(B, **u8)
         hyp = torch.zeros(B, cap, device=dev, dtype=torch.int64)
@@ -556,7 +556,7 @@ class BatchedCIFStreamingAgent(CIFAgent):
         st["tok"].fill_(cfg.eos)
         ctl = _lib.CifStreamCtl(online.data_ptr(), done.data_ptr(), delays.data_ptr(), hyp.data_ptr(), cap, 0, 0, n_chunks,
                                 sched_len.data_ptr(), sched[0].data_ptr(), sched[1].data_ptr(), chunk_idx.data_ptr(),
-                                st["cif_len"].data_ptr(), tok_chunk.data_ptr())
+                                st["cif_len"].data_ptr(), tok_chunk.data_ptr(), None)
         bound, n_run = mlen[-1] + 2, 0
         while True:                                        # every round of an unfinished row is a WRITE
             n = max(1, min(bound - n_run, 32))
@@ -625,7 +625,7 @@ class BatchedCIFStreamingAgent(CIFAgent):
             # ---- WRITE phase: masked steps until no row can write any more
             online.fill_(0 if src.finished else 1)
             ctl = _lib.CifStreamCtl(online.data_ptr(), done.data_ptr(), delays.data_ptr(), hyp.data_ptr(), cap,
-                                    src.elapsed_ms(), int(self.max_len(src.pos)), 0, None, None, None, None, None, None)
+                                    src.elapsed_ms(), int(self.max_len(src.pos)), 0, None, None, None, None, None, None, None)
             while True:
                 if src.finished:
                     n_iter = 8                                     # rows write until EOS / the length cap

@@ -33,7 +33,8 @@ struct CifCtl {
   int* delays;
   long* hyp;
   int cap, cur_ms, max_len_now;
-  const int* sched_cif_len; const int* sched_ms; const int* sched_max_len;   // [n_chunks][B], [n_chunks], [n_chunks]
+  const int* sched_cif_len; const int* sched_ms; const int* sched_max_len;   // [B][n_chunks]
+  const int* row_chunks;                                                     // [B] chunks of each row's source (null: n_chunks)
   int* chunk_idx; int* cif_len; int* tok_chunk;
   int n_chunks;
 };
@@ -61,10 +62,12 @@ __global__ __launch_bounds__(256) void cif_commit_kernel(const float* __restrict
   // self-paced rows: thread 0 may move the row to a later chunk below; everything after the barrier reads s_clen
   int clen = (paced && tid != 0) ? 0 : cif_len[b];
   int ci = (paced && tid == 0) ? ctl.chunk_idx[b] : 0;
+  const long sb = (long)b * ctl.n_chunks;                  // this row's line of the schedule
   auto take_chunks = [&](int np_next) {                    // thread 0: READ until a vector is waiting or the source has ended
     if (paced && !ctl.done[b]) {
-      while (clen <= np_next && ci + 1 < ctl.n_chunks) { ++ci; clen = ctl.sched_cif_len[(long)ci * B_ + b]; }
-      ctl.chunk_idx[b] = ci; ctl.cif_len[b] = clen; ctl.online[b] = ci + 1 < ctl.n_chunks;
+      const int nc = ctl.row_chunks ? ctl.row_chunks[b] : ctl.n_chunks;
+      while (clen <= np_next && ci + 1 < nc) { ++ci; clen = ctl.sched_cif_len[sb + ci]; }
+      ctl.chunk_idx[b] = ci; ctl.cif_len[b] = clen; ctl.online[b] = ci + 1 < nc;
     }
     s_clen = clen;
   };
@@ -98,13 +101,13 @@ __global__ __launch_bounds__(256) void cif_commit_kernel(const float* __restrict
         if (writes) {
           if (np < ctl.cap) {
             ctl.hyp[(long)b * ctl.cap + np] = bi;
-            if (ctl.delays) ctl.delays[(long)b * ctl.cap + np] = paced ? ctl.sched_ms[ci] : ctl.cur_ms;
+            if (ctl.delays) ctl.delays[(long)b * ctl.cap + np] = paced ? ctl.sched_ms[sb + ci] : ctl.cur_ms;
             if (ctl.tok_chunk) ctl.tok_chunk[(long)b * ctl.cap + np] = ci;
           }
           tok_next = bi; np_next = np + 1;
           tokens[b] = bi;
           n_prev[b] = np_next;
-          if (bi == eos_idx || np_next > (paced ? ctl.sched_max_len[ci] : ctl.max_len_now)) ctl.done[b] = 1;
+          if (bi == eos_idx || np_next > (paced ? ctl.sched_max_len[sb + ci] : ctl.max_len_now)) ctl.done[b] = 1;
         }
       } else {
         tokens[b] = bi;
@@ -294,6 +297,7 @@ extern "C" int simulst_cif_stream_steps(simulst_handle* h, const simulst_cif_dec
   ctl.cur_ms = c->cur_ms; ctl.max_len_now = c->max_len_now;
   ctl.sched_cif_len = c->sched_cif_len; ctl.sched_ms = c->sched_ms; ctl.sched_max_len = c->sched_max_len;
   ctl.chunk_idx = c->chunk_idx; ctl.cif_len = c->cif_len; ctl.tok_chunk = c->tok_chunk; ctl.n_chunks = c->n_chunks;
+  ctl.row_chunks = c->row_chunks;
   if (c->sched_cif_len) {
     SL_CHECK_NULL(h, c->sched_ms); SL_CHECK_NULL(h, c->sched_max_len); SL_CHECK_NULL(h, c->chunk_idx); SL_CHECK_NULL(h, c->cif_len);
     SL_REQUIRE(h, c->n_chunks > 0, SIMULST_E_SHAPE, "simulst_cif_stream_steps: n_chunks");

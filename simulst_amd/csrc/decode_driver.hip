@@ -31,7 +31,8 @@ struct StreamCtl {
   int cap, cur_ms, max_len_now;
   int layer;            // 1-based id of the launching layer: read_flag holds the id of the layer that fired
   // self-paced rows (sched_rows != nullptr, simulst_stream_ctl in the header): the chunk schedule and each row's place in it
-  const int* sched_rows; const int* sched_ms; const int* sched_max_len;
+  const int* sched_rows; const int* sched_ms; const int* sched_max_len;   // [B][n_chunks]
+  const int* row_chunks;                                                 // [B] chunks of each row's source (null: n_chunks)
   int* chunk_idx; int* enc_len; int* tok_chunk;
   int n_chunks;
 };
@@ -358,8 +359,10 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
       const bool act = ctl.active[b] != 0, rd = ctl.read_flag[b] != 0;
       int tok_next = (int)tokens[b], np_next = np;
       const int ci = ctl.sched_rows ? ctl.chunk_idx[b] : 0;
-      const int cur_ms = ctl.sched_rows ? ctl.sched_ms[ci] : ctl.cur_ms;
-      const int max_len_now = ctl.sched_rows ? ctl.sched_max_len[ci] : ctl.max_len_now;
+      const long sb = (long)b * ctl.n_chunks;             // this row's line of the schedule
+      const int nc = ctl.row_chunks ? ctl.row_chunks[b] : ctl.n_chunks;
+      const int cur_ms = ctl.sched_rows ? ctl.sched_ms[sb + ci] : ctl.cur_ms;
+      const int max_len_now = ctl.sched_rows ? ctl.sched_max_len[sb + ci] : ctl.max_len_now;
       if (act && !rd) {                                   // WRITE: commit, stamp, maybe finish
         if (np < ctl.cap) {
           ctl.hyp[(long)b * ctl.cap + np] = bi;
@@ -371,10 +374,10 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
         n_prev[b] = np_next;
         if (bi == eos_idx || np_next > max_len_now) { ctl.done[b] = 1; ctl.active[b] = 0; }
       } else if (act && rd) {
-        if (ctl.sched_rows && ci + 1 < ctl.n_chunks) {    // READ, self-paced: the row takes its next chunk and tries again
+        if (ctl.sched_rows && ci + 1 < nc) {              // READ, self-paced: the row takes its next chunk and tries again
           ctl.chunk_idx[b] = ci + 1;
-          ctl.enc_len[b] = ctl.sched_rows[ci + 1];
-          ctl.online[b] = ci + 2 < ctl.n_chunks;
+          ctl.enc_len[b] = ctl.sched_rows[sb + ci + 1];
+          ctl.online[b] = ci + 2 < nc;
         } else {
           ctl.active[b] = 0;                              // READ: wait for the next source chunk
         }
@@ -732,6 +735,7 @@ extern "C" int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder
   ctl.max_len_now = c->max_len_now;
   ctl.sched_rows = c->sched_rows; ctl.sched_ms = c->sched_ms; ctl.sched_max_len = c->sched_max_len;
   ctl.chunk_idx = c->chunk_idx; ctl.enc_len = c->enc_len; ctl.tok_chunk = c->tok_chunk; ctl.n_chunks = c->n_chunks;
+  ctl.row_chunks = c->row_chunks;
   if (c->sched_rows) {
     SL_CHECK_NULL(h, c->sched_ms); SL_CHECK_NULL(h, c->sched_max_len); SL_CHECK_NULL(h, c->chunk_idx); SL_CHECK_NULL(h, c->enc_len);
     SL_REQUIRE(h, c->n_chunks > 0, SIMULST_E_SHAPE, "simulst_mma_stream_steps: n_chunks");

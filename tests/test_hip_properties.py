@@ -125,6 +125,34 @@ def test_full_size_streaming_equals_offline_fp32(ops):
     torch.testing.assert_close(st, off, atol=1e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("T", [777, 1003])
+def test_full_size_ragged_offline_batch_equals_streaming_each_utterance(ops, T):
+    """What the self-paced evaluation with offline encoder states relies on: row b of a PADDED offline batch == the streaming
+    encoder on utterance b alone (lengths that are no multiple of the segment; same tolerance as the reference's check)."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.encoder import S2TEmformerEncoder
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s()
+    enc = S2TEmformerEncoder(cfg, init_model(cfg, seed=999), dtype=torch.float32, ops=ops)
+    Ls = [T, 312, 1100]
+    fb = torch.randn(3, max(Ls), 80, generator=torch.Generator().manual_seed(T)).cuda()
+    for b, n in enumerate(Ls):
+        fb[b, n:] = 0
+    e = enc.forward(fb, torch.tensor(Ls, device="cuda"))
+    off, off_len = e["encoder_out_btd"], e["encoder_lengths"].tolist()
+    for b in (0, 1):
+        n = Ls[b]
+        inc, pos, outs, expected = {}, 0, [], 96
+        while pos < n:
+            m = min(expected, n - pos)
+            pos += m
+            outs.append(enc.infer(fb[b:b + 1, :pos], torch.tensor([pos]), inc, finish=(m < expected) or pos >= n)["encoder_out_btd"])
+            expected = 64
+        st = torch.cat(outs, 1)
+        assert st.size(1) == off_len[b]
+        torch.testing.assert_close(st[0], off[b, :off_len[b]], atol=1e-3, rtol=1e-3)
+
+
 def test_full_size_expected_alignment_mass(ops):
     """(1536, 110, 32): alpha rows are probabilities; after mass preservation every row sums to 1; the
     infinite-lookback beta rows sum to the same mass as alpha."""

@@ -217,3 +217,41 @@ def test_stream_row_schedule_predicts_the_streaming_encoder(ops, T):
     assert got == plan, (T, got, plan)
     off = model.encoder.forward(fb, torch.full((2,), T, device="cuda"))["encoder_out_btd"]
     assert off.size(1) == plan[-1]
+
+
+@pytest.mark.parametrize("attn,kw", [("waitk_fixed_pre_decision", dict(waitk_lagging=3)),
+                                     ("hard_aligned_fixed_pre_decision", dict(mass_preservation=True)),
+                                     ("infinite_lookback_fixed_pre_decision", {})])
+def test_self_paced_rows_of_different_lengths(ops, attn, kw):
+    """Sources of different lengths in ONE self-paced batch (encoder states of one padded offline forward, every row on the chunk
+    schedule of its own length): each row's READ / WRITE string, tokens, delays and Average Lagging are those of the B = 1 agent
+    streaming that utterance alone, and of the CPU oracle (a flip would need a near-tie under the encoder's rounding)."""
+    from oracle import agent as oag
+    from oracle.configs import from_model_config
+    from simulst_amd.agent import BatchedStreamingAgent, FairseqSimulSTAgent
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, simul_attn_type=attn, max_target_positions=48, **kw)
+    w = init_model(cfg, seed=4243)
+    if "waitk" not in attn:
+        for l in range(2):
+            w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 8
+    w["decoder.embed_tokens.weight"][cfg.eos] *= 1.5
+    model = SimulSTModel(cfg, w, dtype=torch.float32, ops=ops)
+    Ls = [333, 96, 640, 641, 40, 500]
+    fb = torch.randn(len(Ls), max(Ls), 80, generator=torch.Generator().manual_seed(79))
+    for b, n in enumerate(Ls):
+        fb[b, n:] = 0
+    got = BatchedStreamingAgent(model).run_batch(fb, self_paced=True, encoder="offline", lengths=Ls)
+    single = FairseqSimulSTAgent(model)
+    ecfg, dcfg = from_model_config(cfg)
+    for b, n in enumerate(Ls):
+        ref = single.run_utterance(fb[b, :n].cuda())
+        for k in ("actions", "tokens", "delays_ms", "AL"):
+            assert got[b][k] == ref[k], (attn, b, n, k)
+        if b in (1, 3):
+            orc = oag.simulate_mma(w, ecfg, dcfg, fb[b, :n])
+            assert got[b]["actions"] == orc["actions"] and got[b]["tokens"] == orc["tokens"] and got[b]["delays_ms"] == orc["delays_ms"]
+    with pytest.raises(ValueError):
+        BatchedStreamingAgent(model).run_batch(fb, self_paced=True, encoder="chunked", lengths=Ls)
