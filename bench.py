@@ -385,6 +385,28 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             recs, lock = timed_stream()
             recs_p, paced = timed_stream(self_paced=True)
             recs_o, paced_off = timed_stream(self_paced=True, encoder="offline")
+            # the plan's own launch sequences (the utterances of the offline leg) as self-paced streaming batches on the plan's streams
+            from simulst_amd.agent import ConcurrentStreamingEval
+            mk_agent = ((lambda m: BatchedCIFStreamingAgent(m, max_len_a=0.1, max_len_b=10)) if cif
+                        else (lambda m: BatchedStreamingAgent(m, max_len_a=0.1, max_len_b=10)))
+            cse = ConcurrentStreamingEval(model, w, min(args.concurrency, len(plan)), agent_factory=mk_agent, model_factory=factory)
+            work = [(f_, None) for f_, _ in seqs()]
+            cse.run(work)
+            ts_c, recs_c = [], None
+            for _ in range(max(1, args.passes)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                recs_c = cse.run(work)
+                torch.cuda.synchronize()
+                ts_c.append(time.perf_counter() - t0)
+            n_c = sum(len(r["tokens"]) for rb in recs_c for r in rb)
+            rows_c = sum(len(rb) for rb in recs_c)
+            whole_plan = {"tokens_per_s": round(n_c / sorted(ts_c)[len(ts_c) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts_c],
+                          "tokens_per_pass": n_c, "rows": rows_c, "plan_batches_per_sequence": plan, "streams": len(cse.agents),
+                          "average_lagging_ms_mean": round(sum(r["AL"] for rb in recs_c for r in rb) / rows_c, 2),
+                          "form": "self-paced rows, encoder states of one offline forward per launch sequence (agent.ConcurrentStreamingEval): "
+                                  "the utterances and the schedule of this config's offline leg, decoded with the simultaneous policy"}
+            del cse
             keys3 = ("actions", "tokens", "delays_ms")
             paced["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_p, recs))
             paced_off["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_o, recs))
@@ -395,6 +417,7 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                               "semantics": "every row takes its own READ / WRITE decisions on the device; chunk schedule 96 then 64 frames "
                                            "(agents/default_agent.py:367,407); sources advance in lockstep, the host feeds one chunk at a time",
                               "evaluation_form_self_paced_rows": paced, "evaluation_form_offline_encoder_states": paced_off,
+                              "evaluation_form_whole_plan_on_streams": whole_plan,
                               "evaluation_form": "sources already on the device (SimulEval reading files): every chunk encoded first, then "
                                                  "one device loop in which a row takes its next chunk itself when its policy says READ "
                                                  "(simulst_stream_ctl / simulst_cif_stream_ctl schedules); same READ / WRITE strings, "
@@ -479,7 +502,8 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             out[key].update({"offline": offline, "roofline": roof})
         log(f"{key}: " + ("" if waitk else f"offline {offline['tokens_per_s']:.0f} tokens/s, ") +
             f"batched streaming {streaming['tokens_per_s']:.0f} tokens/s (AL {streaming['average_lagging_ms_mean']} ms; self-paced "
-            f"{paced['tokens_per_s']:.0f}, with offline encoder states {paced_off['tokens_per_s']:.0f}), parity " +
+            f"{paced['tokens_per_s']:.0f}, with offline encoder states {paced_off['tokens_per_s']:.0f}, the whole plan on streams "
+            f"{whole_plan['tokens_per_s']:.0f}), parity " +
             ("" if waitk else f"{parity['offline_fp32_tokens_identical_to_oracle']} / ") +
             f"{parity['streaming_fp32_actions_tokens_delays_AL_identical_to_oracle']}")
         del pipe, model, m32

@@ -346,3 +346,60 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
             recs.append({"tokens": hyp_h[b][:n], "delays_ms": d, "actions": "".join(actions[b]),
                          "AL": average_lagging(d, src.total_ms()), "n_enc": st.enc_rows})
         return recs
+
+
+class ConcurrentStreamingEval:
+    """Streaming evaluation of a test set: C self-paced batches in flight on C HIP streams, one host thread each -- the streaming
+    counterpart of model.ConcurrentOffline (the reference evaluates one utterance per SimulEval process; a test set has thousands
+    of independent ones, BASELINE.json configs[4]).  Every batch is ``BatchedStreamingAgent.run_batch(fbank, self_paced=True,
+    encoder=..., lengths=...)`` (or the CIF agent's) on a replica that shares the device weights and owns its stream, handle and
+    states, so a row's record does not depend on what rides beside it."""
+
+    def __init__(self, model, weights, concurrency: int = 3, agent_factory=None, model_factory=None):
+        """agent_factory(model_replica) -> an agent with run_batch; model_factory(ops) -> a replica of another model class (the CIF
+        model); defaults: BatchedStreamingAgent over SimulSTModel replicas that share ``model``'s device weights."""
+        from . import _lib
+        from .model import SimulSTModel
+        from .ops import Ops
+        self.agents, self.streams = [], []
+        self.device = model.device
+        for _ in range(max(1, concurrency)):
+            st = torch.cuda.Stream(device=model.device)
+            with torch.cuda.stream(st):
+                ops = Ops(_lib.Handle(st.cuda_stream))
+                m = model_factory(ops) if model_factory is not None else \
+                    SimulSTModel(model.cfg, weights, device=model.device, dtype=model.dtype, ops=ops, share_with=model)
+                self.agents.append(agent_factory(m) if agent_factory is not None else BatchedStreamingAgent(m))
+            self.streams.append(st)
+
+    def run(self, batches, encoder: str = "offline"):
+        """batches: (fbank [B, T, 80], lengths or None) pairs, already on the device.  Returns one list of records per batch."""
+        import threading
+        batches = list(batches)
+        out, errs = [None] * len(batches), []
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(cur)
+        dev_index = self.device.index
+
+        def worker(c):
+            try:
+                if dev_index is not None:
+                    torch.cuda.set_device(dev_index)
+                with torch.no_grad(), torch.cuda.stream(self.streams[c]):
+                    for i in range(c, len(batches), len(self.agents)):
+                        fb, lengths = batches[i]
+                        out[i] = self.agents[c].run_batch(fb, self_paced=True, encoder=encoder, lengths=lengths)
+            except Exception as e:          # surfaced to the caller below
+                errs.append(e)
+
+        threads = [threading.Thread(target=worker, args=(c,)) for c in range(len(self.agents))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for st in self.streams:             # host-side join (model.ConcurrentOffline.run explains why not wait_stream)
+            st.synchronize()
+        if errs:
+            raise errs[0]
+        return out

@@ -490,13 +490,16 @@ class BatchedCIFStreamingAgent(CIFAgent):
     tokens, delays and action string are those of ``CIFAgent.run_utterance`` on that utterance alone
     (tests/test_hip_cif_decode.py)."""
 
-    def run_batch(self, fbank: torch.Tensor, self_paced: bool = False, encoder: str = "chunked"):
-        """fbank [B, T, 80] (equal lengths).  One record per row, same keys as run_utterance.
+    def run_batch(self, fbank: torch.Tensor, self_paced: bool = False, encoder: str = "chunked", lengths=None):
+        """fbank [B, T, 80] (equal lengths; ``lengths`` is accepted for interface parity and must not differ between rows: the
+        batched CIF integration advances its rows in lockstep).  One record per row, same keys as run_utterance.
 
         self_paced=True: the evaluation form (agent.BatchedStreamingAgent.run_batch): every chunk is encoded and integrated first,
         then ONE device loop decodes; a row that would READ takes its next chunks inside the commit (this policy's READ does not
         look at the decoder, so it costs no decoder step) -- at most cap rounds.  encoder="offline": the encoder states of one
         offline forward, cut at the rows the streaming schedule releases, go through the same chunk-by-chunk CIF integration."""
+        if lengths is not None and len({int(x) for x in lengths} | {fbank.size(1)}) > 1:
+            raise ValueError("BatchedCIFStreamingAgent: the rows of a batch must have the same number of frames")
         if self_paced:
             return self._run_batch_self_paced(fbank, encoder)
         if encoder != "chunked":

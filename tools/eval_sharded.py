@@ -32,6 +32,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--waitk", type=int, default=3)
     ap.add_argument("--streams", type=int, default=3, help="launch sequences in flight per GPU (HIP streams)")
+    ap.add_argument("--streaming", action="store_true",
+                    help="streaming evaluation instead of offline decoding: every utterance through the simultaneous policy with its "
+                         "own READ / WRITE decisions (agent.ConcurrentStreamingEval: self-paced rows, encoder states of one offline "
+                         "forward per launch sequence), reporting Average Lagging too")
+    ap.add_argument("--policy", default="waitk", choices=["waitk", "hard"], help="--streaming: wait-k or MMA-hard (mass preservation)")
     ap.add_argument("--no-warmup", dest="warmup", action="store_false",
                     help="time the cold run too (first launches, allocator growth)")
     args = ap.parse_args()
@@ -51,10 +56,20 @@ def main():
     from simulst_amd.offline_eval import (decode_batch, make_batch, plan_shard, synthetic_lengths,
                                           trim_hypotheses)
     lengths = synthetic_lengths(args.utterances)
-    cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=args.waitk)
+    if args.streaming and args.policy == "hard":
+        cfg = mma_model_s(simul_attn_type="hard_aligned_fixed_pre_decision", fixed_pre_decision_ratio=8, mass_preservation=True)
+    else:
+        cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=args.waitk)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = f"cuda:{local}"
     weights = init_model(cfg, seed=999)
+    if args.streaming:
+        # agent.predict masks nothing (agents/default_agent.py:415-424) and a random-init model with a tied embedding answers <eos>
+        # with <eos>: the EOS row is zeroed so that hypotheses run to their length cap, as in bench.py's streaming legs
+        weights["decoder.embed_tokens.weight"][cfg.eos] = 0
+    if args.streaming and args.policy == "hard":        # a random-init policy does not move: as bench.py's configs[2] leg
+        for l in range(cfg.decoder_layers):
+            weights[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] *= 8
     model = SimulSTModel(cfg, weights, device=dev, dtype=dtype)
     width = int(0.1 * 3000 + 10)
     # ---- this rank's launch sequences: neighbours in length, sizes balanced over the streams; the synthetic fbank is
@@ -62,6 +77,9 @@ def main():
     from simulst_amd.model import ConcurrentOffline
     S = max(1, args.streams)
     batches = [(idx,) + make_batch(idx, lengths, dev, dtype) for idx in plan_shard(lengths, world, rank, args.batch, S)]
+    if args.streaming:
+        # a streamed hypothesis ends when it holds MORE than max_len tokens (agents/default_agent.py:268-271): one more than the offline cap
+        return streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width + 1)
     pipe = ConcurrentOffline(model, weights, S)
     outs = [None] * len(batches)
 
@@ -125,6 +143,58 @@ def main():
                           "utterances_per_sequence": args.batch, "streams": args.streams,
                           "timed": "decode of every launch sequence + D2H + hypothesis trimming" +
                                    ("" if args.warmup else " (cold: first launches and allocator growth included)")}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width):
+    """configs[4] in its stated semantics (batched STREAMING eval): hypotheses, delays and Average Lagging of every utterance"""
+    from simulst_amd.agent import BatchedStreamingAgent, ConcurrentStreamingEval
+    from simulst_amd.sharding import gather_records
+    pipe = ConcurrentStreamingEval(model, weights, S, agent_factory=lambda m: BatchedStreamingAgent(m, max_len_a=0.1, max_len_b=10))
+    work = [(b[1], b[3].tolist()) for b in batches]
+    if args.warmup:
+        pipe.run(work[:S])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    recs_b = pipe.run(work)
+    ids, n_tokens, al_sum, reads = [], 0, 0.0, 0
+    toks = torch.full((sum(len(b[0]) for b in batches), width), cfg.padding_idx, dtype=torch.int64)
+    dl = torch.zeros_like(toks)
+    ntok, r = [], 0
+    for b, recs in zip(batches, recs_b):
+        for i, rec in zip(b[0], recs):
+            n = len(rec["tokens"])
+            toks[r, :n] = torch.tensor(rec["tokens"], dtype=torch.int64)
+            dl[r, :n] = torch.tensor(rec["delays_ms"], dtype=torch.int64)
+            ids.append(i); ntok.append(n)
+            n_tokens += n; al_sum += rec["AL"]; reads += rec["actions"].count("R")
+            r += 1
+    local_s = time.perf_counter() - t0
+    n_utt = len(ids)
+    if dist is not None:
+        recs = gather_records(torch.tensor(ids, device=dev), torch.tensor(ntok, device=dev), toks.to(dev), dl.to(dev), dist, width=width)
+        tt = torch.tensor([local_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        acc = torch.tensor([n_tokens, al_sum, reads, n_utt], device=dev, dtype=torch.float64)
+        dist.all_reduce(acc)
+        total_s, (n_tokens, al_sum, reads, n_utt) = float(tt.item()), acc.tolist()
+        n_rec = len(recs)
+    else:
+        total_s, n_rec = local_s, n_utt
+    if rank == 0:
+        assert n_rec == args.utterances, (n_rec, args.utterances)
+        print(json.dumps({"workload": f"configs[4]: batched STREAMING eval, utterance-sharded ({args.policy})", "utterances": args.utterances,
+                          "n_gpus": world, "tokens": int(n_tokens), "seconds": round(total_s, 3),
+                          "tokens_per_s": round(n_tokens / total_s, 1), "utterances_per_s": round(args.utterances / total_s, 1),
+                          "average_lagging_ms_mean": round(al_sum / n_utt, 2), "reads_per_utterance": round(reads / n_utt, 2),
+                          "dtype": args.dtype, "utterances_per_sequence": args.batch, "streams": S,
+                          "form": "self-paced rows, encoder states of one padded offline forward per launch sequence, every row on the "
+                                  "chunk schedule of its own length; max_len 0.1 * frames + 10",
+                          "timed": "encoder + device decode loop of every launch sequence + D2H + record building"}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
