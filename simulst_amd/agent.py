@@ -152,6 +152,25 @@ class FairseqSimulSTAgent:
                 "AL": average_lagging(delays, src.total_ms()), "n_enc": st.enc_rows if st is not None else 0}
 
 
+def self_paced_records(hyp, delays, tok_chunk, n_prev, chunk_idx, cap, total_ms, extra_key, extra_of):
+    """Host records of a self-paced run: the READ / WRITE string is rebuilt from the chunk index stamped on every token ("R" for
+    every chunk the row took, then the tokens written at it); Average Lagging for all rows at once (latency.average_lagging_batch,
+    bit-identical to the scalar function)."""
+    import numpy as np
+    from .latency import average_lagging_batch
+    n_prev = np.minimum(n_prev.cpu().numpy(), cap)
+    ci = chunk_idx.cpu().numpy()
+    hyp_h, dl, tc = hyp.cpu().numpy(), delays.cpu().numpy(), tok_chunk.cpu().numpy()
+    al = average_lagging_batch(dl, n_prev, total_ms)
+    recs = []
+    for b in range(len(n_prev)):
+        n = int(n_prev[b])
+        counts = np.bincount(tc[b, :n], minlength=int(ci[b]) + 1)
+        recs.append({"tokens": hyp_h[b, :n].tolist(), "delays_ms": dl[b, :n].tolist(),
+                     "actions": "".join("R" + "W" * int(c) for c in counts), "AL": al[b], extra_key: extra_of(b, int(ci[b]))})
+    return recs
+
+
 class BatchedStreamingAgent(FairseqSimulSTAgent):
     """B simultaneous streams through ONE encoder/decoder batch, each row taking its own READ / WRITE
     decisions.  The reference streams one utterance per process (models/s2t_emformer.py:200 asserts B == 1);
@@ -266,21 +285,9 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
                 break
             if n_run >= bound:
                 raise RuntimeError("self-paced rows still active after cap + n_chunks rounds")
-        n_prev, ci_h = st.n_prev.tolist(), chunk_idx.tolist()
-        hyp_h, delays_h, tc_h = hyp.tolist(), delays.tolist(), tok_chunk.tolist()
-        recs = []
-        for b in range(B):
-            n = min(n_prev[b], cap)
-            acts, k = [], 0
-            for c in range(ci_h[b] + 1):                   # "R" for every chunk the row took, then the tokens written at it
-                acts.append("R")
-                while k < n and tc_h[b][k] == c:
-                    acts.append("W"); k += 1
-            d = [int(x) for x in delays_h[b][:n]]
-            recs.append({"tokens": hyp_h[b][:n], "delays_ms": d, "actions": "".join(acts),
-                         "AL": average_lagging(d, Ls[b] * SHIFT_SIZE + (WINDOW_SIZE - SHIFT_SIZE)),
-                         "n_enc": per_T[Ls[b]][1][ci_h[b]]})
-        return recs
+        return self_paced_records(hyp, delays, tok_chunk, st.n_prev, chunk_idx, cap,
+                                  [t * SHIFT_SIZE + (WINDOW_SIZE - SHIFT_SIZE) for t in Ls], "n_enc",
+                                  lambda b, c: per_T[Ls[b]][1][c])
 
     def _run_batch_lockstep(self, fbank: torch.Tensor):
         import ctypes as C

@@ -569,20 +569,10 @@ class BatchedCIFStreamingAgent(CIFAgent):
                 break
             if n_run >= bound:
                 raise RuntimeError("self-paced CIF rows unfinished after cap rounds")
-        n_prev, ci_h, clen_h = st["n_prev"].tolist(), chunk_idx.tolist(), st["cif_len"].tolist()
-        hyp_h, delays_h, tc_h = hyp.tolist(), delays.tolist(), tok_chunk.tolist()
-        recs = []
-        for b in range(B):
-            n = min(n_prev[b], cap)
-            acts, k = [], 0
-            for c in range(ci_h[b] + 1):
-                acts.append("R")
-                while k < n and tc_h[b][k] == c:
-                    acts.append("W"); k += 1
-            d = [int(x) for x in delays_h[b][:n]]
-            recs.append({"tokens": hyp_h[b][:n], "delays_ms": d, "actions": "".join(acts),
-                         "AL": average_lagging(d, src.total_ms()), "n_cif": clen_h[b]})
-        return recs
+        from .agent import self_paced_records
+        clen_h = st["cif_len"].tolist()
+        return self_paced_records(hyp, delays, tok_chunk, st["n_prev"], chunk_idx, cap, [src.total_ms()] * B, "n_cif",
+                                  lambda b, c: clen_h[b])
 
     def _run_batch_lockstep(self, fbank: torch.Tensor):
         from .latency import average_lagging

@@ -19,6 +19,29 @@ def average_lagging(delays: Sequence[float], src_len: float, ref_len=None) -> fl
     return total / tau
 
 
+def average_lagging_batch(delays, n_tok, src_len):
+    """average_lagging for every row of delays [B, cap] (first n_tok[b] entries valid, src_len[b] ms of source): the same IEEE
+    double operations in the same order as the scalar loop (cumsum is sequential), so the values are bit-identical."""
+    import numpy as np
+    d = np.asarray(delays, dtype=np.float64)
+    n = np.asarray(n_tok, dtype=np.int64)
+    src = np.asarray(src_len, dtype=np.float64)
+    B, cap = d.shape
+    out = np.zeros(B)
+    ok = n > 0
+    if not ok.any():
+        return out.tolist()
+    gamma = np.where(ok, n, 1) / src
+    idx = np.arange(cap, dtype=np.float64)
+    cs = np.cumsum(d - idx[None, :] / gamma[:, None], axis=1)
+    valid = idx[None, :] < n[:, None]
+    hit = (d >= src[:, None]) & valid
+    tau = np.where(hit.any(1), hit.argmax(1) + 1, n)
+    rows = np.nonzero(ok)[0]
+    out[rows] = cs[rows, tau[rows] - 1] / tau[rows]
+    return out.tolist()
+
+
 def average_proportion(delays: Sequence[float], src_len: float) -> float:
     return sum(delays) / (src_len * len(delays)) if len(delays) else 0.0
 

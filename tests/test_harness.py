@@ -92,3 +92,26 @@ def test_run_instance_words_and_delays():
     assert all(a <= b for a, b in zip(inst["delays"], inst["delays"][1:]))
     assert all(e >= dl for e, dl in zip(inst["elapsed"], inst["delays"])) and inst["delays"][-1] <= inst["source_length"]
     assert set(inst["metric"]["latency"]) == {"AL", "AL_CA", "AP", "AP_CA", "DAL", "DAL_CA"}
+
+
+def test_average_lagging_batch_is_bit_identical_to_the_scalar_scorer():
+    """latency.average_lagging_batch (all rows of a streamed batch at once) == latency.average_lagging row by row, exactly:
+    the evaluation-form agents report AL through it and the parity tests compare AL with ==."""
+    import random
+    import numpy as np
+    from simulst_amd.latency import average_lagging, average_lagging_batch
+    rnd = random.Random(5)
+    B, cap = 96, 130
+    d = np.zeros((B, cap), dtype=np.int64)
+    n, src = [], []
+    for b in range(B):
+        nb = rnd.randint(0, cap)
+        T = rnd.randint(40, 3000) * 10 + 15
+        n.append(nb); src.append(T)
+        cur = 0
+        for i in range(nb):
+            cur = min(T, cur + rnd.choice([0, 0, 640, 960, 1280]))
+            d[b, i] = cur
+    got = average_lagging_batch(d, n, src)
+    ref = [average_lagging([int(x) for x in d[b, :n[b]]], src[b]) for b in range(B)]
+    assert got == ref
