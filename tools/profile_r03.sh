@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 measurement point on the GPU box (through gpurun, from the repo root):  tools/profile_r03.sh <tag>
-# Writes under gpurun_out/<tag>/: the driver-shaped bench line (with the configs[2] / configs[3] legs), the default bench line,
+# Writes under gpurun_out/<tag>/ (r03_c adds the self-paced streaming runs and the configs[4] shard in both semantics): the driver-shaped bench line (with the configs[2] / configs[3] legs), the default bench line,
 # rocprofv3 --kernel-trace --stats of the driver-shaped command (main leg only) and of the batched streaming runs of configs[2] /
 # configs[3], two --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only) of the dominant kernel.
 # The program itself follows `--` (no wrapper).
@@ -15,6 +15,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_k20
 for c in 2 3; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_stream_c$c -- python3 $R/tools/profile_streaming.py --config $c --rows 448 --repeats 2 > $O/stream_c$c.log 2>&1; echo "stream c$c rc=$?"
 done
+# the evaluation form (self-paced rows, encoder states of one offline forward) of configs[1] / [2] / [3]
+for c in 1 2 3; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_paced_c$c -- python3 $R/tools/profile_streaming.py --config $c --rows 448 --repeats 2 --self-paced --encoder offline > $O/paced_c$c.log 2>&1; echo "paced c$c rc=$?"
+done
+# configs[4]: one rank's shard of the 40 000-utterance set, offline decode and streaming evaluation (wait-k, MMA-hard)
+( cd $R; timeout 600 python tools/eval_sharded.py --utterances 5000 2>/dev/null | tail -n 1 > $O/config5_shard_offline.json
+  timeout 600 python tools/eval_sharded.py --utterances 5000 --streaming 2>/dev/null | tail -n 1 > $O/config5_shard_streaming_waitk.json
+  timeout 600 python tools/eval_sharded.py --utterances 5000 --streaming --policy hard 2>/dev/null | tail -n 1 > $O/config5_shard_streaming_hard.json ); echo "shard rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/tools/kernel_bench.py cross_attn --utterances 448 4096 > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/kernel_bench.py cross_attn --utterances 448 4096 > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
 cd $R
