@@ -380,10 +380,13 @@ class ConcurrentStreamingEval:
             self.streams.append(st)
 
     def run(self, batches, encoder: str = "offline"):
-        """batches: (fbank [B, T, 80], lengths or None) pairs, already on the device.  Returns one list of records per batch."""
+        """batches: (fbank [B, T, 80], lengths or None) pairs, already on the device.  Returns one list of records per batch.
+        The streams take the batches from a queue in the given order (a run ends with a read-back, so a free host thread means a
+        free stream): put the expensive ones first."""
         import threading
         batches = list(batches)
         out, errs = [None] * len(batches), []
+        queue, qlock = list(range(len(batches))), threading.Lock()
         cur = torch.cuda.current_stream()
         for st in self.streams:
             st.wait_stream(cur)
@@ -394,7 +397,11 @@ class ConcurrentStreamingEval:
                 if dev_index is not None:
                     torch.cuda.set_device(dev_index)
                 with torch.no_grad(), torch.cuda.stream(self.streams[c]):
-                    for i in range(c, len(batches), len(self.agents)):
+                    while True:
+                        with qlock:
+                            if not queue:
+                                break
+                            i = queue.pop(0)
                         fb, lengths = batches[i]
                         out[i] = self.agents[c].run_batch(fb, self_paced=True, encoder=encoder, lengths=lengths)
             except Exception as e:          # surfaced to the caller below

@@ -40,6 +40,59 @@ def plan_shard(lengths: Sequence[int], world: int, rank: int, max_rows: int, str
     return out
 
 
+def plan_shard_by_work(lengths: Sequence[int], world: int, rank: int, max_rows: int, streams: int,
+                       step_floor_rows: float = None, min_rows: int = 64) -> List[List[int]]:
+    """plan_shard with the cuts placed by cost instead of by count.  A launch sequence runs as many steps as its LONGEST member
+    needs and every row rides along, so sequences of equal row count waste row-steps where the lengths fall off fast (the long
+    tail: 24 % of the row-steps of a 5 000-utterance shard of the synthetic set at 834 rows per sequence).  Cost model of a
+    sequence of n rows whose longest member decodes U steps: U * (step_floor_rows + n) -- a step costs a latency floor worth
+    ~400 rows (one 448-row step takes 0.48 ms, every further row 0.56 us: DESIGN.md section 3) plus its rows; the floors of
+    sequences on different streams overlap, hence the default 400 / streams.  Callers should hand the sequences to their streams
+    from a queue, most expensive first (sequence_cost), not round-robin: the costs differ by up to 10 x.  The cuts of the
+    length-sorted shard that minimise the total cost are found by dynamic programming over the sequence count (numpy, O(n^2) per
+    count); counts are tried up to 8 x the streams and the cheapest plan wins.  Same contract as plan_shard: every utterance of the
+    rank exactly once, longest first, at most max_rows per sequence."""
+    import numpy as np
+    if step_floor_rows is None:
+        step_floor_rows = 400.0 / max(1, streams)
+    mine = shard_utterances(lengths, world, rank)
+    mine.sort(key=lambda i: (-lengths[i], i))
+    n = len(mine)
+    if n == 0:
+        return []
+    U = np.array([max_steps(lengths[i]) for i in mine], dtype=np.float64)      # non-increasing
+    k_min = -(-n // max_rows)
+    k_max = max(k_min, min(n // max(1, min_rows), 8 * max(1, streams)))
+    INF = float("inf")
+    ar = np.arange(n + 1)
+    # best[k][j] = cheapest way to cut the first j utterances into k sequences; cost of (i, j] = U[i] * (floor + j - i)
+    best = np.full(n + 1, INF); best[0] = 0.0
+    plans, arg_all = {}, []
+    for k in range(1, k_max + 1):
+        nxt, arg = np.full(n + 1, INF), np.zeros(n + 1, dtype=np.int64)
+        for j in range(1, n + 1):
+            lo = max(0, j - max_rows)
+            cand = best[lo:j] + U[lo:j] * (step_floor_rows + (j - ar[lo:j]))
+            a = int(np.argmin(cand))
+            nxt[j], arg[j] = cand[a], lo + a
+        arg_all.append(arg)
+        best = nxt
+        if k >= k_min and best[n] < INF:
+            plans[k] = best[n]
+    k_best = min(plans, key=lambda k: (plans[k], k))
+    cuts, j = [], n
+    for k in range(k_best, 0, -1):
+        i = int(arg_all[k - 1][j])
+        cuts.append((i, j))
+        j = i
+    return [mine[i:j] for i, j in reversed(cuts)]
+
+
+def sequence_cost(idx: Sequence[int], lengths: Sequence[int], streams: int = 3) -> float:
+    """the planner's cost of one launch sequence (steps of its longest member x (latency floor + rows))"""
+    return max(max_steps(lengths[i]) for i in idx) * (400.0 / max(1, streams) + len(idx))
+
+
 def make_batch(idx: Sequence[int], lengths: Sequence[int], device, dtype, fbank_of=synthetic_fbank):
     """Padded ragged batch of the utterances idx: (fbank [n, Tpad, 80] zero past each length, lengths on device,
     lengths on host, decode steps of the longest, Tpad).  Tpad is rounded up to 256 frames so that a few shapes

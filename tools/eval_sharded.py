@@ -24,6 +24,24 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # as bench.py: lets 3 streams 
 import torch  # noqa: E402
 
 
+def shard_path_bytes(cfg, lengths, idx_lists, esz, waitk, kind, streamed):
+    """Algorithmic HBM bytes of this rank's shard under bench.py's path byte model, summed per utterance with ITS
+    length and ITS token count (the decoder weights once per step of every launch sequence).  Long utterances cost more bytes per
+    token: the keys a step may look at grow with the source."""
+    import bench
+    from simulst_amd.offline_eval import max_steps
+    total = 0.0
+    for idx in idx_lists:
+        U_seq = max(max_steps(lengths[i]) for i in idx) + (1 if streamed else 0)
+        enc_w, dec_w = bench.model_param_bytes(cfg, esz)
+        total += enc_w + dec_w * U_seq
+        for i in idx:
+            U = max_steps(lengths[i]) + (1 if streamed else 0)
+            # per-utterance part of path_bytes_per_token: B = 1 with the weights taken out
+            total += bench.path_bytes_per_token(cfg, 1, lengths[i], U, esz, waitk, kind) * U - (enc_w + dec_w * U)
+    return total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--utterances", type=int, default=40000)
@@ -37,6 +55,9 @@ def main():
                          "own READ / WRITE decisions (agent.ConcurrentStreamingEval: self-paced rows, encoder states of one offline "
                          "forward per launch sequence), reporting Average Lagging too")
     ap.add_argument("--policy", default="waitk", choices=["waitk", "hard"], help="--streaming: wait-k or MMA-hard (mass preservation)")
+    ap.add_argument("--plan", default="work", choices=["work", "rows"],
+                    help="work: sequence cuts by cost (offline_eval.plan_shard_by_work) and a queue, most expensive first; rows: equal row "
+                         "counts dealt round-robin (round 2)")
     ap.add_argument("--no-warmup", dest="warmup", action="store_false",
                     help="time the cold run too (first launches, allocator growth)")
     args = ap.parse_args()
@@ -53,8 +74,8 @@ def main():
     from simulst_amd.sharding import gather_records
     from simulst_amd.weights import init_model
 
-    from simulst_amd.offline_eval import (decode_batch, make_batch, plan_shard, synthetic_lengths,
-                                          trim_hypotheses)
+    from simulst_amd.offline_eval import (decode_batch, make_batch, plan_shard, plan_shard_by_work, sequence_cost,
+                                          synthetic_lengths, trim_hypotheses)
     lengths = synthetic_lengths(args.utterances)
     if args.streaming and args.policy == "hard":
         cfg = mma_model_s(simul_attn_type="hard_aligned_fixed_pre_decision", fixed_pre_decision_ratio=8, mass_preservation=True)
@@ -76,25 +97,40 @@ def main():
     #      resident in HBM before the clock starts (as in bench.py)
     from simulst_amd.model import ConcurrentOffline
     S = max(1, args.streams)
-    batches = [(idx,) + make_batch(idx, lengths, dev, dtype) for idx in plan_shard(lengths, world, rank, args.batch, S)]
+    plan = (plan_shard_by_work if args.plan == "work" else plan_shard)(lengths, world, rank, args.batch, S)
+    if args.plan == "work":                             # the queue order: most expensive sequence first
+        plan.sort(key=lambda idx: -sequence_cost(idx, lengths, S))
+    batches = [(idx,) + make_batch(idx, lengths, dev, dtype) for idx in plan]
     if args.streaming:
         # a streamed hypothesis ends when it holds MORE than max_len tokens (agents/default_agent.py:268-271): one more than the offline cap
-        return streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width + 1)
+        return streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width + 1, lengths, dtype)
     pipe = ConcurrentOffline(model, weights, S)
     outs = [None] * len(batches)
 
     def decode(m, b):
         return decode_batch(m, b[1:])
 
+    import threading
+    qlock = threading.Lock()
+
     def worker(c, which):
         torch.cuda.set_device(local)
         with torch.no_grad(), torch.cuda.stream(pipe.streams[c]):
-            for bi in which:
+            while True:
+                with qlock:                              # a queue: the stream that is free takes the next sequence
+                    if not which:
+                        return
+                    bi = which.pop(0)
                 outs[bi] = decode(pipe.models[c], batches[bi])
+                if args.plan == "work":
+                    pipe.streams[c].synchronize()        # "free" means the device has finished, not the host's enqueueing
 
     def run(assign):
-        import threading
-        th = [threading.Thread(target=worker, args=(c, assign[c])) for c in range(S)]
+        shared = args.plan == "work"
+        q = [bi for a in assign for bi in a] if shared else None
+        if shared:
+            q.sort()
+        th = [threading.Thread(target=worker, args=(c, q if shared else assign[c])) for c in range(S)]
         for t in th:
             t.start()
         for t in th:
@@ -140,7 +176,10 @@ def main():
                           "n_gpus": world, "tokens": total_tokens, "seconds": round(total_s, 3),
                           "tokens_per_s": round(total_tokens / total_s, 1),
                           "utterances_per_s": round(args.utterances / total_s, 1), "dtype": args.dtype,
-                          "utterances_per_sequence": args.batch, "streams": args.streams,
+                          "utterances_per_sequence": args.batch, "streams": args.streams, "plan": args.plan,
+                          "rows_per_sequence": [len(b[0]) for b in batches],
+                          "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk, "waitk", False,
+                                                       total_tokens / total_s, world),
                           "timed": "decode of every launch sequence + D2H + hypothesis trimming" +
                                    ("" if args.warmup else " (cold: first launches and allocator growth included)")}))
     if dist is not None:
@@ -148,7 +187,20 @@ def main():
         dist.destroy_process_group()
 
 
-def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width):
+def path_model(cfg, lengths, idx_lists, dtype, waitk, kind, streamed, tokens_per_s, world):
+    """this rank's shard against the HBM roofline (every rank holds an equally long shard: x world for the job)"""
+    esz = 2 if dtype == torch.bfloat16 else 4
+    from simulst_amd.offline_eval import max_steps
+    by = shard_path_bytes(cfg, lengths, idx_lists, esz, waitk, kind, streamed)
+    toks = sum(max_steps(lengths[i]) + (1 if streamed else 0) for idx in idx_lists for i in idx)
+    bpt = by / toks
+    peak = 8.0e12 / bpt * world
+    return {"bytes_per_token": round(bpt), "tokens_per_s_at_peak": round(peak), "frac": round(tokens_per_s / peak, 4),
+            "definition": "bench.py's SURVEY 8(d) byte model summed per utterance with its own length and token cap "
+                          "(2.135 MB/token at 1000 frames; longer sources cost more bytes per token)"}
+
+
+def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width, lengths=None, dtype=None):
     """configs[4] in its stated semantics (batched STREAMING eval): hypotheses, delays and Average Lagging of every utterance"""
     from simulst_amd.agent import BatchedStreamingAgent, ConcurrentStreamingEval
     from simulst_amd.sharding import gather_records
@@ -192,6 +244,8 @@ def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev
                           "tokens_per_s": round(n_tokens / total_s, 1), "utterances_per_s": round(args.utterances / total_s, 1),
                           "average_lagging_ms_mean": round(al_sum / n_utt, 2), "reads_per_utterance": round(reads / n_utt, 2),
                           "dtype": args.dtype, "utterances_per_sequence": args.batch, "streams": S,
+                          "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk,
+                                                       "hard" if args.policy == "hard" else "waitk", True, n_tokens / total_s, world),
                           "form": "self-paced rows, encoder states of one padded offline forward per launch sequence, every row on the "
                                   "chunk schedule of its own length; max_len 0.1 * frames + 10",
                           "timed": "encoder + device decode loop of every launch sequence + D2H + record building"}))
