@@ -195,9 +195,11 @@ __device__ __forceinline__ void prefetch2(Regs2<T, NP>& r, const T* qp, const T*
 // d = NP * W; threads tid < d return ctx[tid]; q_lds != nullptr: already scaled query in LDS, else the register chunk
 // r.q scaled by qscale; red: LDS [RED_FLOATS]; beta (normalised probabilities per key) costs a second
 // barrier-free pass over the scores kept in registers.
+// ml_out != nullptr (key-blocked callers): the block's softmax partial instead -- returns the UNNORMALISED channel sum relative to
+// the block maximum ml_out[0], with ml_out[1] the sum of exponentials; the caller merges blocks (flash-decoding).
 template <typename T, int NP>
 __device__ __forceinline__ float finish3(const Regs2<T, NP>& r, int n, int n_max, float qscale, float* red,
-                                         float* beta, const float* q_lds = nullptr) {
+                                         float* beta, const float* q_lds = nullptr, float* ml_out = nullptr) {
   constexpr int W = VL<T>::W, RP = 256 / (NP > 0 ? NP : 1), d = NP * W;
   constexpr int GW = 64 / (NP > 0 ? NP : 1);     // row groups per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -277,8 +279,9 @@ __device__ __forceinline__ float finish3(const Regs2<T, NP>& r, int n, int n_max
   if (tid < d) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) o += red[w * (d + 2) + 2 + tid] * sw[w];
-    o *= inv;
+    if (!ml_out) o *= inv;
   }
+  if (ml_out) { ml_out[0] = m; ml_out[1] = l; }
   if (beta) {
 #pragma unroll
     for (int i = 0; i < NP; ++i)

@@ -318,6 +318,102 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross
   if (tid < d) ctx[(long)b * D + h * d + tid] = from_f32<T>(o);
 }
 
+// ---- long sources (S_cap > 256), wait-k: the keys in blocks of 256, one workgroup per (head, row, block) ----------------------
+// Each workgroup is the single-latency form of the kernel above on its own block (every K / V load of the block requested up
+// front, split-softmax finish) and leaves the block's softmax partial (max, sum of exponentials, unnormalised channels);
+// cross_attn_merge_kernel folds the blocks of a (head, row) -- flash-decoding over the source.  The thread-per-key loop this
+// replaces moved 3.7 TB/s of K / V at 1024 rows x 384-750 keys where the single-latency form moves 6.1-6.4 (tools/kernel_bench.py
+// cross_attn --keys).  The closed-form wait-k policy is computed by every block workgroup (it reads head_step and block 0 writes
+// it: a workgroup that reads the NEW value finds the same step again, the minimum over candidates >= head_step is idempotent).
+constexpr int KB_KEYS = 256;
+template <typename T, int NP>
+__global__ __launch_bounds__(256, NP >= 16 ? 2 : 4) void waitk_cross_attn_block_kernel(
+    const T* __restrict__ qs, const T* __restrict__ Ks, const T* __restrict__ Vc, const int* __restrict__ key_len,
+    const int* __restrict__ tgt_idx, long* __restrict__ head_step, unsigned char* __restrict__ head_read,
+    float* __restrict__ part, int H, int d, int S_cap, int ratio, int waitk_k, int online, int mass_pres, int n_hint,
+    StreamCtl ctl) {
+  if (ctl.active) {
+    const unsigned char rf = ctl.read_flag[blockIdx.y];
+    if (!ctl.active[blockIdx.y] || (rf && rf != ctl.layer)) return;
+  }
+  if (ctl.online) online = ctl.online[blockIdx.y];
+  __shared__ float red[attn::RED_FLOATS];
+  const int h = blockIdx.x, b = blockIdx.y, kb = blockIdx.z, nblk = gridDim.z, tid = threadIdx.x;
+  const int D = H * d;
+  const int len = key_len ? key_len[b] : S_cap;
+  const int r = b * H + h;
+  const bool pool_last = ratio < 0;
+  ratio = ratio < 0 ? -ratio : ratio;
+  const int P = pooled_count(len, ratio, true, pool_last);
+  const long hb = ((long)b * H + h) * S_cap * d;
+  const int tg = tgt_idx[b];
+  const long hs = head_step[r];
+  if (n_hint < 0) n_hint = (tg + waitk_k) * ratio;
+  const int j0 = kb * KB_KEYS;
+  const int n_pref = max(0, min(min(S_cap, n_hint) - j0, KB_KEYS));
+  attn::Regs2<T, NP> rg2;
+  if (n_pref > 0)
+    attn::prefetch2<T, NP>(rg2, qs + (long)b * D + h * d, Ks + hb + (long)j0 * d, d, Vc + hb + (long)j0 * d, d, n_pref, -1, nullptr, nullptr);
+  // the closed-form wait-k policy of policy_cross_attn_kernel
+  int wk = tg + waitk_k - 1;
+  if (!online) wk = min(wk, P - 1);
+  int s1 = -1, s2 = -1;
+  if (wk < P) {
+    const int c1 = (wk + 1) * ratio - 1;
+    if (c1 < len) s1 = c1;
+    if (wk == P - 1 && P * ratio >= len) s2 = len - 1;
+  }
+  const int max_steps = mass_pres ? len - 1 : len;
+  int found = max_steps;
+  if (s1 >= 0 && (long)s1 >= hs) found = min(found, s1);
+  if (s2 >= 0 && (long)s2 >= hs) found = min(found, s2);
+  if (found < 0) found = 0;
+  if (kb == 0 && tid == 0) {
+    const int clampi = min(max(found, 0), len - 1);
+    const bool one = clampi >= 0 && (clampi == s1 || clampi == s2);
+    const bool hr = found == max_steps && !one;
+    head_step[r] = found;
+    head_read[r] = hr ? 1 : 0;
+    if (ctl.read_flag && hr && online) ctl.read_flag[b] = (unsigned char)ctl.layer;
+  }
+  const long st = found;
+  const int n = (int)(st < len - 1 ? st : len - 1) + 1;                  // keys [0, n) take part
+  const int nb = (st > 0 && n > 0) ? max(0, min(n - j0, KB_KEYS)) : 0;   // ... of them in this block (uniform over the workgroup)
+  float* pw = part + ((long)r * nblk + kb) * (d + 2);
+  if (nb <= 0 || n_pref <= 0) {
+    if (tid == 0) { pw[0] = -INFINITY; pw[1] = 0.f; }
+    return;
+  }
+  float ml[2];
+  const float o = attn::finish3<T, NP>(rg2, nb, n_pref, rsqrtf((float)d), red, nullptr, nullptr, ml);
+  if (tid == 0) { pw[0] = ml[0]; pw[1] = ml[1]; }
+  if (tid < d) pw[2 + tid] = o;
+}
+
+// ctx[b][h] = sum_blocks exp(m_k - m) o_k / sum_blocks exp(m_k - m) l_k, blocks in index order; no live block: zeros
+template <typename T>
+__global__ __launch_bounds__(64) void cross_attn_merge_kernel(const float* __restrict__ part, T* __restrict__ ctx, int H, int d,
+                                                              int nblk, StreamCtl ctl) {
+  const int r = blockIdx.x, b = r / H, h = r - b * H, tid = threadIdx.x;
+  if (ctl.active) {
+    const unsigned char rf = ctl.read_flag[b];
+    if (!ctl.active[b] || (rf && rf != ctl.layer)) return;
+  }
+  const float* p = part + (long)r * nblk * (d + 2);
+  float m = -INFINITY;
+  for (int k = 0; k < nblk; ++k) m = fmaxf(m, p[k * (d + 2)]);
+  float l = 0.f, o = 0.f;
+  if (m != -INFINITY)
+    for (int k = 0; k < nblk; ++k) {
+      const float mk = p[k * (d + 2)];
+      if (mk == -INFINITY) continue;
+      const float w = expf(mk - m);
+      l += p[k * (d + 2) + 1] * w;
+      if (tid < d) o += p[k * (d + 2) + 2 + tid] * w;
+    }
+  if (tid < d) ctx[(long)b * H * d + h * d + tid] = from_f32<T>(l > 0.f ? o / l : 0.f);
+}
+
 // greedy pick (lowest index on ties, pad never, eos masked on request / at the first position),
 // commit, and the next step's input embedding.
 template <typename T>
@@ -434,6 +530,32 @@ int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         const float* bqs, const StreamCtl& ctl, const HeadSplit& hs, const float* kpool, int P_cap) {
   const size_t lds = (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
+  const int np = attn::lanes_per_row<T>(d);
+  if (attn_type == SIMULST_ATTN_WAITK && S_cap > KB_KEYS && !xres && qs && Ks && np > 0 && !h->force_unfused_decode) {
+    // long sources: key blocks of 256 on their own workgroups + a merge (waitk_cross_attn_block_kernel)
+    const int nblk = (S_cap + KB_KEYS - 1) / KB_KEYS;
+    const size_t need = (size_t)B * H * nblk * (d + 2) * sizeof(float);
+    if (h->ws_bytes < need) {
+      if (h->capturing) { h->err = "simulst_policy_cross_attention: scratch too small while capturing a graph"; return SIMULST_E_ARG; }
+      if (h->ws) (void)hipFree(h->ws);
+      h->ws = nullptr; h->ws_bytes = 0;
+      const size_t want = need < ((size_t)4 << 20) ? ((size_t)4 << 20) : need;
+      hipError_t e = hipMalloc(&h->ws, want);
+      if (e != hipSuccess) { h->err = "simulst_policy_cross_attention: scratch allocation failed"; return (int)e; }
+      h->ws_bytes = want;
+    }
+    float* part = (float*)h->ws;
+#define KB_LAUNCH(NP)                                                                                                  \
+    hipLaunchKernelGGL((waitk_cross_attn_block_kernel<T, NP>), dim3(H, B, nblk), dim3(256), 0, h->stream, (const T*)qs,     \
+                       (const T*)Ks, (const T*)Vc, key_len, tgt_idx, (long*)head_step, head_read, part, H, d, S_cap, ratio,  \
+                       waitk_k, online, mass_pres, n_hint, ctl)
+    switch (np) { case 2: KB_LAUNCH(2); break; case 4: KB_LAUNCH(4); break; case 8: KB_LAUNCH(8); break; default: KB_LAUNCH(16); break; }
+#undef KB_LAUNCH
+    int rc = sl_launch_status(h, "simulst_policy_cross_attention(blocks)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(B * H), dim3(64), 0, h->stream, (const float*)part, (T*)ctx, H, d, nblk, ctl);
+    return sl_launch_status(h, "simulst_policy_cross_attention(merge)");
+  }
 #define PC_LAUNCH_Q(NP, FQ)                                                                                            \
   hipLaunchKernelGGL((policy_cross_attn_kernel<T, NP, FQ>), dim3(H, B), dim3(256), lds, h->stream, (const T*)qm,       \
                      (const T*)qs, (const T*)Km, (const T*)Ks, (const T*)Vc, energy_bias, key_len, tgt_idx,            \

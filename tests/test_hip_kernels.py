@@ -934,3 +934,49 @@ def test_expected_alignment_small_source_kernels(ops, S):
     # no padding mask at all
     torch.testing.assert_close(ops.expected_alignment(p.cuda(), None, 1e-6).cpu(), omo.expected_alignment_from_p_choose(p, None, 1e-6),
                                atol=1e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S_cap", [257, 300, 512, 750])
+def test_waitk_cross_attention_long_sources_in_key_blocks(ops, dtype, S_cap):
+    """Sources longer than 256 encoder rows, wait-k: key blocks of 256 on their own workgroups + the merge of the blocks' softmax
+    partials (waitk_cross_attn_block_kernel / cross_attn_merge_kernel) against the thread-per-key loop of the one-workgroup kernel
+    (test hook simulst_debug_force_unfused_decode) and against a torch softmax: same head_step / head_read, context to rounding.
+    Rows of every kind: sources shorter than one block, ending inside a block, on a block edge; early and late target positions."""
+    from simulst_amd import _lib
+    g = torch.Generator().manual_seed(S_cap)
+    B, H, d, ratio, k = 9, 4, 64, 8, 5
+    D = H * d
+    lens = [S_cap, S_cap - 1, 256, 255, 257, 100, 8, (S_cap + 256) // 2, 300 if S_cap >= 300 else S_cap][:B]
+    tgts = [0, 3, 40, 27, 29, 60, 1, 200, 31][:B]
+    q = (torch.randn(B, D, generator=g) * 2).to(dtype).cuda()
+    K = torch.randn(B, H, S_cap, d, generator=g).to(dtype).cuda()
+    V = torch.randn(B, H, S_cap, d, generator=g).to(dtype).cuda()
+    kl = torch.tensor(lens, dtype=torch.int32).cuda()
+    tg = torch.tensor(tgts, dtype=torch.int32).cuda()
+    for online in (False, True):
+        res = []
+        for forced in (0, 1):
+            hs = torch.zeros(B * H, dtype=torch.int64, device="cuda")
+            ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, forced)
+            try:
+                ctx, hr = ops.policy_cross_attention(q, q, K, K, V, hs, H=H, ratio=ratio, attn_type=_lib.ATTN_ENUM["waitk"],
+                                                     key_len=kl, tgt_idx=tg, waitk_k=k, online=online)
+            finally:
+                ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
+            res.append((ctx.float().cpu(), hs.cpu(), hr.cpu()))
+        (c_new, hs_new, hr_new), (c_old, hs_old, hr_old) = res
+        assert torch.equal(hs_new, hs_old) and torch.equal(hr_new, hr_old)
+        tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
+        torch.testing.assert_close(c_new, c_old, **tol)
+        # torch softmax over the keys [0, head_step]
+        qf, Kf, Vf = q.float().cpu().view(B, H, d), K.float().cpu(), V.float().cpu()
+        for b in range(B):
+            for h in range(H):
+                st = int(hs_new[b * H + h])
+                n = min(st, lens[b] - 1) + 1
+                ref = torch.zeros(d)
+                if st > 0 and n > 0:
+                    p = torch.softmax((Kf[b, h, :n] @ qf[b, h]) / d ** 0.5, 0)
+                    ref = p @ Vf[b, h, :n]
+                torch.testing.assert_close(c_new[b, h * d:(h + 1) * d], ref, **tol)

@@ -1,6 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for plan in rows work; do
-timeout 600 python tools/eval_sharded.py --utterances 5000 --plan $plan 2>&1 | tail -1 | cut -c1-420
-timeout 600 python tools/eval_sharded.py --utterances 5000 --plan $plan --streaming 2>&1 | tail -1 | cut -c1-420
-done
-timeout 600 python tools/eval_sharded.py --utterances 5000 --plan work --streaming --policy hard 2>&1 | tail -1 | cut -c1-420
+timeout 1500 python -m pytest tests/test_hip_configs.py tests/test_hip_decoder.py tests/test_hip_properties.py tests/test_hip_streaming.py -x -q 2>&1 | tail -4
+timeout 600 python tools/eval_sharded.py --utterances 5000 2>&1 | tail -1 | cut -c1-330
+timeout 600 python tools/eval_sharded.py --utterances 5000 --streaming 2>&1 | tail -1 | cut -c1-330

@@ -130,15 +130,15 @@ def cross_attn(args, ops):
     rows per utterance, 4 heads x 64, target index late enough that every key is visible (90 % of the 110 steps);
     bytes = K and V rows read + q + context"""
     from simulst_amd import _lib
-    D, H, d, S = 256, 4, 64, 250
+    D, H, d = 256, 4, 64
     out = {}
-    for B in args.utterances:
+    for B, S in [(b, s_) for b in args.utterances for s_ in args.keys]:
         q = torch.randn(B, D, device="cuda").to(torch.bfloat16)
         K = torch.randn(B, H, S, d, device="cuda").to(torch.bfloat16)
         V = torch.randn(B, H, S, d, device="cuda").to(torch.bfloat16)
         hs = torch.zeros(B * H, dtype=torch.int64, device="cuda")
         kl = torch.full((B,), S, dtype=torch.int32, device="cuda")
-        tg = torch.full((B,), 60, dtype=torch.int32, device="cuda")
+        tg = torch.full((B,), max(60, S // 8 + 2), dtype=torch.int32, device="cuda")
         ctx = torch.empty(B, D, device="cuda", dtype=torch.bfloat16)
 
         def run():
@@ -146,8 +146,9 @@ def cross_attn(args, ops):
                                        key_len=kl, tgt_idx=tg, waitk_k=5, out=ctx)
         us = timeit(run, 50 if B >= 1024 else 200)
         nbytes = B * (2 * S * D + 2 * D) * 2
-        out[str(B)] = {"us": round(us, 1), "GBps": round(nbytes / us / 1e3, 1), "bytes": nbytes}
-        print("cross_attn", B, out[str(B)], flush=True)
+        key = str(B) if len(args.keys) == 1 else f"{B}x{S}"
+        out[key] = {"us": round(us, 1), "GBps": round(nbytes / us / 1e3, 1), "bytes": nbytes, "keys": S}
+        print("cross_attn", key, out[key], flush=True)
     return out
 
 
@@ -156,6 +157,7 @@ def main():
     ap.add_argument("what", choices=["emf_attn", "self_attn", "dec_chain", "cross_attn"])
     ap.add_argument("--utterances", type=int, nargs="+", default=[448, 4096])
     ap.add_argument("--n-prev", type=int, nargs="+", default=[55, 109])
+    ap.add_argument("--keys", type=int, nargs="+", default=[250], help="cross_attn: encoder rows per utterance")
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
     from simulst_amd.ops import Ops
