@@ -233,16 +233,27 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
         if len(set(Ls)) > 1 and encoder != "offline":
             raise ValueError("sources of different lengths need encoder='offline' (encoder.infer advances its rows in lockstep)")
         # ---- every row's schedule: frames offered after each READ, encoder rows released, source time, length cap
+        #      (integer arithmetic per distinct length, cached on the agent; the [B, n_chunks] tables assembled with numpy)
+        import numpy as np
+        cache = self.__dict__.setdefault("_schedule_cache", {})
         per_T = {}
         for t in set(Ls):
-            positions = self._chunk_positions(t)
-            per_T[t] = (positions, enc.stream_row_schedule(positions),
-                        [p * SHIFT_SIZE + (WINDOW_SIZE - SHIFT_SIZE) for p in positions], [int(self.max_len(p)) for p in positions])
+            if t not in cache:
+                positions = self._chunk_positions(t)
+                cache[t] = (positions, enc.stream_row_schedule(positions),
+                            [p * SHIFT_SIZE + (WINDOW_SIZE - SHIFT_SIZE) for p in positions], [int(self.max_len(p)) for p in positions])
+            per_T[t] = cache[t]
         n_chunks = max(len(v[0]) for v in per_T.values())
-        pad = lambda v: list(v) + [v[-1]] * (n_chunks - len(v))
+        uniq, inv = np.unique(np.asarray(Ls), return_inverse=True)
+        tab = np.zeros((3, len(uniq), n_chunks), dtype=np.int32)
+        for u, t in enumerate(uniq.tolist()):
+            for k in (1, 2, 3):
+                v = per_T[t][k]
+                tab[k - 1, u, :len(v)] = v
+                tab[k - 1, u, len(v):] = v[-1]
         i32 = dict(device=dev, dtype=torch.int32)
-        sched = torch.tensor([[pad(per_T[t][k]) for t in Ls] for k in (1, 2, 3)], **i32)      # [3][B][n_chunks]
-        row_chunks = torch.tensor([len(per_T[t][0]) for t in Ls], **i32)
+        sched = torch.from_numpy(np.ascontiguousarray(tab[:, inv])).to(dev)                       # [3][B][n_chunks]
+        row_chunks = torch.from_numpy(np.array([len(per_T[t][0]) for t in uniq.tolist()], dtype=np.int32)[inv]).to(dev)
         rows_total = [per_T[t][1][-1] for t in Ls]
         cap = int(self.max_len(max(Ls))) + 4
         st = dec.new_state(B, cap=cap, S_cap=max(max(rows_total), 1))
