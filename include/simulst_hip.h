@@ -532,6 +532,10 @@ typedef struct {
   int32_t* enc_len;               /* [B] in/out: simulst_decoder_desc.enc_len, advanced with the row's chunk */
   int32_t* tok_chunk;             /* [B][cap] out or NULL: chunk index at which each token was committed */
   const int32_t* row_chunks;      /* [B] chunks of each row's source, or NULL: n_chunks for every row */
+  int32_t ff_waitk, ff_ratio;     /* wait-k rows (0: off): the descriptor's waitk_k and ratio.  Wait-k's READ is a closed form of the row's
+                                     position and source length, so the commit takes every chunk the row is going to ask for on the
+                                     spot (position u can be written once the source holds u + k pooled keys) and no round is spent on
+                                     asking; the caller starts every row at the first chunk that allows position 0 */
 } simulst_stream_ctl;
 
 int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,

@@ -273,23 +273,44 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
                 rows.append(st.enc_rows)
             if rows != list(per_T[T][1]):
                 raise RuntimeError(f"streaming encoder released {rows}, stream_row_schedule predicted {per_T[T][1]}")
-        st.enc_len = sched[0, :, 0].contiguous()
+        # wait-k: READ is a closed form of position and source length (position u needs u + k pooled keys), so every row starts at
+        # the first chunk that allows position 0 and the commit kernel keeps taking chunks the same way (simulst_stream_ctl.ff_waitk)
+        ff_k = cfg.waitk_lagging if cfg.attn_type == "waitk" else 0
+        ratio_abs, pool_last = abs(dec.ratio_arg), dec.ratio_arg < 0
+
+        def pooled_count(n):                                     # csrc/common.h pooled_count, incremental
+            if pool_last and n < ratio_abs:
+                return max(n - 1, 1)
+            return min(-(-n // ratio_abs), max(n // ratio_abs, 1))
+        c0_of = {}
+        for t in uniq.tolist():
+            rows_t, c = per_T[t][1], 0
+            while ff_k > 0 and c + 1 < len(rows_t) and ff_k - 1 >= pooled_count(rows_t[c]):
+                c += 1
+            c0_of[t] = c
+        c0 = np.array([c0_of[t] for t in uniq.tolist()], dtype=np.int32)[inv]
+        chunk_idx = torch.from_numpy(c0.copy()).to(dev)
+        st.enc_len = torch.from_numpy(np.ascontiguousarray(tab[0][inv, c0])).to(dev)
         st.enc_len_bh = st.enc_len.repeat_interleave(cfg.num_heads).contiguous()
         u8 = dict(device=dev, dtype=torch.uint8)
         active, read_flag, done = torch.ones(B, **u8), torch.zeros(B, **u8), torch.zeros(B, **u8)
-        online = (row_chunks > 1).to(torch.uint8)
+        online = (chunk_idx + 1 < row_chunks).to(torch.uint8)
         hyp = torch.zeros(B, cap, device=dev, dtype=torch.int64)
         delays, tok_chunk = torch.zeros(B, cap, **i32), torch.zeros(B, cap, **i32)
-        chunk_idx = torch.zeros(B, **i32)
         tokens = torch.full((B,), cfg.eos, device=dev, dtype=torch.int64)
         ctl = _lib.StreamCtl(active.data_ptr(), read_flag.data_ptr(), online.data_ptr(), done.data_ptr(), delays.data_ptr(),
                              hyp.data_ptr(), cap, 0, 0, n_chunks, sched[0].data_ptr(), sched[1].data_ptr(), sched[2].data_ptr(),
-                             chunk_idx.data_ptr(), st.enc_len.data_ptr(), tok_chunk.data_ptr(), row_chunks.data_ptr())
+                             chunk_idx.data_ptr(), st.enc_len.data_ptr(), tok_chunk.data_ptr(), row_chunks.data_ptr(),
+                             ff_k, dec.ratio_arg if ff_k else 0)
         # ---- one device loop; a row needs at most (tokens it may hold + 1) + (its chunks - 1) rounds
         bound = max(per_T[t][3][-1] + 1 + len(per_T[t][0]) for t in set(Ls))
+        # no row can finish its cap in fewer rounds than it may hold tokens: that many rounds go out before the first look at the
+        # masks (wait-k rows, whose READs cost no round, are then done unless they met EOS earlier -- which the look finds), short
+        # calls after it
+        first = max(per_T[t][3][-1] + 1 for t in set(Ls))
         n_run = 0
         while True:                                        # rows that meet EOS early end the loop before the bound
-            n = max(1, min(bound - n_run, 32))
+            n = max(1, min(64, first - n_run) if n_run < first else min(8, bound - n_run))
             dec.stream_steps(st, tokens, ctl, n)
             n_run += n
             if not bool(active.any().item()):
@@ -345,7 +366,7 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
             active.copy_(1 - done)
             ctl = _lib.StreamCtl(active.data_ptr(), read_flag.data_ptr(), online.data_ptr(), done.data_ptr(),
                                  delays.data_ptr(), hyp.data_ptr(), cap, src.elapsed_ms(),
-                                 int(self.max_len(src.pos)), 0, None, None, None, None, None, None, None)
+                                 int(self.max_len(src.pos)), 0, None, None, None, None, None, None, None, 0, 0)
             while True:
                 dec.stream_steps(st, tokens, ctl, self.steps_per_call)
                 if not bool(active.any().item()):

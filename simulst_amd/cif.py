@@ -560,9 +560,9 @@ class BatchedCIFStreamingAgent(CIFAgent):
         ctl = _lib.CifStreamCtl(online.data_ptr(), done.data_ptr(), delays.data_ptr(), hyp.data_ptr(), cap, 0, 0, n_chunks,
                                 sched_len.data_ptr(), sched[0].data_ptr(), sched[1].data_ptr(), chunk_idx.data_ptr(),
                                 st["cif_len"].data_ptr(), tok_chunk.data_ptr(), None)
-        bound, n_run = mlen[-1] + 2, 0
-        while True:                                        # every round of an unfinished row is a WRITE
-            n = max(1, min(bound - n_run, 32))
+        bound, first, n_run = mlen[-1] + 2, mlen[-1] + 1, 0
+        while True:                                        # every round of an unfinished row is a WRITE: cap + 1 rounds, unless EOS
+            n = max(1, min(64, first - n_run) if n_run < first else min(8, bound - n_run))
             dec.stream_steps(st, ctl, n, self.overshoot_weight)
             n_run += n
             if bool(done.all().item()):

@@ -35,6 +35,7 @@ struct StreamCtl {
   const int* row_chunks;                                                 // [B] chunks of each row's source (null: n_chunks)
   int* chunk_idx; int* enc_len; int* tok_chunk;
   int n_chunks;
+  int ff_waitk, ff_ratio;                                                // wait-k rows: lagging and signed pre-decision ratio (0: off)
 };
 
 // head-split projections around the policy kernel (all null: separate GEMM launches do the projections)
@@ -459,6 +460,8 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
       const int nc = ctl.row_chunks ? ctl.row_chunks[b] : ctl.n_chunks;
       const int cur_ms = ctl.sched_rows ? ctl.sched_ms[sb + ci] : ctl.cur_ms;
       const int max_len_now = ctl.sched_rows ? ctl.sched_max_len[sb + ci] : ctl.max_len_now;
+      int c_now = ci;                                     // self-paced rows: the chunk the row holds after this round
+      bool live = act;
       if (act && !rd) {                                   // WRITE: commit, stamp, maybe finish
         if (np < ctl.cap) {
           ctl.hyp[(long)b * ctl.cap + np] = bi;
@@ -468,14 +471,28 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
         tok_next = bi; np_next = np + 1;
         tokens[b] = bi;
         n_prev[b] = np_next;
-        if (bi == eos_idx || np_next > max_len_now) { ctl.done[b] = 1; ctl.active[b] = 0; }
+        if (bi == eos_idx || np_next > max_len_now) { ctl.done[b] = 1; ctl.active[b] = 0; live = false; }
       } else if (act && rd) {
         if (ctl.sched_rows && ci + 1 < nc) {              // READ, self-paced: the row takes its next chunk and tries again
-          ctl.chunk_idx[b] = ci + 1;
-          ctl.enc_len[b] = ctl.sched_rows[sb + ci + 1];
-          ctl.online[b] = ci + 2 < nc;
+          c_now = ci + 1;
         } else {
           ctl.active[b] = 0;                              // READ: wait for the next source chunk
+          live = false;
+        }
+      }
+      if (ctl.sched_rows && live) {
+        // wait-k rows (ff_waitk = the lagging): READ is a closed form of the row's position and source length -- the position
+        // np_next can be written once the source has np_next + k pooled keys (policy_cross_attn_kernel: wk < P) -- so the row
+        // takes every chunk it is going to ask for right here and no round is spent on asking
+        if (ctl.ff_waitk > 0) {
+          const int ra = ctl.ff_ratio < 0 ? -ctl.ff_ratio : ctl.ff_ratio;
+          while (c_now + 1 < nc &&
+                 np_next + ctl.ff_waitk - 1 >= pooled_count(ctl.sched_rows[sb + c_now], ra, true, ctl.ff_ratio < 0)) ++c_now;
+        }
+        if (c_now != ci) {
+          ctl.chunk_idx[b] = c_now;
+          ctl.enc_len[b] = ctl.sched_rows[sb + c_now];
+          ctl.online[b] = c_now + 1 < nc;
         }
       }
       ctl.read_flag[b] = 0;
@@ -858,7 +875,10 @@ extern "C" int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder
   ctl.sched_rows = c->sched_rows; ctl.sched_ms = c->sched_ms; ctl.sched_max_len = c->sched_max_len;
   ctl.chunk_idx = c->chunk_idx; ctl.enc_len = c->enc_len; ctl.tok_chunk = c->tok_chunk; ctl.n_chunks = c->n_chunks;
   ctl.row_chunks = c->row_chunks;
+  ctl.ff_waitk = c->sched_rows ? c->ff_waitk : 0; ctl.ff_ratio = c->ff_ratio;
   if (c->sched_rows) {
+    SL_REQUIRE(h, c->ff_waitk == 0 || (dd && dd->attn_type == SIMULST_ATTN_WAITK && c->ff_waitk == dd->waitk_k && c->ff_ratio == dd->ratio),
+               SIMULST_E_ARG, "simulst_mma_stream_steps: ff_waitk / ff_ratio must be the descriptor's wait-k lagging and ratio");
     SL_CHECK_NULL(h, c->sched_ms); SL_CHECK_NULL(h, c->sched_max_len); SL_CHECK_NULL(h, c->chunk_idx); SL_CHECK_NULL(h, c->enc_len);
     SL_REQUIRE(h, c->n_chunks > 0, SIMULST_E_SHAPE, "simulst_mma_stream_steps: n_chunks");
     SL_REQUIRE(h, dd && c->enc_len == dd->enc_len, SIMULST_E_SHAPE, "simulst_mma_stream_steps: ctl.enc_len must be the descriptor's enc_len");
