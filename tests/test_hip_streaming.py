@@ -255,3 +255,39 @@ def test_self_paced_rows_of_different_lengths(ops, attn, kw):
             assert got[b]["actions"] == orc["actions"] and got[b]["tokens"] == orc["tokens"] and got[b]["delays_ms"] == orc["delays_ms"]
     with pytest.raises(ValueError):
         BatchedStreamingAgent(model).run_batch(fb, self_paced=True, encoder="chunked", lengths=Ls)
+
+
+def test_concurrent_streaming_eval_equals_one_agent(ops):
+    """agent.ConcurrentStreamingEval (self-paced batches on three HIP streams, replicas sharing the device weights, batches taken
+    from a queue) returns for every batch exactly the records of one BatchedStreamingAgent run on it alone -- ragged batches,
+    MMA-hard rows that diverge."""
+    from simulst_amd.agent import BatchedStreamingAgent, ConcurrentStreamingEval
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, simul_attn_type="hard_aligned_fixed_pre_decision", mass_preservation=True,
+                      max_target_positions=40)
+    w = init_model(cfg, seed=4244)
+    for l in range(2):
+        w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 8
+    w["decoder.embed_tokens.weight"][cfg.eos] *= 1.5
+    model = SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=ops)
+    g = torch.Generator().manual_seed(80)
+    batches = []
+    for n, Ls in ((5, [400, 333, 96, 250, 401]), (3, [640, 600, 590]), (4, [120, 120, 120, 120]), (2, [1100, 777]), (6, [300] * 6)):
+        fb = torch.randn(n, max(Ls), 80, generator=g)
+        for b, L in enumerate(Ls):
+            fb[b, L:] = 0
+        batches.append((fb.cuda().to(torch.bfloat16), Ls))
+    one = BatchedStreamingAgent(model, max_len_a=0.1, max_len_b=10)
+    want = [one.run_batch(fb, self_paced=True, encoder="offline", lengths=Ls) for fb, Ls in batches]
+    pipe = ConcurrentStreamingEval(model, w, 3, agent_factory=lambda m: BatchedStreamingAgent(m, max_len_a=0.1, max_len_b=10))
+    for _ in range(2):
+        got = pipe.run(batches)
+        assert len(got) == len(want)
+        for gb, wb in zip(got, want):
+            assert len(gb) == len(wb)
+            for gr, wr in zip(gb, wb):
+                for k in ("actions", "tokens", "delays_ms", "AL"):
+                    assert gr[k] == wr[k], k
+    assert len({r["actions"] for r in want[0]}) > 1
