@@ -77,6 +77,20 @@ __global__ __launch_bounds__(256) void cif_commit_kernel(const float* __restrict
     const float bias = eos_bias[b];
     float best = -INFINITY;
     int bi = 0x7fffffff;
+    if ((V & 3) == 0) {                                  // 16-byte loads: a thread's candidates still arrive in index order
+      for (int c4 = tid; c4 < (V >> 2); c4 += 256) {
+        const float4 q = *reinterpret_cast<const float4*>(row + 4 * c4);
+        const float vv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * c4 + e;
+          float v = vv[e];
+          if (c == eos_idx) v += bias;
+          if ((!streaming && c == pad_idx) || (no_eos && c == eos_idx)) v = -INFINITY;
+          if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+        }
+      }
+    } else
     for (int c = tid; c < V; c += 256) {
       float v = row[c];
       if (c == eos_idx) v += bias;
