@@ -309,7 +309,7 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
     fb_cpu = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + i)) for i in range(n_off)])
     g_max = max(plan)
     out = {}
-    for key in ("configs1_batched_streaming", "configs2_mma_hard", "configs3_cif"):
+    def one_leg(key):
         t_leg = time.perf_counter()
         cif, waitk = key == "configs3_cif", key == "configs1_batched_streaming"
         if waitk:
@@ -508,6 +508,15 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             f"{parity['streaming_fp32_actions_tokens_delays_AL_identical_to_oracle']}")
         del pipe, model, m32
         torch.cuda.empty_cache()
+
+    for key in ("configs1_batched_streaming", "configs2_mma_hard", "configs3_cif"):
+        try:
+            one_leg(key)
+        except Exception as e:                               # a failing leg must not cost the line its main measurement
+            import traceback
+            out[key] = {"error": repr(e), "traceback_tail": traceback.format_exc().strip().splitlines()[-3:]}
+            log(f"{key}: FAILED {e!r}")
+            torch.cuda.empty_cache()
     return out
 
 
