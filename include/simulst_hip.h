@@ -149,6 +149,12 @@ typedef struct {
   int32_t c_head_dim;          /* > 0 (bias epilogue only): HEAD-MAJOR output, column c of row (b, i) is stored at */
   int64_t c_head_stride;       /*   b*c_batch_stride + (c / c_head_dim)*c_head_stride + i*c_row_stride + c % c_head_dim */
                                /* -- how the cross-attention K / V projections land in [B][H][S_cap][head_dim].   */
+  int32_t c_tensor_heads;      /* > 0 (with c_head_dim): the output columns are SEVERAL head-major tensors side by side, each   */
+  int64_t c_tensor_stride;     /*   c_tensor_heads heads wide and c_tensor_stride elements apart: head plane p = c / c_head_dim */
+                               /*   goes to (p / c_tensor_heads)*c_tensor_stride + b*c_batch_stride +                           */
+                               /*   (p % c_tensor_heads)*c_head_stride + ...  -- the K and V projections of EVERY decoder layer */
+                               /*   (models/mma_model.py: 2 x decoder_layers nn.Linear calls over the same encoder states) as   */
+                               /*   ONE contraction that reads the encoder states once.                                         */
 } simulst_linear_desc;
 
 int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, const void* A, const void* W,

@@ -33,7 +33,8 @@ class LinearDesc(C.Structure):
                 ("epilogue", C.c_int32), ("dtype", C.c_int32), ("scale", C.c_float),
                 ("n_main", C.c_int32), ("aux_rows", C.c_int32), ("aux_batch_stride", C.c_int64),
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("w_fragment_major", C.c_int32),
-                ("c_head_dim", C.c_int32), ("c_head_stride", C.c_int64)]
+                ("c_head_dim", C.c_int32), ("c_head_stride", C.c_int64),
+                ("c_tensor_heads", C.c_int32), ("c_tensor_stride", C.c_int64)]
 
 
 class EmfAttnDesc(C.Structure):

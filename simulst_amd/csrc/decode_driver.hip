@@ -547,7 +547,7 @@ int lin(simulst_handle* h, int dtype, int B, int N, int K, const void* A, const 
   d.c_batch_stride = 0; d.c_row_stride = N;
   d.r_batch_stride = 0; d.r_row_stride = N;
   d.epilogue = epi; d.dtype = dtype; d.scale = 1.f; d.n_main = 0; d.aux_rows = 0; d.aux_batch_stride = 0;
-  d.ln_gamma = ln_g; d.ln_beta = ln_b; d.w_fragment_major = w_packed; d.c_head_dim = 0; d.c_head_stride = 0;
+  d.ln_gamma = ln_g; d.ln_beta = ln_b; d.w_fragment_major = w_packed; d.c_head_dim = 0; d.c_head_stride = 0; d.c_tensor_heads = 0; d.c_tensor_stride = 0;
   return simulst_linear(h, &d, A, W, bias, R, C, nullptr);
 }
 

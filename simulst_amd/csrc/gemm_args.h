@@ -17,11 +17,16 @@ struct LinArgs {
   int w_packed;        // weights in fragment-major order (gemv_mfma.h); decode-step shapes only
   int c_hd;            // > 0: head-major output -- column c of row (b, ii) goes to b*c_bs + (c/c_hd)*c_hs + ii*c_rs + c%c_hd
   long c_hs;           //      (cross-attention K/V projections stored [B][H][S_cap][head_dim]); 0: plain [.., N] rows
+  int c_th;            // > 0: several head-major tensors side by side, c_th heads each, c_ts elements apart
+  long c_ts;
 };
 
 __device__ __forceinline__ long c_index(const LinArgs& p, int b, int ii, int c) {
   const long base = (long)b * p.c_bs + (long)ii * p.c_rs;
-  return p.c_hd > 0 ? base + (long)(c / p.c_hd) * p.c_hs + (c % p.c_hd) : base + c;
+  if (p.c_hd <= 0) return base + c;
+  const int plane = c / p.c_hd;
+  if (p.c_th > 0) return base + (long)(plane / p.c_th) * p.c_ts + (long)(plane % p.c_th) * p.c_hs + (c % p.c_hd);
+  return base + (long)plane * p.c_hs + (c % p.c_hd);
 }
 
 

@@ -109,9 +109,12 @@ class DecoderState:
         self.n_prev_host = 0                 # lockstep batches: every row has written this many tokens
         # cached cross-attention projections of the encoder states, per layer
         # cached cross-attention projections, HEAD-MAJOR [B, H, S_cap, d]: a head's key rows are contiguous lines
-        self.Kmono = [torch.zeros(B, H, S_cap, d, device=device, dtype=dtype) for _ in range(Ld)]
+        # ... of ALL layers in one allocation [2 Ld][B][H][S_cap][d] (layer l: K at 2 l, V at 2 l + 1), so that one contraction
+        # over the encoder states can write every layer's K and V (MMADecoder.append_encoder_out)
+        self.KV = torch.zeros(2 * Ld, B, H, S_cap, d, device=device, dtype=dtype)
+        self.Kmono = [self.KV[2 * l] for l in range(Ld)]
         self.Ksoft = None
-        self.V = [torch.zeros(B, H, S_cap, d, device=device, dtype=dtype) for _ in range(Ld)]
+        self.V = [self.KV[2 * l + 1] for l in range(Ld)]
         # pooled monotonic keys of the complete pre-decision windows (simulst_pool_keys), [B, H, P_cap, d] fp32 per layer;
         # allocated by MMADecoder.new_state for learned policies with 'average' pooling
         self.Kpool = None
@@ -135,7 +138,11 @@ class DecoderState:
         if cap is not None and cap > self.cap:
             self.k_cache, self.v_cache, self.cap = regrow(self.k_cache, cap), regrow(self.v_cache, cap), cap
         if S_cap is not None and S_cap > self.S_cap:
-            self.Kmono, self.V = regrow(self.Kmono, S_cap), regrow(self.V, S_cap)
+            kv = torch.zeros(*self.KV.shape[:3], S_cap, self.KV.shape[4], device=self.KV.device, dtype=self.KV.dtype)
+            kv[:, :, :, :self.S_cap] = self.KV
+            self.KV = kv
+            Ld = kv.shape[0] // 2
+            self.Kmono, self.V = [kv[2 * l] for l in range(Ld)], [kv[2 * l + 1] for l in range(Ld)]
             if self.Ksoft is not None:
                 self.Ksoft = regrow(self.Ksoft, S_cap)
             if self.Kpool is not None:
@@ -207,6 +214,9 @@ class MMADecoder:
         # frames arrive (simulst_pool_keys) instead of being pooled from the frames at every decode step
         self.pool_cache = (cfg.attn_type != "waitk" and cfg.pre_decision_ratio > 1 and cfg.fixed_pre_decision_type == "average"
                            and os.environ.get("SIMULST_POOL_CACHE", "1") == "1")
+        # K and V projections of every layer over new encoder rows as ONE contraction (tall bf16 batches; SIMULST_FUSE_KV=0: one
+        # launch per projection as in round 2)
+        self.fuse_kv_projections = os.environ.get("SIMULST_FUSE_KV", "1") == "1"
         self.soft = cfg.attn_type != "hard_aligned"
         self.separate_soft = cfg.attn_type in ("infinite_lookback", "chunkwise")
         self.embed_scale = 1.0 if cfg.no_scale_embedding else math.sqrt(cfg.embed_dim)
@@ -263,8 +273,17 @@ class MMADecoder:
         if n > 0:
             a_bs = enc_new.stride(0)
             assert enc_new.stride(2) == 1 and enc_new.stride(1) == D
+            hd, H = cfg.head_dim, cfg.num_heads
+            fused = B * n >= 4096 and getattr(self.w, "kv_all_packed", None) is not None      # row-panel kernel's domain
+            if fused:
+                # K and V of every layer in one launch (12 for this model): a row panel keeps its encoder rows in registers and
+                # sweeps all 2 Ld D columns; column block j lands in tensor j of st.KV
+                ops.linear_raw(enc_new, self.w.kv_all_packed, self.w.kv_all_bias, st.KV[0][:, :, r0:], M_batches=B, rows_per_batch=n,
+                               N=2 * cfg.decoder_layers * D, K=D, a_bs=a_bs, a_rs=D, c_bs=H * st.S_cap * hd, c_rs=hd,
+                               epilogue=EPI_BIAS, c_head_dim=hd, c_head_stride=st.S_cap * hd, w_fragment_major=True,
+                               c_tensor_heads=H, c_tensor_stride=B * H * st.S_cap * hd)
             for l, L in enumerate(self.w.layers):
-                jobs = [(L["c_wk"], L["c_bk"], st.Kmono[l]), (L["c_wv"], L["c_bv"], st.V[l])]
+                jobs = [] if fused else [(L["c_wk"], L["c_bk"], st.Kmono[l]), (L["c_wv"], L["c_bv"], st.V[l])]
                 if self.separate_soft:
                     jobs.append((L["c_wk_soft"], L["c_bk_soft"], st.Ksoft[l]))
                 for Wt, bt, dst in jobs:
@@ -408,6 +427,13 @@ class MMADecoder:
                 for n in ("c_wk", "c_wv") + (("c_wk_soft",) if self.separate_soft else ()):
                     kv_packed[L[n].data_ptr()] = self.ops.pack_fragment_major(L[n])
         w.packed, w.out_proj_packed, w.kv_packed = packed, out_proj_packed, kv_packed
+        # every layer's K and V projection as ONE [2 Ld D, D] weight (rows: layer 0 K, layer 0 V, layer 1 K, ...): the encoder
+        # states are read once instead of 2 Ld times (append_encoder_out)
+        w.kv_all_packed = w.kv_all_bias = None
+        if kv_packed and self.fuse_kv_projections:
+            Wall = torch.cat([L[n] for L in w.layers for n in ("c_wk", "c_wv")], 0).contiguous()
+            w.kv_all_packed = self.ops.pack_fragment_major(Wall)
+            w.kv_all_bias = torch.cat([L[n] for L in w.layers for n in ("c_bk", "c_bv")], 0).contiguous()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 

@@ -47,11 +47,12 @@ class Ops:
     # ------------------------------------------------------------------ dense
     def linear_raw(self, A, W, bias, C_out, *, M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead=0,
                    c_bs, c_rs, epilogue=EPI_BIAS, R=None, r_bs=0, r_rs=0, scale=1.0, n_main=0, aux=None,
-                   aux_rows=0, aux_bs=0, ln=None, w_fragment_major=False, c_head_dim=0, c_head_stride=0):
+                   aux_rows=0, aux_bs=0, ln=None, w_fragment_major=False, c_head_dim=0, c_head_stride=0, c_tensor_heads=0,
+                   c_tensor_stride=0):
         d = LinearDesc(M_batches, rows_per_batch, N, K, a_bs, a_rs, a_lead, c_bs, c_rs, r_bs, r_rs,
                        epilogue, dt(A), scale, n_main, aux_rows, aux_bs,
                        ln[0].data_ptr() if ln is not None else None, ln[1].data_ptr() if ln is not None else None,
-                       int(w_fragment_major), c_head_dim, c_head_stride)
+                       int(w_fragment_major), c_head_dim, c_head_stride, c_tensor_heads, c_tensor_stride)
         self.h.check(self.lib.simulst_linear(self.h.ptr, C.byref(d), _p(A), _p(W), _p(bias), _p(R), _p(C_out),
                                              _p(aux)), "simulst_linear")
         return C_out

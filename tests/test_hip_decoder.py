@@ -345,3 +345,38 @@ def test_ragged_offline_batch_equals_the_references_padded_batch_decoding(ops, a
     assert differing == 0, differing
     steps = torch.stack([h.cpu() for h in info["state"].head_step])
     assert len(torch.unique(steps)) > 6, "the policies did not move"
+
+
+def test_fused_kv_projection_of_all_layers_equals_one_launch_per_projection(ops):
+    """append_encoder_out on a tall bf16 batch: ONE contraction writes the K and V projections of every decoder layer
+    (simulst_linear_desc.c_tensor_heads: the output columns are 2 x layers head-major tensors side by side) -- bit-identical to
+    the 2 x layers launches it replaces, also when the rows are appended in two pieces and with ragged lengths."""
+    import torch
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=1, decoder_layers=3, simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=3)
+    model = SimulSTModel(cfg, init_model(cfg, seed=11), dtype=torch.bfloat16, ops=ops)
+    dec = model.decoder
+    assert dec.w.kv_all_packed is not None
+    B, n1, n2 = 40, 120, 130
+    enc = torch.randn(B, n1 + n2, cfg.embed_dim, generator=torch.Generator().manual_seed(3)).cuda().to(torch.bfloat16)
+    lens = torch.randint(50, n1 + n2 + 1, (B,), generator=torch.Generator().manual_seed(4))
+
+    def run():
+        st = dec.new_state(B, cap=8, S_cap=n1 + n2 + 6)
+        dec.append_encoder_out(st, enc[:, :n1], torch.clamp(lens, max=n1))
+        dec.append_encoder_out(st, enc[:, n1:], lens)
+        torch.cuda.synchronize()
+        return st
+    fused = run()
+    keep = dec.w.kv_all_packed
+    dec.w.kv_all_packed = None
+    try:
+        plain = run()
+    finally:
+        dec.w.kv_all_packed = keep
+    assert torch.equal(fused.KV, plain.KV)
+    assert float(fused.KV[:, :, :, :n1 + n2].float().abs().sum()) > 0
+    for l in range(3):
+        assert fused.Kmono[l].data_ptr() == fused.KV[2 * l].data_ptr() and fused.V[l].data_ptr() == fused.KV[2 * l + 1].data_ptr()
