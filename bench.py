@@ -89,6 +89,9 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="replay the decode step as a hipGraph (measured neutral on MI355X: the step is bound by "
                          "kernel bodies, not by launch cost)")
+    ap.add_argument("--joint-encoder-max-rows", type=int, default=2048,
+                    help="plans with at most this many utterances in all run ONE encoder pass for every launch sequence before the "
+                         "sequences decode side by side (0: an encoder pass per sequence)")
     ap.add_argument("--passes", type=int, default=3,
                     help="timed passes of the K-step plan; value = the MEDIAN pass, all of them are reported")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] streaming / configs[2] / configs[3] legs")
@@ -334,7 +337,8 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
         Model = CIFTransformerModel if cif else SimulSTModel
         model = Model(cfg, w, device=dev, dtype=dtype)
         factory = (lambda ops: CIFTransformerModel(cfg, w, device=dev, dtype=dtype, ops=ops)) if cif else None
-        pipe = ConcurrentOffline(model, w, args.concurrency, factory=factory) if args.concurrency > 1 else None
+        pipe = (ConcurrentOffline(model, w, args.concurrency, factory=factory, joint_encoder_max_rows=args.joint_encoder_max_rows)
+                if args.concurrency > 1 else None)
 
         def seqs():
             o, r0 = [], 0
@@ -634,7 +638,8 @@ def main(argv=None):
     pipe = None
     if args.concurrency > 1:
         from simulst_amd.model import ConcurrentOffline
-        pipe = ConcurrentOffline(model, weights, args.concurrency, graph=args.graph, stagger_encoders=args.stagger)
+        pipe = ConcurrentOffline(model, weights, args.concurrency, graph=args.graph, stagger_encoders=args.stagger,
+                                 joint_encoder_max_rows=args.joint_encoder_max_rows)
     elif not args.no_pipeline:
         from simulst_amd.model import OfflinePipeline
         pipe = OfflinePipeline(model)

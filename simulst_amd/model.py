@@ -234,7 +234,7 @@ class ConcurrentOffline:
     generate_offline; replicas share the device weights and own their stream, handle and decoder state."""
 
     def __init__(self, model: SimulSTModel, weights, concurrency: int = 4, graph: bool = False,
-                 stagger_encoders: bool = False, factory=None):
+                 stagger_encoders: bool = False, factory=None, joint_encoder_max_rows: int = 0):
         """stagger_encoders chains the encoder passes of the streams on the device (each waits for the previous
         stream's). Measured on MI355X it is SLOWER than letting them run side by side (20-step form 1.235 M vs
         1.290 M tokens/s, 384-step form 1.757 M vs 1.786 M): the side-by-side encoders already share the MFMA pipes
@@ -244,6 +244,9 @@ class ConcurrentOffline:
         from . import _lib
         self.models, self.streams = [], []
         self.stagger_encoders = stagger_encoders
+        # small plans: ONE encoder pass over the utterances of every launch sequence (the encoder's kernels are throughput-bound
+        # and run closer to their rates on 1 280 rows than on three times 448), then the sequences decode side by side
+        self.joint_encoder_max_rows = 0 if factory is not None else joint_encoder_max_rows
         self._enc_lock, self._enc_event = threading.Lock(), None
         dev = model.device
         for c in range(concurrency):
@@ -272,6 +275,28 @@ class ConcurrentOffline:
             self._enc_event = ev
         return m.decoder.greedy_offline(enc["encoder_out_btd"], enc["encoder_lengths"], n_steps, mask_eos)[0]
 
+    def _joint_encoder(self, batches):
+        """one encoder.forward over all batches on stream 0 -> per batch (encoder_out rows, lengths) + the event to wait for"""
+        toks = [b[0] for b in batches]
+        esz = toks[0].element_size()
+        adjacent = all(t.is_contiguous() and t.shape[1:] == toks[0].shape[1:] for t in toks) and all(
+            toks[i].data_ptr() + toks[i].numel() * esz == toks[i + 1].data_ptr() for i in range(len(toks) - 1))
+        total = sum(t.size(0) for t in toks)
+        if adjacent and toks[0].untyped_storage().data_ptr() == toks[-1].untyped_storage().data_ptr():
+            allt = toks[0].as_strided((total,) + tuple(toks[0].shape[1:]), toks[0].stride())     # the batches are slices of one tensor
+        else:
+            allt = torch.cat(toks, 0)
+        lens = torch.cat([b[1].to(allt.device) for b in batches], 0)
+        with torch.no_grad(), torch.cuda.stream(self.streams[0]):
+            enc = self.models[0].encoder.forward(allt, lens)
+            ev = torch.cuda.Event()
+            ev.record(self.streams[0])
+        parts, r0 = [], 0
+        for t in toks:
+            parts.append((enc["encoder_out_btd"][r0:r0 + t.size(0)], enc["encoder_lengths"][r0:r0 + t.size(0)]))
+            r0 += t.size(0)
+        return parts, ev, enc
+
     def run(self, batches, n_steps: int, mask_eos: bool = False, on_tokens=None):
         import threading
         batches = list(batches)
@@ -281,6 +306,11 @@ class ConcurrentOffline:
         for st in self.streams:
             st.wait_stream(cur)
         dev_index = self.models[0].device.index
+        joint = None
+        if (self.joint_encoder_max_rows > 0 and len(batches) > 1 and not self.stagger_encoders and
+                sum(b[0].size(0) for b in batches) <= self.joint_encoder_max_rows and
+                len({tuple(b[0].shape[1:]) for b in batches}) == 1):
+            joint = self._joint_encoder(batches)
 
         def worker(c):
             try:
@@ -288,7 +318,12 @@ class ConcurrentOffline:
                     torch.cuda.set_device(dev_index)
                 with torch.no_grad(), torch.cuda.stream(self.streams[c]):
                     for i in range(c, len(batches), len(self.models)):
-                        toks = self._generate(c, batches[i][0], batches[i][1], n_steps, mask_eos).clone()
+                        if joint is not None:
+                            self.streams[c].wait_event(joint[1])
+                            e_out, e_len = joint[0][i]
+                            toks = self.models[c].decoder.greedy_offline(e_out, e_len, n_steps, mask_eos)[0].clone()
+                        else:
+                            toks = self._generate(c, batches[i][0], batches[i][1], n_steps, mask_eos).clone()
                         out[i] = on_tokens(toks) if on_tokens is not None else toks
             except Exception as e:          # surfaced to the caller below
                 errs.append(e)

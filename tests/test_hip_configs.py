@@ -111,6 +111,28 @@ def test_config2_concurrent_replicas_reached_cold(cfg_w):
             assert torch.equal(t, ref)
 
 
+def test_config2_joint_encoder_pass_of_a_small_plan(cfg_w):
+    """ConcurrentOffline(joint_encoder_max_rows=...): ONE encoder pass over the utterances of every launch sequence of a small
+    plan (the driver's [7, 7, 6] batches: slices of one tensor, taken as a view; and separate tensors, concatenated), the
+    sequences then decode side by side -- every sequence's tokens equal the serial generate_offline result."""
+    from simulst_amd.model import ConcurrentOffline, SimulSTModel
+    cfg, w = cfg_w
+    model = SimulSTModel(cfg, w, dtype=torch.bfloat16)
+    pool = ConcurrentOffline(model, w, 3, joint_encoder_max_rows=2048)
+    g = torch.Generator().manual_seed(12)
+    fb_all = torch.randn(1280, 1000, 80, generator=g).to(torch.bfloat16).cuda()
+    L = lambda n: torch.full((n,), 1000, device="cuda")
+    slices = [(fb_all[:448], L(448)), (fb_all[448:896], L(448)), (fb_all[896:], L(384))]
+    separate = [(fb_all[:192].clone(), L(192)), (fb_all[192:448].clone(), L(256))]
+    with torch.no_grad():
+        for seqs in (slices, separate):
+            got = pool.run(seqs, 16, mask_eos=True)
+            torch.cuda.synchronize()
+            for (fb, Ln), t in zip(seqs, got):
+                ref, _ = model.generate_offline(fb, Ln, n_steps=16, mask_eos=True)
+                assert torch.equal(t, ref)
+
+
 def _parity_args(**kw):
     base = dict(max_tokens=24, threads=min(os.cpu_count() or 1, 16), utterances=1, batched=False, attn=None)
     base.update(kw)
