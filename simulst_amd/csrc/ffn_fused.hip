@@ -154,8 +154,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ffn_fused_kernel(const bf16* __
         for (int i = 0; i < FF_PF; ++i) wf[i] = w1[(t * 16 + i) * 64 + lane];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
+          if constexpr (VARIANT != 3 && VARIANT != 4)         // timing ablations 3 / 4: without the first product
           hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wf[s % FF_PF]),
                                                          *reinterpret_cast<const bf16x8_t*>(&xa[s]), hacc, 0, 0, 0);
+          else hacc[s] += __uint_as_float(wf[s % FF_PF].x);
           if (s + FF_PF < 16) wf[s % FF_PF] = w1[(t * 16 + s + FF_PF) * 64 + lane];
         }
       }
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ffn_fused_kernel(const bf16* __
         const float4 bv = *reinterpret_cast<const float4*>(b1s + h0 + 8 * g);
         f32x2 v0 = f32x2{hacc[4 * g] + bv.x, hacc[4 * g + 1] + bv.y};
         f32x2 v1 = f32x2{hacc[4 * g + 2] + bv.z, hacc[4 * g + 3] + bv.w};
-        if constexpr (VARIANT != 1) { v0 = gelu_fast2(v0); v1 = gelu_fast2(v1); }   // VARIANT 1: timing ablation only
+        if constexpr (VARIANT != 1 && VARIANT != 5) { v0 = gelu_fast2(v0); v1 = gelu_fast2(v1); }   // VARIANT 1 / 5: timing ablations only
         unsigned int* dst = reinterpret_cast<unsigned int*>(&hb[g >> 1]) + (g & 1) * 2;
         dst[0] = pack_bf16x2(v0.x, v0.y);
         dst[1] = pack_bf16x2(v1.x, v1.y);
@@ -179,8 +181,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ffn_fused_kernel(const bf16* __
         for (int i = 0; i < FF_PF; ++i) wf[i] = w2[(t * 16 + i) * 64 + lane];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {                      // i = s * 8 + n
+          if constexpr (VARIANT != 2 && VARIANT != 4)         // timing ablations 2 / 4: without the second product
           y[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&hb[i >> 3]),
                                                              *reinterpret_cast<const bf16x8_t*>(&wf[i % FF_PF]), y[i & 7], 0, 0, 0);
+          else y[i & 7][i] += __uint_as_float(wf[i % FF_PF].x ^ hb[i >> 3].x);
           if (i + FF_PF < 16) wf[i % FF_PF] = w2[(t * 16 + i + FF_PF) * 64 + lane];
         }
       }
@@ -240,6 +244,10 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
       e = hipFuncSetAttribute((const void*)ffn_fused_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<8>::LDS);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)ffn_fused_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_fused_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_fused_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_fused_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_fused_kernel<5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
     if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit"; return (int)e; }
     h->ffn_lds_attr_set = true;
   }
@@ -252,6 +260,10 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
   // simulst_debug_ffn_variant: 1 = no-GELU timing ablation (8 waves), 2 / 3 = force the 8- / 4-wave geometry
   const bool four = h->ffn_variant == 3 || (h->ffn_variant == 0 && FF_DEFAULT_FOUR_WAVES);
   if (h->ffn_variant == 1) FFN(1, 8);
+  else if (h->ffn_variant == 12) FFN(2, 4);      // 4-wave geometry ablations (results are NOT the operator's): no second product,
+  else if (h->ffn_variant == 13) FFN(3, 4);      //   no first product,
+  else if (h->ffn_variant == 14) FFN(4, 4);      //   no product at all (staging + barriers + GELU + fragment reads),
+  else if (h->ffn_variant == 15) FFN(5, 4);      //   no GELU
   else if (four && F <= FFG<4>::MAX_F) FFN(0, 4);
   else FFN(0, 8);
 #undef FFN

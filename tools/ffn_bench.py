@@ -55,7 +55,9 @@ def main():
 
         # variant 1: the kernel WITHOUT the GELU arithmetic -- a timing ablation, how much of the launch the un-hidden GELU is
         fns = (("fused", fused), ("two_launch", two), ("fused_no_gelu_ablation", variant(1)),
-               ("fused_one_8wave_workgroup_per_cu", variant(2)), ("fused_two_4wave_workgroups_per_cu", variant(3)))
+               ("fused_one_8wave_workgroup_per_cu", variant(2)), ("fused_two_4wave_workgroups_per_cu", variant(3)),
+               ("ablation_4wave_no_second_product", variant(12)), ("ablation_4wave_no_first_product", variant(13)),
+               ("ablation_4wave_no_products", variant(14)), ("ablation_4wave_no_gelu", variant(15)))
         t = {name: [] for name, _ in fns}
         for _, fn in fns:
             fn()
