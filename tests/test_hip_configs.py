@@ -332,3 +332,58 @@ def test_config5_one_ranks_shard(cfg_w):
             k = len(hyp[i])
             agree = sum(a == b for a, b in zip(alone[:k], hyp[i])) / k
             assert agree > 0.9, (i, agree)
+
+
+def test_config5_one_ranks_shard_as_streaming_evaluation():
+    """configs[4] in its stated semantics ("batched streaming eval"): one rank's shard (256 of 2 048 utterances, 100-3000 frames) cut
+    into launch sequences by cost, streamed by agent.ConcurrentStreamingEval (self-paced rows, encoder states of one padded offline
+    forward per sequence, three streams), fp32: every utterance once; delays non-decreasing, stamped at chunk boundaries of ITS
+    source and never later than its end; token counts within the cap; and the READ / WRITE string, tokens, delays and Average
+    Lagging of sampled utterances -- the longest, the shortest, two in between -- equal the CPU oracle's simulation of that
+    utterance alone (a flip would need a near-tie under the encoder's rounding)."""
+    from oracle import agent as oag
+    from oracle.configs import from_model_config
+    from simulst_amd.agent import BatchedStreamingAgent, ConcurrentStreamingEval
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.offline_eval import make_batch, plan_shard_by_work, sequence_cost, synthetic_fbank, synthetic_lengths
+    from simulst_amd.weights import init_model
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=3)
+    w = init_model(cfg, seed=999)
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0                      # hypotheses run to their cap (bench.py's streaming legs)
+    lengths = synthetic_lengths(2048)
+    seqs = plan_shard_by_work(lengths, 8, 3, max_rows=96, streams=3)
+    seqs.sort(key=lambda idx: -sequence_cost(idx, lengths, 3))
+    mine = [i for s in seqs for i in s]
+    assert len(mine) == 256 and len(set(mine)) == 256
+    model = SimulSTModel(cfg, w, dtype=torch.float32)
+    mk = lambda m: BatchedStreamingAgent(m, max_len_a=0.1, max_len_b=10)
+    pipe = ConcurrentStreamingEval(model, w, 3, agent_factory=mk)
+    work = []
+    for idx in seqs:
+        fb, _, L, _, _ = make_batch(idx, lengths, "cuda", torch.float32)
+        work.append((fb, L.tolist()))
+    with torch.no_grad():
+        recs = pipe.run(work)
+    by_utt = {}
+    for idx, rb in zip(seqs, recs):
+        assert len(rb) == len(idx)
+        for i, r in zip(idx, rb):
+            by_utt[i] = r
+    assert sorted(by_utt) == sorted(mine)
+    for i, r in by_utt.items():
+        T = lengths[i]
+        end_ms = T * 10 + 15
+        assert 1 <= len(r["tokens"]) <= int(0.1 * T + 10) + 1
+        d = r["delays_ms"]
+        assert all(a <= b for a, b in zip(d, d[1:])) and d[-1] <= end_ms
+        assert all(x == end_ms or (x - 15) % 640 == 320 for x in d)       # 96 frames, then 64 more per READ: 975, 1615, ... ms
+        assert r["actions"].count("W") == len(r["tokens"]) and r["actions"][0] == "R"
+    ecfg, dcfg = from_model_config(cfg)
+    order = sorted(mine, key=lambda i: lengths[i])
+    for i in (order[0], order[len(order) // 3], order[2 * len(order) // 3], order[-1]):
+        ref = oag.simulate_mma(w, ecfg, dcfg, synthetic_fbank(i, lengths[i]), max_len_a=0.1, max_len_b=10)
+        got = by_utt[i]
+        for k in ("actions", "tokens", "delays_ms", "AL"):
+            assert got[k] == ref[k], (i, lengths[i], k)
