@@ -54,8 +54,11 @@ struct HeadSplit {
 //  3. hard gather / softmax over keys <= step (:261-297), PV
 // FQ = the fused-query instantiation (LN2 + q-projection inside the launch, <= 128 rows); the plain one drops that code
 // and its registers and runs 4 workgroups per CU
+#ifndef SL_POLICY_WGS
+#define SL_POLICY_WGS 4
+#endif
 template <typename T, int NP, bool FQ>
-__global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : 4)) void policy_cross_attn_kernel(
+__global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void policy_cross_attn_kernel(
     const T* __restrict__ qm, const T* __restrict__ qs, const T* __restrict__ Km, const T* __restrict__ Ks,
     const T* __restrict__ Vc, float energy_bias, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
     long* __restrict__ head_step, unsigned char* __restrict__ head_read, T* __restrict__ ctx, int H, int d,
