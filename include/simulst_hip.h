@@ -73,7 +73,7 @@ int simulst_create(simulst_handle** out, void* hip_stream);
 int simulst_destroy(simulst_handle* h);
 int simulst_set_stream(simulst_handle* h, void* hip_stream);
 const char* simulst_last_error(simulst_handle* h);
-int simulst_version(void);
+int simulst_version(void);            /* 103 (round 3: descriptors grew, see the structs); a binding built for another value must not pass them */
 /* per-kernel-class HIP-event timing on the handle's stream (off by default) */
 int simulst_timer_enable(simulst_handle* h, int kernel_class, int on);
 int simulst_timer_read(simulst_handle* h, int kernel_class, double* total_ms, int64_t* launches);

@@ -155,6 +155,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 103          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
 
 
 def load():
@@ -173,6 +174,9 @@ def load():
         fn.restype = (C.c_char_p if name == "simulst_last_error"
                       else C.c_int64 if name in ("simulst_ctc_best_alignment_scratch_bytes", "simulst_debug_chain_probe_bytes")
                       else C.c_int)
+    if lib.simulst_version() != ABI_VERSION:          # the ctypes structures above mirror ONE layout of the descriptors
+        raise RuntimeError(f"simulst_amd: {LIB_PATH} reports ABI version {lib.simulst_version()}, this binding is written for "
+                           f"{ABI_VERSION} -- rebuild the library (make -C simulst_amd/csrc)")
     _lib = lib
     return lib
 

@@ -2,7 +2,9 @@
 #include "common.h"
 #include <cstdlib>
 
-extern "C" int simulst_version(void) { return 100; }
+// 100: rounds 1-2.  103: round 3 -- simulst_linear_desc, simulst_stream_ctl and simulst_cif_stream_ctl grew at their ends
+// (c_tensor_heads / c_tensor_stride; the chunk schedules of self-paced rows), simulst_decoder_desc gained P_cap.
+extern "C" int simulst_version(void) { return 103; }
 
 extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (!out) return SIMULST_E_NULL;

@@ -23,7 +23,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/simulst_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert lib.simulst_version() >= 100
+    from simulst_amd._lib import ABI_VERSION
+    assert lib.simulst_version() == ABI_VERSION
 
 
 def test_library_exports_nothing_but_the_declared_abi():
