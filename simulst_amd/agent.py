@@ -220,7 +220,6 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
 
     def _run_batch_self_paced(self, fbank: torch.Tensor, encoder: str = "chunked", lengths=None):
         from . import _lib
-        from .latency import average_lagging
         model, dec, enc = self.model, self.model.decoder, self.model.encoder
         cfg, dev = model.cfg, model.device
         B, T = fbank.size(0), fbank.size(1)
@@ -322,7 +321,6 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
                                   lambda b, c: per_T[Ls[b]][1][c])
 
     def _run_batch_lockstep(self, fbank: torch.Tensor):
-        import ctypes as C
         from . import _lib
         from .latency import average_lagging
         model, dec, enc = self.model, self.model.decoder, self.model.encoder

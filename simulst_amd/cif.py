@@ -507,7 +507,6 @@ class BatchedCIFStreamingAgent(CIFAgent):
         return self._run_batch_lockstep(fbank)
 
     def _run_batch_self_paced(self, fbank: torch.Tensor, encoder: str):
-        from .latency import average_lagging
         if encoder not in ("chunked", "offline"):
             raise ValueError(f"encoder={encoder!r}: 'chunked' or 'offline'")
         model, dec, enc = self.model, self.model.decoder, self.model.encoder
