@@ -881,6 +881,19 @@ def main(argv=None):
             "roofline": roofline, "cpu_baseline": cpu_base,
         }
         out.update(extra)
+        # the other half of BASELINE.json's metric ("decoded tgt tokens/sec + Average Lagging"): AL of the streamed runs of the
+        # legs and whether READ / WRITE strings, tokens, delays and AL of the fp32 sample equal the CPU oracle's
+        al = {}
+        for key, name in (("configs1_batched_streaming", "configs1_waitk5"), ("configs2_mma_hard", "configs2_mma_hard"),
+                          ("configs3_cif", "configs3_cif")):
+            leg = extra.get(key) or {}
+            if "batched_streaming" in leg:
+                al[name] = {"average_lagging_ms_mean": leg["batched_streaming"]["average_lagging_ms_mean"],
+                            "rows": leg["batched_streaming"]["rows"],
+                            "identical_to_cpu_oracle_on_fp32_sample":
+                                leg["parity_on_sample"]["streaming_fp32_actions_tokens_delays_AL_identical_to_oracle"]}
+        if al:
+            out["average_lagging"] = al
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
