@@ -485,6 +485,13 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             ag32 = (BatchedCIFStreamingAgent(m32, max_len_a=0.1, max_len_b=10) if cif
                     else BatchedStreamingAgent(m32, max_len_a=0.1, max_len_b=10, steps_per_call=8))
             got32 = ag32.run_batch(fb_cpu[:n_str].to(dev))
+            # fp32, 64 rows: do the encoder states of ONE offline forward change any decision against the chunk-by-chunk encoder?
+            # (they are the same function up to rounding; the bf16 rows above flip at near-ties of a random-init model)
+            fb64 = fbs[:64].float()
+            r_ch = ag32.run_batch(fb64, self_paced=True)
+            r_of = ag32.run_batch(fb64, self_paced=True, encoder="offline")
+            paced_off["fp32_rows_identical_to_chunked_encoder_states"] = {
+                "identical": sum(all(a[k] == b[k] for k in keys3) for a, b in zip(r_of, r_ch)), "rows": len(r_ch)}
             same32, same16 = [], []
             for i in range(n_str):
                 rs = (oag.simulate_cif(w, ecfg, dcfg, cfg.cif_beta, fb_cpu[i], max_len_a=0.1, max_len_b=10) if cif
