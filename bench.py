@@ -209,27 +209,61 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="wait
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 5), "traffic": None, "launches_per_sequence": n_launch,
                 "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_flop_per_launch": round(flops / n_launch)}
-    if name in ("linear_skinny", "linear_tile64"):
-        # decode-step contractions (and the row-local chains, timed under linear_skinny).  Bytes DELIVERED from L2 per
-        # launch: every row tile of rt rows (16: wave-per-tile GEMMs and chains, 64: the 64 x 64 tile kernel) pulls the
-        # [N][K] weights once, plus activations in and out.
-        rt = 64 if name == "linear_tile64" else 16
-        tiles = -(-Bs // rt)
-
-        def gb(n, k):
-            return (tiles * n * k + Bs * k + Bs * n) * esz
-        wide = Ld * (gb(3 * D, D) + gb(F, D)) + gb(V, D)          # N >= 512: QKV, fc1, vocabulary projection
-        narrow = Ld * (3 * gb(D, D) + gb(D, F))                    # out-proj x2, q-proj, fc2
+    if name in ("linear_skinny", "linear_tile64", "dec_qkv_chain", "dec_proj_chain", "dec_ffn_chain", "dec_attn_proj_chain"):
+        # decode-step contractions: the launch-site groups of the per-GEMM kernels and, one class per kernel, the row-local layer
+        # chains (csrc/dec_chain.hip).  SCORED on algorithmic bytes -- every weight matrix of the launch once + its activations in
+        # and out (+ the cached K / V rows for the chain that carries the self-attention) -- against HBM, the only rate a
+        # better tiling cannot inflate; what the workgroups pull from L2 (the weights once per row tile) is reported beside it as
+        # information only (scoring the delivered bytes rewards redundant re-reads).
         tile64 = Bs >= 256
-        byts = U * ((wide if tile64 else 0) if name == "linear_tile64" else (narrow if tile64 else wide + narrow))
+        chains = Bs > 128 and dtype_name == "bf16"                # the chains' domain (csrc/handle.cpp dec_chain_min_rows)
+
+        def alg(n, k):
+            return (n * k + Bs * k + Bs * n) * esz
+
+        def delivered(n, k, rt):
+            return (-(-Bs // rt) * n * k + Bs * k + Bs * n) * esz
+        per_step = {"qkv": (3 * D, D), "out": (D, D), "q": (D, D), "c_out": (D, D), "fc1": (F, D), "fc2": (D, F)}
+        if name == "dec_qkv_chain":
+            # slab sum (F / 256 fp32 slabs in, x out) + LN1 + QKV; once more per step for the last layer's slabs
+            byts = U * (Ld * (alg(3 * D, D) + (F // 256) * Bs * D * 4) + (F // 256) * Bs * D * 4)
+            dl = U * Ld * delivered(3 * D, D, 16)
+        elif name == "dec_proj_chain":
+            byts = U * Ld * (alg(D, D) + alg(D, D))
+            dl = U * Ld * 2 * delivered(D, D, 16)
+        elif name == "dec_attn_proj_chain":
+            kv = sum(2 * (u + 1) * D for u in range(U)) * Bs * esz          # cached K / V rows read, as decoder_self_attention
+            byts = U * Ld * (alg(D, D) + alg(D, D)) + Ld * kv
+            dl = U * Ld * 2 * delivered(D, D, 4) + Ld * kv
+        elif name == "dec_ffn_chain":
+            byts = U * Ld * (alg(D, D) + alg(F, D) + alg(D, F) + (F // 256) * Bs * D * 4)
+            dl = U * Ld * ((F // 256) * delivered(D, D, 16) + delivered(F, D, 16) + delivered(D, F, 16))
+        else:
+            rt = 64 if name == "linear_tile64" else 16
+            if chains:            # with the chains only layer 0's QKV and the vocabulary projection stay in these groups
+                shapes = [(3 * D, D)] * (name == "linear_tile64" and tile64) + [(V, D)] * (name == "linear_tile64" and tile64)
+                if name == "linear_skinny" and not tile64:
+                    shapes = [(3 * D, D), (V, D)]
+                byts = U * sum(alg(n, k) for n, k in shapes)
+                dl = U * sum(delivered(n, k, rt) for n, k in shapes)
+            else:
+                wide = [(3 * D, D), (F, D)]
+                narrow = [(D, D)] * 3 + [(D, F)]
+                sel = (wide if tile64 else []) if name == "linear_tile64" else (narrow if tile64 else wide + narrow)
+                extra_v = [(V, D)] if (name == "linear_tile64") == tile64 else []
+                byts = U * (Ld * sum(alg(n, k) for n, k in sel) + sum(alg(n, k) for n, k in extra_v))
+                dl = U * (Ld * sum(delivered(n, k, rt) for n, k in sel) + sum(delivered(n, k, rt) for n, k in extra_v))
         if byts <= 0:
             return None
         ach = byts / (ms * 1e-3) / 1e9
-        return {"kernel": name, "bound": "l2", "achieved": round(ach, 2), "peak": L2_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / L2_PEAK_GBS, 5), "traffic": None, "launches_per_sequence": n_launch,
-                "avg_launch_us": round(ms * 1e3 / n_launch, 3), "delivered_bytes_per_launch": round(byts / n_launch),
-                "model": f"operand bytes delivered from L2: weights once per {rt}-row tile + activations; peak = 34.5 TB/s aggregate "
-                         "L2 (MI355X_MICROARCH.md); a dependent launch cannot finish under ~3 us (one operand round trip + one store)"}
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "launches_per_sequence": n_launch,
+                "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_bytes_per_launch": round(byts / n_launch),
+                "informational_l2_delivered": {"bytes_per_launch": round(dl / n_launch), "GBps": round(dl / (ms * 1e-3) / 1e9, 1),
+                                               "frac_of_l2_peak": round(dl / (ms * 1e-3) / 1e9 / L2_PEAK_GBS, 5)},
+                "model": "algorithmic bytes: each weight matrix of the launch once + activations in / out (+ fp32 slabs, + cached K / V "
+                         "rows); these launches are latency-bound (28-224 workgroups, a dependent launch cannot finish under ~3 us), "
+                         "the fraction says how far from any rate they run"}
     elif name == "emformer_attention":
         byts = cfg.encoder_layers * Bs * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
     elif name == "decoder_cross_attention":
@@ -308,7 +342,7 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
     U, esz = N_STEPS_DECODE, (2 if dtype == torch.bfloat16 else 4)
     dtn = "bf16" if dtype == torch.bfloat16 else "f32"
     rows_s = min(args.extra_rows, fb_all.size(0))
-    n_off, n_str = 8, 2
+    n_off, n_str = 8, 8            # offline tokens / streaming READ-WRITE records compared with the oracle (was 2)
     fb_cpu = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + i)) for i in range(n_off)])
     g_max = max(plan)
     out = {}
@@ -389,6 +423,10 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             recs, lock = timed_stream()
             recs_p, paced = timed_stream(self_paced=True)
             recs_o, paced_off = timed_stream(self_paced=True, encoder="offline")
+            # which encoder produced the states a streamed rate was decoded over: the chunked streaming encoder
+            # (Emformer.infer chunk by chunk: the streaming workload proper) or ONE offline forward cut at the schedule's rows
+            lock["encoder"] = paced["encoder"] = "chunked (streaming encoder, one infer pass per 640 ms chunk)"
+            paced_off["encoder"] = "offline states (one offline forward; equal to the chunked states to rounding)"
             # the plan's own launch sequences (the utterances of the offline leg) as self-paced streaming batches on the plan's streams
             from simulst_amd.agent import ConcurrentStreamingEval
             mk_agent = ((lambda m: BatchedCIFStreamingAgent(m, max_len_a=0.1, max_len_b=10)) if cif
@@ -406,6 +444,7 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             n_c = sum(len(r["tokens"]) for rb in recs_c for r in rb)
             rows_c = sum(len(rb) for rb in recs_c)
             whole_plan = {"tokens_per_s": round(n_c / sorted(ts_c)[len(ts_c) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts_c],
+                          "encoder": "offline states (one offline forward per launch sequence; equal to the chunked states to rounding)",
                           "tokens_per_pass": n_c, "rows": rows_c, "plan_batches_per_sequence": plan, "streams": len(cse.agents),
                           "average_lagging_ms_mean": round(sum(r["AL"] for rb in recs_c for r in rb) / rows_c, 2),
                           "form": "self-paced rows, encoder states of one offline forward per launch sequence (agent.ConcurrentStreamingEval): "
@@ -454,7 +493,7 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                 fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, U)
                 entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, dtn, kind=kind) for k, v in per_class.items()}
                 entries = {k: e for k, e in entries.items() if e is not None}
-                dom = max(entries, key=lambda k: per_class[k][0] / {"linear_skinny": 4, "linear_tile64": 3}.get(k, 1))
+                dom = max(entries, key=lambda k: per_class[k][0])     # every chain kernel is a class of its own: real device time
                 bpt = path_bytes_per_token(cfg, B, T_FRAMES, U, esz, 0, kind=kind)
                 roof = dict(entries[dom])
                 roof["path_hbm_model"] = {"bytes_per_token": round(bpt), "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / bpt),
@@ -497,12 +536,27 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                 rs = (oag.simulate_cif(w, ecfg, dcfg, cfg.cif_beta, fb_cpu[i], max_len_a=0.1, max_len_b=10) if cif
                       else oag.simulate_mma(w, ecfg, dcfg, fb_cpu[i], max_len_a=0.1, max_len_b=10))
                 same32.append(all(got32[i][k] == rs[k] for k in ("actions", "tokens", "delays_ms", "AL")))
+                # where the timed bf16 row leaves the oracle's record, HOW CLOSE the oracle's own decision was to flipping there:
+                # |p - 0.5| of the policy comparison (monotonic_multihead_attention.py:230-237) / |accumulated weight - k beta|
+                # of the CIF count (cif_agent.py:385-389) for a READ / WRITE divergence, the top-2 log-probability gap for a token
+                div = oag.first_divergence(rs, recs[i])
                 same16.append({"actions_identical": recs[i]["actions"] == rs["actions"],
                                "token_agreement": round(sum(a == b for a, b in zip(recs[i]["tokens"], rs["tokens"])) /
                                                         max(len(rs["tokens"]), 1), 4),
-                               "AL_ms": [round(recs[i]["AL"], 2), round(rs["AL"], 2)]})
+                               "AL_ms": [round(recs[i]["AL"], 2), round(rs["AL"], 2)],
+                               "first_divergence": div,
+                               "oracle_smallest_policy_margin_of_the_row": round(min(rs["action_margins"]), 6),
+                               "oracle_smallest_top2_gap_of_the_row": round(min(rs["token_gaps"]), 6)})
             parity = {"streaming_fp32_actions_tokens_delays_AL_identical_to_oracle": all(same32), "streaming_sample_utterances": n_str,
-                      f"streaming_{dtn}_timed_rows_vs_oracle": same16}
+                      f"streaming_{dtn}_timed_rows_vs_oracle": same16,
+                      f"streaming_{dtn}_rows_identical_to_oracle": sum(1 for r_ in same16 if r_["first_divergence"] is None),
+                      f"streaming_{dtn}_oracle_margin_at_first_divergence":
+                          sorted((d_["first_divergence"]["policy_margin"] if d_["first_divergence"]["cause"] == "action"
+                                  else d_["first_divergence"]["token_gap"]) for d_ in same16 if d_["first_divergence"] is not None),
+                      "margin_definition": "policy: |p - 0.5| (MMA) / |accumulated weight - k * beta| (CIF) of the ORACLE at the first "
+                                           "differing READ / WRITE; token: the oracle's top-2 log-probability gap at the first differing token "
+                                           "(whichever comes first in the action string); bounded in tests/test_hip_configs.py::"
+                                           "test_bf16_streamed_rows_leave_the_oracle_only_at_near_ties"}
             if not waitk:
                 parity.update({"offline_fp32_tokens_identical_to_oracle": bool(torch.equal(t32, ref)), "offline_sample_utterances": n_off,
                                f"offline_{dtn}_timed_rows_identical_to_oracle": int(sum(torch.equal(h16[r], ref[r]) for r in range(n_off))),
@@ -529,6 +583,44 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             log(f"{key}: FAILED {e!r}")
             torch.cuda.empty_cache()
     return out
+
+
+def configs4_rank_shard_leg(dtype_name):
+    """BASELINE.json configs[4] (utterance-sharded evaluation of ~40 k utterances over 8 GPUs; eval/generate.py:141-155,187-209) on ONE
+    GPU: rank 3's shard of the 40 000-utterance seeded length distribution -- 5 000 ragged utterances, 100 .. 3000 frames -- decoded
+    offline and as a streaming evaluation (wait-k 3), through tools/eval_sharded.py in this process: tokens/s, mean Average Lagging,
+    property checks of the hypotheses, the shard's own path roofline."""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import eval_sharded
+    base = ["--utterances", "40000", "--shard-of", "8", "--shard-rank", "3", "--dtype", dtype_name]
+    out = {"workload": "configs[4]: one rank's shard (rank 3 of 8) of the 40 000-utterance set, lengths log-normal clipped to 100 .. 3000 "
+                       "frames (seed 999), int(0.1 T + 10) tokens per utterance, wait-k 3",
+           "note": "the other 7 shards are equally long (length-sorted snake deal, simulst_amd/sharding.py): an 8-GPU job is this x 8 plus one "
+                   "all_gather of hypotheses"}
+    for key, extra in (("offline", []), ("streaming_evaluation", ["--streaming"])):
+        t0 = time.perf_counter()
+        rec = []
+        eval_sharded.main(base + extra, collect=rec)
+        r = rec[0]
+        r["seconds_spent_in_leg"] = round(time.perf_counter() - t0, 1)
+        out[key] = r
+        log(f"configs4_rank_shard {key}: {r['utterances_decoded']} utterances, {r['tokens_per_s']:.0f} tokens/s" +
+            (f", AL {r['average_lagging_ms_mean']} ms" if "average_lagging_ms_mean" in r else ""))
+    return out
+
+
+def b1_latency_leg():
+    """The B = 1 agent's computation-aware latency beside the oracle at one thread (tools/b1_latency.py)"""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import b1_latency
+    r = b1_latency.run()
+    log(f"configs0 B = 1 agent: per WRITE {r['hip_b1_agent']['per_write']['mean_ms']} ms, per READ {r['hip_b1_agent']['per_read']['mean_ms']} ms, "
+        f"AL_CA - AL {r['hip_b1_agent']['AL_CA_minus_AL_ms']} ms (oracle, 1 thread: {r['oracle_cpu']['AL_CA_minus_AL_ms']} ms)")
+    return r
 
 
 _T0 = time.perf_counter()
@@ -561,10 +653,14 @@ def dry_run_gloo(args):
     allt = gather_hypotheses(torch.cat(rows, 0), dist)
     dist.barrier()
     tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    tmin = tmax.clone()
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
     if rank == 0:
         ids = sorted(set(allt[:, 0].tolist()))
         print(json.dumps({"metric": "dry run of the multi-rank plumbing (gloo, CPU): nothing measured", "value": None,
+                          "ranks_seen": dist.get_world_size(),
+                          "per_rank_pass_ms_min_max": [[round(float(tmin) * 1e3, 3), round(float(tmax) * 1e3, 3)]],
                           "unit": "tokens/s", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "scaling": "weak", "gathered_utterances": len(ids),
                           "gathered_ids_complete": ids == list(range(world * B * args.steps)),
@@ -677,7 +773,7 @@ def main(argv=None):
         log(f"warm-up: {warm_done} steps (asked for {args.warmup}) as the timed plan's launch sequences")
         # EXACTLY K steps per timed pass, bracketed by barrier + synchronize on both sides, MAX over ranks; --passes such
         # passes, the MEDIAN one is `value` (a single 0.1 s pass is at the mercy of one scheduling hiccup), all are reported
-        pass_s = []
+        pass_s, rank_spread = [], []
         for _ in range(max(1, args.passes)):
             if dist is not None:
                 dist.barrier()
@@ -690,7 +786,10 @@ def main(argv=None):
             el = time.perf_counter() - t0
             if dist is not None:
                 tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+                tmin = tmax.clone()
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+                rank_spread.append((float(tmin.item()), float(tmax.item())))
                 el = float(tmax.item())
             pass_s.append(el)
     elapsed = sorted(pass_s)[len(pass_s) // 2]
@@ -749,14 +848,12 @@ def main(argv=None):
         fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, N_STEPS_DECODE)
         entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, args.dtype) for k, v in per_class.items()}
         entries = {k: e for k, e in entries.items() if e is not None}
-        # the dominant KERNEL: "linear_skinny" / "linear_tile64" are launch-site groups of several different decode GEMM
-        # kernels (QKV, out-proj x2, q-proj, fc1, fc2, vocabulary projection: 7 kernels per layer and step), so they are
-        # ranked by their per-kernel share; the group totals stay in `classes` and `class_ms_per_sequence`
-        group_kernels = {"linear_skinny": 4, "linear_tile64": 3}
-        dom = max(entries, key=lambda k: per_class[k][0] / group_kernels.get(k, 1))
+        # the dominant kernel class by device time
+        dom = max(entries, key=lambda k: per_class[k][0])
         roofline = dict(entries[dom])
-        roofline["dominance"] = ("largest device time of a single kernel in the instrumented replay; the decode-GEMM launch groups "
-                                 "are ranked per kernel (their group totals are in class_ms_per_sequence)")
+        roofline["dominance"] = ("largest device time of a kernel class in the instrumented replay; since round 4 every layer-chain kernel "
+                                 "is a class of its own (dec_qkv_chain, dec_proj_chain / dec_attn_proj_chain, dec_ffn_chain), the remaining "
+                                 "decode GEMM launches (layer 0's QKV, vocabulary projection) sit in linear_skinny / linear_tile64")
         other = [k for k in sorted(entries, key=lambda k: -per_class[k][0]) if entries[k]["bound"] != roofline["bound"]]
         if other:
             roofline["other_bound_class"] = entries[other[0]]
@@ -813,6 +910,16 @@ def main(argv=None):
         if world == 1 and not args.no_extra_configs:
             torch.set_num_threads(min(os.cpu_count() or 1, 16))
             extra = extra_config_legs(args, dev, dtype, fb_all, plan, B)
+            for key, leg in (("configs4_rank_shard", lambda: configs4_rank_shard_leg(args.dtype)),
+                             ("configs0_b1_compute_aware_latency", b1_latency_leg)):
+                try:
+                    with torch.no_grad():
+                        extra[key] = leg()
+                except Exception as e:                           # a failing leg must not cost the line its main measurement
+                    import traceback
+                    extra[key] = {"error": repr(e), "traceback_tail": traceback.format_exc().strip().splitlines()[-3:]}
+                    log(f"{key}: FAILED {e!r}")
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             cores_all = min(os.cpu_count() or 1, 16)   # the oracle's small ops stop scaling well before this
             cpu_base, ref_toks, ref_fb = run_cpu_baseline(cfg, weights, args.cpu_sample, N_STEPS_DECODE, cores_all)
@@ -866,6 +973,8 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic N(0,1) fbank, one distinct utterance per decoded row (first batch: CPU generator seed 999 + utt_id, "
                     "the rest one device-generator draw seed 999 + rank); random-init weights seed 999",
+            "ranks_seen": (dist.get_world_size() if dist is not None else 1),
+            "per_rank_pass_ms_min_max": [[round(a * 1e3, 3), round(b * 1e3, 3)] for a, b in rank_spread] or None,
             "timed_passes": {"n": len(pass_s), "ms": [round(x * 1e3, 3) for x in pass_s],
                              "tokens_per_s_min_median_max": [round(tokens_per_step * args.steps / max(pass_s), 1), round(value, 1),
                                                              round(tokens_per_step * args.steps / min(pass_s), 1)],

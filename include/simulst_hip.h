@@ -66,14 +66,16 @@ enum { SIMULST_ATTN_HARD = 0, SIMULST_ATTN_INFINITE_LOOKBACK = 1, SIMULST_ATTN_W
 enum { SIMULST_K_LINEAR = 0, SIMULST_K_LAYERNORM = 1, SIMULST_K_EMF_ATTN = 2, SIMULST_K_CONV_POS = 3,
        SIMULST_K_DEC_SELF_ATTN = 4, SIMULST_K_DEC_CROSS_ATTN = 5, SIMULST_K_SCAN = 6,
        SIMULST_K_ARGMAX = 7, SIMULST_K_MISC = 8, SIMULST_K_LINEAR_SKINNY = 9, SIMULST_K_LINEAR_TILE64 = 10,
-       SIMULST_K_COUNT = 11 };
+       /* round 4: the row-local layer chains of the decode step, one class per kernel (csrc/dec_chain.hip) */
+       SIMULST_K_DEC_QKV_CHAIN = 11, SIMULST_K_DEC_PROJ_CHAIN = 12, SIMULST_K_DEC_FFN_CHAIN = 13,
+       SIMULST_K_DEC_ATTN_CHAIN = 14, SIMULST_K_COUNT = 15 };
 
 /* ---- handle ------------------------------------------------------------------ */
 int simulst_create(simulst_handle** out, void* hip_stream);
 int simulst_destroy(simulst_handle* h);
 int simulst_set_stream(simulst_handle* h, void* hip_stream);
 const char* simulst_last_error(simulst_handle* h);
-int simulst_version(void);            /* 103 (round 3: descriptors grew, see the structs); a binding built for another value must not pass them */
+int simulst_version(void);            /* 104 (round 4: kernel classes 11-14, simulst_set_option, simulst_decoder_attn_proj_chain); a binding built for another value must not use the library */
 /* per-kernel-class HIP-event timing on the handle's stream (off by default) */
 int simulst_timer_enable(simulst_handle* h, int kernel_class, int on);
 int simulst_timer_read(simulst_handle* h, int kernel_class, double* total_ms, int64_t* launches);
@@ -83,15 +85,27 @@ int simulst_timer_reset(simulst_handle* h);
  * with identical arguments (same buffers, steps, flags) -- removes the per-launch host cost and about a
  * microsecond of dependent-kernel gap per kernel. */
 int simulst_graph_enable(simulst_handle* h, int on);
-/* test hook: route bf16 Emformer attention through the fp32-VALU kernel instead of the MFMA one */
-/* (also routes the bf16 decoder self-attention through its workgroup kernel instead of the wave-per-head one) */
-int simulst_debug_force_valu_attention(simulst_handle* h, int on);
-/* measurement hook for tools/ffn_bench.py: variant 1 runs simulst_emformer_ffn WITHOUT the GELU arithmetic (a timing
- * ablation -- its results are not the operator's); 0 restores the operator */
+/* Run-time options of a handle.  Path selection -- every alternative is a complete implementation of the same operator, the
+ * parity tests run both -- and the tuning values simulst_create reads from the environment (csrc/handle.cpp).
+ *   VALU_ATTENTION          1: bf16 Emformer attention through the fp32-VALU kernel instead of the MFMA one, bf16 decoder
+ *                              self-attention through its workgroup kernel instead of the wave-per-head one
+ *   UNFUSED_DECODE          1: simulst_mma_decode / simulst_mma_stream_steps with one launch per GEMM (no head-split block, no chains)
+ *   FFN_WAVES               0 the library's choice, 4 / 8: that geometry of simulst_emformer_ffn
+ *   DEC_CHAIN               0: no row-local layer chains (csrc/dec_chain.hip) in the decode loops
+ *   DEC_ATTN_CHAIN_MAX_ROWS rows up to which self-attention rides inside the projection chain (simulst_decoder_attn_proj_chain)
+ *   DEC_ATTN_CHAIN_ROWS     rows per workgroup of that launch: 0 chosen from the row count, 4, 8, 16
+ *   FUSED_ARGMAX            0: the decode loops write fp32 logits and pick from them (default 1: partial maxima out of the
+ *                              vocabulary projection's epilogue where the shapes allow)
+ * Returns SIMULST_E_ARG for an unknown option or a value outside its range. */
+enum { SIMULST_OPT_VALU_ATTENTION = 0, SIMULST_OPT_UNFUSED_DECODE = 1, SIMULST_OPT_FFN_WAVES = 2, SIMULST_OPT_DEC_CHAIN = 3,
+       SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 4, SIMULST_OPT_DEC_ATTN_CHAIN_ROWS = 5, SIMULST_OPT_FUSED_ARGMAX = 6 };
+int simulst_set_option(simulst_handle* h, int32_t option, int32_t value);
+
+#ifdef SIMULST_DEBUG_HOOKS
+/* ---- investigation hooks: compiled only by `make DEBUG_HOOKS=1` (csrc/Makefile); the shipped library does not export them ----
+ * measurement hook for tools/ffn_bench.py --ablations: variant 1 runs simulst_emformer_ffn WITHOUT the GELU arithmetic, 12-15 without
+ * one or both products / the GELU in the 4-wave geometry (timing ablations -- their results are not the operator's); 0 restores it */
 int simulst_debug_ffn_variant(simulst_handle* h, int variant);
-/* test hook: run simulst_mma_decode / simulst_mma_stream_steps with the 7-launch layer even when the head-split
- * workspace is supplied (A/B parity of the two paths) */
-int simulst_debug_force_unfused_decode(simulst_handle* h, int on);
 
 /* Reproducibility investigation of the row-local layer chains (tools/chain_race_probe.py):
  * simulst_debug_chain_lds_bytes sets the dynamic LDS a chain workgroup REQUESTS (0 = default; the kernels use 23 KB, a larger
@@ -100,8 +114,9 @@ int simulst_debug_force_unfused_decode(simulst_handle* h, int on);
  * every value that crossed an LDS hand-off inside the launch to dbg (simulst_debug_chain_probe_bytes(B) bytes; layout in
  * csrc/dec_chain.hip); variant 0 is the production instruction sequence, 1-3 are timing variants of its barriers / LDS writes. */
 int simulst_debug_chain_lds_bytes(simulst_handle* h, int32_t bytes);
-/* how the chains' MFMAs get their activation fragments from LDS: 0 one ds_read_b128 at a time into ONE register quad (the round-2
- * form), 1 all eight reads of a contraction first into distinct quads (default), 2 as 0 with 16 wait states behind every MFMA pair */
+/* how the chains' MFMAs get their activation fragments from LDS and how their LayerNorm reduces, a BITMASK 0..3 (default 3):
+ * bit 0 set = all eight ds_read_b128 of a contraction issued first into distinct register quads (clear: one at a time into ONE quad,
+ * the round-2 form); bit 1 set = the LayerNorm's wave reductions on the DPP data path (clear: ds_bpermute butterfly) */
 int simulst_debug_chain_xmode(simulst_handle* h, int32_t mode);
 /* dbg != NULL: every simulst_decoder_proj_chain launch of this handle ends by copying its two LDS row buffers (rows entering the
  * LayerNorm, rows leaving it; 16 x 256 bf16 each per 16-row workgroup) to dbg [ceil(B / 16)][2][16][256]; NULL switches it off */
@@ -110,6 +125,7 @@ int64_t simulst_debug_chain_probe_bytes(int32_t B);
 int simulst_debug_chain_probe(simulst_handle* h, const void* ctx, void* x, const void* wo_fm, const float* bo,
                               const float* ln_g, const float* ln_b, const void* wq_fm, const float* bq, void* q,
                               int32_t B, int32_t variant, void* dbg);
+#endif /* SIMULST_DEBUG_HOOKS */
 
 /* ---- dense contraction ----------------------------------------------------------
  * C[r, :] = epi(A[r, :] . W^T) for logical rows r = b * rows_per_batch + i.
@@ -475,7 +491,9 @@ typedef struct {
   const int32_t* enc_len;                        /* [B] valid source rows */
   int32_t* n_prev;                               /* [B] in/out: tokens written so far */
   void *x, *qkv, *ctx, *q, *q2, *hidden;         /* workspace: [B][D], [B][3D], [B][D], [B][D], [B][D], [B][F] */
-  float* logits;                                 /* workspace [B][V] */
+  float* logits;                                 /* workspace [B][V] (with SIMULST_OPT_FUSED_ARGMAX the decode loops keep
+                                                    [B][V / 64] (largest value, its index) pairs of the vocabulary projection's
+                                                    column tiles here instead of fp32 rows) */
   /* optional workspace of the head-split self-attention block (both non-NULL, cap <= 256, head_dim % 16 == 0,
    * D <= 512): { LN + QKV GEMM, self-attention, out-proj GEMM } become ONE launch per layer in which every
    * (head, utterance) workgroup projects its own q/k/v rows, appends to the cache, attends, and multiplies by
@@ -656,6 +674,21 @@ int simulst_decoder_ffn_chain(simulst_handle* h, const void* ctx, void* x, const
 int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2,
                                  const float* ln_g, const float* ln_b, const void* wqkv_fm, const float* bqkv, void* qkv,
                                  int32_t B, int32_t D, int32_t F, int32_t dtype);
+
+/* Self-attention INSIDE the projection chain (round 4): simulst_decoder_self_attention + simulst_decoder_proj_chain in ONE launch,
+ * same results bit for bit.  qkv [B][3*256] = this step's q | k | v rows (fairseq MultiheadAttention in_proj of the decoder layer's
+ * self-attention; witness models/cif_transformer.py:405-470), k_cache / v_cache [B][4][cap][64] updated in place at position
+ * n_prev[b], x [B][256] the residual row (in: before the self-attention block, out: after it), q = wq LN(x) + bq, q2 likewise when
+ * wq2_fm != NULL (the soft-energy query of MMA variants, modules/monotonic_multihead_attention.py:88-130), or, when kk_gelu != NULL,
+ * q = gelu(wq LN(x) + bq + kk_gelu[b]) (CIF FakeCrossAttn, models/cif_transformer.py:357-362).  A workgroup owns
+ * rows_per_workgroup rows (0: chosen from B; 4, 8 or 16) and its wave w runs head w.  n_prev_uniform >= 0: every row holds exactly
+ * that many cached positions (lockstep batches: n_prev[] is not read, and below 64 the 8-pass instantiation runs).  bf16, 4 heads x 64, cap <= 128,
+ * fragment-major weights (simulst_pack_fragment_major). */
+int simulst_decoder_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev,
+                                    void* x, const void* wo_fm, const float* bo, const float* ln_g, const float* ln_b,
+                                    const void* wq_fm, const float* bq, void* q, const void* wq2_fm, const float* bq2, void* q2,
+                                    const void* kk_gelu, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t n_prev_uniform,
+                                    int32_t rows_per_workgroup, int32_t dtype);
 
 /* Pooled monotonic keys for fixed pre-decision with 'average' pooling (modules/fixed_pre_decision.py:23-29,104-110): for the
  * windows j in [j_lo, j_hi) that are complete for row b ((j + 1) * ratio <= key_len[b]), Kpool[b][h][j][:] = mean of frames

@@ -54,10 +54,17 @@ def _next_chunk_frames(ecfg):
     return ecfg.segment_length * ecfg.stride * SHIFT_MS // SHIFT_MS
 
 
-def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=False):
+def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=False, timing=None):
     """FairseqSimulSTAgent loop for wait-k / MMA (agents/default_agent.py:303-436).
-    Returns dict(tokens, delays_ms, actions ('R'/'W' string), AL, n_enc)."""
+    Returns dict(tokens, delays_ms, actions ('R'/'W' string), AL, n_enc).
+    ``timing``: a dict that receives wall-clock seconds per READ (policy + source read + encoder update) and per WRITE (policy +
+    predict) and, per committed token, the wall-clock milliseconds since the start of the utterance (computation-aware delays:
+    the *_CA metrics of docs/mma.md:44-56 are the latency metrics over delay + that)."""
+    import time
     src = FrameSource(fbank)
+    t_start = time.perf_counter()
+    if timing is not None:
+        timing.update({"read_s": [], "write_s": [], "wall_ms_at_commit": []})
     enc_state = em.new_encoder_state()
     dec_state = dec.new_decoder_state(dcfg)
     enc_out = None
@@ -66,6 +73,11 @@ def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=
     hyp: List[int] = []
     delays: List[float] = []
     actions = []
+    # parity audit: per action the policy's distance from flipping (min |p - 0.5| over the comparisons of that
+    # decoder call, monotonic_multihead_attention.py:230-237; 0.5 for wait-k and for the reads no decoder call decides), per written
+    # token the gap between the best and second-best log-probability
+    action_margins: List[float] = []
+    token_gaps: List[float] = []
     max_len = lambda n: min(max_len_a * n + max_len_b, dcfg.max_target_positions)  # noqa: E731
 
     def update_encoder():
@@ -81,7 +93,9 @@ def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=
         last_update = src.pos
 
     while True:
+        t_act = time.perf_counter()
         # ---- policy (agents/default_agent.py:364-413)
+        margin = 0.5
         if enc_out is None:
             expected = _first_chunk_frames(ecfg)
             action = 0
@@ -92,29 +106,40 @@ def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=
                                             {"encoder_out": [enc_out], "encoder_padding_mask": []},
                                             dec_state)
             action = extra["action"]
+            margin = float(extra["decision_margin"][0])
             if action == 0:
                 expected = _next_chunk_frames(ecfg)
+        action_margins.append(margin)
         if action == 0:
             actions.append("R")
             if src.finished:          # nothing left to read: SimulEval would spin; guard
                 raise RuntimeError("READ after source finished")
             src.read(expected)
             update_encoder()
+            if timing is not None:
+                timing["read_s"].append(time.perf_counter() - t_act)
             continue
         # ---- predict (agents/default_agent.py:415-436)
         actions.append("W")
-        idx = int(torch.log_softmax(x[:, -1:].float(), dim=-1).argmax(dim=-1)[0, 0])
+        lp = torch.log_softmax(x[:, -1:].float(), dim=-1)
+        idx = int(lp.argmax(dim=-1)[0, 0])
         if force_finish and idx == dcfg.eos and not src.finished:
             dec.clear_cache(dec_state)
             continue
+        top2 = lp[0, 0].topk(2).values
         hyp.append(idx)
+        token_gaps.append(float(top2[0] - top2[1]))
         delays.append(src.elapsed_ms())
+        if timing is not None:
+            timing["write_s"].append(time.perf_counter() - t_act)
+            timing["wall_ms_at_commit"].append((time.perf_counter() - t_start) * 1e3)
         # units_to_segment termination (agents/default_agent.py:268-271)
         if idx == dcfg.eos or len(hyp) > max_len(src.pos):
             break
     return {"tokens": hyp, "delays_ms": delays, "actions": "".join(actions),
             "AL": average_lagging(delays, src.total_ms()),
-            "n_enc": 0 if enc_out is None else enc_out.size(0)}
+            "n_enc": 0 if enc_out is None else enc_out.size(0),
+            "action_margins": action_margins, "token_gaps": token_gaps}
 
 
 def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot_weight=1.0):
@@ -127,9 +152,13 @@ def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot
     last_update = 0
     expected = _first_chunk_frames(ecfg)
     hyp, delays, actions = [], [], []
+    # parity audit: per action the fire margin of the most recent encoder update (cif.cif_layer_infer: |accumulated weight - k beta|,
+    # at the end of the source also |tail - beta / 2|) -- the READ rule looks at nothing else; per token the top-2 log-probability gap
+    action_margins, token_gaps = [], []
+    fire_margin = 0.5 * beta
 
     def update_encoder():
-        nonlocal states, last_update
+        nonlocal states, last_update, fire_margin
         upd = src.pos - last_update
         if upd == 0 and src.finished:
             return
@@ -137,6 +166,7 @@ def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot
         out = em.encoder_infer(w, "encoder", ecfg, src.frames().unsqueeze(0),
                                torch.tensor([src.pos]), enc_state, finish=finish)
         c = cifm.cif_layer_infer(w, "encoder.cif_layer", beta, out["encoder_out"][0], cif_state, finish)
+        fire_margin = float(c["fire_margin"][0][0])
         if states is None:
             states = {"cif_out": [c["cif_out"][0]], "cif_lengths": [c["cif_lengths"][0]]}
         else:
@@ -154,6 +184,7 @@ def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot
             read = enc_len <= len(hyp) and not src.finished
             if read:
                 expected = _next_chunk_frames(ecfg)
+        action_margins.append(fire_margin)      # the decision rests on the count released by the updates so far (the newest one)
         if read:
             actions.append("R")
             if src.finished:
@@ -164,14 +195,18 @@ def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot
         actions.append("W")
         toks = torch.tensor([[dcfg.eos] + hyp])
         x, _ = dec.cif_decoder_step(w, "decoder", dcfg, toks, states, dec_state, overshoot_weight)
-        idx = int(torch.log_softmax(x[:, -1:].float(), dim=-1).argmax(dim=-1)[0, 0])
+        lp = torch.log_softmax(x[:, -1:].float(), dim=-1)
+        idx = int(lp.argmax(dim=-1)[0, 0])
+        top2 = lp[0, 0].topk(2).values
         hyp.append(idx)
+        token_gaps.append(float(top2[0] - top2[1]))
         delays.append(src.elapsed_ms())
         if idx == dcfg.eos or len(hyp) > max_len_a * src.pos + max_len_b:
             break
     return {"tokens": hyp, "delays_ms": delays, "actions": "".join(actions),
             "AL": average_lagging(delays, src.total_ms()),
-            "n_cif": 0 if states is None else int(states["cif_lengths"][0])}
+            "n_cif": 0 if states is None else int(states["cif_lengths"][0]),
+            "action_margins": action_margins, "token_gaps": token_gaps}
 
 
 def greedy_offline(w, ecfg, dcfg, src_tokens, src_lengths, n_steps=None, mask_eos=False,
@@ -255,3 +290,30 @@ def greedy_offline_cif(w, ecfg, dcfg, beta, src_tokens, src_lengths, n_steps=Non
         if bool(done.all()):
             break
     return toks[:, 1:], lengths, enc
+
+
+def first_divergence(ref, got):
+    """Where a run (``got``: dict with 'actions' and 'tokens') leaves the oracle's record ``ref`` (from simulate_mma / simulate_cif),
+    and how close the ORACLE's decision was to flipping there: the policy margin of the first differing READ / WRITE action
+    (|p - 0.5| for MMA, monotonic_multihead_attention.py:230-237; |accumulated weight - k beta| for CIF, agents/cif_agent.py:385-389)
+    and the top-2 log-probability gap of the first differing token -- whichever comes first in the action string is the cause, the
+    other is a consequence.  Returns None when the records agree, else
+    {'cause': 'action' | 'token', 'action_index', 'token_index', 'policy_margin', 'token_gap'}."""
+    ra, ga, rt, gt = ref["actions"], got["actions"], ref["tokens"], list(got["tokens"])
+    if ra == ga and rt == gt:
+        return None
+    ia = next((i for i, (a, b) in enumerate(zip(ra, ga)) if a != b), min(len(ra), len(ga)))
+    it = next((i for i, (a, b) in enumerate(zip(rt, gt)) if a != b), min(len(rt), len(gt)))
+    # position in the action string of the WRITE that committed token `it` (the it-th 'W', counting from zero)
+    w_pos, seen = len(ra), -1
+    for i, a in enumerate(ra):
+        if a == "W":
+            seen += 1
+            if seen == it:
+                w_pos = i
+                break
+    token_first = it < len(rt) and w_pos < ia
+    am = ref["action_margins"][ia] if ia < len(ref["action_margins"]) else None
+    tg = ref["token_gaps"][it] if it < len(ref["token_gaps"]) else None
+    return {"cause": "token" if token_first else "action", "action_index": ia, "token_index": it,
+            "policy_margin": None if am is None else round(am, 6), "token_gap": None if tg is None else round(tg, 6)}

@@ -144,6 +144,15 @@ def cif_layer_infer(w, p, beta, x_tbc, st, finish=False):
     else:
         cs["prev_feat"] = None
         cs["prev_weight"] = None
+    # diagnostic for the bf16 parity audit (not reference state): how far this update's integer outcome -- the number of integrated
+    # vectors released, the only thing the agent's READ rule looks at (agents/cif_agent.py:385-389) -- is from flipping: distance
+    # of the accumulated weight to the nearest multiple of beta, at the end of the source also |tail - beta / 2| (the tail rule)
+    asum = out["alpha_sum"][0].float()
+    frac = asum / beta - (asum / beta).floor()
+    fm = torch.minimum(frac, 1 - frac) * beta
+    if finish:
+        fm = torch.minimum(fm, (tail.float() - beta / 2).abs())
+    out["fire_margin"] = [fm]
     n = n if finish else (n - 1)
     out["cif_out"] = [feats.narrow(1, 0, int(n)).transpose(0, 1)]
     out["cif_lengths"] = [n]

@@ -116,6 +116,7 @@ def mma_decoder_step(w, p, cfg, prev_output_tokens, encoder_out, state, features
     enc_pad = pm[0] if len(pm) > 0 else None
     attn_list = []
     online = bool(state.get("online", False))
+    margin = torch.full((B,), 0.5)            # diagnostic: min |p - 0.5| over every comparison of the layers that ran (per row)
     for i in range(cfg.num_layers):
         lp = f"{p}.layers.{i}"
         lst = state["layers"][i]
@@ -133,13 +134,15 @@ def mma_decoder_step(w, p, cfg, prev_output_tokens, encoder_out, state, features
         h = _lin(w, lp + ".fc2", F.gelu(_lin(w, lp + ".fc1", h)))
         x = res + h
         attn_list.append(attn)
+        if "decision_margin" in lst["mono"]:
+            margin = torch.minimum(margin, lst["mono"]["decision_margin"].min(dim=1).values)
         if online and bool(lst["mono"]["head_read"].any()):
             clear_cache(state, i + 1)
-            return x, {"action": 0, "attn_list": attn_list}
+            return x, {"action": 0, "attn_list": attn_list, "decision_margin": margin}
     x = _ln(w, p + ".layer_norm", x).transpose(0, 1)
     if not features_only:
         x = F.linear(x, w[p + ".output_projection.weight"])
-    return x, {"action": 1, "attn_list": attn_list}
+    return x, {"action": 1, "attn_list": attn_list, "decision_margin": margin}
 
 
 def cif_decoder_step(w, p, cfg, prev_output_tokens, encoder_out, state, overshoot_weight=1.0):

@@ -250,6 +250,18 @@ def step_search(p, head_step, src_lengths, mass_pres):
     return new_step, head_read, alpha
 
 
+def step_search_margin(p, head_step, src_lengths, new_step):
+    """How far the decision of ``step_search`` is from flipping: min |p_j - 0.5| over the positions the search compared with 0.5
+    (monotonic_multihead_attention.py:230-237: head_step <= j <= new_step, valid frames only; the forced stop's own p is compared
+    too, for head_read, :255-257).  Diagnostic for the bf16 parity audit (a flipped comparison is a different READ / WRITE string);
+    not part of the reference's state.  [BH] fp32; 0.5 where nothing was compared (wait-k's 0 / 1 probabilities give 0.5 as well)."""
+    BH, src_len = p.shape
+    cols = torch.arange(src_len).view(1, -1)
+    last = torch.minimum(new_step, src_lengths - 1).view(-1, 1)
+    seen = (cols >= head_step.view(-1, 1)) & (cols <= last)
+    return (p - 0.5).abs().masked_fill(~seen, 0.5).min(dim=1).values
+
+
 def attention_infer(w, prefix, cfg, query, key, key_padding_mask, state):
     """monotonic_attention_process_infer (:152-299). ``state`` is this layer's
     monotonic buffer dict {head_step [B,H], head_read [B,H], tgt_len, online}."""
@@ -267,6 +279,7 @@ def attention_infer(w, prefix, cfg, query, key, key_padding_mask, state):
     new_step, head_read, alpha = step_search(p, head_step, src_lengths, cfg.mass_preservation)
     state["head_step"] = new_step.view(bsz, H)
     state["head_read"] = head_read.view(bsz, H)
+    state["decision_margin"] = step_search_margin(p, head_step, src_lengths, new_step).view(bsz, H)   # diagnostic, not reference state
     if cfg.soft_attention:
         beta_mask = (torch.arange(src_len).expand(BH, -1) > new_step.view(-1, 1)).unsqueeze(1)
         e = energy_from_qk(w, prefix, cfg, query, key, "soft", key_padding_mask)

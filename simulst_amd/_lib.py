@@ -17,9 +17,11 @@ F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_GLU, EPI_EMF_OUT, EPI_BIAS_F32OUT, EPI_BIAS_RES_GELU = range(7)
 ATTN_HARD, ATTN_INFINITE_LOOKBACK, ATTN_WAITK, ATTN_CHUNKWISE = range(4)
 (K_LINEAR, K_LAYERNORM, K_EMF_ATTN, K_CONV_POS, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_SCAN, K_ARGMAX,
- K_MISC, K_LINEAR_SKINNY, K_LINEAR_TILE64, K_COUNT) = range(12)
+ K_MISC, K_LINEAR_SKINNY, K_LINEAR_TILE64, K_DEC_QKV_CHAIN, K_DEC_PROJ_CHAIN, K_DEC_FFN_CHAIN, K_DEC_ATTN_CHAIN,
+ K_COUNT) = range(16)
 KERNEL_CLASS_NAMES = ["linear", "layernorm", "emformer_attention", "conv_pos", "decoder_self_attention",
-                      "decoder_cross_attention", "scan", "argmax", "misc", "linear_skinny", "linear_tile64"]
+                      "decoder_cross_attention", "scan", "argmax", "misc", "linear_skinny", "linear_tile64",
+                      "dec_qkv_chain", "dec_proj_chain", "dec_ffn_chain", "dec_attn_proj_chain"]
 
 ATTN_ENUM = {"hard_aligned": ATTN_HARD, "infinite_lookback": ATTN_INFINITE_LOOKBACK,
              "waitk": ATTN_WAITK, "chunkwise": ATTN_CHUNKWISE}
@@ -99,14 +101,7 @@ SIGNATURES = {
     "simulst_timer_read": [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(_i64)],
     "simulst_timer_reset": [_vp],
     "simulst_graph_enable": [_vp, C.c_int],
-    "simulst_debug_force_valu_attention": [_vp, C.c_int],
-    "simulst_debug_force_unfused_decode": [_vp, C.c_int],
-    "simulst_debug_ffn_variant": [_vp, C.c_int],
-    "simulst_debug_chain_lds_bytes": [_vp, _i32],
-    "simulst_debug_chain_xmode": [_vp, _i32],
-    "simulst_debug_chain_tail": [_vp, _vp],
-    "simulst_debug_chain_probe_bytes": [_i32],
-    "simulst_debug_chain_probe": [_vp] * 10 + [_i32, _i32, _vp],
+    "simulst_set_option": [_vp, _i32, _i32],
     "simulst_pack_fragment_major": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
@@ -152,10 +147,23 @@ SIGNATURES = {
     "simulst_decoder_proj_chain": [_vp] * 13 + [_i32, _i32, _i32],
     "simulst_decoder_ffn_chain": [_vp] * 14 + [_i32, _i32, _i32, _i32],
     "simulst_decoder_slab_sum_qkv": [_vp] * 10 + [_i32, _i32, _i32, _i32],
+    "simulst_decoder_attn_proj_chain": [_vp] * 17 + [_i32] * 7,
 }
 
+# investigation hooks, present only in a `make DEBUG_HOOKS=1` build of the library (include/simulst_hip.h, SIMULST_DEBUG_HOOKS)
+DEBUG_SIGNATURES = {
+    "simulst_debug_ffn_variant": [_vp, C.c_int],
+    "simulst_debug_chain_lds_bytes": [_vp, _i32],
+    "simulst_debug_chain_xmode": [_vp, _i32],
+    "simulst_debug_chain_tail": [_vp, _vp],
+    "simulst_debug_chain_probe_bytes": [_i32],
+    "simulst_debug_chain_probe": [_vp] * 10 + [_i32, _i32, _vp],
+}
+(OPT_VALU_ATTENTION, OPT_UNFUSED_DECODE, OPT_FFN_WAVES, OPT_DEC_CHAIN, OPT_DEC_ATTN_CHAIN_MAX_ROWS, OPT_DEC_ATTN_CHAIN_ROWS,
+ OPT_FUSED_ARGMAX) = range(7)
+
 _lib = None
-ABI_VERSION = 103          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
+ABI_VERSION = 104          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
 
 
 def load():
@@ -172,8 +180,13 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name == "simulst_last_error"
-                      else C.c_int64 if name in ("simulst_ctc_best_alignment_scratch_bytes", "simulst_debug_chain_probe_bytes")
+                      else C.c_int64 if name == "simulst_ctc_best_alignment_scratch_bytes"
                       else C.c_int)
+    for name, argtypes in DEBUG_SIGNATURES.items():          # only a DEBUG_HOOKS build has them
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = argtypes
+            fn.restype = C.c_int64 if name == "simulst_debug_chain_probe_bytes" else C.c_int
     if lib.simulst_version() != ABI_VERSION:          # the ctypes structures above mirror ONE layout of the descriptors
         raise RuntimeError(f"simulst_amd: {LIB_PATH} reports ABI version {lib.simulst_version()}, this binding is written for "
                            f"{ABI_VERSION} -- rebuild the library (make -C simulst_amd/csrc)")
@@ -208,6 +221,10 @@ class Handle:
         if rc != 0:
             msg = self.lib.simulst_last_error(self._h)
             raise RuntimeError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+    def set_option(self, option, value):
+        """simulst_set_option: path selection / tuning values of this handle (OPT_* above, include/simulst_hip.h)"""
+        self.check(self.lib.simulst_set_option(self._h, int(option), int(value)), "simulst_set_option")
 
     def timer_enable(self, kernel_class=-1, on=True):
         self.check(self.lib.simulst_timer_enable(self._h, kernel_class, int(on)), "simulst_timer_enable")

@@ -191,8 +191,10 @@ def _plain(o):
     return o
 
 
-def read_checkpoint(path: str) -> Dict:
-    """-> {"cfg": {"model": {...}, "task": {...}}, "model": {name: tensor}} from a fairseq-layout ``.pt``."""
+def read_checkpoint(path: str, arg_overrides: Optional[Mapping] = None) -> Dict:
+    """-> {"cfg": {"model": {...}, "task": {...}}, "model": {name: tensor}} from a fairseq-layout ``.pt``.  ``arg_overrides`` are merged
+    into the model args BEFORE the architecture is resolved, so {'arch': ...} rescues a checkpoint whose ``_name`` maps to no or to
+    several registered architectures (the agent's own override route, agents/default_agent.py:205-211)."""
     state = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_make_unpickler())
     if not isinstance(state, Mapping) or "model" not in state:
         raise ValueError(f"{path}: not a fairseq checkpoint (no 'model' entry)")
@@ -204,6 +206,9 @@ def read_checkpoint(path: str) -> Dict:
         model_args = task_args = _plain(state["args"])
     else:
         raise ValueError(f"{path}: checkpoint carries neither 'cfg' nor 'args'")
+    if arg_overrides:
+        model_args = dict(model_args)
+        model_args.update(arg_overrides)
     if "arch" not in model_args and "_name" in model_args:
         # hydra configs carry the MODEL name in `_name` ('mma_model'), not the architecture ('mma_model_s'): take the one
         # architecture registered for that model, or say what is missing
@@ -227,9 +232,8 @@ def load(path: str, arg_overrides: Optional[Mapping] = None, dtype="f32", device
     import argparse
     from . import cif, model  # noqa: F401  (register the models and archs)
     from .registry import build_model_from_args
-    st = read_checkpoint(path)
+    st = read_checkpoint(path, arg_overrides)          # overrides first: {'arch': ...} must reach the `_name` -> arch resolution
     args = dict(st["cfg"]["model"])
-    args.update(arg_overrides or {})
     args["simulst_dtype"] = "bf16" if dtype in ("bf16", torch.bfloat16) else "f32"
     args["simulst_device"] = device
     ns = argparse.Namespace(**args)

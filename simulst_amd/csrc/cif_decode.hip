@@ -237,6 +237,7 @@ int run_cif(simulst_handle* h, const simulst_cif_decoder_desc* dd, const simulst
   // row-local chains for co-scheduled bf16 batches (dec_chain.hip): same domain as the MMA decode loop
   const bool chain = dd->ffn_partial && dd->x_mid && sl_dec_chain_ok(h, dt, B, D, F, pk != 0);
   const bool chain_ffn = chain && B <= h->dec_chain_ffn_max_rows;
+  const bool attn_chain = chain && sl_dec_attn_chain_ok(h, dt, B, H, d, dd->cap);
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_cif_dec_layer& L = layers[l];
@@ -247,15 +248,22 @@ int run_cif(simulst_handle* h, const simulst_cif_decoder_desc* dd, const simulst
       } else {
         if ((rc = lin(h, dt, B, 3 * D, D, dd->x, L.wqkv, L.bqkv, nullptr, dd->qkv, SIMULST_EPI_BIAS, L.ln1_g, L.ln1_b, pk))) return rc;
       }
-      if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s, dd->ctx, B,
-                                  H, d, dd->cap, dt))) return rc;
-      if (chain) {
-        // x += Wo ctx + bo;  q = gelu(Wq LN2(x) + kk): one launch
-        if ((rc = sl_dec_proj_chain(h, dd->ctx, dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, nullptr, dd->q, nullptr, nullptr,
-                                    nullptr, B, kk_l))) return rc;
+      if (attn_chain) {
+        // self-attention; x += Wo ctx + bo;  q = gelu(Wq LN2(x) + kk): one launch
+        if ((rc = sl_dec_attn_proj_chain(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s, dd->cap,
+                                         dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, nullptr, dd->q, nullptr, nullptr, nullptr, B,
+                                         kk_l))) return rc;
       } else {
-        if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
-        if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq, nullptr, kk_l, dd->q, SIMULST_EPI_BIAS_RES_GELU, L.ln2_g, L.ln2_b, pk))) return rc;
+        if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s, dd->ctx, B,
+                                    H, d, dd->cap, dt))) return rc;
+        if (chain) {
+          // x += Wo ctx + bo;  q = gelu(Wq LN2(x) + kk): one launch
+          if ((rc = sl_dec_proj_chain(h, dd->ctx, dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, nullptr, dd->q, nullptr, nullptr,
+                                      nullptr, B, kk_l))) return rc;
+        } else {
+          if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
+          if ((rc = lin(h, dt, B, D, D, dd->x, L.c_wq, nullptr, kk_l, dd->q, SIMULST_EPI_BIAS_RES_GELU, L.ln2_g, L.ln2_b, pk))) return rc;
+        }
       }
       if (chain_ffn) {
         if ((rc = sl_dec_ffn_chain(h, dd->q, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2, dd->ffn_partial,

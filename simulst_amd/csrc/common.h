@@ -41,7 +41,8 @@ struct simulst_handle {
   uint64_t graph_key;
   bool ffn_lds_attr_set;       // simulst_emformer_ffn did the same for the fused feed-forward kernel
   bool ea_general_only;        // SIMULST_EA_GENERAL=1: expected alignment through the chunked log-space kernel for every S (A/B measurements)
-  int ffn_variant;             // simulst_debug_ffn_variant (timing ablations of the fused feed-forward launch)
+  int ffn_variant;             // simulst_debug_ffn_variant (DEBUG_HOOKS builds: timing ablations of the fused feed-forward launch)
+  int ffn_waves;               // SIMULST_OPT_FFN_WAVES: 0 the library's choice, 4 / 8 force that geometry of the fused feed-forward
   bool conv_pos_lds_attr_set;  // simulst_conv_pos raised its kernels' dynamic-LDS limit through this handle
   bool ctc_lds_attr_set;       // simulst_ctc_best_alignment raised its kernel's dynamic-LDS limit through this handle
   // row-local chains of the decoder layer (dec_chain.hip) for co-scheduled bf16 batches
@@ -54,6 +55,9 @@ struct simulst_handle {
   bool dec_chain_probe_attr_set;
   void* dec_chain_tail;        // investigation: the projection chain dumps its two LDS row buffers here at its end (null: off)
   int dec_chain_xmode;         // how the chains' MFMAs get their activation fragments (dec_chain.hip mma_unit)
+  int dec_attn_chain_max_rows; // rows up to which self-attention rides inside the projection chain (dec_attn_proj_chain_kernel)
+  int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
+  bool fused_argmax;           // decode loops: per-tile (max, index) partials out of the vocabulary projection instead of fp32 logits
 };
 
 #define SL_CHECK_NULL(h, p)                                   \
@@ -260,6 +264,10 @@ bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bo
 int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* Wo, const float* bo, const float* ln_g,
                       const float* ln_b, const void* Wq, const float* bq, void* q, const void* Wq2, const float* bq2,
                       void* q2, int B, const void* kk_gelu = nullptr);
+bool sl_dec_attn_chain_ok(const simulst_handle* h, int dtype, int B, int H, int d, int cap);
+int sl_dec_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev, int np_uniform,
+                           int cap, void* x, const void* Wo, const float* bo, const float* ln_g, const float* ln_b, const void* Wq,
+                           const float* bq, void* q, const void* Wq2, const float* bq2, void* q2, int B, const void* kk_gelu = nullptr);
 int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
                      const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
                      int32_t* sem, void* x_mid, int B, int F);

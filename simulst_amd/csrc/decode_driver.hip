@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
                                                            const T* __restrict__ E, const float* __restrict__ pos,
                                                            T* __restrict__ x, int V, int D, int pad_idx, int eos_idx,
                                                            int mask_eos, float scale, int B_, int np_base,
-                                                           StreamCtl ctl) {
+                                                           StreamCtl ctl, const float2* __restrict__ partial, int n_tiles) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int s_tok;
@@ -438,6 +438,15 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
   const bool no_eos = !streaming && (mask_eos || np == 0);
   float best = -INFINITY;
   int bi = 0x7fffffff;
+  if (partial) {
+    // the vocabulary projection left one (largest value, its lowest index) pair per 64-column tile, pad / masked eos already
+    // excluded there (gemm_mid.hip, LinArgs::amax): fold the tiles with the same rule
+    for (int t = tid; t < n_tiles; t += 256) {
+      const float2 pr = partial[(long)b * n_tiles + t];
+      const int c = __float_as_int(pr.y);
+      if (pr.x > best || (pr.x == best && c < bi)) { best = pr.x; bi = c; }
+    }
+  } else
   if ((V & 3) == 0) {                                    // 16-byte loads: a thread's candidates still arrive in index order
     for (int c4 = tid; c4 < (V >> 2); c4 += 256) {
       const float4 q = *reinterpret_cast<const float4*>(row + 4 * c4);
@@ -794,6 +803,8 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   const bool chain = !split && !fuse_q && !h->force_unfused_decode && dd->ffn_partial &&
                      sl_dec_chain_ok(h, dt, B, D, F, pk != 0);
   const bool chain_ffn = chain && B <= h->dec_chain_ffn_max_rows && dd->x_mid;
+  // round 4: the self-attention of a layer inside its projection chain (4 launches per layer)
+  const bool attn_chain = chain && sl_dec_attn_chain_ok(h, dt, B, H, d, dd->cap);
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_dec_layer& L = layers[l];
@@ -812,8 +823,9 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         } else {
           if ((rc = lin(h, dt, B, 3 * D, D, dd->x, L.wqkv, L.bqkv, nullptr, dd->qkv, SIMULST_EPI_BIAS, L.ln1_g, L.ln1_b, pk))) return rc;
         }
-        if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
-                                    dd->ctx, B, H, d, dd->cap, dt))) return rc;
+        if (!attn_chain)
+          if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
+                                      dd->ctx, B, H, d, dd->cap, dt))) return rc;
         if (!chain)
           if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
       }
@@ -833,7 +845,11 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         // many rows: every (head, row) workgroup re-streaming its 32 KB of the query projection through L2 costs
         // more than one LN-prologue GEMM launch that reads the weights once per row tile
         const void* qsoft = L.c_wq_soft ? dd->q2 : dd->q;
-        if (chain) {
+        if (attn_chain) {                        // self-attention + out-proj + residual + LN2 + query projection(s): one launch
+          if ((rc = sl_dec_attn_proj_chain(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
+                                           dd->cap, dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, L.c_bq, dd->q, L.c_wq_soft,
+                                           L.c_bq_soft, dd->q2, B))) return rc;
+        } else if (chain) {
           if ((rc = sl_dec_proj_chain(h, dd->ctx, dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, L.c_bq, dd->q, L.c_wq_soft,
                                       L.c_bq_soft, dd->q2, B))) return rc;
         } else {
@@ -858,20 +874,31 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
     if (chain_ffn)                               // the last layer's slabs
       if ((rc = sl_dec_qkv_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[dd->n_layers - 1].b2, nullptr, nullptr, nullptr,
                                  nullptr, nullptr, B, F))) return rc;
-    if ((rc = lin(h, dt, B, V, D, dd->x, dd->out_proj, nullptr, nullptr, dd->logits, SIMULST_EPI_BIAS_F32OUT, dd->ln_g,
-                  dd->ln_b, pk))) return rc;
+    // greedy pick fused into the vocabulary projection where the shapes allow (the 64 x 64 tile kernel's domain): dd->logits then
+    // holds [B][V / 64] (value, index) pairs instead of fp32 rows.  The masks must be known when the projection is launched:
+    // streaming masks nothing, forced decoding masks pad + eos, free offline decoding masks eos only at position 0, which the
+    // host can tell only for lockstep rows (np_uniform).
+    const bool eos_first = !ctlp && !mask_eos;                                     // eos masked iff the row is at position 0
+    const bool amax = sl_vocab_argmax_ok(h, dt, B, V, D, pk != 0) && (!eos_first || np_uniform >= 0);
+    if (amax) {
+      const bool no_eos = !ctlp && (mask_eos || (np_uniform >= 0 && np_uniform + s == 0));
+      if ((rc = sl_launch_vocab_argmax(h, dd->x, dd->out_proj, dd->ln_g, dd->ln_b, (float2*)dd->logits, B, V, D,
+                                       ctlp ? -1 : dd->pad_idx, no_eos ? dd->eos_idx : -1))) return rc;
+    } else if ((rc = lin(h, dt, B, V, D, dd->x, dd->out_proj, nullptr, nullptr, dd->logits, SIMULST_EPI_BIAS_F32OUT, dd->ln_g,
+                         dd->ln_b, pk))) return rc;
     {
+      const float2* part = amax ? (const float2*)dd->logits : nullptr;
       KTimer t(h, SIMULST_K_ARGMAX);
       if (dt == SIMULST_F32)
         hipLaunchKernelGGL(argmax_embed_kernel<float>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
                            (long*)out_tokens + (device_indexed ? 0 : (long)s * B), dd->n_prev, (const float*)dd->E,
                            dd->pos_table, (float*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, B,
-                           np_base, ctl);
+                           np_base, ctl, part, V / 64);
       else
         hipLaunchKernelGGL(argmax_embed_kernel<bf16>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
                            (long*)out_tokens + (device_indexed ? 0 : (long)s * B), dd->n_prev, (const bf16*)dd->E,
                            dd->pos_table, (bf16*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, B,
-                           np_base, ctl);
+                           np_base, ctl, part, V / 64);
       if ((rc = sl_launch_status(h, "simulst_mma_decode(argmax)")) != 0) return rc;
     }
   }

@@ -241,13 +241,15 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
   if (!h->ffn_lds_attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)ffn_fused_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<8>::LDS);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)ffn_fused_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<8>::LDS);
-    if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)ffn_fused_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
+#ifdef SL_DEBUG_HOOKS
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ffn_fused_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_fused_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_fused_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_fused_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_fused_kernel<5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FFG<4>::LDS);
+#endif
     if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit"; return (int)e; }
     h->ffn_lds_attr_set = true;
   }
@@ -256,23 +258,29 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
   hipLaunchKernelGGL((ffn_fused_kernel<V, W>), dim3((unsigned)((rows + FFG<W>::ROWS - 1) / FFG<W>::ROWS)),         \
                      dim3(FFG<W>::THREADS), FFG<W>::LDS, h->stream, (const bf16*)x, ln_gamma, ln_beta,             \
                      (const bf16*)w1_packed, b1, (const bf16*)w2_packed, b2, (bf16*)out, (long)rows, F)
-  // geometry: two 4-wave workgroups per CU when the fc1 bias fits their LDS budget (F <= 2048), else one 8-wave workgroup;
-  // simulst_debug_ffn_variant: 1 = no-GELU timing ablation (8 waves), 2 / 3 = force the 8- / 4-wave geometry
-  const bool four = h->ffn_variant == 3 || (h->ffn_variant == 0 && FF_DEFAULT_FOUR_WAVES);
-  if (h->ffn_variant == 1) FFN(1, 8);
-  else if (h->ffn_variant == 12) FFN(2, 4);      // 4-wave geometry ablations (results are NOT the operator's): no second product,
+  // geometry: two 4-wave workgroups per CU when the fc1 bias fits their LDS budget (F <= 2048), else one 8-wave workgroup
+  // (SIMULST_OPT_FFN_WAVES forces one of the two)
+  const bool four = h->ffn_waves == 4 || (h->ffn_waves == 0 && FF_DEFAULT_FOUR_WAVES);
+#ifdef SL_DEBUG_HOOKS
+  // simulst_debug_ffn_variant: timing ablations, results are NOT the operator's
+  if (h->ffn_variant == 1) FFN(1, 8);            // no GELU arithmetic (8 waves)
+  else if (h->ffn_variant == 12) FFN(2, 4);      // 4-wave geometry: no second product,
   else if (h->ffn_variant == 13) FFN(3, 4);      //   no first product,
   else if (h->ffn_variant == 14) FFN(4, 4);      //   no product at all (staging + barriers + GELU + fragment reads),
   else if (h->ffn_variant == 15) FFN(5, 4);      //   no GELU
-  else if (four && F <= FFG<4>::MAX_F) FFN(0, 4);
+  else
+#endif
+  if (four && F <= FFG<4>::MAX_F) FFN(0, 4);
   else FFN(0, 8);
 #undef FFN
   return sl_launch_status(h, "simulst_emformer_ffn");
 }
 
-// measurement hook (tools/ffn_bench.py): 1 = the same launch without the GELU arithmetic (results are NOT the operator's)
+#ifdef SL_DEBUG_HOOKS
+// measurement hook (tools/ffn_bench.py --ablations, DEBUG_HOOKS build): timing ablations of the launch, results are NOT the operator's
 extern "C" int simulst_debug_ffn_variant(simulst_handle* h, int variant) {
   if (!h) return SIMULST_E_NULL;
   h->ffn_variant = variant;
   return SIMULST_OK;
 }
+#endif

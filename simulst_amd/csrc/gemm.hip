@@ -402,6 +402,7 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
   p.w_packed = d->w_fragment_major;
   p.c_hd = d->c_head_dim; p.c_hs = d->c_head_stride;
   p.c_th = d->c_tensor_heads; p.c_ts = d->c_tensor_stride;
+  p.amax = nullptr; p.amax_tiles = 0; p.amax_skip_a = p.amax_skip_b = -1;
   SL_REQUIRE(h, p.c_th == 0 || (p.c_th > 0 && p.c_hd > 0 && d->N % (p.c_hd * p.c_th) == 0 && (p.c_ts & 7) == 0), SIMULST_E_ARG,
              "simulst_linear: c_tensor_heads needs c_head_dim, N a multiple of one tensor's width, c_tensor_stride % 8 == 0");
   SL_REQUIRE(h, p.c_hd == 0 || (p.c_hd > 0 && p.c_hd % 8 == 0 && d->N % p.c_hd == 0 && d->epilogue == SIMULST_EPI_BIAS),

@@ -19,6 +19,11 @@ struct LinArgs {
   long c_hs;           //      (cross-attention K/V projections stored [B][H][S_cap][head_dim]); 0: plain [.., N] rows
   int c_th;            // > 0: several head-major tensors side by side, c_th heads each, c_ts elements apart
   long c_ts;
+  // greedy pick fused into the vocabulary projection (gemm_mid.hip, fp32 outputs only): when amax != nullptr the kernel writes, per
+  // row and 64-column tile, the tile's (largest value, its lowest index) to amax[row * amax_tiles + tile] INSTEAD of the
+  // fp32 row segment; columns amax_skip_a / amax_skip_b (pad, masked eos; -1: none) never win.  The commit kernel folds the tiles.
+  float2* amax;
+  int amax_tiles, amax_skip_a, amax_skip_b;
 };
 
 __device__ __forceinline__ long c_index(const LinArgs& p, int b, int ii, int c) {
@@ -89,6 +94,11 @@ int sl_launch_panel_split(simulst_handle* h, int epi, const void* A, const void*
 bool sl_mid_wanted(const simulst_handle* h, int dtype, const LinArgs& p);
 int sl_launch_mid(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                   const void* R, void* C, const LinArgs& p);
+// the vocabulary projection of a decode step with the greedy pick's per-tile maxima as its output (bf16, LayerNorm prologue, no bias):
+// partial [B][V / 64] (value, index) pairs; sl_vocab_argmax_ok says whether the shape is taken
+bool sl_vocab_argmax_ok(const simulst_handle* h, int dtype, int B, int V, int D, bool packed);
+int sl_launch_vocab_argmax(simulst_handle* h, const void* x, const void* W, const float* ln_g, const float* ln_b, float2* partial,
+                           int B, int V, int D, int skip_a, int skip_b);
 
 // one wave per 16 x 16 tile for narrow outputs (N < 512) of co-scheduled batches with K <= 8 k-steps, gemm_mid.hip
 bool sl_wave_tile_wanted(int dtype, const LinArgs& p);

@@ -175,6 +175,29 @@ __global__ __launch_bounds__(256) void mid_kernel(const TA* __restrict__ A, cons
     const int er = q * 64 + (tid >> 2);
     const int erow = m0 + er;
     if (erow >= p.M) continue;
+    if constexpr (std::is_same<TC, float>::value) {
+      if (p.amax) {
+        // greedy pick, first stage: this thread's 16 columns in index order (strict > keeps the lowest index), then the row's four
+        // threads (lanes tid & 3, columns ascending with the lane: on equal values the lower lane wins)
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int c = n0 + ec + e;
+          float v = tile[er][ec + e] + lbias[ec + e];
+          if (c == p.amax_skip_a || c == p.amax_skip_b || c >= p.N) v = -INFINITY;
+          if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 1; o <= 2; o <<= 1) {
+          const float ov = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((tid & 3) == 0) p.amax[(long)erow * p.amax_tiles + blockIdx.x] = make_float2(best, __int_as_float(bi));
+        continue;
+      }
+    }
     const int eb = erow / p.rpb, ei = erow - eb * p.rpb;
     TC* cp = C + c_index(p, eb, ei, n0 + ec);        // 16 consecutive columns stay inside one head (head_dim % 16 == 0)
     float y[16];
@@ -384,6 +407,25 @@ bool sl_mid_wanted(const simulst_handle* h, int dtype, const LinArgs& p) {
   // out-proj, 12.8 -> 7.6 us LN + q-proj).  fc2 (K = 2048) measured the same on both kernels and keeps the k-split one.
   const bool narrow = p.N >= 64 && p.N < 512 && p.K <= 8 * KS && p.M >= h->mid_narrow_min_rows;
   return p.M >= 256 && (p.N >= 512 || narrow) && blocks >= h->mid_min_blocks && p.K % KS == 0 && (!p.ln_g || p.K <= 8 * KS);
+}
+
+// the decode loops' vocabulary projection with the greedy pick's per-tile maxima as output: the shapes the 64 x 64 tile kernel
+// takes anyway (co-scheduled bf16 batches below the split-panel threshold), final LayerNorm as prologue
+bool sl_vocab_argmax_ok(const simulst_handle* h, int dtype, int B, int V, int D, bool packed) {
+  if (!h->fused_argmax || dtype != SIMULST_BF16 || !packed || V % 64 != 0 || D % 32 != 0 || D > 256) return false;
+  LinArgs p = {};
+  p.M = B; p.rpb = B; p.N = V; p.K = D; p.a_rs = D; p.c_rs = V; p.w_packed = 1; p.ln_g = (const float*)h;   // any non-null: LN prologue
+  return sl_mid_wanted(h, dtype, p) && !sl_panel_split_wanted(h, dtype, SIMULST_EPI_BIAS_F32OUT, p);
+}
+
+int sl_launch_vocab_argmax(simulst_handle* h, const void* x, const void* W, const float* ln_g, const float* ln_b, float2* partial,
+                           int B, int V, int D, int skip_a, int skip_b) {
+  LinArgs p = {};
+  p.M = B; p.rpb = B; p.N = V; p.K = D;
+  p.a_bs = 0; p.a_rs = D; p.a_lead = 0; p.c_bs = 0; p.c_rs = V; p.r_bs = 0; p.r_rs = V;
+  p.scale = 1.f; p.ln_g = ln_g; p.ln_b = ln_b; p.w_packed = 1;
+  p.amax = partial; p.amax_tiles = V / 64; p.amax_skip_a = skip_a; p.amax_skip_b = skip_b;
+  return launch_mid<bf16, float, SIMULST_EPI_BIAS>(h, x, W, nullptr, nullptr, partial, p);
 }
 
 // narrow outputs of co-scheduled batches with a short contraction: one wave per tile

@@ -4,7 +4,9 @@
 
 // 100: rounds 1-2.  103: round 3 -- simulst_linear_desc, simulst_stream_ctl and simulst_cif_stream_ctl grew at their ends
 // (c_tensor_heads / c_tensor_stride; the chunk schedules of self-paced rows), simulst_decoder_desc gained P_cap.
-extern "C" int simulst_version(void) { return 103; }
+// 104: round 4 -- kernel classes 11-14 (one per layer-chain kernel), simulst_set_option replaces the two path-selection hooks,
+// simulst_decoder_attn_proj_chain, the simulst_debug_* entry points only in DEBUG_HOOKS builds.
+extern "C" int simulst_version(void) { return 104; }
 
 extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (!out) return SIMULST_E_NULL;
@@ -43,13 +45,24 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->dec_chain_lds_bytes = 0;
   h->dec_chain_xmode = 3;      // fragments hoisted + LayerNorm reductions on the DPP path: 1.378 -> 1.401 M tokens/s in the driver form
   h->dec_chain_tail = nullptr;
-  if (const char* e = getenv("SIMULST_DEC_CHAIN_XMODE")) h->dec_chain_xmode = atoi(e);
-  if (const char* e = getenv("SIMULST_DEC_CHAIN_LDS_BYTES")) h->dec_chain_lds_bytes = atoi(e);
+#ifdef SL_DEBUG_HOOKS
+  // investigation knobs (bitmask 0..3: bit 0 hoisted fragment reads, bit 1 DPP reductions; LDS request up to the CU's 160 KB):
+  // out-of-range values are ignored, like the simulst_debug_* setters refuse them
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_XMODE")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->dec_chain_xmode = v; }
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_LDS_BYTES")) { const int v = atoi(e); if (v >= 0 && v <= 160 * 1024) h->dec_chain_lds_bytes = v; }
+#endif
+  h->dec_attn_chain_max_rows = 0;      // OFF: measured slower than the two launches at every cache length (dec_chain.hip)
+  if (const char* e = getenv("SIMULST_DEC_ATTN_CHAIN_MAX_ROWS")) h->dec_attn_chain_max_rows = atoi(e);
+  h->dec_attn_chain_rows = 0;
+  h->fused_argmax = true;      // greedy pick's partial maxima in the vocabulary projection's epilogue (decode loops, bf16, co-scheduled rows)
+  if (const char* e = getenv("SIMULST_FUSED_ARGMAX")) h->fused_argmax = atoi(e) != 0;
+  if (const char* e = getenv("SIMULST_DEC_ATTN_CHAIN_ROWS")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->dec_attn_chain_rows = v; }
   h->graph_exec = nullptr;
   h->ctc_lds_attr_set = false;
   h->conv_pos_lds_attr_set = false;
   h->ffn_lds_attr_set = false;
   h->ffn_variant = 0;
+  h->ffn_waves = 0;
   h->ea_general_only = false;
   if (const char* e = getenv("SIMULST_EA_GENERAL")) h->ea_general_only = atoi(e) != 0;
   h->graph_key = 0;
@@ -128,14 +141,26 @@ extern "C" int simulst_graph_enable(simulst_handle* h, int on) {
   return SIMULST_OK;
 }
 
-extern "C" int simulst_debug_force_valu_attention(simulst_handle* h, int on) {
+// Run-time options of a handle: path selection (each alternative is a complete, valid implementation -- the tests use them for
+// A/B parity) and the tuning values that simulst_create reads from the environment.
+extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t value) {
   if (!h) return SIMULST_E_NULL;
-  h->force_valu_attention = on != 0;
-  return SIMULST_OK;
-}
-
-extern "C" int simulst_debug_force_unfused_decode(simulst_handle* h, int on) {
-  if (!h) return SIMULST_E_NULL;
-  h->force_unfused_decode = on != 0;
-  return SIMULST_OK;
+  switch (option) {
+    case SIMULST_OPT_VALU_ATTENTION: h->force_valu_attention = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_UNFUSED_DECODE: h->force_unfused_decode = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_FFN_WAVES:
+      SL_REQUIRE(h, value == 0 || value == 4 || value == 8, SIMULST_E_ARG, "simulst_set_option(FFN_WAVES): 0, 4 or 8");
+      h->ffn_waves = value; return SIMULST_OK;
+    case SIMULST_OPT_DEC_CHAIN: h->dec_chain_on = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS:
+      SL_REQUIRE(h, value >= 0, SIMULST_E_ARG, "simulst_set_option(DEC_ATTN_CHAIN_MAX_ROWS): >= 0");
+      h->dec_attn_chain_max_rows = value; return SIMULST_OK;
+    case SIMULST_OPT_DEC_ATTN_CHAIN_ROWS:
+      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG, "simulst_set_option(DEC_ATTN_CHAIN_ROWS): 0, 4, 8 or 16");
+      h->dec_attn_chain_rows = value; return SIMULST_OK;
+    case SIMULST_OPT_FUSED_ARGMAX: h->fused_argmax = value != 0; return SIMULST_OK;
+    default: break;
+  }
+  h->err = "simulst_set_option: unknown option";
+  return SIMULST_E_ARG;
 }

@@ -327,6 +327,24 @@ class Ops:
                      "simulst_decoder_proj_chain")
         return q, q2
 
+    def decoder_attn_proj_chain(self, qkv, k_cache, v_cache, n_prev, x, wo_fm, bo, ln, wq_fm, bq, q=None, wq2_fm=None, bq2=None,
+                                q2=None, kk_gelu=None, rows_per_workgroup=0, n_prev_uniform=-1):
+        """self-attention over the caches [B][4][cap][64] (appending this step's k / v rows at n_prev) + x <- x + Wo ctx + bo +
+        q = Wq LN(x) + bq (+ q2, or gelu(. + kk_gelu)) in ONE launch (simulst_decoder_attn_proj_chain): the same results as
+        decoder_self_attention followed by decoder_proj_chain, bit for bit."""
+        B, D = x.shape
+        H, cap, d = k_cache.shape[1], k_cache.shape[2], k_cache.shape[3]
+        if q is None:
+            q = torch.empty_like(x)
+        if wq2_fm is not None and q2 is None:
+            q2 = torch.empty_like(x)
+        self.h.check(self.lib.simulst_decoder_attn_proj_chain(self.h.ptr, _p(qkv), _p(k_cache), _p(v_cache), _p(n_prev), _p(x),
+                                                              _p(wo_fm), _p(bo), _p(ln[0]), _p(ln[1]), _p(wq_fm), _p(bq), _p(q),
+                                                              _p(wq2_fm), _p(bq2), _p(q2), _p(kk_gelu), B, H, d, cap,
+                                                              int(n_prev_uniform), rows_per_workgroup, dt(x)),
+                     "simulst_decoder_attn_proj_chain")
+        return q, q2
+
     def decoder_ffn_chain(self, ctx, x, wco_fm, bco, ln, w1_fm, b1, w2_fm, b2, partial=None, sem=None, x_mid=None):
         """x <- x' + W2 gelu(W1 LN(x') + b1) + b2 with x' = x + Wco ctx + bco, in ONE launch
         (simulst_decoder_ffn_chain; bf16, D == 256, F % 256 == 0, fragment-major weights).  With x_mid the launch stops

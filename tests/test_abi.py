@@ -9,9 +9,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
+def header_functions(debug_hooks=False):
     src = open(os.path.join(ROOT, "include", "simulst_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    if not debug_hooks:        # the investigation hooks exist only in a `make DEBUG_HOOKS=1` build (hygiene)
+        src = re.sub(r"#ifdef SIMULST_DEBUG_HOOKS.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(simulst_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -35,6 +37,24 @@ def test_library_exports_nothing_but_the_declared_abi():
     out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
     exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
     assert exported == header_functions(), set(exported) ^ set(header_functions())
+
+
+def test_shipped_library_has_no_debug_hooks():
+    """the product ABI only: no simulst_debug_* entry point (timing ablations with invalid results, probe kernels) in the shipped
+    library; the header declares them behind SIMULST_DEBUG_HOOKS and the binding lists them apart"""
+    from simulst_amd import _lib
+    lib = _lib.load()
+    dbg = sorted(set(header_functions(debug_hooks=True)) - set(header_functions()))
+    assert dbg == sorted(_lib.DEBUG_SIGNATURES) and all(n.startswith("simulst_debug_") for n in dbg) and len(dbg) == 6
+    assert not any(n.startswith("simulst_debug_") for n in header_functions())
+    for n in dbg:
+        assert not hasattr(lib, n), n
+    h = ctypes.c_void_p()
+    assert lib.simulst_create(ctypes.byref(h), None) == 0
+    assert lib.simulst_set_option(h, _lib.OPT_FFN_WAVES, 4) == 0
+    assert lib.simulst_set_option(h, _lib.OPT_FFN_WAVES, 5) == -4 and b"FFN_WAVES" in lib.simulst_last_error(h)
+    assert lib.simulst_set_option(h, 99, 1) == -4
+    assert lib.simulst_destroy(h) == 0
 
 
 def test_null_handle_and_null_pointer_statuses():

@@ -28,6 +28,38 @@ def test_gpus_2_starts_two_ranks_and_gathers_both_shards():
     assert out["config"]["tokens_per_step"] == 8 * 110 * 2
 
 
+def test_gpus_8_starts_eight_ranks_and_reports_what_it_saw():
+    """The driver's SCALE run at N = 8: eight ranks from the bare `python bench.py --gpus 8` command, every shard gathered, and the
+    line carries the world size observed after init_process_group (ranks_seen) and the spread of the per-rank pass times, so a
+    SCALE_r*.json can show imbalance."""
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "0", "--batch", "4", "--dry-run-gloo"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8
+    assert out["gathered_utterances"] == 8 * 3 * 4 and out["gathered_ids_complete"] is True
+    (lo, hi), = out["per_rank_pass_ms_min_max"]
+    assert 0 < lo <= hi
+    assert out["config"]["tokens_per_step"] == 4 * 110 * 8
+
+
+def test_gpus_1_under_the_launcher_equals_the_plain_run():
+    """`torchrun --nproc-per-node 1 bench.py --gpus 1` (what a driver may do for N = 1) and the plain `python bench.py --gpus 1`
+    take the same plan and decode the same utterances"""
+    plain = _run(["--gpus", "1", "--steps", "5", "--warmup", "0", "--batch", "8", "--dry-run-gloo"])
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    under = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5",
+                            "--warmup", "0", "--batch", "8", "--dry-run-gloo"], env=env, capture_output=True, text=True, timeout=300)
+    assert under.returncode == 0, under.stderr[-2000:]
+    a, b = (json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0]) for r in (plain, under))
+    for k in ("n_gpus", "ranks_seen", "gathered_utterances", "gathered_ids_complete", "config"):
+        assert a[k] == b[k], k
+    assert a["ranks_seen"] == 1
+
+
 def test_failed_rank_gives_nonzero_exit():
     """No GPU here: the real (non-dry-run) ranks raise, and the launcher must report it."""
     import torch

@@ -187,6 +187,8 @@ def test_read_checkpoint_layouts(tmp_path):
     torch.save({"cfg": {"model": {"_name": "no_such_model"}, "task": {}}, "model": w}, p4)
     with pytest.raises(ValueError, match="no architecture"):
         ck.read_checkpoint(p4)
+    # ... and the remedy the message names works: the override reaches the `_name` -> arch resolution
+    assert ck.read_checkpoint(p4, {"arch": "mma_model_s"})["cfg"]["model"]["arch"] == "mma_model_s"
     # a pickle that refers to an un-importable class OUTSIDE the configuration namespaces fails loudly instead of loading as a shell
     evil = types.ModuleType("somewhere_else")
     exec("class Thing:\n    pass\n", evil.__dict__)

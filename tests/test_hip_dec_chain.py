@@ -6,6 +6,8 @@ TransformerDecoderLayer as run by models/mma_model.py:99-135."""
 import pytest
 import torch
 
+from simulst_amd import _lib  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 D = 256
@@ -109,6 +111,67 @@ def test_ffn_chain_vs_torch(ops, B, F):
             assert qkv is None
 
 
+@pytest.mark.parametrize("B,rows", [(1, 4), (5, 4), (130, 4), (448, 4), (448, 8), (448, 16), (700, 0), (1100, 8)])
+@pytest.mark.parametrize("variant", ["plain", "soft", "cif"])
+@pytest.mark.parametrize("uniform", [-1, 0, 7, 63, 64, 109])
+def test_attention_projection_chain_equals_the_two_launches(ops, B, rows, variant, uniform):
+    """simulst_decoder_attn_proj_chain (round 4: self-attention inside the projection chain, a workgroup per 4 / 8 / 16 rows) against
+    simulst_decoder_self_attention + simulst_decoder_proj_chain on the same operands: x, q (q2), and the appended cache rows are
+    IDENTICAL bit for bit, for ragged cache lengths (0 .. 109 cached positions, i.e. both pass-count instantiations) and for the
+    three forms of the second epilogue (query projection, + soft-energy projection, CIF's gelu(. + gathered row))."""
+    H, d, cap = 4, 64, 128
+    g = torch.Generator().manual_seed(B * 7 + rows)
+    cu = lambda t: t.cuda().to(torch.bfloat16).contiguous()
+    pk = lambda W: ops.pack_fragment_major(cu(W))
+    qkv = cu(_rand((B, 3 * D), g))
+    kc0, vc0 = cu(_rand((B, H, cap, d), g)), cu(_rand((B, H, cap, d), g))
+    x0 = cu(_rand((B, D), g))
+    n_prev = torch.randint(0, 110, (B,), generator=g).to(torch.int32)
+    n_prev[0] = 109
+    if B > 2:
+        n_prev[1], n_prev[2] = 0, 63
+    if uniform >= 0:                                       # lockstep rows: the host-known position (8-pass instantiation below 64)
+        n_prev[:] = uniform
+    n_prev = n_prev.cuda()
+    Wo, Wq, Wq2 = (pk(_bf(_rand((D, D), g, D ** -0.5))) for _ in range(3))
+    bo, bq, bq2 = (_rand((D,), g, 0.1).cuda() for _ in range(3))
+    ln = ((1 + _rand((D,), g, 0.1)).cuda(), _rand((D,), g, 0.1).cuda())
+    kk = cu(_rand((B, D), g)) if variant == "cif" else None
+    soft = variant == "soft"
+    # reference: the two launches
+    kc_a, vc_a, x_a = kc0.clone(), vc0.clone(), x0.clone()
+    ctx = ops.decoder_self_attention(qkv, kc_a, vc_a, n_prev)
+    if variant == "cif":
+        # the proj chain's gathered-row form is internal to the CIF loop; its public twin: out-proj GEMM, then LN + q-proj + row + GELU
+        from simulst_amd._lib import EPI_BIAS_RES, EPI_BIAS_RES_GELU
+        ops.linear(ctx, Wo, bo, epilogue=EPI_BIAS_RES, residual=x_a, out=x_a, w_fragment_major=True)
+        q_a = ops.linear(x_a, Wq, None, epilogue=EPI_BIAS_RES_GELU, residual=kk, w_fragment_major=True, ln=ln)
+        q2_a = None
+    else:
+        q_a, q2_a = ops.decoder_proj_chain(ctx, x_a, Wo, bo, ln, Wq, bq, wq2_fm=Wq2 if soft else None, bq2=bq2 if soft else None)
+    kc_b, vc_b, x_b = kc0.clone(), vc0.clone(), x0.clone()
+    q_b, q2_b = ops.decoder_attn_proj_chain(qkv, kc_b, vc_b, n_prev, x_b, Wo, bo, ln, Wq, None if variant == "cif" else bq,
+                                            wq2_fm=Wq2 if soft else None, bq2=bq2 if soft else None, kk_gelu=kk,
+                                            rows_per_workgroup=rows, n_prev_uniform=uniform)
+    torch.cuda.synchronize()
+    assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
+    if variant == "cif":
+        # different kernels for the reference here (GEMM launches, erf GELU for fp32 / fast GELU for bf16 alike): to bf16 resolution
+        torch.testing.assert_close(x_b.float(), x_a.float(), atol=0.04, rtol=0.01)
+        torch.testing.assert_close(q_b.float(), q_a.float(), atol=0.06, rtol=0.02)
+    else:
+        assert torch.equal(x_a, x_b)
+        assert torch.equal(q_a, q_b)
+        if soft:
+            assert torch.equal(q2_a, q2_b)
+    for _ in range(3):                                     # repeats bit for bit
+        kc_c, vc_c, x_c = kc0.clone(), vc0.clone(), x0.clone()
+        q_c, _ = ops.decoder_attn_proj_chain(qkv, kc_c, vc_c, n_prev, x_c, Wo, bo, ln, Wq, None if variant == "cif" else bq,
+                                             wq2_fm=Wq2 if soft else None, bq2=bq2 if soft else None, kk_gelu=kk,
+                                             rows_per_workgroup=rows, n_prev_uniform=uniform)
+        assert torch.equal(x_c, x_b) and torch.equal(q_c, q_b) and torch.equal(kc_c, kc_b)
+
+
 def test_chain_rejects_what_it_cannot_do(ops):
     x = torch.zeros(4, 128, device="cuda", dtype=torch.bfloat16)
     w = torch.zeros(128, 128, device="cuda", dtype=torch.bfloat16)
@@ -149,13 +212,13 @@ def test_decode_loop_with_chains_vs_one_launch_per_gemm(monkeypatch, attn, ffn):
     assert "ffn_partial" in i1["state"].ws
     lg1 = i1["state"].ws["logits"].clone()
     tN, _ = model.generate_offline(fb, L, n_steps=10, mask_eos=True)
-    ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 1)
+    ops.h.set_option(_lib.OPT_UNFUSED_DECODE, 1)
     try:
         t0, i0 = model.generate_offline(fb, L, n_steps=1, mask_eos=True)
         lg0 = i0["state"].ws["logits"].clone()
         tM, _ = model.generate_offline(fb, L, n_steps=10, mask_eos=True)
     finally:
-        ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
+        ops.h.set_option(_lib.OPT_UNFUSED_DECODE, 0)
     assert not torch.equal(lg0, lg1)                        # the hook really switched paths
     # a learned policy (infinite_lookback) decides READ / WRITE on a threshold: a row whose p_choose sits on it may take one
     # more source step on one path, which changes that row's context and logits -- rows, not elements, are compared
@@ -163,6 +226,56 @@ def test_decode_loop_with_chains_vs_one_launch_per_gemm(monkeypatch, attn, ffn):
     assert close >= (1.0 if attn.startswith("waitk") else 0.9), close
     assert (t1 == t0).float().mean().item() >= 0.9
     assert (tN == tM).float().mean().item() > 0.6
+
+
+@pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback", "cif"])
+@pytest.mark.parametrize("mask_eos", [True, False])
+def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):
+    """The decode loops with round 4's two fusions -- self-attention inside the projection chain (4 launches per layer; an option,
+    off by default because it measured slower) and the greedy pick's partial maxima out of the vocabulary projection (on by
+    default) -- against the same loops with both switched off
+    (simulst_set_option): the arithmetic and its order are unchanged, so the hypotheses are IDENTICAL, every token of every row,
+    bf16, 320 ragged rows, 24 steps (cache lengths cross nothing special here; the kernel-level test covers 0 .. 109)."""
+    from simulst_amd.cif import CIFTransformerModel
+    from simulst_amd.config import cif_transformer_s, mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.ops import Ops
+    from simulst_amd.weights import init_model
+    B, T, U = 320, 240, 24
+    fb = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(8))
+    L = torch.randint(100, T + 1, (B,), generator=torch.Generator().manual_seed(9))
+    L[0] = T
+    for b in range(B):
+        fb[b, L[b]:] = 0
+    fb = fb.cuda().to(torch.bfloat16)
+    if model_kind == "cif":
+        cfg = cif_transformer_s(encoder_layers=1, decoder_layers=3, cif_beta=1.0)
+        w = init_model(cfg, seed=21)
+        w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
+        w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.0
+        make = lambda ops: CIFTransformerModel(cfg, w, dtype=torch.bfloat16, ops=ops)
+    else:
+        attn = "waitk_fixed_pre_decision" if model_kind == "waitk" else "infinite_lookback"
+        cfg = mma_model_s(encoder_layers=1, decoder_layers=3, simul_attn_type=attn, waitk_lagging=3)
+        w = init_model(cfg, seed=21)
+        make = lambda ops: SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=ops)
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0          # free decoding must not stop at once
+    o_new, o_old = Ops(), Ops()
+    o_new.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 1024)      # off by default: measured slower (csrc/dec_chain.hip)
+    o_old.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 0)
+    o_old.h.set_option(_lib.OPT_FUSED_ARGMAX, 0)
+    t_new = make(o_new).generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)[0].clone()
+    t_old = make(o_old).generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(t_new, t_old), (t_new != t_old).sum().item()
+    assert len(set(t_new.flatten().tolist())) > 50         # not a degenerate hypothesis
+    # ... and the fused launches really ran: the attention-chain kernel class has launches on the new handle only
+    for o, want in ((o_new, True), (o_old, False)):
+        o.h.timer_reset(); o.h.timer_enable(-1, True)
+        make(o).generate_offline(fb, L, n_steps=2, mask_eos=mask_eos)
+        torch.cuda.synchronize()
+        o.h.timer_enable(-1, False)
+        assert (o.h.timer_read(_lib.K_DEC_ATTN_CHAIN)[1] > 0) == want
 
 
 def test_chains_repeat_beside_other_streams(ops):
@@ -190,6 +303,10 @@ def test_chains_repeat_beside_other_streams(ops):
     bD, bF, b3 = _rand((D,), g, 0.1).cuda(), _rand((F,), g, 0.1).cuda(), _rand((3 * D,), g, 0.1).cuda()
     ln = (torch.ones(D).cuda(), torch.zeros(D).cuda())
     partial = torch.empty(F // 256, B, D, device="cuda")
+    # round 4: the self-attention + projection chain launch rides in the same gate (4-row workgroups, ragged cache lengths)
+    qkv_in = bf(_rand((B, 3 * D), g))
+    kc0, vc0 = bf(_rand((B, 4, 128, 64), g)), bf(_rand((B, 4, 128, 64), g))
+    n_prev = torch.randint(0, 110, (B,), generator=g).to(torch.int32).cuda()
 
     def chains():
         x = x0.clone()
@@ -197,8 +314,10 @@ def test_chains_repeat_beside_other_streams(ops):
         x_mid, x2 = torch.empty_like(x), torch.empty_like(x)
         ops.decoder_ffn_chain(ctx, x, Wco, bD, ln, W1, bF, W2, bD, partial=partial, x_mid=x_mid)
         qkv = ops.decoder_slab_sum_qkv(x_mid, x2, partial, bD, ln, Wqkv, b3)
+        x3, kc, vc = x0.clone(), kc0.clone(), vc0.clone()
+        q3, _ = ops.decoder_attn_proj_chain(qkv_in, kc, vc, n_prev, x3, Wo, bD, ln, Wq, bD)
         torch.cuda.synchronize()
-        return x, q, x2, qkv
+        return x, q, x2, qkv, x3, q3
 
     quiet = chains()
     for _ in range(20):

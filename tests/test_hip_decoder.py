@@ -2,6 +2,8 @@
 import pytest
 import torch
 
+from simulst_amd import _lib  # noqa: E402
+
 from conftest import load_golden, split_weights
 
 pytestmark = pytest.mark.gpu
@@ -263,7 +265,7 @@ def test_head_split_layer_equals_seven_launch_layer(ops, attn, dtype):
 
 
 def test_force_unfused_hook(ops):
-    """simulst_debug_force_unfused_decode routes a head-split descriptor through the 7-launch layer."""
+    """simulst_set_option(SIMULST_OPT_UNFUSED_DECODE) routes a head-split descriptor through the 7-launch layer."""
     from simulst_amd.config import mma_model_s
     from simulst_amd.model import SimulSTModel
     from simulst_amd.weights import init_model
@@ -272,11 +274,11 @@ def test_force_unfused_hook(ops):
     fb = torch.randn(3, 200, 80, generator=torch.Generator().manual_seed(5)).cuda()
     L = torch.tensor([200, 200, 200])
     t_split, _ = model.generate_offline(fb, L, n_steps=8, mask_eos=True, fused=True)
-    ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 1)
+    ops.h.set_option(_lib.OPT_UNFUSED_DECODE, 1)
     try:
         t_seven, _ = model.generate_offline(fb, L, n_steps=8, mask_eos=True, fused=True)
     finally:
-        ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
+        ops.h.set_option(_lib.OPT_UNFUSED_DECODE, 0)
     assert torch.equal(t_split, t_seven)
 
 

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from simulst_amd import _lib  # noqa: E402
+
 from conftest import load_golden, split_weights
 
 pytestmark = pytest.mark.gpu
@@ -423,11 +425,11 @@ def test_emformer_attention_mfma_equals_valu(ops, streaming):
                   n_mem_valid=torch.tensor([5, 2, 0, 1, 3], dtype=torch.int32).cuda())
     out = {}
     for force in (1, 0):
-        ops.h.check(ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, force), "force")
+        ops.h.set_option(_lib.OPT_VALU_ATTENTION, force)
         CTX = torch.zeros(B, rows_c, D, device="cuda", dtype=torch.bfloat16)
         ops.emformer_attention(QKV, lengths, CTX, **kw)
         out[force] = CTX.float().cpu()
-    ops.h.check(ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, 0), "force")
+    ops.h.set_option(_lib.OPT_VALU_ATTENTION, 0)
     torch.testing.assert_close(out[0], out[1], atol=2e-2, rtol=2e-2)
     assert float(out[1].abs().max()) > 0.1
 
@@ -551,7 +553,7 @@ def test_conv_pos_mfma_equals_valu_kernel(ops):
 def test_decoder_self_attention_wave_kernel(ops):
     """bf16, head_dim 64, cache capacity <= 128: the barrier-free wave-per-(head, utterance) kernel, rows at DIFFERENT
     target positions (device-side n_prev), every position up to the capacity, against torch fp32 and against the
-    workgroup kernel (test hook simulst_debug_force_valu_attention)."""
+    workgroup kernel (test hook simulst_set_option(SIMULST_OPT_VALU_ATTENTION))."""
     g = torch.Generator().manual_seed(18)
     B, H, d, cap = 7, 4, 64, 128
     D = H * d
@@ -568,11 +570,11 @@ def test_decoder_self_attention_wave_kernel(ops):
     for step in range(27):
         qkv = dev(torch.randn(B, 3 * D, generator=g), torch.bfloat16)
         ctx = ops.decoder_self_attention(qkv, kc, vc, dev(n_prev))
-        ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, 1)
+        ops.h.set_option(_lib.OPT_VALU_ATTENTION, 1)
         try:
             ctx_blk = ops.decoder_self_attention(qkv, kc2, vc2, dev(n_prev))
         finally:
-            ops.lib.simulst_debug_force_valu_attention(ops.h.ptr, 0)
+            ops.h.set_option(_lib.OPT_VALU_ATTENTION, 0)
         f = qkv.float().cpu()
         for b in range(B):
             n = int(n_prev[b]) + 1
@@ -857,6 +859,37 @@ def test_g19_pre_decision_last_vs_golden(ops, name, ratio):
                     tgt += 1
 
 
+@pytest.mark.parametrize("name", ["hard_aligned_fixed_pre_decision", "infinite_lookback_fixed_pre_decision"])
+@pytest.mark.parametrize("ptype", ["average", "last"])
+@pytest.mark.parametrize("ratio", [2, 4])
+def test_step_p_choose_padded_vs_reference_fixture(ops, name, ptype, ratio):
+    """simulst_step_p_choose_padded against g20_predecision_padded.npz DIRECTLY: the reference's own FixedStride p_choose on a ragged
+    padded batch with and without incremental state (modules/fixed_pre_decision.py:97-167), not through the
+    oracle."""
+    a, _ = load_golden("g20_predecision_padded")
+    tag = f"{name}.{ptype}.r{ratio}"
+    w = split_weights(a, tag)
+    H, D = 2, 32
+    d = D // H
+    lens = a[f"lens.r{ratio}"].tolist()
+    keys = a["keys"]                                            # [S_pad, B, D]
+    S_pad, B = keys.size(0), keys.size(1)
+    S_cap = 16
+    K = torch.nn.functional.linear(keys, w["k_proj.weight"], w["k_proj.bias"])
+    Km = torch.zeros(B, H, S_cap, d)
+    Km[:, :, :S_pad] = K.view(S_pad, B, H, d).permute(1, 2, 0, 3)
+    Km = Km.cuda().contiguous()
+    kl = torch.tensor(lens, dtype=torch.int32).cuda()
+    ratio_arg = -ratio if ptype == "last" else ratio
+    for key_, qname, incremental in (("incr", "q", True), ("train", "q3", False)):
+        ref = a[f"{tag}.{key_}"]                                # [B*H, tgt, S_pad]
+        for t in range(ref.size(1)):
+            q = torch.nn.functional.linear(a[qname][t], w["q_proj.weight"], w["q_proj.bias"]).cuda()
+            p = torch.zeros(B * H, S_cap, device="cuda")
+            ops.step_p_choose_padded(q, Km, p, kl, S_pad=S_pad, ratio=ratio_arg, incremental=incremental, attn_type=_lib.ATTN_HARD)
+            torch.testing.assert_close(p[:, :S_pad].cpu(), ref[:, t], atol=2e-5, rtol=1e-4)
+
+
 @pytest.mark.parametrize("incremental", [True, False])
 @pytest.mark.parametrize("ptype", ["average", "last"])
 def test_step_p_choose_padded_batch_vs_oracle(ops, incremental, ptype):
@@ -941,7 +974,7 @@ def test_expected_alignment_small_source_kernels(ops, S):
 def test_waitk_cross_attention_long_sources_in_key_blocks(ops, dtype, S_cap):
     """Sources longer than 256 encoder rows, wait-k: key blocks of 256 on their own workgroups + the merge of the blocks' softmax
     partials (waitk_cross_attn_block_kernel / cross_attn_merge_kernel) against the thread-per-key loop of the one-workgroup kernel
-    (test hook simulst_debug_force_unfused_decode) and against a torch softmax: same head_step / head_read, context to rounding.
+    (test hook simulst_set_option(SIMULST_OPT_UNFUSED_DECODE)) and against a torch softmax: same head_step / head_read, context to rounding.
     Rows of every kind: sources shorter than one block, ending inside a block, on a block edge; early and late target positions."""
     from simulst_amd import _lib
     g = torch.Generator().manual_seed(S_cap)
@@ -958,12 +991,12 @@ def test_waitk_cross_attention_long_sources_in_key_blocks(ops, dtype, S_cap):
         res = []
         for forced in (0, 1):
             hs = torch.zeros(B * H, dtype=torch.int64, device="cuda")
-            ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, forced)
+            ops.h.set_option(_lib.OPT_UNFUSED_DECODE, forced)
             try:
                 ctx, hr = ops.policy_cross_attention(q, q, K, K, V, hs, H=H, ratio=ratio, attn_type=_lib.ATTN_ENUM["waitk"],
                                                      key_len=kl, tgt_idx=tg, waitk_k=k, online=online)
             finally:
-                ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
+                ops.h.set_option(_lib.OPT_UNFUSED_DECODE, 0)
             res.append((ctx.float().cpu(), hs.cpu(), hr.cpu()))
         (c_new, hs_new, hr_new), (c_old, hs_old, hr_old) = res
         assert torch.equal(hs_new, hs_old) and torch.equal(hr_new, hr_old)

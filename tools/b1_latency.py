@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Computation-aware latency of the B = 1 streaming agent.
+
+The reference's only timing-bearing published signal is AL_CA - AL = 154 / 241 / 198 ms (docs/waitk.md:39-40, docs/mma.md:49-50,
+docs/cif.md:45-46): SimulEval on CPU, one worker thread (eval/1-simuleval.sh:65,78-82), i.e. the wall-clock the model spends per
+READ / WRITE folded into the delays.  This tool drives the HIP agent (agent.FairseqSimulSTAgent, fp32, B = 1) and the CPU oracle
+(oracle.agent.simulate_mma at ONE thread, the reference's setting) over BASELINE.json configs[0]'s 8 utterances (wait-k 3, ratio 8,
+T in {312 .. 1534} frames) and reports, for each: wall time per READ (policy + encoder update of the new chunk) and per WRITE (policy
+= one decoder step + predict), and AL / AL_CA / DAL / DAL_CA (token-level: delay_i + wall-clock since the start of the utterance at
+commit i), with the identity of the two records checked on the way.
+
+    python tools/b1_latency.py [--max-len-a 0.1 --max-len-b 10] [--utterances 8]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+FRAMES = [312, 498, 640, 777, 845, 1000, 1203, 1534]
+
+
+def _stats(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return {"n": n, "mean_ms": round(1e3 * sum(xs) / max(n, 1), 3), "median_ms": round(1e3 * xs[n // 2], 3) if n else None,
+            "max_ms": round(1e3 * xs[-1], 3) if n else None}
+
+
+def _lat(delays, wall_ms, total_ms):
+    from simulst_amd.latency import average_lagging, differentiable_average_lagging
+    ca = [d + w for d, w in zip(delays, wall_ms)]
+    return {"AL": round(average_lagging(delays, total_ms), 2), "AL_CA": round(average_lagging(ca, total_ms), 2),
+            "DAL": round(differentiable_average_lagging(delays, total_ms), 2),
+            "DAL_CA": round(differentiable_average_lagging(ca, total_ms), 2)}
+
+
+def timed_hip_utterance(agent, fbank):
+    """agent.run_utterance with a stopwatch around every READ and WRITE (the device is synchronised inside: policy reads the action
+    back, predict reads the token)"""
+    from simulst_amd.agent import READ_ACTION, FrameSource, States
+    src = FrameSource(fbank)
+    states = States(src)
+    agent.initialize_states(states)
+    rd, wr, delays, wall, actions = [], [], [], [], []
+    t0 = time.perf_counter()
+    while True:
+        ta = time.perf_counter()
+        action = agent.policy(states)
+        if action == READ_ACTION:
+            actions.append("R")
+            src.read(agent.expected_frames)
+            agent.update_states_read(states)
+            torch.cuda.synchronize()
+            rd.append(time.perf_counter() - ta)
+            continue
+        actions.append("W")
+        tok = agent.predict(states)
+        states.target.append(tok)
+        agent.model.decoder.commit(states.dec_incremental_states["dec"])
+        delays.append(src.elapsed_ms())
+        wr.append(time.perf_counter() - ta)
+        wall.append((time.perf_counter() - t0) * 1e3)
+        if tok == agent.eos or len(states.target) > agent.max_len(src.pos):
+            break
+    return {"tokens": list(states.target), "delays_ms": delays, "actions": "".join(actions)}, rd, wr, wall, src.total_ms()
+
+
+def run(max_len_a=0.1, max_len_b=10, n_utt=8, oracle_threads=1, device="cuda:0"):
+    from oracle import agent as oag
+    from oracle.configs import from_model_config
+    from simulst_amd.agent import FairseqSimulSTAgent
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=3, fixed_pre_decision_ratio=8)
+    w = init_model(cfg, seed=999)
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0       # hypotheses run to their cap (a random-init tied embedding answers <eos> with <eos>)
+    ecfg, dcfg = from_model_config(cfg)
+    utts = [torch.randn(T, 80, generator=torch.Generator().manual_seed(999 + i)) for i, T in enumerate(FRAMES[:n_utt])]
+    model = SimulSTModel(cfg, w, device=device, dtype=torch.float32)
+    agent = FairseqSimulSTAgent(model, max_len_a=max_len_a, max_len_b=max_len_b)
+    with torch.no_grad():
+        timed_hip_utterance(agent, utts[0].to(device))                  # warm: code objects, allocator
+        hip = [timed_hip_utterance(agent, u.to(device)) for u in utts]
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(oracle_threads)
+    ora = []
+    with torch.no_grad():
+        oag.simulate_mma(w, ecfg, dcfg, utts[0][:200], max_len_a=max_len_a, max_len_b=max_len_b)
+        for u in utts:
+            tm = {}
+            r = oag.simulate_mma(w, ecfg, dcfg, u, max_len_a=max_len_a, max_len_b=max_len_b, timing=tm)
+            ora.append((r, tm))
+    torch.set_num_threads(threads_before)
+    identical = all(h[0]["actions"] == r["actions"] and h[0]["tokens"] == r["tokens"] and h[0]["delays_ms"] == r["delays_ms"]
+                    for h, (r, _) in zip(hip, ora))
+    per_utt = []
+    for T, h, (r, tm) in zip(FRAMES, hip, ora):
+        lh = _lat(h[0]["delays_ms"], h[3], h[4])
+        lo = _lat(r["delays_ms"], tm["wall_ms_at_commit"], h[4])
+        per_utt.append({"frames": T, "tokens": len(r["tokens"]), "reads": r["actions"].count("R"), "hip": lh, "oracle_cpu": lo})
+    mean = lambda key, side: round(sum(p[side][key] for p in per_utt) / len(per_utt), 2)   # noqa: E731
+    out = {
+        "workload": f"configs[0]: wait-k 3, ratio 8, full dims, B = 1 through the agent schedule, {len(per_utt)} utterances "
+                    f"{FRAMES[:n_utt]} frames, max_len {max_len_a} * frames + {max_len_b}, fp32",
+        "records_identical_to_oracle": identical,
+        "hip_b1_agent": {"per_read": _stats([x for h in hip for x in h[1]]), "per_write": _stats([x for h in hip for x in h[2]]),
+                         "AL_ms_mean": mean("AL", "hip"), "AL_CA_ms_mean": mean("AL_CA", "hip"),
+                         "AL_CA_minus_AL_ms": round(mean("AL_CA", "hip") - mean("AL", "hip"), 2),
+                         "DAL_ms_mean": mean("DAL", "hip"), "DAL_CA_ms_mean": mean("DAL_CA", "hip"),
+                         "note": "per-op launches from Python through the C ABI (decoder.step: ~45 launches per WRITE, one read-back "
+                                 "per policy call); the batched entry points simulst_mma_stream_steps / simulst_mma_decode are what "
+                                 "removes the host from the loop"},
+        "oracle_cpu": {"threads": oracle_threads, "per_read": _stats([x for _, tm in ora for x in tm["read_s"]]),
+                       "per_write": _stats([x for _, tm in ora for x in tm["write_s"]]),
+                       "AL_ms_mean": mean("AL", "oracle_cpu"), "AL_CA_ms_mean": mean("AL_CA", "oracle_cpu"),
+                       "AL_CA_minus_AL_ms": round(mean("AL_CA", "oracle_cpu") - mean("AL", "oracle_cpu"), 2),
+                       "DAL_ms_mean": mean("DAL", "oracle_cpu"), "DAL_CA_ms_mean": mean("DAL_CA", "oracle_cpu")},
+        "reference_published": {"AL_CA_minus_AL_ms": {"waitk": 154, "mma": 241, "cif": 198},
+                                "source": "docs/waitk.md:39-40, docs/mma.md:49-50, docs/cif.md:45-46 (trained checkpoints, MuST-C "
+                                          "tst-COMMON, CPU, 1 worker: eval/1-simuleval.sh:65,78-82); not comparable token for token "
+                                          "with random-init hypotheses, quoted for scale"},
+        "per_utterance": per_utt,
+    }
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--max-len-a", type=float, default=0.1)
+    ap.add_argument("--max-len-b", type=int, default=10)
+    ap.add_argument("--utterances", type=int, default=8)
+    ap.add_argument("--oracle-threads", type=int, default=1)
+    a = ap.parse_args()
+    print(json.dumps(run(a.max_len_a, a.max_len_b, a.utterances, a.oracle_threads)))
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,8 @@ def main():
     from simulst_amd.ops import Ops, _p
     ops = Ops()
     lib, h = ops.lib, ops.h
+    if not hasattr(lib, "simulst_debug_chain_probe"):
+        sys.exit("tools/chain_race_probe.py needs the investigation hooks: rebuild with `make -C simulst_amd/csrc clean all DEBUG_HOOKS=1`")
     B = args.rows
     n_wg = (B + 15) // 16
     g = torch.Generator().manual_seed(12)

@@ -11,6 +11,9 @@
    recogniser and register allocator: between the first MFMA on an accumulator and the `s_nop 15` that closes the unit nothing
    but MFMAs may touch an accumulator register.
 
+3. In the same kernels no v_accvgpr_read_b32 may feed the A / B operand of an MFMA one or two instructions later (round 4, see
+   check_accvgpr_feeds_mfma).
+
     python tools/check_isa.py [path/to/libsimulst_hip.so]        # exit status 1 on a violation
 """
 import glob
@@ -86,6 +89,25 @@ def check_chain_accumulators(body):
     return out
 
 
+def check_accvgpr_feeds_mfma(body):
+    """chain kernels: no v_accvgpr_read_b32 may write a register that an MFMA within the next two instructions reads as its A / B
+    operand.  hipcc parks values in AGPRs under register pressure and copies them back right where they are used; in front of an
+    inline-assembly MFMA it cannot see the VALU-write -> MFMA-read hazard (round 4: the <4 rows, 8 passes> instantiation of the
+    attention + projection chain with four problems in flight returned wrong rows on MI355X for exactly this pair)."""
+    out = []
+    for i, ins in enumerate(body):
+        if not ins.startswith("v_accvgpr_read_b32"):
+            continue
+        dst = regs(ins.split(None, 1)[1].split(",")[0].strip())
+        for nxt in body[i + 1:i + 3]:
+            if nxt.startswith("v_mfma"):
+                ops = [t.strip() for t in nxt.split(None, 1)[1].split(",")]
+                if len(ops) >= 3 and dst & (regs(ops[1]) | regs(ops[2])):
+                    out.append(f"'{ins}' feeds '{nxt}'")
+                break
+    return out
+
+
 def main():
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "simulst_amd", "libsimulst_hip.so")
     kernels = disassemble(so)
@@ -99,14 +121,14 @@ def main():
     for name, n, ex in bad:
         print(f"  SWIZZLED packed fp32 in {name}: {n}, e.g. '{ex}'")
         rc = 1
-    chains = {k: b for k, b in kernels.items() if re.search(r"dec_(proj|ffn|qkv)_chain_kernel", k)}
+    chains = {k: b for k, b in kernels.items() if re.search(r"dec_(proj|ffn|qkv|attn_proj)_chain_kernel", k)}
     if not chains:
         print("the layer-chain kernels are missing from the library", file=sys.stderr)
         return 2
     for name, body in sorted(chains.items()):
-        v = check_chain_accumulators(body)
+        v = check_chain_accumulators(body) + check_accvgpr_feeds_mfma(body)
         n_mfma = sum(1 for ins in body if ins.startswith("v_mfma"))
-        print(f"  {name[:70]}: {n_mfma} MFMAs, {len(v)} accumulator finding(s)")
+        print(f"  {name[:70]}: {n_mfma} MFMAs, {len(v)} accumulator / AGPR-copy finding(s)")
         for msg in v[:3]:
             print("     ", msg)
         rc = rc or (1 if v else 0)

@@ -42,7 +42,9 @@ def shard_path_bytes(cfg, lengths, idx_lists, esz, waitk, kind, streamed):
     return total
 
 
-def main():
+def main(argv=None, collect=None):
+    """argv: the command line (None: sys.argv); collect: a list that receives rank 0's record instead of it being printed (bench.py's
+    configs4_rank_shard leg runs the tool in-process on the GPU it already holds)"""
     ap = argparse.ArgumentParser()
     ap.add_argument("--utterances", type=int, default=40000)
     ap.add_argument("--batch", type=int, default=1024,
@@ -60,12 +62,19 @@ def main():
                          "counts dealt round-robin (round 2)")
     ap.add_argument("--no-warmup", dest="warmup", action="store_false",
                     help="time the cold run too (first launches, allocator growth)")
-    args = ap.parse_args()
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="decode ONE rank's shard of an N-rank job on this GPU (rank --shard-rank): the rank shard of configs[4] "
+                         "without the other 7 GPUs")
+    ap.add_argument("--shard-rank", type=int, default=3)
+    args = ap.parse_args(argv)
+    emit = (lambda rec: collect.append(rec)) if collect is not None else (lambda rec: print(json.dumps(rec)))
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if collect is not None:
+        rank, world = 0, 1
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 and collect is None:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -97,13 +106,15 @@ def main():
     #      resident in HBM before the clock starts (as in bench.py)
     from simulst_amd.model import ConcurrentOffline
     S = max(1, args.streams)
-    plan = (plan_shard_by_work if args.plan == "work" else plan_shard)(lengths, world, rank, args.batch, S)
+    # --shard-of N: this GPU decodes rank --shard-rank's shard of an N-rank job (nothing is gathered: the other shards do not exist)
+    world_plan, rank_plan = (args.shard_of, args.shard_rank) if args.shard_of > 0 else (world, rank)
+    plan = (plan_shard_by_work if args.plan == "work" else plan_shard)(lengths, world_plan, rank_plan, args.batch, S)
     if args.plan == "work":                             # the queue order: most expensive sequence first
         plan.sort(key=lambda idx: -sequence_cost(idx, lengths, S))
     batches = [(idx,) + make_batch(idx, lengths, dev, dtype) for idx in plan]
     if args.streaming:
         # a streamed hypothesis ends when it holds MORE than max_len tokens (agents/default_agent.py:268-271): one more than the offline cap
-        return streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width + 1, lengths, dtype)
+        return streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width + 1, lengths, dtype, emit)
     pipe = ConcurrentOffline(model, weights, S)
     outs = [None] * len(batches)
 
@@ -171,17 +182,24 @@ def main():
         recs = {int(i): None for i in ids}
         total_s, total_tokens = local_s, n_tokens
     if rank == 0:
-        assert len(recs) == args.utterances, (len(recs), args.utterances)
-        print(json.dumps({"workload": "configs[4]: batched offline eval, utterance-sharded", "utterances": args.utterances,
-                          "n_gpus": world, "tokens": total_tokens, "seconds": round(total_s, 3),
-                          "tokens_per_s": round(total_tokens / total_s, 1),
-                          "utterances_per_s": round(args.utterances / total_s, 1), "dtype": args.dtype,
-                          "utterances_per_sequence": args.batch, "streams": args.streams, "plan": args.plan,
-                          "rows_per_sequence": [len(b[0]) for b in batches],
-                          "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk, "waitk", False,
-                                                       total_tokens / total_s, world),
-                          "timed": "decode of every launch sequence + D2H + hypothesis trimming" +
-                                   ("" if args.warmup else " (cold: first launches and allocator growth included)")}))
+        n_shard = sum(len(b[0]) for b in batches)
+        want = args.utterances if args.shard_of <= 0 else n_shard
+        assert len(recs) == want, (len(recs), want)
+        from simulst_amd.offline_eval import max_steps
+        caps_ok = all(int(n) <= max_steps(lengths[i]) for i, n in zip(ids, torch.cat(ntok).tolist())) if ntok else True
+        emit({"workload": "configs[4]: batched offline eval, utterance-sharded" +
+                          (f" (rank {args.shard_rank} of {args.shard_of}: one rank's shard on one GPU)" if args.shard_of > 0 else ""),
+              "utterances": args.utterances, "utterances_decoded": n_shard,
+              "n_gpus": world, "tokens": total_tokens, "seconds": round(total_s, 3),
+              "tokens_per_s": round(total_tokens / total_s, 1),
+              "utterances_per_s": round(n_shard / total_s, 1), "dtype": args.dtype,
+              "utterances_per_sequence": args.batch, "streams": args.streams, "plan": args.plan,
+              "rows_per_sequence": [len(b[0]) for b in batches],
+              "properties": {"one_hypothesis_per_utterance": len(set(ids)) == n_shard, "every_length_within_its_cap": bool(caps_ok)},
+              "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk, "waitk", False,
+                                           total_tokens / total_s, world),
+              "timed": "decode of every launch sequence + D2H + hypothesis trimming" +
+                       ("" if args.warmup else " (cold: first launches and allocator growth included)")})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -200,7 +218,7 @@ def path_model(cfg, lengths, idx_lists, dtype, waitk, kind, streamed, tokens_per
                           "(2.135 MB/token at 1000 frames; longer sources cost more bytes per token)"}
 
 
-def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width, lengths=None, dtype=None):
+def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev, width, lengths=None, dtype=None, emit=None):
     """configs[4] in its stated semantics (batched STREAMING eval): hypotheses, delays and Average Lagging of every utterance"""
     from simulst_amd.agent import BatchedStreamingAgent, ConcurrentStreamingEval
     from simulst_amd.sharding import gather_records
@@ -238,17 +256,26 @@ def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev
     else:
         total_s, n_rec = local_s, n_utt
     if rank == 0:
-        assert n_rec == args.utterances, (n_rec, args.utterances)
-        print(json.dumps({"workload": f"configs[4]: batched STREAMING eval, utterance-sharded ({args.policy})", "utterances": args.utterances,
-                          "n_gpus": world, "tokens": int(n_tokens), "seconds": round(total_s, 3),
-                          "tokens_per_s": round(n_tokens / total_s, 1), "utterances_per_s": round(args.utterances / total_s, 1),
-                          "average_lagging_ms_mean": round(al_sum / n_utt, 2), "reads_per_utterance": round(reads / n_utt, 2),
-                          "dtype": args.dtype, "utterances_per_sequence": args.batch, "streams": S,
-                          "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk,
-                                                       "hard" if args.policy == "hard" else "waitk", True, n_tokens / total_s, world),
-                          "form": "self-paced rows, encoder states of one padded offline forward per launch sequence, every row on the "
-                                  "chunk schedule of its own length; max_len 0.1 * frames + 10",
-                          "timed": "encoder + device decode loop of every launch sequence + D2H + record building"}))
+        emit = emit or (lambda rec: print(json.dumps(rec)))
+        want = args.utterances if args.shard_of <= 0 else len(ids)
+        assert n_rec == want, (n_rec, want)
+        from simulst_amd.offline_eval import max_steps
+        caps_ok = all(n <= max_steps(lengths[i]) + 1 for i, n in zip(ids, ntok))
+        emit({"workload": f"configs[4]: batched STREAMING eval, utterance-sharded ({args.policy}; decoder over the encoder states of ONE "
+                          "OFFLINE forward per launch sequence, not the chunked streaming encoder)" +
+                          (f" (rank {args.shard_rank} of {args.shard_of}: one rank's shard on one GPU)" if args.shard_of > 0 else ""),
+              "utterances": args.utterances, "utterances_decoded": len(ids),
+              "n_gpus": world, "tokens": int(n_tokens), "seconds": round(total_s, 3),
+              "tokens_per_s": round(n_tokens / total_s, 1), "utterances_per_s": round(len(ids) / total_s, 1),
+              "average_lagging_ms_mean": round(al_sum / n_utt, 2), "reads_per_utterance": round(reads / n_utt, 2),
+              "dtype": args.dtype, "utterances_per_sequence": args.batch, "streams": S,
+              "encoder": "offline states (one padded forward per launch sequence)",
+              "properties": {"one_record_per_utterance": len(set(ids)) == len(ids), "every_length_within_its_cap": bool(caps_ok)},
+              "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk,
+                                           "hard" if args.policy == "hard" else "waitk", True, n_tokens / total_s, world),
+              "form": "self-paced rows, encoder states of one padded offline forward per launch sequence, every row on the "
+                      "chunk schedule of its own length; max_len 0.1 * frames + 10",
+              "timed": "encoder + device decode loop of every launch sequence + D2H + record building"})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

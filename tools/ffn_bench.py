@@ -14,6 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
+from simulst_amd import _lib  # noqa: E402
 
 
 def main():
@@ -46,18 +47,27 @@ def main():
             ops.linear(x, w1fm, b1, epilogue=EPI_BIAS_GELU, out=hid, w_fragment_major=True, ln=(gam, bet))
             ops.linear(hid, W2, b2, epilogue=EPI_BIAS_RES, residual=x, out=y)
 
-        def variant(v):
+        def waves(n):                    # SIMULST_OPT_FFN_WAVES: force one geometry of the operator (valid results)
+            def run():
+                ops.h.set_option(_lib.OPT_FFN_WAVES, n)
+                fused()
+                ops.h.set_option(_lib.OPT_FFN_WAVES, 0)
+            return run
+
+        def variant(v):                  # timing ablations (results invalid): DEBUG_HOOKS builds of the library only
             def run():
                 ops.lib.simulst_debug_ffn_variant(ops.h.ptr, v)
                 fused()
                 ops.lib.simulst_debug_ffn_variant(ops.h.ptr, 0)
             return run
 
-        # variant 1: the kernel WITHOUT the GELU arithmetic -- a timing ablation, how much of the launch the un-hidden GELU is
-        fns = (("fused", fused), ("two_launch", two), ("fused_no_gelu_ablation", variant(1)),
-               ("fused_one_8wave_workgroup_per_cu", variant(2)), ("fused_two_4wave_workgroups_per_cu", variant(3)),
-               ("ablation_4wave_no_second_product", variant(12)), ("ablation_4wave_no_first_product", variant(13)),
-               ("ablation_4wave_no_products", variant(14)), ("ablation_4wave_no_gelu", variant(15)))
+        fns = [("fused", fused), ("two_launch", two), ("fused_one_8wave_workgroup_per_cu", waves(8)),
+               ("fused_two_4wave_workgroups_per_cu", waves(4))]
+        if hasattr(ops.lib, "simulst_debug_ffn_variant"):
+            # variant 1: the kernel WITHOUT the GELU arithmetic -- how much of the launch the un-hidden GELU is; 12-15: 4-wave geometry
+            fns += [("fused_no_gelu_ablation", variant(1)), ("ablation_4wave_no_second_product", variant(12)),
+                    ("ablation_4wave_no_first_product", variant(13)), ("ablation_4wave_no_products", variant(14)),
+                    ("ablation_4wave_no_gelu", variant(15))]
         t = {name: [] for name, _ in fns}
         for _, fn in fns:
             fn()

@@ -125,6 +125,40 @@ def dec_chain(args, ops):
     return out
 
 
+def attn_chain(args, ops):
+    """self-attention + projection chain: the two launches (simulst_decoder_self_attention, simulst_decoder_proj_chain) against the
+    one launch of round 4 (simulst_decoder_attn_proj_chain) at 4 / 8 / 16 rows per workgroup, lockstep rows (host-known position).
+    Host launch cost included -- use rocprofv3 --kernel-trace --stats around this command for kernel durations."""
+    D, H, d, cap = 256, 4, 64, 128
+    g = torch.Generator().manual_seed(0)
+    mk = lambda n, k: (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16).cuda()
+    Wo, Wq = ops.pack_fragment_major(mk(D, D)), ops.pack_fragment_major(mk(D, D))
+    bD = torch.randn(D, generator=g).cuda() * 0.1
+    ln = (torch.ones(D).cuda(), torch.zeros(D).cuda())
+    out = {}
+    for B in args.utterances:
+        qkv = torch.randn(B, 3 * D, device="cuda").to(torch.bfloat16)
+        kc = torch.randn(B, H, cap, d, device="cuda").to(torch.bfloat16)
+        vc = torch.randn(B, H, cap, d, device="cuda").to(torch.bfloat16)
+        x = torch.randn(B, D, device="cuda").to(torch.bfloat16)
+        ctx, q = torch.empty_like(x), torch.empty_like(x)
+        for n_prev in args.n_prev:
+            npv = torch.full((B,), n_prev, dtype=torch.int32, device="cuda")
+
+            def two():
+                ops.decoder_self_attention(qkv, kc, vc, npv, ctx)
+                ops.decoder_proj_chain(ctx, x, Wo, bD, ln, Wq, bD, q=q)
+            r = {"two_launches_us": round(timeit(two, 200), 2)}
+            for rows in (4, 8, 16):
+                def one():
+                    ops.decoder_attn_proj_chain(qkv, kc, vc, npv, x, Wo, bD, ln, Wq, bD, q=q, rows_per_workgroup=rows,
+                                                n_prev_uniform=n_prev)
+                r[f"one_launch_{rows}_rows_us"] = round(timeit(one, 200), 2)
+            out[f"{B}x{n_prev}"] = r
+            print("attn_chain", B, n_prev, r, flush=True)
+    return out
+
+
 def cross_attn(args, ops):
     """policy + cross-attention launch of the wait-k decoder (simulst_policy_cross_attention) at the configs[1] shape: 250 encoder
     rows per utterance, 4 heads x 64, target index late enough that every key is visible (90 % of the 110 steps);
@@ -154,7 +188,7 @@ def cross_attn(args, ops):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["emf_attn", "self_attn", "dec_chain", "cross_attn"])
+    ap.add_argument("what", choices=["emf_attn", "self_attn", "dec_chain", "cross_attn", "attn_chain"])
     ap.add_argument("--utterances", type=int, nargs="+", default=[448, 4096])
     ap.add_argument("--n-prev", type=int, nargs="+", default=[55, 109])
     ap.add_argument("--keys", type=int, nargs="+", default=[250], help="cross_attn: encoder rows per utterance")
@@ -162,7 +196,7 @@ def main():
     args = ap.parse_args()
     from simulst_amd.ops import Ops
     ops = Ops()
-    res = {"emf_attn": emf_attn, "self_attn": self_attn, "dec_chain": dec_chain, "cross_attn": cross_attn}[args.what](args, ops)
+    res = {"emf_attn": emf_attn, "self_attn": self_attn, "dec_chain": dec_chain, "cross_attn": cross_attn, "attn_chain": attn_chain}[args.what](args, ops)
     print(json.dumps({"kernel": args.what, "tag": args.tag, "device": torch.cuda.get_device_name(0), "results": res}))
 
 
