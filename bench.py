@@ -455,6 +455,27 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             paced_off["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_o, recs))
             paced_off["note"] = ("encoder states from ONE offline forward, cut at the rows the streaming schedule releases: equal to the "
                                  "chunked states to rounding (agents/default_agent.py:438-476), so a decision can flip at a near-tie")
+            # census of the microphone form's masked steps: after chunk c the batch repeats decoder steps until its
+            # SLOWEST row has written everything chunk c allows; a row is active in as many of them as it writes tokens.  The step count
+            # is set by the slowest row, its cost by ~33 dependent launches (latency-bound at any row count), so
+            # compacting the active rows cannot shorten a step by more than the policy / attention share -- the self-paced form
+            # (evaluation_form_*) removes the waiting instead
+            per_chunk = []                                   # per row: {number of READs so far: tokens written at that point}
+            for r_ in recs:
+                d_, k_ = {}, 0
+                for ch_ in r_["actions"]:
+                    if ch_ == "R":
+                        k_ += 1
+                    else:
+                        d_[k_] = d_.get(k_, 0) + 1
+                per_chunk.append(d_)
+            n_ch = max(max(x) for x in per_chunk if x) + 1
+            steps_c = [max(x.get(c, 0) for x in per_chunk) for c in range(n_ch)]
+            act_c = [sum(x.get(c, 0) for x in per_chunk) for c in range(n_ch)]
+            lock["masked_step_census"] = {"masked_steps_lower_bound": int(sum(steps_c)), "active_row_steps": int(sum(act_c)),
+                                          "mean_active_rows_per_step": round(sum(act_c) / max(sum(steps_c), 1), 1),
+                                          "rows": rows_s,
+                                          "note": "steps after chunk c = the most tokens any row writes there; a row is active in as many as it writes"}
             streaming = dict(lock)
             streaming.update({"rows": rows_s, "reads_per_row": recs[0]["actions"].count("R"), "max_len": "0.1 * frames + 10 tokens",
                               "semantics": "every row takes its own READ / WRITE decisions on the device; chunk schedule 96 then 64 frames "
@@ -552,10 +573,14 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                       f"streaming_{dtn}_rows_identical_to_oracle": sum(1 for r_ in same16 if r_["first_divergence"] is None),
                       f"streaming_{dtn}_oracle_margin_at_first_divergence":
                           sorted((d_["first_divergence"]["policy_margin"] if d_["first_divergence"]["cause"] == "action"
-                                  else d_["first_divergence"]["token_gap"]) for d_ in same16 if d_["first_divergence"] is not None),
+                                  else min(x for x in (d_["first_divergence"]["token_gap"],
+                                                       d_["first_divergence"]["policy_margin_of_the_call_that_wrote_the_token"]
+                                                       if kind == "hard" else None) if x is not None))
+                                 for d_ in same16 if d_["first_divergence"] is not None),
                       "margin_definition": "policy: |p - 0.5| (MMA) / |accumulated weight - k * beta| (CIF) of the ORACLE at the first "
-                                           "differing READ / WRITE; token: the oracle's top-2 log-probability gap at the first differing token "
-                                           "(whichever comes first in the action string); bounded in tests/test_hip_configs.py::"
+                                           "differing READ / WRITE; token: the oracle's top-2 log-probability gap at the first differing token, or (MMA: hard "
+                                           "attention) the policy margin of the decoder call that wrote it when that is smaller -- a head on a near tie looks "
+                                           "at another frame (whichever comes first in the action string); bounded in tests/test_hip_configs.py::"
                                            "test_bf16_streamed_rows_leave_the_oracle_only_at_near_ties"}
             if not waitk:
                 parity.update({"offline_fp32_tokens_identical_to_oracle": bool(torch.equal(t32, ref)), "offline_sample_utterances": n_off,

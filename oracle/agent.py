@@ -315,5 +315,10 @@ def first_divergence(ref, got):
     token_first = it < len(rt) and w_pos < ia
     am = ref["action_margins"][ia] if ia < len(ref["action_margins"]) else None
     tg = ref["token_gaps"][it] if it < len(ref["token_gaps"]) else None
+    # the policy margin of the decoder call that WROTE the first differing token: with hard monotonic attention a head whose step
+    # search sat on a near tie attends to a different encoder frame without changing the READ / WRITE action, which moves that
+    # token's logits by far more than rounding does (MMA only; for CIF the count margin of the newest update)
+    amw = ref["action_margins"][w_pos] if w_pos < len(ref["action_margins"]) else None
     return {"cause": "token" if token_first else "action", "action_index": ia, "token_index": it,
-            "policy_margin": None if am is None else round(am, 6), "token_gap": None if tg is None else round(tg, 6)}
+            "policy_margin": None if am is None else round(am, 6), "token_gap": None if tg is None else round(tg, 6),
+            "policy_margin_of_the_call_that_wrote_the_token": None if amw is None else round(amw, 6)}

@@ -11,7 +11,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimulst_hip.so")
+# SIMULST_LIB_PATH: another build of the same library (a PROBE / DEBUG_HOOKS build under csrc/build_dbg/, tools/ only); the ABI
+# version check below applies to it as well
+LIB_PATH = os.environ.get("SIMULST_LIB_PATH") or os.path.join(_HERE, "libsimulst_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_GLU, EPI_EMF_OUT, EPI_BIAS_F32OUT, EPI_BIAS_RES_GELU = range(7)

@@ -32,6 +32,9 @@
 // contraction, again for the residual: L2/MALL-hot) + rows * D * 2 written; weights 2 * D * F * 2 B from L2 per workgroup.
 #include "gemm_args.h"
 
+int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
+                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed);
+
 namespace {
 
 // Two geometries of the same kernel: WAVES = 8 (512 threads, 256 rows, 64 hidden units per chunk, one workgroup per CU)
@@ -39,6 +42,8 @@ namespace {
 // of phase, so that one's GELU arithmetic runs beside the other's MFMAs; each streams the weights for half as many rows).
 constexpr int FF_D = 256;             // model width (K of fc1, N of fc2)
 constexpr bool FF_DEFAULT_FOUR_WAVES = true;
+constexpr bool FF_PIPELINED_PACKED = false;   // packed GELU inside the MFMA stream measured SLOWER (826 vs 887 TFLOP/s): an anti-lever beside MFMAs
+constexpr bool FF_DEFAULT_PIPELINED = true;   // ffn_pipe.hip, 4 waves: 804 / 887 / 875 TFLOP/s at 448 / 1280 / 4096 utterances against 758 / 863 / 851     // ffn_pipe.hip: SIMULST_OPT_FFN_WAVES = 41 selects it
 template <int WAVES> struct FFG {
   static constexpr int THREADS = 64 * WAVES;
   static constexpr int ROWS = 32 * WAVES;            // rows per workgroup
@@ -254,6 +259,11 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
     h->ffn_lds_attr_set = true;
   }
   KTimer t(h, SIMULST_K_LINEAR);
+  // the software-pipelined form (ffn_pipe.hip: GELU inside the matrix-core stream): 128 rows per workgroup, two workgroups per CU
+  // SIMULST_OPT_FFN_WAVES 41 / 81: scalar GELU, 4 / 8 waves; 42 / 82: packed GELU
+  if (((h->ffn_waves >= 41 && h->ffn_waves <= 42) || (h->ffn_waves >= 81 && h->ffn_waves <= 82) || (h->ffn_waves == 0 && FF_DEFAULT_PIPELINED)) && F <= 2048)
+    return sl_launch_ffn_pipe(h, x, ln_gamma, ln_beta, w1_packed, b1, w2_packed, b2, out, rows, F, h->ffn_waves >= 81 ? 8 : 4,
+                              h->ffn_waves == 0 ? FF_PIPELINED_PACKED : (h->ffn_waves & 1) == 0);
 #define FFN(V, W)                                                                                                  \
   hipLaunchKernelGGL((ffn_fused_kernel<V, W>), dim3((unsigned)((rows + FFG<W>::ROWS - 1) / FFG<W>::ROWS)),         \
                      dim3(FFG<W>::THREADS), FFG<W>::LDS, h->stream, (const bf16*)x, ln_gamma, ln_beta,             \

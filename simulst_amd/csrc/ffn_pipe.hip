@@ -1,0 +1,369 @@
+// The fused Emformer feed-forward block (ffn_fused.hip) with the GELU INSIDE the matrix-core stream -- gfx950, bf16, D = 256.
+// Compiled WITHOUT the SLP vectoriser (Makefile): it re-packs the per-element scalar GELU of four neighbouring elements into packed
+// fp32 instructions and emits them as one block per four MFMAs, undoing the placement pinned in the source.
+#include "gemm_args.h"
+#include <type_traits>
+#include <cstdio>
+#include <vector>
+
+#ifdef SL_PROBE
+// phase probe (make PROBE=1; tools/probe_ffn.py): per wave the shader cycles (s_memtime) spent waiting for its own LDS-DMA, in the
+// workgroup barrier, in phase A and in phase B, summed over the tiles; [workgroup][wave][4] longs
+__device__ long sl_probe_ffn[4096 * 8 * 4];
+#define FP_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FP_STAMP(v)
+#endif
+
+namespace {
+
+constexpr int FF_D = 256;
+constexpr int FF_PF = 4;               // weight fragments requested ahead of the MFMA that consumes them
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  const bf16 l = __float2bfloat16(lo), h = __float2bfloat16(hi);
+  return (unsigned int)(*reinterpret_cast<const unsigned short*>(&l)) |
+         ((unsigned int)(*reinterpret_cast<const unsigned short*>(&h)) << 16);
+}
+
+// Round 4.  ffn_fused_kernel runs [fc1 MFMAs | GELU block | fc2 MFMAs] per 32-unit tile: hipcc emits the GELU as one block of ~130 vector
+// instructions between two runs of 16 MFMAs, so a wave's matrix cores idle through its own GELU and overlap only happens when the
+// SIMD's other wave is in an MFMA run at that moment (40.7 % matrix-core busy, profiles/r04_pmc_ffn_*.json).  Here the tile loop is
+// software-pipelined by one tile and the instruction order is pinned in the source:
+//   phase A of tile t:   16 x { one fc1 MFMA of tile t + 1 ;  bias + GELU + bf16 pack of ONE hidden element of tile t }
+//   phase B of tile t:   16 fc2 MFMAs of tile t
+// with __builtin_amdgcn_sched_barrier(0) between the groups, so every MFMA of phase A is followed by ~20 scalar fp32 instructions
+// that do not depend on it.  The GELU is written on scalar fp32 (MI355X_MICROARCH.md: packed fp32 beside MFMAs is an anti-lever) with
+// explicit fma contraction in the order of gelu_fast2 (common.h), operand for operand: results are bit-identical to ffn_fused_kernel
+// (tests/test_hip_kernels.py::test_emformer_ffn_pipelined_equals_the_block_form).
+// LDS: the weight tiles of fc1 run ONE tile ahead of those of fc2, so they are two rings of two 16 KB slots each (64 KB, as the
+// 4-wave geometry of ffn_fused.hip): at the start of iteration t every wave has finished iteration t - 1, the DMA of W1(t + 2) goes to the slot
+// W1(t) left and that of W2(t + 1) to the slot W2(t - 1) left; both land during iteration t.
+__device__ __forceinline__ float gelu_fast1(float x) {
+  // gelu_fast2, one element: the same operations in the same order (h = x / 2, z = |h| sqrt2, Horner, four squarings, rcp, (h + |h|) - |h| r)
+  const float h = x * 0.5f;
+  const float ha = __builtin_fabsf(h);
+  const float z = ha * 1.41421356237309504880f;
+  float q = __builtin_fmaf(z, 0.0000430638f, 0.0002765672f);
+  q = __builtin_fmaf(q, z, 0.0001520143f);
+  q = __builtin_fmaf(q, z, 0.0092705272f);
+  q = __builtin_fmaf(q, z, 0.0422820123f);
+  q = __builtin_fmaf(q, z, 0.0705230784f);
+  q = __builtin_fmaf(q, z, 1.0f);
+  q = q * q; q = q * q; q = q * q; q = q * q;
+  const float r = __builtin_amdgcn_rcpf(q);
+  return __builtin_fmaf(-ha, r, h + ha);
+}
+
+// two floats -> one register of two bf16 in ONE instruction.  hipcc lowers __float2bfloat16 to v_cvt_pk_bf16_f32 as well, but with
+// the two values produced in different scheduling regions it converted each on its own and merged them (2 x v_cvt_pk + v_lshlrev +
+// v_or_sdwa per pair); the vector pipe is what paces phase A, so the three instructions matter
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
+  unsigned int r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+constexpr int FP_W = 16 * 1024;         // one weight tile: 32 hidden units x 256 x bf16
+// Geometries: WAVES = 4 (128 rows per workgroup, two workgroups per CU, rings of NS = 2 slots) and WAVES = 8 (256 rows, ONE workgroup per
+// CU, rings of NS = 4 slots).  The 4-wave form streams the 2 MB of weights once per 128 rows: two workgroups per CU pull 2 x 32 KB per
+// tile time (~2.2 us) = 28 GB/s per CU, which is what LDS-DMA delivers (MI355X_MICROARCH.md, ldsdma-fill: ~25 GB/s per CU) -- its waves
+// sit 37 % of their cycles in s_waitcnt / s_barrier (profiles/r04_pmc_ffn.json).  The 8-wave form halves the stream per CU and, with
+// four slots per ring, requests every tile TWO iterations ahead: the wait in front of the barrier is a counted vmcnt that leaves the
+// newest requests in flight.
+template <int WAVES> struct FPG {
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr int NS = WAVES == 8 ? 4 : 2;              // slots per ring
+  static constexpr int AHEAD = WAVES == 8 ? 2 : 1;           // iterations between a tile's request and its first use
+  static constexpr int PIECES = FP_W / (THREADS * 16);       // DMA instructions per wave and tile
+  static constexpr int LDS = 2 * NS * FP_W + 3072 + 2048 * 4;
+};
+
+template <int WAVES>
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ wp, int tile, char* dst, unsigned voff, int wave) {
+  const char* g = reinterpret_cast<const char*>(wp) + (long)tile * FP_W;
+#pragma unroll
+  for (int q = 0; q < FPG<WAVES>::PIECES; ++q)
+    __builtin_amdgcn_global_load_lds((gbl_void*)(g + (unsigned)(voff + q * FPG<WAVES>::THREADS * 16)),
+                                     (lds_void*)(dst + q * FPG<WAVES>::THREADS * 16 + wave * 1024), 16, 0, 0);
+}
+
+template <int WAVES, bool PK>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kernel(
+    const bf16* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const bf16* __restrict__ W1p,
+    const float* __restrict__ b1, const bf16* __restrict__ W2p, const float* __restrict__ b2, bf16* __restrict__ out, long M, int F) {
+  using G = FPG<WAVES>;
+  constexpr int NS = G::NS, AH = G::AHEAD;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* w1ring = lds;                                        // NS slots
+  char* w2ring = lds + NS * FP_W;                            // NS slots
+  float* lng = reinterpret_cast<float*>(lds + 2 * NS * FP_W);
+  float* lnb = lng + FF_D;
+  float* b2s = lnb + FF_D;
+  float* b1s = b2s + FF_D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const long row0 = (long)blockIdx.x * (32 * WAVES) + wave * 32;
+  const int nt = F / 32;
+  const unsigned voff = (unsigned)tid * 16u;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // the packed images are tile-major: tile t of W1 at t * 16 KB of W1p, of W2 likewise.  Iteration t reads W1(t + 1) and W2(t); the
+  // prologue reads W1(0).  Requested here: everything iterations 0 .. AH - 1 need (the loop requests W1(t + 1 + AH), W2(t + AH))
+  stage_tile<WAVES>(W1p, 0, w1ring, voff, wave_u);
+  stage_tile<WAVES>(W2p, 0, w2ring, voff, wave_u);
+#pragma unroll
+  for (int a = 1; a <= AH; ++a) {
+    if (a < nt) stage_tile<WAVES>(W1p, a, w1ring + (a % NS) * FP_W, voff, wave_u);
+    if (a < AH && a < nt) stage_tile<WAVES>(W2p, a, w2ring + (a % NS) * FP_W, voff, wave_u);
+  }
+  for (int k = tid; k < FF_D; k += G::THREADS) { lng[k] = ln_g[k]; lnb[k] = ln_b[k]; b2s[k] = b2[k]; }
+  for (int k = tid; k < F; k += G::THREADS) b1s[k] = b1[k];
+  uint4 xa[16];
+  {
+    const long r = row0 + lr;
+    const bool ok = r < M;
+    const bf16* xr = X + (ok ? r : 0) * FF_D + lh * 8;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const uint4 v = ld16(xr + s * 16);
+      xa[s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+  }
+  __syncthreads();
+  {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) moments_mid(xa[s], s1, s2, bf16());
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float mean = s1 * (1.0f / FF_D);
+    const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / FF_D) - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xa[s] = ln_frag_mid(xa[s], mean, rstd, lng, lnb, s * 16 + lh * 8, bf16());
+  }
+  f32x16 y[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) y[n][e] = 0.f;
+  // ---- prologue of the pipeline: fc1 of tile 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 hcur;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) hcur[e] = 0.f;
+  {
+    const uint4* w1 = reinterpret_cast<const uint4*>(w1ring);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const uint4 wf = w1[s * 64 + lane];
+      hcur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wf), *reinterpret_cast<const bf16x8_t*>(&xa[s]),
+                                                     hcur, 0, 0, 0);
+    }
+  }
+#ifdef SL_PROBE
+  unsigned long long pr_dma = 0, pr_bar = 0, pr_a = 0, pr_b = 0;
+#endif
+  // one iteration of the pipeline; MORE = false only for the last tile (no tile t + 1 to start: phase A is the GELU alone), as a
+  // compile-time flag: a run-time test around the MFMAs would split the basic block and let hipcc regroup the instructions
+  auto iteration = [&](int t, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    // every wave is past iteration t - 1: the slots of W1(t) and W2(t - 1) are free; W1(t + 1) and W2(t) were requested AH iterations
+    // ago.  AH = 1: everything in flight must have landed.  AH = 2: the requests of iteration t - 1 (2 * PIECES instructions of
+    // this wave, the newest in its in-order queue) may stay in flight -- a counted wait; near the end, where an iteration requested
+    // fewer, the full wait
+#ifdef SL_PROBE
+    unsigned long long p0, p1, p2, p3, p4;
+    FP_STAMP(p0);
+#endif
+    if (AH == 1 || t == 0 || t + AH + 1 > nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * G::PIECES) : "memory");
+    FP_STAMP(p1);
+    __syncthreads();
+    FP_STAMP(p2);
+    if (t + 1 + AH < nt) stage_tile<WAVES>(W1p, t + 1 + AH, w1ring + ((t + 1 + AH) % NS) * FP_W, voff, wave_u);
+    if (t + AH < nt) stage_tile<WAVES>(W2p, t + AH, w2ring + ((t + AH) % NS) * FP_W, voff, wave_u);
+    const uint4* w1 = reinterpret_cast<const uint4*>(w1ring + ((t + 1) % NS) * FP_W);    // fc1 weights of tile t + 1
+    const uint4* w2 = reinterpret_cast<const uint4*>(w2ring + (t % NS) * FP_W);          // fc2 weights of tile t
+    const float* bt = b1s + t * 32 + 4 * lh;
+    f32x16 hnext;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) hnext[e] = 0.f;
+    unsigned int hb[8];
+    // ---- phase A: one fc1 MFMA of tile t + 1, then bias + GELU of element s of tile t (pairs packed as they complete)
+    uint4 wfa[FF_PF];
+    if constexpr (MORE) {
+#pragma unroll
+      for (int i = 0; i < FF_PF; ++i) wfa[i] = w1[i * 64 + lane];
+    }
+    float4 bv = *reinterpret_cast<const float4*>(bt);
+    float gprev = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!PK) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if constexpr (MORE)
+          hnext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wfa[s % FF_PF]),
+                                                          *reinterpret_cast<const bf16x8_t*>(&xa[s]), hnext, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE) { if (s + FF_PF < 16) wfa[s % FF_PF] = w1[(s + FF_PF) * 64 + lane]; }
+        const float bias = (s & 3) == 0 ? bv.x : (s & 3) == 1 ? bv.y : (s & 3) == 2 ? bv.z : bv.w;
+        const float gv = gelu_fast1(hcur[s] + bias);
+        if ((s & 3) == 3 && s < 15) bv = *reinterpret_cast<const float4*>(bt + 8 * ((s + 1) >> 2));
+        if (s & 1) hb[s >> 1] = cvt_pk_bf16(gprev, gv); else gprev = gv;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // packed form: the GELU of an element PAIR (gelu_fast2, the arithmetic of ffn_fused_kernel) in two halves behind two MFMAs --
+      // 15 packed instructions + 2 v_rcp per pair instead of 2 x 17 scalar ones (the phase probe of the scalar form: both waves of a
+      // SIMD sit in phase A 74 % of the time and their 2 x 21 vector instructions per MFMA, not the matrix cores, pace it)
+      f32x2 ph, pha, pq, pz;
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) {
+        if constexpr (MORE)
+          hnext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wfa[(2 * sp) % FF_PF]),
+                                                          *reinterpret_cast<const bf16x8_t*>(&xa[2 * sp]), hnext, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE) { if (2 * sp + FF_PF < 16) wfa[(2 * sp) % FF_PF] = w1[(2 * sp + FF_PF) * 64 + lane]; }
+        {
+          const f32x2 b2v = (sp & 1) ? f32x2{bv.z, bv.w} : f32x2{bv.x, bv.y};
+          const f32x2 xv = f32x2{hcur[2 * sp] + b2v.x, hcur[2 * sp + 1] + b2v.y};
+          ph = xv * 0.5f;
+          pha = __builtin_elementwise_abs(ph);
+          pz = pha * 1.41421356237309504880f;
+          pq = pz * 0.0000430638f + 0.0002765672f;
+          pq = pq * pz + 0.0001520143f;
+          pq = pq * pz + 0.0092705272f;
+          pq = pq * pz + 0.0422820123f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE)
+          hnext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wfa[(2 * sp + 1) % FF_PF]),
+                                                          *reinterpret_cast<const bf16x8_t*>(&xa[2 * sp + 1]), hnext, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE) { if (2 * sp + 1 + FF_PF < 16) wfa[(2 * sp + 1) % FF_PF] = w1[(2 * sp + 1 + FF_PF) * 64 + lane]; }
+        {
+          pq = pq * pz + 0.0705230784f;
+          pq = pq * pz + 1.0f;
+          pq = pq * pq; pq = pq * pq; pq = pq * pq; pq = pq * pq;
+          f32x2 r;
+          r.x = __builtin_amdgcn_rcpf(pq.x);
+          r.y = __builtin_amdgcn_rcpf(pq.y);
+          const f32x2 gv2 = (ph + pha) - pha * r;
+          hb[sp] = pack_bf16x2(gv2.x, gv2.y);
+          if ((sp & 1) && sp < 7) bv = *reinterpret_cast<const float4*>(bt + 8 * ((sp + 1) >> 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    FP_STAMP(p3);
+    // ---- phase B: the 16 fc2 MFMAs of tile t
+    {
+      uint4 wf[FF_PF];
+#pragma unroll
+      for (int i = 0; i < FF_PF; ++i) wf[i] = w2[i * 64 + lane];
+      const uint4 hb0 = make_uint4(hb[0], hb[1], hb[2], hb[3]), hb1 = make_uint4(hb[4], hb[5], hb[6], hb[7]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        y[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(i < 8 ? &hb0 : &hb1),
+                                                           *reinterpret_cast<const bf16x8_t*>(&wf[i % FF_PF]), y[i & 7], 0, 0, 0);
+        if (i + FF_PF < 16) wf[i % FF_PF] = w2[(i + FF_PF) * 64 + lane];
+      }
+    }
+#ifdef SL_PROBE
+    FP_STAMP(p4);
+    pr_dma += p1 - p0; pr_bar += p2 - p1; pr_a += p3 - p2; pr_b += p4 - p3;
+#endif
+    if constexpr (MORE) hcur = hnext;
+  };
+  for (int t = 0; t + 1 < nt; ++t) iteration(t, std::true_type());
+  iteration(nt - 1, std::false_type());
+#ifdef SL_PROBE
+  if (lane == 0 && blockIdx.x < 4096) {
+    long* d = sl_probe_ffn + ((long)blockIdx.x * 8 + wave) * 4;
+    d[0] = (long)pr_dma; d[1] = (long)pr_bar; d[2] = (long)pr_a; d[3] = (long)pr_b;
+  }
+#endif
+  // ---- epilogue: as ffn_fused_kernel (WAVES x 16 KB staging = the 2 * NS weight slots)
+  __syncthreads();
+  constexpr int RS = FF_D * 2;
+  char* st = lds + wave * (32 * RS);
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const float bvv = b2s[n * 32 + lr];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      *reinterpret_cast<bf16*>(st + r * RS + (n * 32 + lr) * 2) = __float2bfloat16(y[n][e] + bvv);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int rl = it * 2 + lh;
+    const long r = row0 + rl;
+    if (r >= M) continue;
+    const uint4 yv = *reinterpret_cast<const uint4*>(st + rl * RS + lr * 16);
+    const uint4 xv = ld16(X + r * FF_D + lr * 8);
+    const unsigned int yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
+    unsigned int ou[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      ou[q] = pack_bf16x2(__uint_as_float(yu[q] << 16) + __uint_as_float(xu[q] << 16),
+                          __uint_as_float(yu[q] & 0xffff0000u) + __uint_as_float(xu[q] & 0xffff0000u));
+    st_stream16(out + r * FF_D + lr * 8, make_uint4(ou[0], ou[1], ou[2], ou[3]));
+  }
+}
+
+}  // namespace
+
+int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
+                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed) {
+  // the packed-GELU instantiations (measured slower: 826 vs 887 TFLOP/s at 1280 utterances) exist in DEBUG_HOOKS builds only
+#ifndef SL_DEBUG_HOOKS
+  packed = 0;
+#endif
+  if (!h->ffn_pipe_lds_attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
+#ifdef SL_DEBUG_HOOKS
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
+#endif
+    if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit (pipelined form)"; return (int)e; }
+    h->ffn_pipe_lds_attr_set = true;
+  }
+#define FPL(W, P)                                                                                                                   \
+  hipLaunchKernelGGL((ffn_pipe_kernel<W, P>), dim3((unsigned)((rows + 32 * W - 1) / (32 * W))), dim3(64 * W), FPG<W>::LDS, h->stream, \
+                     (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F)
+#ifdef SL_DEBUG_HOOKS
+  if (packed) { if (waves == 8) FPL(8, true); else FPL(4, true); } else
+#endif
+  { if (waves == 8) FPL(8, false); else FPL(4, false); }
+#undef FPL
+#ifdef SL_PROBE
+  {
+    static int calls[4] = {0, 0, 0, 0};
+    if ((++calls[(waves == 8) * 2 + (packed != 0)] % 8) == 0) {
+      (void)hipStreamSynchronize(h->stream);
+      const int nwg = (int)((rows + (waves == 8 ? 255 : 127)) / (waves == 8 ? 256 : 128)), n = nwg < 4096 ? nwg : 4096;
+      std::vector<long> t((size_t)4096 * 8 * 4);
+      (void)hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(sl_probe_ffn), t.size() * sizeof(long));
+      double a[4] = {0, 0, 0, 0}, mx = 0, mn = 1e30;
+      for (int g = 0; g < n; ++g)
+        for (int w = 0; w < waves; ++w) {
+          double tot = 0;
+          for (int k = 0; k < 4; ++k) { a[k] += (double)t[((size_t)g * 8 + w) * 4 + k]; tot += (double)t[((size_t)g * 8 + w) * 4 + k]; }
+          mx = tot > mx ? tot : mx; mn = tot < mn ? tot : mn;
+        }
+      const double tot = a[0] + a[1] + a[2] + a[3];
+      fprintf(stderr, "[probe ffn_pipe<%d, packed %d>] rows %ld F %d: per wave cycles in the tile loop %.0f (min %.0f max %.0f): own-DMA wait %.1f %%  barrier %.1f %%  phase A %.1f %%  phase B %.1f %%\n",
+              waves, packed, rows, F, tot / (n * waves), mn, mx, 100 * a[0] / tot, 100 * a[1] / tot, 100 * a[2] / tot, 100 * a[3] / tot);
+    }
+  }
+#endif
+  return sl_launch_status(h, "simulst_emformer_ffn(pipelined)");
+}

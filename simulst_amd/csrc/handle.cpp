@@ -61,6 +61,7 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->ctc_lds_attr_set = false;
   h->conv_pos_lds_attr_set = false;
   h->ffn_lds_attr_set = false;
+  h->ffn_pipe_lds_attr_set = false;
   h->ffn_variant = 0;
   h->ffn_waves = 0;
   h->ea_general_only = false;
@@ -149,7 +150,9 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
     case SIMULST_OPT_VALU_ATTENTION: h->force_valu_attention = value != 0; return SIMULST_OK;
     case SIMULST_OPT_UNFUSED_DECODE: h->force_unfused_decode = value != 0; return SIMULST_OK;
     case SIMULST_OPT_FFN_WAVES:
-      SL_REQUIRE(h, value == 0 || value == 4 || value == 8, SIMULST_E_ARG, "simulst_set_option(FFN_WAVES): 0, 4 or 8");
+      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 41 || value == 42 || value == 81 || value == 82, SIMULST_E_ARG,
+                 "simulst_set_option(FFN_WAVES): 0 (the library's choice), 4 / 8 (GELU as a block between the products), 41 / 81 (GELU inside the "
+                 "MFMA stream, 4 / 8 waves; 42 / 82: packed GELU, DEBUG_HOOKS builds, else the scalar form)");
       h->ffn_waves = value; return SIMULST_OK;
     case SIMULST_OPT_DEC_CHAIN: h->dec_chain_on = value != 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS:

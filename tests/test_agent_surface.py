@@ -415,3 +415,77 @@ def test_cif_simuleval_agent_on_the_hip_model_equals_frame_agent(beta):
             break
     assert "".join(actions) == want["actions"] and toks == want["tokens"]
     assert int(states.encoder_states["cif_lengths"][0].item()) == want["n_cif"]
+
+
+# ------------------------------------------------------------------- the fairseq branch of load_model_vocab (VERDICT r3 hygiene)
+def test_load_model_vocab_through_a_fairseq_package(tmp_path, monkeypatch):
+    """simuleval_agent.FairseqSimulSTAgent.load_model_vocab with `fairseq` importable (a stub: fairseq is in neither image): the
+    branch that mirrors agents/default_agent.py:205-221 runs -- user module import, checkpoint_utils.load_checkpoint_to_cpu with the
+    --model-overrides dict, the task set up from the checkpoint's task config with data / config_yaml replaced by the agent's flags,
+    the model built BY THE TASK from the checkpoint's model config with the pretrained-path / simul_type fields cleared, strict
+    load_state_dict, eval / share_memory / cuda, the task's target dictionary as dict['tgt'] -- in that order, on a recording
+    model (the HIP model has no CPU form)."""
+    import types
+    calls = []
+
+    class Model:
+        def load_state_dict(self, sd, strict=True):
+            calls.append(("load_state_dict", sorted(sd), strict))
+
+        def eval(self):
+            calls.append(("eval",))
+
+        def share_memory(self):
+            calls.append(("share_memory",))
+
+        def cuda(self):
+            calls.append(("cuda",))
+
+    class Task:
+        target_dictionary = object()
+
+        def __init__(self, targs):
+            self.targs = targs
+
+        def build_model(self, margs):
+            calls.append(("build_model", margs.arch, margs.load_pretrained_encoder_from, margs.load_pretrained_decoder_from,
+                          margs.simul_type, margs.simulst_dtype))
+            return Model()
+
+    fs = types.ModuleType("fairseq")
+    fs.__path__ = []
+    cu, tk, ut = types.ModuleType("fairseq.checkpoint_utils"), types.ModuleType("fairseq.tasks"), types.ModuleType("fairseq.utils")
+
+    def load_checkpoint_to_cpu(filename, arg_overrides=None):
+        calls.append(("load_checkpoint_to_cpu", os.path.basename(filename), dict(arg_overrides or {})))
+        margs = argparse.Namespace(arch="mma_model_s", load_pretrained_encoder_from="/some/enc.pt",
+                                   load_pretrained_decoder_from="/some/dec.pt", simul_type="waitk", **(arg_overrides or {}))
+        return {"cfg": {"task": argparse.Namespace(_name="speech_to_text_infer", data="/train/data", config_yaml="config_st.yaml"),
+                        "model": margs}, "model": {"encoder.w": torch.zeros(1), "decoder.w": torch.zeros(1)}}
+
+    def setup_task(targs):
+        calls.append(("setup_task", targs.data, targs.config_yaml))
+        return Task(targs)
+
+    cu.load_checkpoint_to_cpu, tk.setup_task = load_checkpoint_to_cpu, setup_task
+    ut.import_user_module = lambda a: calls.append(("import_user_module", getattr(a, "user_dir", None)))
+    fs.checkpoint_utils, fs.tasks, fs.utils = cu, tk, ut
+    for name, m in (("fairseq", fs), ("fairseq.checkpoint_utils", cu), ("fairseq.tasks", tk), ("fairseq.utils", ut)):
+        monkeypatch.setitem(sys.modules, name, m)
+    from simulst_amd import simuleval_agent as sa
+    ck = tmp_path / "checkpoint_avg.pt"
+    ck.write_bytes(b"x")
+    agent = object.__new__(sa.FairseqSimulSTAgent)
+    args = argparse.Namespace(model_path=str(ck), model_overrides="{'waitk_lagging': 7}", data_bin="/eval/data-bin", config="config_eval.yaml",
+                              user_dir="codebase", simulst_dtype="bf16")
+    agent.load_model_vocab(args)
+    assert calls == [("import_user_module", "codebase"),
+                     ("load_checkpoint_to_cpu", "checkpoint_avg.pt", {"waitk_lagging": 7}),
+                     ("setup_task", "/eval/data-bin", "config_eval.yaml"),
+                     ("build_model", "mma_model_s", None, None, None, "bf16"),
+                     ("load_state_dict", ["decoder.w", "encoder.w"], True),
+                     ("eval",), ("share_memory",), ("cuda",)]
+    assert agent.dict["tgt"] is Task.target_dictionary and agent.pre_tokenizer is None
+    # a missing checkpoint is reported before anything is imported (agents/default_agent.py:196-197)
+    with pytest.raises(IOError, match="Model file not found"):
+        agent.load_model_vocab(argparse.Namespace(model_path=str(tmp_path / "nope.pt")))

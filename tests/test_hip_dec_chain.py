@@ -260,6 +260,9 @@ def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):
         w = init_model(cfg, seed=21)
         make = lambda ops: SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=ops)
     w["decoder.embed_tokens.weight"][cfg.eos] = 0          # free decoding must not stop at once
+    # an UNTIED output projection: with the tied random embedding a row repeats one token forever, a degenerate check
+    w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(5)) \
+        * cfg.embed_dim ** -0.5
     o_new, o_old = Ops(), Ops()
     o_new.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 1024)      # off by default: measured slower (csrc/dec_chain.hip)
     o_old.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 0)

@@ -768,6 +768,48 @@ def test_emformer_ffn_exact_integer_operands(ops):
     assert float(err.max(dim=1).values.max()) < 6e-2 and float(err.max(dim=0).values.max()) < 6e-2
 
 
+@pytest.mark.parametrize("rows,F", [(1, 64), (100, 128), (128, 2048), (129, 2048), (5000, 2048), (24192, 2048), (300, 1024)])
+def test_emformer_ffn_pipelined_equals_the_block_form(ops, rows, F):
+    """csrc/ffn_pipe.hip (round 4: one fc1 MFMA of the NEXT tile, then one element's bias + GELU + pack of the current tile, ... --
+    the instruction order pinned in the source, scalar fp32 GELU) against ffn_fused_kernel (GELU as a block of packed fp32
+    instructions between the two products): the same operations in the same order on every element, so the outputs are IDENTICAL
+    bit for bit, on random operands and on the exact-integer operands of the layout test."""
+    from simulst_amd.encoder import ffn_pack_w1, ffn_pack_w2
+    g_ = torch.Generator().manual_seed(rows + F)
+    D = 256
+    for exact in (False, True):
+        if exact:
+            x = torch.randint(-3, 4, (rows, D), generator=g_).float().to(torch.bfloat16)
+            W1 = (torch.randint(-2, 3, (F, D), generator=g_).float() / 16).to(torch.bfloat16)
+            W2 = (torch.randint(-2, 3, (D, F), generator=g_).float() / 8).to(torch.bfloat16)
+            b1, b2 = torch.zeros(F), torch.arange(D).float() / 64
+            gam, bet = torch.ones(D), torch.zeros(D)
+        else:
+            x = torch.randn(rows, D, generator=g_).to(torch.bfloat16)
+            W1 = (torch.randn(F, D, generator=g_) * D ** -0.5).to(torch.bfloat16)
+            W2 = (torch.randn(D, F, generator=g_) * F ** -0.5).to(torch.bfloat16)
+            b1, b2 = torch.randn(F, generator=g_) * 0.1, torch.randn(D, generator=g_) * 0.1
+            gam, bet = 1 + 0.1 * torch.randn(D, generator=g_), 0.1 * torch.randn(D, generator=g_)
+        args = (x.cuda(), gam.cuda(), bet.cuda(), ffn_pack_w1(W1.cuda()), b1.cuda(), ffn_pack_w2(W2.cuda()), b2.cuda())
+        outs = {}
+        for waves in (0, 4, 8, 41, 81):
+            out = torch.full((rows, D), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ops.h.set_option(_lib.OPT_FFN_WAVES, waves)
+            try:
+                ops.emformer_ffn(*args, out)
+            finally:
+                ops.h.set_option(_lib.OPT_FFN_WAVES, 0)
+            outs[waves] = out
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[41].float()).all()
+        assert torch.equal(outs[4], outs[8])
+        for wv in (0, 41, 81):       # 0: the default; 4 waves x 2 workgroups per CU (rings of 2 slots); 8 waves, one workgroup per CU (rings of 4, tiles two ahead)
+            assert torch.equal(outs[wv], outs[4]), (wv, exact, int((outs[wv] != outs[4]).sum()),
+                                                    float((outs[wv].float() - outs[4].float()).abs().max()))
+        if not exact:
+            torch.testing.assert_close(outs[41].float().cpu(), _ffn_reference(x, gam, bet, W1, b1, W2, b2), atol=3e-2, rtol=2e-2)
+
+
 def test_encoder_with_fused_ffn_equals_two_launch_path(ops):
     """The full-size bf16 encoder with the fused feed-forward block against the same encoder with it switched off."""
     from simulst_amd.config import mma_model_s

@@ -60,10 +60,29 @@ def test_co_scheduled_rows_consistency_and_determinism(full_model):
     for t, lg, enc in runs[1:]:
         assert torch.equal(t, runs[0][0]) and torch.equal(lg, runs[0][1]) and torch.equal(enc, runs[0][2])
     t, lg, enc = runs[0]
+    # round 4: with the greedy pick fused into the vocabulary projection (the default at this row count) the logits workspace holds
+    # [448][V / 64] (largest value, index) pairs of the projection's column tiles instead of fp32 rows: the same consistency
+    # statement on what is there -- a copy's 64 tile maxima and their indices are bit-identical to the original's
+    pairs = lg.flatten()[:448 * (cfg.vocab // 64) * 2].view(448, cfg.vocab // 64, 2)
     for r in range(24, 448):
-        assert torch.equal(lg[r], lg[r % 24]), r
+        assert torch.equal(pairs[r], pairs[r % 24]), r
         assert torch.equal(t[r], t[r % 24]), r
-    assert torch.isfinite(lg).all()
+    assert torch.isfinite(pairs[..., 0]).all()
+    idx = pairs[..., 1].contiguous().view(torch.int32)
+    tile = torch.arange(cfg.vocab // 64, device=idx.device).view(1, -1)
+    assert bool(((idx >= 64 * tile) & (idx < 64 * tile + 64)).all())    # every pair's index lies in its own tile
+    # ... and fp32 logit rows with the fused pick switched off: the same statement on whole rows, the same tokens
+    from simulst_amd import _lib
+    model.ops.h.set_option(_lib.OPT_FUSED_ARGMAX, 0)
+    try:
+        t2, info2 = model.generate_offline(fb, L, n_steps=40, mask_eos=True)
+        lg2 = info2["state"].ws["logits"]
+        assert torch.equal(t2, t)
+        for r in range(24, 448):
+            assert torch.equal(lg2[r], lg2[r % 24]), r
+        assert torch.isfinite(lg2).all()
+    finally:
+        model.ops.h.set_option(_lib.OPT_FUSED_ARGMAX, 1)
 
 
 def test_multi_stream_pass_repeats_bit_for_bit(full_model):

@@ -61,8 +61,11 @@ def main():
                 ops.lib.simulst_debug_ffn_variant(ops.h.ptr, 0)
             return run
 
-        fns = [("fused", fused), ("two_launch", two), ("fused_one_8wave_workgroup_per_cu", waves(8)),
-               ("fused_two_4wave_workgroups_per_cu", waves(4))]
+        fns = [("fused_default", fused), ("two_launch", two), ("fused_one_8wave_workgroup_per_cu", waves(8)),
+               ("fused_two_4wave_workgroups_per_cu", waves(4)), ("pipelined_gelu_inside_the_mfma_stream", waves(41)),
+               ("pipelined_8_waves_one_workgroup_per_cu", waves(81))]
+        if hasattr(ops.lib, "simulst_debug_ffn_variant"):      # DEBUG_HOOKS build: the packed-GELU instantiations exist
+            fns += [("pipelined_packed_gelu", waves(42)), ("pipelined_packed_gelu_8_waves", waves(82))]
         if hasattr(ops.lib, "simulst_debug_ffn_variant"):
             # variant 1: the kernel WITHOUT the GELU arithmetic -- how much of the launch the un-hidden GELU is; 12-15: 4-wave geometry
             fns += [("fused_no_gelu_ablation", variant(1)), ("ablation_4wave_no_second_product", variant(12)),
