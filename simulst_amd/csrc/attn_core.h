@@ -228,13 +228,21 @@ __device__ __forceinline__ float finish3(const Regs2<T, NP>& r, int n, int n_max
 #pragma unroll
         for (int e = 0; e < W; ++e) s = fmaf(qf[e], ka[e], s);
       }
-#pragma unroll
-      for (int o = 1; o < NP; o <<= 1) s += __shfl_xor(s, o, 64);
+      // the NP lanes of a key row: DPP butterfly steps (common.h lane_xor; NP <= 16, i.e. inside a 16-lane row)
+      if constexpr (NP > 1) s += lane_xor<1>(s);
+      if constexpr (NP > 2) s += lane_xor<2>(s);
+      if constexpr (NP > 4) s += lane_xor<4>(s);
+      if constexpr (NP > 8) s += lane_xor<8>(s);
       if (rg + RP * i < n) { sc[i] = s; mw = fmaxf(mw, s); }
     }
   }
-#pragma unroll
-  for (int o = NP; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));      // across the wave's row groups
+  // across the wave's row groups: the steps below 16 on the DPP path as well (after the NP-lane steps the values are uniform
+  // within NP-lane groups, so lane_xor<4>'s half-mirror partner is as good as lane ^ 4)
+  if constexpr (NP <= 2) mw = fmaxf(mw, lane_xor<2>(mw));
+  if constexpr (NP <= 4) mw = fmaxf(mw, lane_xor<4>(mw));
+  if constexpr (NP <= 8) mw = fmaxf(mw, lane_xor<8>(mw));
+  mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+  mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
   float lw = 0.f, a[W];
 #pragma unroll
   for (int w = 0; w < W; ++w) a[w] = 0.f;
@@ -249,11 +257,19 @@ __device__ __forceinline__ float finish3(const Regs2<T, NP>& r, int n, int n_max
       for (int w = 0; w < W; ++w) a[w] = fmaf(p, va[w], a[w]);
     }
   }
+  // (a[] / lw of different lanes of an NP-lane group hold DIFFERENT channels: only exact-partner steps here -- 8 via row_ror, the
+  //  steps 2 / 4 of narrow heads stay on __shfl_xor, where lane_xor<4>'s half-mirror partner would be the wrong channel)
 #pragma unroll
   for (int o = NP; o < 64; o <<= 1) {
-    lw += __shfl_xor(lw, o, 64);
+    if (o == 8) {
+      lw += lane_xor<8>(lw);
 #pragma unroll
-    for (int w = 0; w < W; ++w) a[w] += __shfl_xor(a[w], o, 64);
+      for (int w = 0; w < W; ++w) a[w] += lane_xor<8>(a[w]);
+    } else {
+      lw += __shfl_xor(lw, o, 64);
+#pragma unroll
+      for (int w = 0; w < W; ++w) a[w] += __shfl_xor(a[w], o, 64);
+    }
   }
   // partial of this wave: red[wave*(d+2)] = max, +1 = sum, +2.. = channels
   float* pw = red + wave * (d + 2);

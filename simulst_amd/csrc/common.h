@@ -188,6 +188,25 @@ __device__ __forceinline__ float wave_scan_incl_dpp(float v) {
 #undef SL_DPP_ADD
   return v;
 }
+// The value of lane (lane ^ M) for M in {1, 2, 4, 8} on the DPP data path -- a VALU operand permutation instead of a ds_bpermute
+// round trip through the LDS crossbar (v_xor + v_cmp + v_cndmask + v_lshlrev + ds_bpermute + its wait per __shfl_xor): quad_perm
+// [1,0,3,2] / [2,3,0,1] for 1 / 2, row_ror:8 for 8 (exact partners).  M = 4 uses row_half_mirror, lane i <-> 7 - i: a lane of the
+// OTHER quad of the 8-lane group, which is lane ^ 4's value whenever the values are already uniform within quads -- i.e. as the third
+// step of a 1, 2, 4 butterfly, the only place it is used.  Sums and maxima come out bit-identical to the __shfl_xor butterfly (the same
+// pairs are combined, fp add / max are commutative).  Needs the whole wave active (the reductions sit under wave-uniform branches).
+template <int M>
+__device__ __forceinline__ float lane_xor_dpp(float v) {
+  static_assert(M == 1 || M == 2 || M == 4 || M == 8, "DPP butterfly steps inside a 16-lane row");
+  constexpr int ctrl = M == 1 ? 0xB1 : M == 2 ? 0x4E : M == 4 ? 0x141 : 0x128;
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false));
+}
+// butterfly step O of a wave reduction: DPP inside a 16-lane row, ds_bpermute across rows
+template <int O>
+__device__ __forceinline__ float lane_xor(float v) {
+  if constexpr (O <= 8) return lane_xor_dpp<O>(v);
+  else return __shfl_xor(v, O, 64);
+}
+
 __device__ __forceinline__ float wave_last(float v) {        // lane 63's value in every lane (scalar broadcast)
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }

@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restr
     sc[i] = -INFINITY;
     if (i * RPP < n) {
       float s = attn::dot8_bf16(qv, kk[i]) * qscale;
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      s += lane_xor<1>(s); s += lane_xor<2>(s); s += lane_xor<4>(s);      // the 8 lanes of a key row: DPP butterfly (common.h)
       if (rg + RPP * i < n) { sc[i] = s; mx = fmaxf(mx, s); }
     }
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  mx = fmaxf(mx, lane_xor<8>(mx)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float den = 0.f, a[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) a[e] = 0.f;
@@ -128,10 +128,10 @@ __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restr
     }
   }
   // across the 8 row groups (lanes 8, 16, 32 apart); den is identical on the 8 lanes of a row
-  den += __shfl_xor(den, 8, 64); den += __shfl_xor(den, 16, 64); den += __shfl_xor(den, 32, 64);
+  den += lane_xor<8>(den); den += __shfl_xor(den, 16, 64); den += __shfl_xor(den, 32, 64);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    a[e] += __shfl_xor(a[e], 8, 64); a[e] += __shfl_xor(a[e], 16, 64); a[e] += __shfl_xor(a[e], 32, 64);
+    a[e] += lane_xor<8>(a[e]); a[e] += __shfl_xor(a[e], 16, 64); a[e] += __shfl_xor(a[e], 32, 64);
   }
   if (rg == 0) {
     const float inv = 1.0f / den;

@@ -595,11 +595,11 @@ __device__ __forceinline__ void attn_finish(const AttnProblem<MAXP>& r, unsigned
     sc[i] = -INFINITY;
     if (i * RPP < n) {
       float s = attn_dot8(r.q, r.k[i]) * qscale;
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      s += lane_xor<1>(s); s += lane_xor<2>(s); s += lane_xor<4>(s);
       if (rg + RPP * i < n) { sc[i] = s; mx = fmaxf(mx, s); }
     }
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  mx = fmaxf(mx, lane_xor<8>(mx)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float den = 0.f, a[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) a[e] = 0.f;
@@ -616,10 +616,10 @@ __device__ __forceinline__ void attn_finish(const AttnProblem<MAXP>& r, unsigned
       }
     }
   }
-  den += __shfl_xor(den, 8, 64); den += __shfl_xor(den, 16, 64); den += __shfl_xor(den, 32, 64);
+  den += lane_xor<8>(den); den += __shfl_xor(den, 16, 64); den += __shfl_xor(den, 32, 64);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    a[e] += __shfl_xor(a[e], 8, 64); a[e] += __shfl_xor(a[e], 16, 64); a[e] += __shfl_xor(a[e], 32, 64);
+    a[e] += lane_xor<8>(a[e]); a[e] += __shfl_xor(a[e], 16, 64); a[e] += __shfl_xor(a[e], 32, 64);
   }
   if (rg == 0) {
     const float inv = 1.0f / den;

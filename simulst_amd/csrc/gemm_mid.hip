@@ -411,20 +411,27 @@ bool sl_mid_wanted(const simulst_handle* h, int dtype, const LinArgs& p) {
 
 // the decode loops' vocabulary projection with the greedy pick's per-tile maxima as output: the shapes the 64 x 64 tile kernel
 // takes anyway (co-scheduled bf16 batches below the split-panel threshold), final LayerNorm as prologue
-bool sl_vocab_argmax_ok(const simulst_handle* h, int dtype, int B, int V, int D, bool packed) {
-  if (!h->fused_argmax || dtype != SIMULST_BF16 || !packed || V % 64 != 0 || D % 32 != 0 || D > 256) return false;
-  LinArgs p = {};
-  p.M = B; p.rpb = B; p.N = V; p.K = D; p.a_rs = D; p.c_rs = V; p.w_packed = 1; p.ln_g = (const float*)h;   // any non-null: LN prologue
-  return sl_mid_wanted(h, dtype, p) && !sl_panel_split_wanted(h, dtype, SIMULST_EPI_BIAS_F32OUT, p);
-}
-
-int sl_launch_vocab_argmax(simulst_handle* h, const void* x, const void* W, const float* ln_g, const float* ln_b, float2* partial,
-                           int B, int V, int D, int skip_a, int skip_b) {
+static LinArgs vocab_args(int B, int V, int D, const float* ln_g, const float* ln_b) {
   LinArgs p = {};
   p.M = B; p.rpb = B; p.N = V; p.K = D;
   p.a_bs = 0; p.a_rs = D; p.a_lead = 0; p.c_bs = 0; p.c_rs = V; p.r_bs = 0; p.r_rs = V;
   p.scale = 1.f; p.ln_g = ln_g; p.ln_b = ln_b; p.w_packed = 1;
+  return p;
+}
+
+bool sl_vocab_argmax_ok(const simulst_handle* h, int dtype, int B, int V, int D, bool packed) {
+  if (!h->fused_argmax || dtype != SIMULST_BF16 || !packed || V % 64 != 0 || D % 32 != 0 || D > 256) return false;
+  const LinArgs p = vocab_args(B, V, D, (const float*)h, (const float*)h);      // any non-null: the LayerNorm prologue is part of the shape test
+  return sl_panel_split_wanted(h, dtype, SIMULST_EPI_BIAS_F32OUT, p) || sl_mid_wanted(h, dtype, p);
+}
+
+int sl_launch_vocab_argmax(simulst_handle* h, const void* x, const void* W, const float* ln_g, const float* ln_b, float2* partial,
+                           int B, int V, int D, int skip_a, int skip_b) {
+  LinArgs p = vocab_args(B, V, D, ln_g, ln_b);
   p.amax = partial; p.amax_tiles = V / 64; p.amax_skip_a = skip_a; p.amax_skip_b = skip_b;
+  // the kernel simulst_linear would pick for these rows: the split row panel from thousands of rows on, else the 64 x 64 tile
+  if (sl_panel_split_wanted(h, SIMULST_BF16, SIMULST_EPI_BIAS_F32OUT, p))
+    return sl_launch_panel_split(h, SIMULST_EPI_BIAS_F32OUT, x, W, nullptr, nullptr, partial, p);
   return launch_mid<bf16, float, SIMULST_EPI_BIAS>(h, x, W, nullptr, nullptr, partial, p);
 }
 

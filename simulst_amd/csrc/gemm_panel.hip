@@ -195,6 +195,27 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int q = 0; q < 8; ++q) y[q] = fs[q];
       if constexpr (EPI == SIMULST_EPI_BIAS_F32OUT) {           // fp32 logits: C is a float buffer
+        if (p.amax) {
+          // greedy pick, first stage (LinArgs::amax, as gemm_mid.hip): this lane's 8 columns in index order, then the 8 lanes of
+          // the row (columns ascending with the lane); one (largest value, lowest index) pair per row and 64-column step
+          float best = -INFINITY;
+          int bi = 0x7fffffff;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int cc = c + q;
+            float v = y[q];
+            if (cc == p.amax_skip_a || cc == p.amax_skip_b || cc >= p.N) v = -INFINITY;
+            if (v > best || (v == best && cc < bi)) { best = v; bi = cc; }
+          }
+#pragma unroll
+          for (int o = 1; o <= 4; o <<= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+          }
+          if ((lane & 7) == 0) p.amax[((long)b * p.rpb + ii) * p.amax_tiles + step] = make_float2(best, __int_as_float(bi));
+          continue;
+        }
         float* dstf = reinterpret_cast<float*>(C) + c_index(p, b, ii, c);
         if (c + 8 <= p.N && ((p.c_rs | p.c_bs) & 3) == 0) {
           *reinterpret_cast<float4*>(dstf) = float4{y[0], y[1], y[2], y[3]};

@@ -228,6 +228,33 @@ def test_decode_loop_with_chains_vs_one_launch_per_gemm(monkeypatch, attn, ffn):
     assert (tN == tM).float().mean().item() > 0.6
 
 
+def test_fused_greedy_pick_in_the_split_panel_kernel_changes_no_token():
+    """Thousands of co-scheduled rows (the default bench run's 4096-row sequences) take the vocabulary projection on the split
+    row-panel kernel (csrc/gemm_panel.hip); its epilogue leaves the same per-tile (largest value, index) pairs as the 64 x 64 tile
+    kernel does for hundreds of rows.  2 624 rows, wait-k, 6 steps: tokens identical to the run that writes fp32 logits and picks
+    from them, with EOS masked (forced decoding) and free."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.ops import Ops
+    from simulst_amd.weights import init_model
+    B, T = 2624, 160
+    fb = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(18)).cuda().to(torch.bfloat16)
+    L = torch.full((B,), T, device="cuda")
+    cfg = mma_model_s(encoder_layers=1, decoder_layers=2, simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=3)
+    w = init_model(cfg, seed=22)
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0
+    w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(6)) \
+        * cfg.embed_dim ** -0.5
+    o_new, o_old = Ops(), Ops()
+    o_old.h.set_option(_lib.OPT_FUSED_ARGMAX, 0)
+    for mask_eos in (True, False):
+        t_new = SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=o_new).generate_offline(fb, L, n_steps=6, mask_eos=mask_eos)[0].clone()
+        t_old = SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=o_old).generate_offline(fb, L, n_steps=6, mask_eos=mask_eos)[0].clone()
+        torch.cuda.synchronize()
+        assert torch.equal(t_new, t_old), (mask_eos, int((t_new != t_old).sum()))
+        assert len(set(t_new.flatten().tolist())) > 200
+
+
 @pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback", "cif"])
 @pytest.mark.parametrize("mask_eos", [True, False])
 def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):

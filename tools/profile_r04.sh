@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-4 measurement point on the GPU box (through gpurun, from the repo root):  tools/profile_r04.sh <tag>
+# Writes under gpurun_out/<tag>/: the driver-shaped bench line (with every leg), the default bench line, rocprofv3 --kernel-trace
+# --stats of the driver-shaped command (main leg only), FETCH_SIZE / WRITE_SIZE passes of the dominant kernel (separate runs,
+# --kernel-trace only), a SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE pass of the main leg (matrix-core busy share per kernel).
+# The program itself follows `--` (no wrapper).
+TAG=${1:-r04_a}
+R=$PWD
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_k20.json 2> $O/bench_k20.err; echo "bench k20 rc=$?"
+timeout 900 python bench.py --no-extra-configs > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$?"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_k20 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs > $O/bench_k20_under_rocprofv3.json 2> $O/trace_k20.err; echo "trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 20 --warmup 5 --concurrency 1 --no-pipeline --no-cpu-baseline --no-extra-configs --timed-only --min-warmup-seconds 0 > $O/pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/tools/kernel_bench.py cross_attn --utterances 448 4096 > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/tools/kernel_bench.py cross_attn --utterances 448 4096 > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
+cd $R
+timeout 120 python tools/kernel_bench.py cross_attn --utterances 448 4096 > $O/kernel_bench_cross_attn.json 2>/dev/null
+F=$(ls $O/pmc_fetch/*/*counter_collection.csv 2>/dev/null | head -1); W=$(ls $O/pmc_write/*/*counter_collection.csv 2>/dev/null | head -1)
+if [ -n "$F" ] && [ -n "$W" ]; then python tools/pmc_cross_attn.py "$F" "$W" $O/kernel_bench_cross_attn.json $O/pmc_cross_attention_traffic.json; fi
+M=$(ls $O/pmc_mfma/*/*counter_collection.csv 2>/dev/null | head -1)
+[ -n "$M" ] && python tools/pmc_kernel.py $O/pmc_mfma.json "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 20 --warmup 5 --concurrency 1 --no-pipeline --no-cpu-baseline --no-extra-configs --timed-only --min-warmup-seconds 0" "." "$M" > /dev/null
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_mfma
+find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete
+grep -h "passes of" $O/*.err | cut -c1-160
+ls $O
