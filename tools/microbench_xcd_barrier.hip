@@ -43,6 +43,8 @@ __device__ __forceinline__ unsigned pull(const uint4* __restrict__ w, int work16
 // mode 1: XCD-local counter, sc1 stores + sc1 loads, no fence
 // mode 2: one grid-wide counter, acquire fence
 // mode 3: XCD-local counter and NOTHING read afterwards (the counter alone)
+// mode 4: mode 1 with the NEXT phase's weight pull issued between arriving and polling (weights do not depend on the hand-off:
+//         the most a persistent layer could hide)
 __global__ __launch_bounds__(256) void k_persist(Ctl* c, float* slots, const uint4* w, unsigned* sink, int phases,
                                                  int mode, int work16) {
   __shared__ unsigned s_x, s_me, s_n;
@@ -59,16 +61,20 @@ __global__ __launch_bounds__(256) void k_persist(Ctl* c, float* slots, const uin
   const unsigned nb = (me + 1) % n;
   unsigned acc = 0, stale = 0;
   for (int p = 0; p < phases; ++p) {
-    acc ^= pull(w, work16, p);
+    if (mode != 4 || p == 0) acc ^= pull(w, work16, p);
     float* mine = slots + ((size_t)(p & 1) * 8 * MAX_PER_XCD + x * MAX_PER_XCD + me) * SLOT;
     const float* theirs = slots + ((size_t)(p & 1) * 8 * MAX_PER_XCD + x * MAX_PER_XCD + nb) * SLOT;
     if (threadIdx.x < SLOT) {
-      if (mode == 1) __hip_atomic_store(mine + threadIdx.x, (float)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (mode == 1 || mode == 4) __hip_atomic_store(mine + threadIdx.x, (float)(p + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else mine[threadIdx.x] = (float)(p + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (mode == 4) {
+      if (threadIdx.x == 0) atomicAdd(&c->cnt[x][0], 1u);
+      acc ^= pull(w, work16, p + 1);
+      if (threadIdx.x == 0) wait_for(&c->cnt[x][0], n * (unsigned)(p + 1), &c->gave_up[0]);
+    } else if (threadIdx.x == 0) {
       if (mode == 2) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         atomicAdd(&c->all[0], 1u);
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void k_persist(Ctl* c, float* slots, const uin
     }
     __syncthreads();
     if (mode != 3 && threadIdx.x < SLOT) {
-      const float v = mode == 1 ? __hip_atomic_load(theirs + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+      const float v = (mode == 1 || mode == 4) ? __hip_atomic_load(theirs + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                 : theirs[threadIdx.x];
       if (v != (float)(p + 1)) ++stale;
     }
@@ -113,25 +119,39 @@ int main() {
   hipMalloc(&w, wbytes); hipMemset(w, 1, wbytes); hipMalloc(&sink, 64);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int grid = 256, phases = 400;
-  const char* names[4] = {"in one launch: XCD counter + acquire fence", "in one launch: XCD counter + sc1 stores/loads",
-                          "in one launch: one grid counter, release + acquire", "in one launch: XCD counter alone (nothing read)"};
+  const char* names[5] = {"in one launch: XCD counter + acquire fence", "in one launch: XCD counter + sc1 stores/loads",
+                          "in one launch: one grid counter, release + acquire", "in one launch: XCD counter alone (nothing read)",
+                          "in one launch: XCD counter + sc1 stores/loads, next pull issued before polling"};
   printf("{\"grid\": %d, \"threads\": 256, \"phases\": %d, \"rows\": [\n", grid, phases);
   bool first = true;
   for (int work16 : {0, 16, 64}) {
-    // dependent launches
-    float best = 1e30f; unsigned stale = 0;
-    for (int rep = 0; rep < 5; ++rep) {
-      hipMemsetAsync(c, 0, sizeof(Ctl), st); hipMemsetAsync(slots, 0, sizeof(float) * 2 * 8 * MAX_PER_XCD * SLOT, st);
-      hipEventRecord(e0, st);
-      for (int p = 0; p < phases; ++p) hipLaunchKernelGGL(k_phase, dim3(grid), dim3(256), 0, st, c, slots, w, sink, p, work16);
-      hipEventRecord(e1, st); hipEventSynchronize(e1);
-      float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
-      Ctl hc; hipMemcpy(&hc, c, sizeof(Ctl), hipMemcpyDeviceToHost); stale += hc.stale[0];
+    // dependent launches: eager (one host call each: host-bound below ~3 us per kernel) and replayed from a captured graph
+    for (int graph = 0; graph < 2; ++graph) {
+      float best = 1e30f; unsigned stale = 0;
+      hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+      if (graph) {
+        hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+        for (int p = 0; p < phases; ++p) hipLaunchKernelGGL(k_phase, dim3(grid), dim3(256), 0, st, c, slots, w, sink, p, work16);
+        hipStreamEndCapture(st, &g);
+        hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+      }
+      for (int rep = 0; rep < 5; ++rep) {
+        hipMemsetAsync(c, 0, sizeof(Ctl), st); hipMemsetAsync(slots, 0, sizeof(float) * 2 * 8 * MAX_PER_XCD * SLOT, st);
+        hipStreamSynchronize(st);
+        hipEventRecord(e0, st);
+        if (graph) hipGraphLaunch(ge, st);
+        else for (int p = 0; p < phases; ++p) hipLaunchKernelGGL(k_phase, dim3(grid), dim3(256), 0, st, c, slots, w, sink, p, work16);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+        Ctl hc; hipMemcpy(&hc, c, sizeof(Ctl), hipMemcpyDeviceToHost); stale += hc.stale[0];
+      }
+      if (graph) { hipGraphExecDestroy(ge); hipGraphDestroy(g); }
+      printf("%s{\"form\": \"one launch per phase, %s\", \"weight_kb_per_workgroup\": %d, \"us_per_phase\": %.3f, \"stale_reads\": %u}",
+             first ? "" : ",\n", graph ? "graph replay" : "eager", work16 * 4, best * 1000.f / phases, stale);
+      first = false;
     }
-    printf("%s{\"form\": \"one launch per phase\", \"weight_kb_per_workgroup\": %d, \"us_per_phase\": %.3f, \"stale_reads\": %u}",
-           first ? "" : ",\n", work16 * 4, best * 1000.f / phases, stale);
-    first = false;
-    for (int mode = 0; mode < 4; ++mode) {
+    float best; unsigned stale;
+    for (int mode = 0; mode < 5; ++mode) {
       best = 1e30f; stale = 0; unsigned gave_up = 0; unsigned mn = 1u << 30, mx = 0;
       for (int rep = 0; rep < 5; ++rep) {
         hipMemsetAsync(c, 0, sizeof(Ctl), st); hipMemsetAsync(slots, 0, sizeof(float) * 2 * 8 * MAX_PER_XCD * SLOT, st);
