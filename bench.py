@@ -209,7 +209,8 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="wait
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 5), "traffic": None, "launches_per_sequence": n_launch,
                 "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_flop_per_launch": round(flops / n_launch)}
-    if name in ("linear_skinny", "linear_tile64", "dec_qkv_chain", "dec_proj_chain", "dec_ffn_chain", "dec_attn_proj_chain"):
+    if name in ("linear_skinny", "linear_tile64", "dec_qkv_chain", "dec_proj_chain", "dec_ffn_chain", "dec_attn_proj_chain",
+                "dec_vocab_chain"):
         # decode-step contractions: the launch-site groups of the per-GEMM kernels and, one class per kernel, the row-local layer
         # chains (csrc/dec_chain.hip).  SCORED on algorithmic bytes -- every weight matrix of the launch once + its activations in
         # and out (+ the cached K / V rows for the chain that carries the self-attention) -- against HBM, the only rate a
@@ -217,6 +218,9 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="wait
         # information only (scoring the delivered bytes rewards redundant re-reads).
         tile64 = Bs >= 256
         chains = Bs > 128 and dtype_name == "bf16"                # the chains' domain (csrc/handle.cpp dec_chain_min_rows)
+        # the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial pick): feed-forward chain domain,
+        # split 8 by default (csrc/handle.cpp dec_vocab_chain_split, dec_chain.hip sl_dec_vocab_chain_split)
+        vsplit = 8 if (chains and Bs <= 1024 and V % 2048 == 0 and kind != "cif") else 0
 
         def alg(n, k):
             return (n * k + Bs * k + Bs * n) * esz
@@ -226,8 +230,13 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="wait
         per_step = {"qkv": (3 * D, D), "out": (D, D), "q": (D, D), "c_out": (D, D), "fc1": (F, D), "fc2": (D, F)}
         if name == "dec_qkv_chain":
             # slab sum (F / 256 fp32 slabs in, x out) + LN1 + QKV; once more per step for the last layer's slabs
-            byts = U * (Ld * (alg(3 * D, D) + (F // 256) * Bs * D * 4) + (F // 256) * Bs * D * 4)
-            dl = U * Ld * delivered(3 * D, D, 16)
+            last = 0 if vsplit else (F // 256) * Bs * D * 4
+            byts = U * ((Ld - 1) * (alg(3 * D, D) + (F // 256) * Bs * D * 4) + last)
+            dl = U * (Ld - 1) * delivered(3 * D, D, 16)
+        elif name == "dec_vocab_chain":
+            # the last layer's slabs + x' in, x out, the output projection once, `split` (value, index) pairs per row out
+            byts = U * ((F // 256) * Bs * D * 4 + 2 * Bs * D * esz + V * D * esz + Bs * vsplit * 8)
+            dl = U * ((F // 256) * Bs * D * 4 * vsplit + -(-Bs // 16) * V * D * esz)
         elif name == "dec_proj_chain":
             byts = U * Ld * (alg(D, D) + alg(D, D))
             dl = U * Ld * 2 * delivered(D, D, 16)
@@ -241,9 +250,10 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="wait
         else:
             rt = 64 if name == "linear_tile64" else 16
             if chains:            # with the chains only layer 0's QKV and the vocabulary projection stay in these groups
-                shapes = [(3 * D, D)] * (name == "linear_tile64" and tile64) + [(V, D)] * (name == "linear_tile64" and tile64)
+                shapes = [(3 * D, D)] * (name == "linear_tile64" and tile64) + \
+                         [(V, D)] * (name == "linear_tile64" and tile64 and not vsplit)
                 if name == "linear_skinny" and not tile64:
-                    shapes = [(3 * D, D), (V, D)]
+                    shapes = [(3 * D, D)] + [(V, D)] * (not vsplit)
                 byts = U * sum(alg(n, k) for n, k in shapes)
                 dl = U * sum(delivered(n, k, rt) for n, k in shapes)
             else:

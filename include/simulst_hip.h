@@ -68,14 +68,14 @@ enum { SIMULST_K_LINEAR = 0, SIMULST_K_LAYERNORM = 1, SIMULST_K_EMF_ATTN = 2, SI
        SIMULST_K_ARGMAX = 7, SIMULST_K_MISC = 8, SIMULST_K_LINEAR_SKINNY = 9, SIMULST_K_LINEAR_TILE64 = 10,
        /* round 4: the row-local layer chains of the decode step, one class per kernel (csrc/dec_chain.hip) */
        SIMULST_K_DEC_QKV_CHAIN = 11, SIMULST_K_DEC_PROJ_CHAIN = 12, SIMULST_K_DEC_FFN_CHAIN = 13,
-       SIMULST_K_DEC_ATTN_CHAIN = 14, SIMULST_K_COUNT = 15 };
+       SIMULST_K_DEC_ATTN_CHAIN = 14, SIMULST_K_DEC_VOCAB_CHAIN = 15, SIMULST_K_COUNT = 16 };
 
 /* ---- handle ------------------------------------------------------------------ */
 int simulst_create(simulst_handle** out, void* hip_stream);
 int simulst_destroy(simulst_handle* h);
 int simulst_set_stream(simulst_handle* h, void* hip_stream);
 const char* simulst_last_error(simulst_handle* h);
-int simulst_version(void);            /* 104 (round 4: kernel classes 11-14, simulst_set_option, simulst_decoder_attn_proj_chain); a binding built for another value must not use the library */
+int simulst_version(void);            /* 104 (round 4: kernel classes 11-15, simulst_set_option, simulst_decoder_attn_proj_chain, simulst_decoder_vocab_chain); a binding built for another value must not use the library */
 /* per-kernel-class HIP-event timing on the handle's stream (off by default) */
 int simulst_timer_enable(simulst_handle* h, int kernel_class, int on);
 int simulst_timer_read(simulst_handle* h, int kernel_class, double* total_ms, int64_t* launches);
@@ -98,9 +98,13 @@ int simulst_graph_enable(simulst_handle* h, int on);
  *   DEC_ATTN_CHAIN_ROWS     rows per workgroup of that launch: 0 chosen from the row count, 4, 8, 16
  *   FUSED_ARGMAX            0: the decode loops write fp32 logits and pick from them (default 1: partial maxima out of the
  *                              vocabulary projection's epilogue where the shapes allow)
+ *   DEC_VOCAB_CHAIN_SPLIT   workgroups per 16-row tile of the decode step's closing launch (last layer's slab sum + final LayerNorm +
+ *                              vocabulary projection + partial greedy pick, simulst_decoder_vocab_chain): 0 off (reduction launch +
+ *                              64 x 64 tile GEMM), 1, 2, 4, 8, 16 (halved until V is a multiple of 256 x the split)
  * Returns SIMULST_E_ARG for an unknown option or a value outside its range. */
 enum { SIMULST_OPT_VALU_ATTENTION = 0, SIMULST_OPT_UNFUSED_DECODE = 1, SIMULST_OPT_FFN_WAVES = 2, SIMULST_OPT_DEC_CHAIN = 3,
-       SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 4, SIMULST_OPT_DEC_ATTN_CHAIN_ROWS = 5, SIMULST_OPT_FUSED_ARGMAX = 6 };
+       SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 4, SIMULST_OPT_DEC_ATTN_CHAIN_ROWS = 5, SIMULST_OPT_FUSED_ARGMAX = 6,
+       SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT = 7 };
 int simulst_set_option(simulst_handle* h, int32_t option, int32_t value);
 
 #ifdef SIMULST_DEBUG_HOOKS
@@ -676,6 +680,18 @@ int simulst_decoder_ffn_chain(simulst_handle* h, const void* ctx, void* x, const
 int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2,
                                  const float* ln_g, const float* ln_b, const void* wqkv_fm, const float* bqkv, void* qkv,
                                  int32_t B, int32_t D, int32_t F, int32_t dtype);
+
+/* The closing launch of a decode step for co-scheduled bf16 batches (csrc/dec_chain.hip dec_vocab_chain_kernel): the last layer's
+ * slab sum (as simulst_decoder_slab_sum_qkv), the decoder's final LayerNorm, the output projection (models/mma_model.py:212-220;
+ * fairseq TransformerDecoder.output_layer, no bias) and the first half of the greedy choice (SequenceGenerator with beam 1,
+ * eval/generate.py:141-155):  x <- bf16(x_mid + b2 + slabs);  pairs[row][s] = (largest logit, its lowest column, the column's
+ * int32 bits in the second float) over columns [s V / split, (s + 1) V / split) of Wout LN(x), columns skip_a / skip_b (pad, a
+ * masked eos; -1: none) excluded.  The fold over the `split` pairs of a row uses the same (value, lowest column) rule
+ * (simulst_mma_decode's commit kernel).  wout_fm: [V][256] in fragment-major order; pairs [B][split][2] floats.
+ * bf16, D == 256, V a multiple of 256 x split. */
+int simulst_decoder_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2,
+                                const float* ln_g, const float* ln_b, const void* wout_fm, float* pairs, int32_t B, int32_t D,
+                                int32_t F, int32_t V, int32_t split, int32_t skip_a, int32_t skip_b, int32_t dtype);
 
 /* Self-attention INSIDE the projection chain (round 4): simulst_decoder_self_attention + simulst_decoder_proj_chain in ONE launch,
  * same results bit for bit.  qkv [B][3*256] = this step's q | k | v rows (fairseq MultiheadAttention in_proj of the decoder layer's

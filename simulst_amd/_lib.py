@@ -20,10 +20,10 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_GLU, EPI_EMF_OUT, EPI_BIAS_F32OUT, EP
 ATTN_HARD, ATTN_INFINITE_LOOKBACK, ATTN_WAITK, ATTN_CHUNKWISE = range(4)
 (K_LINEAR, K_LAYERNORM, K_EMF_ATTN, K_CONV_POS, K_DEC_SELF_ATTN, K_DEC_CROSS_ATTN, K_SCAN, K_ARGMAX,
  K_MISC, K_LINEAR_SKINNY, K_LINEAR_TILE64, K_DEC_QKV_CHAIN, K_DEC_PROJ_CHAIN, K_DEC_FFN_CHAIN, K_DEC_ATTN_CHAIN,
- K_COUNT) = range(16)
+ K_DEC_VOCAB_CHAIN, K_COUNT) = range(17)
 KERNEL_CLASS_NAMES = ["linear", "layernorm", "emformer_attention", "conv_pos", "decoder_self_attention",
                       "decoder_cross_attention", "scan", "argmax", "misc", "linear_skinny", "linear_tile64",
-                      "dec_qkv_chain", "dec_proj_chain", "dec_ffn_chain", "dec_attn_proj_chain"]
+                      "dec_qkv_chain", "dec_proj_chain", "dec_ffn_chain", "dec_attn_proj_chain", "dec_vocab_chain"]
 
 ATTN_ENUM = {"hard_aligned": ATTN_HARD, "infinite_lookback": ATTN_INFINITE_LOOKBACK,
              "waitk": ATTN_WAITK, "chunkwise": ATTN_CHUNKWISE}
@@ -149,6 +149,7 @@ SIGNATURES = {
     "simulst_decoder_proj_chain": [_vp] * 13 + [_i32, _i32, _i32],
     "simulst_decoder_ffn_chain": [_vp] * 14 + [_i32, _i32, _i32, _i32],
     "simulst_decoder_slab_sum_qkv": [_vp] * 10 + [_i32, _i32, _i32, _i32],
+    "simulst_decoder_vocab_chain": [_vp] * 9 + [_i32] * 8,
     "simulst_decoder_attn_proj_chain": [_vp] * 17 + [_i32] * 7,
 }
 
@@ -162,7 +163,7 @@ DEBUG_SIGNATURES = {
     "simulst_debug_chain_probe": [_vp] * 10 + [_i32, _i32, _vp],
 }
 (OPT_VALU_ATTENTION, OPT_UNFUSED_DECODE, OPT_FFN_WAVES, OPT_DEC_CHAIN, OPT_DEC_ATTN_CHAIN_MAX_ROWS, OPT_DEC_ATTN_CHAIN_ROWS,
- OPT_FUSED_ARGMAX) = range(7)
+ OPT_FUSED_ARGMAX, OPT_DEC_VOCAB_CHAIN_SPLIT) = range(8)
 
 _lib = None
 ABI_VERSION = 104          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)

@@ -58,6 +58,7 @@ struct simulst_handle {
   int dec_chain_xmode;         // how the chains' MFMAs get their activation fragments (dec_chain.hip mma_unit)
   int dec_attn_chain_max_rows; // rows up to which self-attention rides inside the projection chain (dec_attn_proj_chain_kernel)
   int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
+  int dec_vocab_chain_split;   // workgroups per row tile of the step's closing launch (dec_vocab_chain_kernel); 0: off
   bool fused_argmax;           // decode loops: per-tile (max, index) partials out of the vocabulary projection instead of fp32 logits
 };
 
@@ -285,6 +286,11 @@ int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* W
                       const float* ln_b, const void* Wq, const float* bq, void* q, const void* Wq2, const float* bq2,
                       void* q2, int B, const void* kk_gelu = nullptr);
 bool sl_dec_attn_chain_ok(const simulst_handle* h, int dtype, int B, int H, int d, int cap);
+// the closing launch of a decode step (slab sum + final LayerNorm + vocabulary projection + partial greedy pick): the column split
+// to use for this shape, 0 = not taken
+int sl_dec_vocab_chain_split(const simulst_handle* h, int dtype, int B, int V, int D, bool packed, bool has_ln);
+int sl_dec_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
+                       const float* ln_b, const void* Wout, float2* pairs, int B, int F, int V, int n_cb, int skip_a, int skip_b);
 int sl_dec_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev, int np_uniform,
                            int cap, void* x, const void* Wo, const float* bo, const float* ln_g, const float* ln_b, const void* Wq,
                            const float* bq, void* q, const void* Wq2, const float* bq2, void* q2, int B, const void* kk_gelu = nullptr);

@@ -525,6 +525,92 @@ __global__ __launch_bounds__(256, 2) void dec_qkv_chain_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The end of a decode step as ONE launch (round 4): the last layer's slab sum, the decoder's final LayerNorm and the vocabulary
+// projection with the greedy pick's partial maxima as its only output:
+//   x <- bf16(x' + b2 + slabs);  pairs[row][cb] = (largest logit, its lowest column) over columns [cb VC, (cb + 1) VC) of W_out LN(x)
+// (models/mma_model.py:212-220 output_layer on the last position + the greedy choice of eval/generate.py's SequenceGenerator with
+// beam 1.)  Replaces dec_qkv_chain_kernel's reduction-only launch and the 64 x 64 tile GEMM (gemm_mid.hip, LinArgs::amax): the tile
+// GEMM ran 448 workgroups that each normalise 64 rows for 32 KB of weights, 17 us at 448 rows for 0.9 GFLOP.  Here a workgroup owns
+// 16 rows and VC = V / n_cb columns: it adds the slabs of its row tile itself (as every column block of dec_qkv_chain_kernel does),
+// normalises the tile once and walks VC / 256 weight blocks, wave w taking 64 columns of each block; a lane keeps the running
+// (value, column) of ITS row (strictly-greater keeps the lowest column: a lane meets its columns in ascending order), lanes of
+// a row and then the four waves are folded with the (value, column) rule of argmax_embed_kernel, which folds the n_cb pairs of a row.
+// Columns skip_a / skip_b (pad, masked eos; -1: none) never win.  No bias (the output projection has none).
+template <int XM>
+__global__ __launch_bounds__(256, 2) void dec_vocab_chain_kernel(
+    const bf16* __restrict__ x_mid, bf16* __restrict__ x, const float* __restrict__ partial, const float* __restrict__ b2,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W, float2* __restrict__ pairs,
+    int M, int splits, int n_cb, int n_blk, int skip_a, int skip_b) {
+  constexpr int RT = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // lds_bytes(1)
+  unsigned short* bufA = lds;
+  unsigned short* bufB = lds + RT * XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int cb = blockIdx.x % n_cb, m0 = (blockIdx.x / n_cb) * RT;
+  int tw = 16 * (cb * n_blk) + 4 * wave;                          // this wave's four column tiles of the current block
+  WUnit u0, u1;
+  load_unit(u0, W, tw, NKS, 0, lane);
+  load_unit(u1, W, tw + 2, NKS, 0, lane);
+  float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS);       // [fold scratch | gamma | beta] x 256
+  vec[256 + tid] = ln_g[tid]; vec[512 + tid] = ln_b[tid];
+  const float4 b24 = *reinterpret_cast<const float4*>(b2 + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave + 4 * i, g = m0 + row;
+    uint2 o = make_uint2(0, 0);
+    if (g < M) {
+      float r[4];
+      unpack4(*reinterpret_cast<const uint2*>(x_mid + (long)g * CD + 4 * lane), r);
+      o = add_slabs(r, b24, partial, splits, M, g, lane);
+      if (cb == 0) *reinterpret_cast<uint2*>(x + (long)g * CD + 4 * lane) = o;
+    }
+    *reinterpret_cast<uint2*>(bufB + row * XS + 4 * lane) = o;
+  }
+  lds_barrier();
+  ln_rows<1, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 256 + 4 * lane),
+                 *reinterpret_cast<const float4*>(vec + 512 + 4 * lane), wave, lane);
+  lds_barrier();
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = 0; j < n_blk; ++j) {
+    f32x4 acc[1][4];
+    zero_acc<1>(acc);
+    mma_unit<1, 0, XM>(acc, u0, bufA, lr, lg);
+    if (j + 1 < n_blk) load_unit(u0, W, tw + 16, NKS, 0, lane);
+    mma_unit<1, 2, XM>(acc, u1, bufA, lr, lg);
+    if (j + 1 < n_blk) load_unit(u1, W, tw + 18, NKS, 0, lane);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 16 * (tw + ct) + 4 * lg + e;
+        float v = acc[0][ct][e];
+        if (c == skip_a || c == skip_b) v = -INFINITY;
+        if (v > best) { best = v; bi = c; }
+      }
+    tw += 16;
+  }
+  // the four lanes of a row (lr, lr + 16, lr + 32, lr + 48), then the four waves
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  float2* red = reinterpret_cast<float2*>(vec);                    // [4 waves][16 rows]
+  if (lane < 16) red[wave * 16 + lane] = make_float2(best, __int_as_float(bi));
+  lds_barrier();
+  if (tid < 16 && m0 + tid < M) {
+    float2 r = red[tid];
+    for (int w = 1; w < 4; ++w) {
+      const float2 o = red[w * 16 + tid];
+      if (o.x > r.x || (o.x == r.x && __float_as_int(o.y) < __float_as_int(r.y))) r = o;
+    }
+    pairs[(long)(m0 + tid) * n_cb + cb] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Self-attention INSIDE the projection chain (round 4):
 //   qkv [M][768], K / V caches [M][4][cap][64] --attention--> ctx (LDS only) --Wo, bo, + x--> x --LN--> --Wq, bq--> q (q2 / kk as above)
 // i.e. dec_attn.hip's self_attn_wave_kernel + dec_proj_chain_kernel in one launch (fairseq TransformerDecoderLayer: self-attention
@@ -950,6 +1036,7 @@ static hipError_t raise_lds_limits_mode() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, true, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, false, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_vocab_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   return e;
 }
 
@@ -1029,6 +1116,28 @@ int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float*
   return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + QKV chain)");
 }
 
+// the end of a decode step in one launch (dec_vocab_chain_kernel): bf16, D = 256, fragment-major output projection with a final
+// LayerNorm, V a multiple of 256 x the column split; the split (workgroups per row tile) is the handle's dec_vocab_chain_split, 0 = off
+int sl_dec_vocab_chain_split(const simulst_handle* h, int dtype, int B, int V, int D, bool packed, bool has_ln) {
+  int n_cb = h->dec_vocab_chain_split;
+  if (n_cb <= 0 || dtype != SIMULST_BF16 || D != CD || !packed || !has_ln || B <= 128) return 0;
+  while (n_cb > 1 && V % (256 * n_cb) != 0) n_cb >>= 1;
+  return V % (256 * n_cb) == 0 ? n_cb : 0;
+}
+int sl_dec_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
+                       const float* ln_b, const void* Wout, float2* pairs, int B, int F, int V, int n_cb, int skip_a, int skip_b) {
+  if (int rc = raise_lds_limits(h)) return rc;
+  KTimer t(h, SIMULST_K_DEC_VOCAB_CHAIN);
+  const int splits = F / 256, n_blk = V / (256 * n_cb);
+#define VC(XM)                                                                                                         \
+  hipLaunchKernelGGL((dec_vocab_chain_kernel<XM>), dim3(((B + 15) / 16) * n_cb), dim3(256), lds_request(h), h->stream, \
+                     (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wout, pairs, B, splits, n_cb, \
+                     n_blk, skip_a, skip_b)
+  SL_XMODE(h, VC);
+#undef VC
+  return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + vocabulary chain)");
+}
+
 // self-attention + projection chain in one launch (dec_attn_proj_chain_kernel): bf16, 4 heads x 64, cache capacity <= 128
 bool sl_dec_attn_chain_ok(const simulst_handle* h, int dtype, int B, int H, int d, int cap) {
   return dtype == SIMULST_BF16 && H == 4 && d == 64 && cap <= 128 && !h->force_valu_attention && B <= h->dec_attn_chain_max_rows;
@@ -1097,6 +1206,24 @@ extern "C" int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid
              "simulst_decoder_slab_sum_qkv: D == 256, F a multiple of 256 up to 8192");
   if (B == 0) return SIMULST_OK;
   return sl_dec_qkv_chain(h, x_mid, x, partial, b2, ln_g, ln_b, wqkv_fm, bqkv, qkv, B, F);
+}
+
+extern "C" int simulst_decoder_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2,
+                                           const float* ln_g, const float* ln_b, const void* wout_fm, float* pairs, int32_t B,
+                                           int32_t D, int32_t F, int32_t V, int32_t split, int32_t skip_a, int32_t skip_b,
+                                           int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, x_mid); SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, partial); SL_CHECK_NULL(h, b2); SL_CHECK_NULL(h, ln_g);
+  SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, wout_fm); SL_CHECK_NULL(h, pairs);
+  SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_decoder_vocab_chain: bf16 only");
+  SL_REQUIRE(h, D == CD && B >= 0 && F >= 256 && F % 256 == 0 && F / 256 <= 32, SIMULST_E_SHAPE,
+             "simulst_decoder_vocab_chain: D == 256, F a multiple of 256 up to 8192");
+  SL_REQUIRE(h, split >= 1 && split <= 64 && V > 0 && V % (256 * split) == 0, SIMULST_E_SHAPE,
+             "simulst_decoder_vocab_chain: V a multiple of 256 x split");
+  SL_REQUIRE(h, x_mid != x, SIMULST_E_ARG, "simulst_decoder_vocab_chain: x_mid must not alias x");
+  if (B == 0) return SIMULST_OK;
+  return sl_dec_vocab_chain(h, x_mid, x, partial, b2, ln_g, ln_b, wout_fm, reinterpret_cast<float2*>(pairs), B, F, V, split, skip_a,
+                            skip_b);
 }
 
 extern "C" int simulst_decoder_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache,

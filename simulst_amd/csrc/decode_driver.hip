@@ -871,17 +871,26 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
       if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b, pk))) return rc;
       if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
     }
-    if (chain_ffn)                               // the last layer's slabs
+    // greedy pick fused into the vocabulary projection where the shapes allow: dd->logits then holds (value, index) pairs per row
+    // and column range instead of fp32 rows.  The masks must be known when the projection is launched: streaming masks nothing,
+    // forced decoding masks pad + eos, free offline decoding masks eos only at position 0, which the host can tell only for
+    // lockstep rows (np_uniform).
+    const bool eos_first = !ctlp && !mask_eos;                                     // eos masked iff the row is at position 0
+    const bool masks_known = !eos_first || np_uniform >= 0;
+    const bool no_eos = !ctlp && (mask_eos || (np_uniform >= 0 && np_uniform + s == 0));
+    // round 4: the last layer's slab sum, the final LayerNorm, the projection and the partial pick in ONE launch (dec_vocab_chain_kernel)
+    const int vsplit = (chain_ffn && masks_known && h->fused_argmax)
+                           ? sl_dec_vocab_chain_split(h, dt, B, V, D, pk != 0, dd->ln_g != nullptr && dd->ln_b != nullptr) : 0;
+    if (chain_ffn && !vsplit)                    // the last layer's slabs
       if ((rc = sl_dec_qkv_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[dd->n_layers - 1].b2, nullptr, nullptr, nullptr,
                                  nullptr, nullptr, B, F))) return rc;
-    // greedy pick fused into the vocabulary projection where the shapes allow (the 64 x 64 tile kernel's domain): dd->logits then
-    // holds [B][V / 64] (value, index) pairs instead of fp32 rows.  The masks must be known when the projection is launched:
-    // streaming masks nothing, forced decoding masks pad + eos, free offline decoding masks eos only at position 0, which the
-    // host can tell only for lockstep rows (np_uniform).
-    const bool eos_first = !ctlp && !mask_eos;                                     // eos masked iff the row is at position 0
-    const bool amax = sl_vocab_argmax_ok(h, dt, B, V, D, pk != 0) && (!eos_first || np_uniform >= 0);
-    if (amax) {
-      const bool no_eos = !ctlp && (mask_eos || (np_uniform >= 0 && np_uniform + s == 0));
+    // ... else the per-tile maxima out of the 64 x 64 tile kernel's (or the split row panel's) epilogue: [B][V / 64] pairs
+    const bool amax = vsplit > 0 || (sl_vocab_argmax_ok(h, dt, B, V, D, pk != 0) && masks_known);
+    if (vsplit) {
+      if ((rc = sl_dec_vocab_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[dd->n_layers - 1].b2, dd->ln_g, dd->ln_b,
+                                   dd->out_proj, (float2*)dd->logits, B, F, V, vsplit, ctlp ? -1 : dd->pad_idx,
+                                   no_eos ? dd->eos_idx : -1))) return rc;
+    } else if (amax) {
       if ((rc = sl_launch_vocab_argmax(h, dd->x, dd->out_proj, dd->ln_g, dd->ln_b, (float2*)dd->logits, B, V, D,
                                        ctlp ? -1 : dd->pad_idx, no_eos ? dd->eos_idx : -1))) return rc;
     } else if ((rc = lin(h, dt, B, V, D, dd->x, dd->out_proj, nullptr, nullptr, dd->logits, SIMULST_EPI_BIAS_F32OUT, dd->ln_g,
@@ -893,12 +902,12 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         hipLaunchKernelGGL(argmax_embed_kernel<float>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
                            (long*)out_tokens + (device_indexed ? 0 : (long)s * B), dd->n_prev, (const float*)dd->E,
                            dd->pos_table, (float*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, B,
-                           np_base, ctl, part, V / 64);
+                           np_base, ctl, part, vsplit ? vsplit : V / 64);
       else
         hipLaunchKernelGGL(argmax_embed_kernel<bf16>, dim3(B), dim3(256), 0, h->stream, dd->logits, (long*)tokens_io,
                            (long*)out_tokens + (device_indexed ? 0 : (long)s * B), dd->n_prev, (const bf16*)dd->E,
                            dd->pos_table, (bf16*)dd->x, V, D, dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, B,
-                           np_base, ctl, part, V / 64);
+                           np_base, ctl, part, vsplit ? vsplit : V / 64);
       if ((rc = sl_launch_status(h, "simulst_mma_decode(argmax)")) != 0) return rc;
     }
   }

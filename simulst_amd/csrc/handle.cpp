@@ -54,6 +54,11 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->dec_attn_chain_max_rows = 0;      // OFF: measured slower than the two launches at every cache length (dec_chain.hip)
   if (const char* e = getenv("SIMULST_DEC_ATTN_CHAIN_MAX_ROWS")) h->dec_attn_chain_max_rows = atoi(e);
   h->dec_attn_chain_rows = 0;
+  // the decode step's closing launch (dec_chain.hip dec_vocab_chain_kernel), workgroups per 16-row tile.  Driver form at 448-row sequences
+  // (bench.py --steps 20, two rounds each): off 1.490 / 1.497 M tokens/s, 1: 1.474, 2: 1.500 / 1.492, 4: 1.515 / 1.514 / 1.504, 8: 1.498 / 1.504 /
+  // 1.503, 16: 1.500; one sequence alone 50.2-50.4 ms with 4 or 8 against 50.6-50.7 ms
+  h->dec_vocab_chain_split = 4;
+  if (const char* e = getenv("SIMULST_DEC_VOCAB_CHAIN_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->dec_vocab_chain_split = v; }
   h->fused_argmax = true;      // greedy pick's partial maxima in the vocabulary projection's epilogue (decode loops, bf16, co-scheduled rows)
   if (const char* e = getenv("SIMULST_FUSED_ARGMAX")) h->fused_argmax = atoi(e) != 0;
   if (const char* e = getenv("SIMULST_DEC_ATTN_CHAIN_ROWS")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->dec_attn_chain_rows = v; }
@@ -162,6 +167,10 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
       SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG, "simulst_set_option(DEC_ATTN_CHAIN_ROWS): 0, 4, 8 or 16");
       h->dec_attn_chain_rows = value; return SIMULST_OK;
     case SIMULST_OPT_FUSED_ARGMAX: h->fused_argmax = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT:
+      SL_REQUIRE(h, value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG,
+                 "simulst_set_option(DEC_VOCAB_CHAIN_SPLIT): 0 (off), 1, 2, 4, 8 or 16");
+      h->dec_vocab_chain_split = value; return SIMULST_OK;
     default: break;
   }
   h->err = "simulst_set_option: unknown option";

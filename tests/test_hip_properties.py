@@ -47,34 +47,48 @@ def test_co_scheduled_rows_consistency_and_determinism(full_model):
     """Seven stacked configs[1] batches in ONE launch sequence (448 rows: the row-local layer chains of csrc/dec_chain.hip are
     on): copies of an utterance that sit in different row tiles / workgroups get bit-identical logits and tokens, and the
     whole pass repeats bit for bit (the chains' first builds did not: DESIGN.md section 3, reproducibility note)."""
+    from simulst_amd import _lib
     cfg, w, model = full_model
     g = torch.Generator().manual_seed(15)
     base = torch.randn(24, 1000, 80, generator=g)                     # 24 distinct utterances; row i == row i + 24 k
     fb = base.repeat(19, 1, 1)[:448].to(torch.bfloat16).cuda()
     L = torch.full((448,), 1000, device="cuda")
-    runs = []
-    for _ in range(3):
-        toks, info = model.generate_offline(fb, L, n_steps=40, mask_eos=True)
-        runs.append((toks.clone(), info["state"].ws["logits"].clone(), info["encoder"]["encoder_out_btd"].clone()))
-    assert "ffn_partial" in info["state"].ws                          # the chain workspace was passed
-    for t, lg, enc in runs[1:]:
-        assert torch.equal(t, runs[0][0]) and torch.equal(lg, runs[0][1]) and torch.equal(enc, runs[0][2])
-    t, lg, enc = runs[0]
-    # round 4: with the greedy pick fused into the vocabulary projection (the default at this row count) the logits workspace holds
-    # [448][V / 64] (largest value, index) pairs of the projection's column tiles instead of fp32 rows: the same consistency
-    # statement on what is there -- a copy's 64 tile maxima and their indices are bit-identical to the original's
-    pairs = lg.flatten()[:448 * (cfg.vocab // 64) * 2].view(448, cfg.vocab // 64, 2)
-    for r in range(24, 448):
-        assert torch.equal(pairs[r], pairs[r % 24]), r
-        assert torch.equal(t[r], t[r % 24]), r
-    assert torch.isfinite(pairs[..., 0]).all()
-    idx = pairs[..., 1].contiguous().view(torch.int32)
-    tile = torch.arange(cfg.vocab // 64, device=idx.device).view(1, -1)
-    assert bool(((idx >= 64 * tile) & (idx < 64 * tile + 64)).all())    # every pair's index lies in its own tile
-    # ... and fp32 logit rows with the fused pick switched off: the same statement on whole rows, the same tokens
-    from simulst_amd import _lib
-    model.ops.h.set_option(_lib.OPT_FUSED_ARGMAX, 0)
+
+    def three_runs():
+        runs = []
+        for _ in range(3):
+            toks, info = model.generate_offline(fb, L, n_steps=40, mask_eos=True)
+            runs.append((toks.clone(), info["state"].ws["logits"].clone(), info["encoder"]["encoder_out_btd"].clone()))
+        assert "ffn_partial" in info["state"].ws                      # the chain workspace was passed
+        for t, lg, enc in runs[1:]:
+            assert torch.equal(t, runs[0][0]) and torch.equal(lg, runs[0][1]) and torch.equal(enc, runs[0][2])
+        return runs[0]
+
+    def check_pairs(t, lg, n_pairs):
+        # the logits workspace holds [448][n_pairs] (largest value, index) pairs of the projection's column ranges instead of fp32
+        # rows: the same consistency statement on what is there -- a copy's maxima and their indices are bit-identical to the original's
+        pairs = lg.flatten()[:448 * n_pairs * 2].view(448, n_pairs, 2)
+        for r in range(24, 448):
+            assert torch.equal(pairs[r], pairs[r % 24]), r
+            assert torch.equal(t[r], t[r % 24]), r
+        assert torch.isfinite(pairs[..., 0]).all()
+        idx = pairs[..., 1].contiguous().view(torch.int32)
+        width = cfg.vocab // n_pairs
+        rng = torch.arange(n_pairs, device=idx.device).view(1, -1)
+        assert bool(((idx >= width * rng) & (idx < width * rng + width)).all())    # every pair's index lies in its own range
+
+    # round 4 default: the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial pick), 8 column ranges
+    t_chain, lg, _ = three_runs()
+    check_pairs(t_chain, lg, 8)
+    model.ops.h.set_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT, 0)
     try:
+        # ... the 64 x 64 tile GEMM with the per-tile maxima in its epilogue
+        t, lg, _ = three_runs()
+        check_pairs(t, lg, cfg.vocab // 64)
+        # the closing launch normalises and accumulates in another order: rows may part where two logits are that close
+        assert (t == t_chain).all(dim=-1 if t.shape[0] == 448 else 0).float().mean().item() >= 0.9
+        # ... and fp32 logit rows with the fused pick switched off: the same statement on whole rows, the same tokens
+        model.ops.h.set_option(_lib.OPT_FUSED_ARGMAX, 0)
         t2, info2 = model.generate_offline(fb, L, n_steps=40, mask_eos=True)
         lg2 = info2["state"].ws["logits"]
         assert torch.equal(t2, t)
@@ -83,6 +97,7 @@ def test_co_scheduled_rows_consistency_and_determinism(full_model):
         assert torch.isfinite(lg2).all()
     finally:
         model.ops.h.set_option(_lib.OPT_FUSED_ARGMAX, 1)
+        model.ops.h.set_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT, 8)
 
 
 def test_multi_stream_pass_repeats_bit_for_bit(full_model):
