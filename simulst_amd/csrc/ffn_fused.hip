@@ -33,7 +33,7 @@
 #include "gemm_args.h"
 
 int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
-                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed);
+                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed, int uniform);
 
 namespace {
 
@@ -42,6 +42,7 @@ namespace {
 // of phase, so that one's GELU arithmetic runs beside the other's MFMAs; each streams the weights for half as many rows).
 constexpr int FF_D = 256;             // model width (K of fc1, N of fc2)
 constexpr bool FF_DEFAULT_FOUR_WAVES = true;
+constexpr bool FF_PIPELINED_UNIFORM = true;   // ffn_pipe.hip UNI (SIMULST_OPT_FFN_WAVES = 43): a quarter of an element pair's GELU behind each of the 32 MFMAs of an iteration: 439 / 830 / 941 / 927 TFLOP/s at 64 / 256 / 1280 / 4096 utterances against 394 / 743 / 889 / 881 for the phase form (41) on the same device
 constexpr bool FF_PIPELINED_PACKED = false;   // packed GELU inside the MFMA stream measured SLOWER (826 vs 887 TFLOP/s): an anti-lever beside MFMAs
 constexpr bool FF_DEFAULT_PIPELINED = true;   // ffn_pipe.hip, 4 waves: 804 / 887 / 875 TFLOP/s at 448 / 1280 / 4096 utterances against 758 / 863 / 851     // ffn_pipe.hip: SIMULST_OPT_FFN_WAVES = 41 selects it
 template <int WAVES> struct FFG {
@@ -261,9 +262,10 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
   KTimer t(h, SIMULST_K_LINEAR);
   // the software-pipelined form (ffn_pipe.hip: GELU inside the matrix-core stream): 128 rows per workgroup, two workgroups per CU
   // SIMULST_OPT_FFN_WAVES 41 / 81: scalar GELU, 4 / 8 waves; 42 / 82: packed GELU
-  if (((h->ffn_waves >= 41 && h->ffn_waves <= 42) || (h->ffn_waves >= 81 && h->ffn_waves <= 82) || (h->ffn_waves == 0 && FF_DEFAULT_PIPELINED)) && F <= 2048)
+  if (((h->ffn_waves >= 41 && h->ffn_waves <= 43) || (h->ffn_waves >= 81 && h->ffn_waves <= 83) || (h->ffn_waves == 0 && FF_DEFAULT_PIPELINED)) && F <= 2048)
     return sl_launch_ffn_pipe(h, x, ln_gamma, ln_beta, w1_packed, b1, w2_packed, b2, out, rows, F, h->ffn_waves >= 81 ? 8 : 4,
-                              h->ffn_waves == 0 ? FF_PIPELINED_PACKED : (h->ffn_waves & 1) == 0);
+                              h->ffn_waves == 0 ? FF_PIPELINED_PACKED : (h->ffn_waves % 10) == 2,
+                              h->ffn_waves == 0 ? FF_PIPELINED_UNIFORM : (h->ffn_waves % 10) == 3);
 #define FFN(V, W)                                                                                                  \
   hipLaunchKernelGGL((ffn_fused_kernel<V, W>), dim3((unsigned)((rows + FFG<W>::ROWS - 1) / FFG<W>::ROWS)),         \
                      dim3(FFG<W>::THREADS), FFG<W>::LDS, h->stream, (const bf16*)x, ln_gamma, ln_beta,             \

@@ -57,6 +57,42 @@ __device__ __forceinline__ float gelu_fast1(float x) {
   return __builtin_fmaf(-ha, r, h + ha);
 }
 
+// The same arithmetic for the uniform schedule.  It takes the fc1 accumulator and HALF the bias: fma(acc, 0.5, b / 2) == (acc + b) * 0.5
+// bit for bit (halving is exact and commutes with the rounding of the sum), which saves the separate bias add.
+struct GeluPair { float h[2], z[2], q[2]; };
+// the GELU of an element PAIR in four quarters (two independent dependency chains per quarter: a dependent fp32 chain issues at ~1.66 x
+// the cost of independent instructions, MI355X_MICROARCH.md constants table), gelu_fast2's operations in gelu_fast2's order per element
+__device__ __forceinline__ void gelu_q1(GeluPair& g, float acc0, float acc1, float hb0, float hb1) {
+  g.h[0] = __builtin_fmaf(acc0, 0.5f, hb0);                 g.h[1] = __builtin_fmaf(acc1, 0.5f, hb1);
+  g.z[0] = __builtin_fabsf(g.h[0]) * 1.41421356237309504880f; g.z[1] = __builtin_fabsf(g.h[1]) * 1.41421356237309504880f;
+  g.q[0] = __builtin_fmaf(g.z[0], 0.0000430638f, 0.0002765672f); g.q[1] = __builtin_fmaf(g.z[1], 0.0000430638f, 0.0002765672f);
+  g.q[0] = __builtin_fmaf(g.q[0], g.z[0], 0.0001520143f);   g.q[1] = __builtin_fmaf(g.q[1], g.z[1], 0.0001520143f);
+}
+__device__ __forceinline__ void gelu_q2(GeluPair& g) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    g.q[k] = __builtin_fmaf(g.q[k], g.z[k], 0.0092705272f);
+    g.q[k] = __builtin_fmaf(g.q[k], g.z[k], 0.0422820123f);
+    g.q[k] = __builtin_fmaf(g.q[k], g.z[k], 0.0705230784f);
+    g.q[k] = __builtin_fmaf(g.q[k], g.z[k], 1.0f);
+  }
+}
+__device__ __forceinline__ void gelu_q3(GeluPair& g) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { float q = g.q[k]; q = q * q; q = q * q; q = q * q; q = q * q; g.q[k] = q; }
+}
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi);
+__device__ __forceinline__ unsigned int gelu_q4(const GeluPair& g) {
+  float v[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float ha = __builtin_fabsf(g.h[k]);
+    const float r = __builtin_amdgcn_rcpf(g.q[k]);
+    v[k] = __builtin_fmaf(-ha, r, g.h[k] + ha);
+  }
+  return cvt_pk_bf16(v[0], v[1]);
+}
+
 // two floats -> one register of two bf16 in ONE instruction.  hipcc lowers __float2bfloat16 to v_cvt_pk_bf16_f32 as well, but with
 // the two values produced in different scheduling regions it converted each on its own and merged them (2 x v_cvt_pk + v_lshlrev +
 // v_or_sdwa per pair); the vector pipe is what paces phase A, so the three instructions matter
@@ -90,7 +126,16 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ wp, int tile
                                      (lds_void*)(dst + q * FPG<WAVES>::THREADS * 16 + wave * 1024), 16, 0, 0);
 }
 
-template <int WAVES, bool PK>
+// UNI (round 4, second form): the GELU of a tile spread over ALL 32 MFMAs of an iteration instead of the 16 of phase A -- a quarter
+// of an element pair (two independent chains) behind every MFMA.  The phase form leaves a wave's 16 fc2 MFMAs without vector work, and since that run is short the two waves
+// of a SIMD spend most of their time BOTH in phase A, where 2 x 21 vector instructions per MFMA pace them (phase probe: A 74 %, B 22 %).
+// What allows it: fc2's MFMAs 0 .. 7 read only the packed elements 0 .. 7 of the tile (k-step 0), MFMAs 8 .. 15 only elements 8 .. 15, and
+// the accumulator of tile t + 1 is complete after the 16th fc1 MFMA.  So, per iteration t:
+//   MFMAs  0 .. 15   fc1 of tile t + 1     with the GELU of elements  4 .. 11 of tile t       (a quarter of an element PAIR per MFMA)
+//   MFMAs 16 .. 23   fc2 k-step 0 of t     with elements 12 .. 15 of tile t
+//   MFMAs 24 .. 31   fc2 k-step 1 of t     with elements 0 .. 3 of tile t + 1 (its registers were freed by MFMAs 16 .. 23)
+// No extra registers: the packed elements are written into the halves of hb that the fc2 MFMAs have already read.
+template <int WAVES, bool PK, bool UNI>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kernel(
     const bf16* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const bf16* __restrict__ W1p,
     const float* __restrict__ b1, const bf16* __restrict__ W2p, const float* __restrict__ b2, bf16* __restrict__ out, long M, int F) {
@@ -119,7 +164,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
     if (a < AH && a < nt) stage_tile<WAVES>(W2p, a, w2ring + (a % NS) * FP_W, voff, wave_u);
   }
   for (int k = tid; k < FF_D; k += G::THREADS) { lng[k] = ln_g[k]; lnb[k] = ln_b[k]; b2s[k] = b2[k]; }
-  for (int k = tid; k < F; k += G::THREADS) b1s[k] = b1[k];
+  for (int k = tid; k < F; k += G::THREADS) b1s[k] = UNI ? 0.5f * b1[k] : b1[k];     // UNI: half the bias (gelu_first_half)
   uint4 xa[16];
   {
     const long r = row0 + lr;
@@ -163,6 +208,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
                                                      hcur, 0, 0, 0);
     }
   }
+  // packed GELU outputs of the current tile (fc2's A operand): [0..3] = elements 0 .. 7 (k-step 0), [4..7] = elements 8 .. 15
+  uint4 hbv[2];
+  unsigned int* hb = reinterpret_cast<unsigned int*>(hbv);
+  float4 bv_carry = float4{0.f, 0.f, 0.f, 0.f};              // UNI: half-bias of elements 4 .. 7 of the next iteration's tile
+  if constexpr (UNI) {
+    const float* bt0 = b1s + 4 * lh;
+    const float4 b0 = *reinterpret_cast<const float4*>(bt0);
+    GeluPair g0;
+    gelu_q1(g0, hcur[0], hcur[1], b0.x, b0.y); gelu_q2(g0); gelu_q3(g0); hb[0] = gelu_q4(g0);
+    gelu_q1(g0, hcur[2], hcur[3], b0.z, b0.w); gelu_q2(g0); gelu_q3(g0); hb[1] = gelu_q4(g0);
+    bv_carry = *reinterpret_cast<const float4*>(bt0 + 8);
+  }
 #ifdef SL_PROBE
   unsigned long long pr_dma = 0, pr_bar = 0, pr_a = 0, pr_b = 0;
 #endif
@@ -191,12 +248,64 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
     f32x16 hnext;
 #pragma unroll
     for (int e = 0; e < 16; ++e) hnext[e] = 0.f;
-    unsigned int hb[8];
     // ---- phase A: one fc1 MFMA of tile t + 1, then bias + GELU of element s of tile t (pairs packed as they complete)
     uint4 wfa[FF_PF];
     if constexpr (MORE) {
 #pragma unroll
       for (int i = 0; i < FF_PF; ++i) wfa[i] = w1[i * 64 + lane];
+    }
+    if constexpr (UNI) {
+      // ---- uniform schedule: 32 MFMAs, a quarter of the GELU of an element PAIR behind each (see the kernel's header).  Pair p =
+      // elements 2p, 2p + 1 (one packed register of fc2's A operand); its four quarters follow four consecutive MFMAs.
+      float4 bv = bv_carry;                                     // half-bias of elements 4 .. 7
+      GeluPair gp;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if constexpr (MORE)
+          hnext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wfa[s % FF_PF]),
+                                                          *reinterpret_cast<const bf16x8_t*>(&xa[s]), hnext, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE) { if (s + FF_PF < 16) wfa[s % FF_PF] = w1[(s + FF_PF) * 64 + lane]; }
+        const int pr = 2 + (s >> 2);                            // pairs 2 .. 5 = elements 4 .. 11 of tile t
+        if ((s & 3) == 0) gelu_q1(gp, hcur[2 * pr], hcur[2 * pr + 1], (pr & 1) ? bv.z : bv.x, (pr & 1) ? bv.w : bv.y);
+        else if ((s & 3) == 1) { gelu_q2(gp); if (pr & 1) bv = *reinterpret_cast<const float4*>(bt + 8 * ((pr + 1) >> 1)); }
+        else if ((s & 3) == 2) gelu_q3(gp);
+        else hb[pr] = gelu_q4(gp);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      FP_STAMP(p3);
+      uint4 wf[FF_PF];
+#pragma unroll
+      for (int i = 0; i < FF_PF; ++i) wf[i] = w2[i * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        y[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&hbv[i >> 3]),
+                                                           *reinterpret_cast<const bf16x8_t*>(&wf[i % FF_PF]), y[i & 7], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + FF_PF < 16) wf[i % FF_PF] = w2[(i + FF_PF) * 64 + lane];
+        if (i < 8) {
+          const int pr = 6 + (i >> 2);                          // pairs 6, 7 = elements 12 .. 15 of tile t
+          if ((i & 3) == 0) gelu_q1(gp, hcur[2 * pr], hcur[2 * pr + 1], (pr & 1) ? bv.z : bv.x, (pr & 1) ? bv.w : bv.y);
+          else if ((i & 3) == 1) { gelu_q2(gp); if (pr == 7) { if constexpr (MORE) bv = *reinterpret_cast<const float4*>(bt + 32); } }
+          else if ((i & 3) == 2) gelu_q3(gp);
+          else hb[pr] = gelu_q4(gp);
+        } else if constexpr (MORE) {
+          const int pr = (i - 8) >> 2;                          // pairs 0, 1 = elements 0 .. 3 of tile t + 1: hb[0], hb[1] were read by MFMAs 16 .. 23
+          if ((i & 3) == 0) gelu_q1(gp, hnext[2 * pr], hnext[2 * pr + 1], (pr & 1) ? bv.z : bv.x, (pr & 1) ? bv.w : bv.y);
+          else if ((i & 3) == 1) { gelu_q2(gp); if (pr == 1) bv_carry = *reinterpret_cast<const float4*>(bt + 32 + 8); }
+          else if ((i & 3) == 2) gelu_q3(gp);
+          else hb[pr] = gelu_q4(gp);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#ifdef SL_PROBE
+      FP_STAMP(p4);
+      pr_dma += p1 - p0; pr_bar += p2 - p1; pr_a += p3 - p2; pr_b += p4 - p3;
+#endif
+      if constexpr (MORE) hcur = hnext;
+      return;
     }
     float4 bv = *reinterpret_cast<const float4*>(bt);
     float gprev = 0.f;
@@ -321,28 +430,31 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
 }  // namespace
 
 int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
-                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed) {
+                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed, int uniform) {
   // the packed-GELU instantiations (measured slower: 826 vs 887 TFLOP/s at 1280 utterances) exist in DEBUG_HOOKS builds only
 #ifndef SL_DEBUG_HOOKS
   packed = 0;
 #endif
   if (!h->ffn_pipe_lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
 #ifdef SL_DEBUG_HOOKS
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
 #endif
     if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit (pipelined form)"; return (int)e; }
     h->ffn_pipe_lds_attr_set = true;
   }
-#define FPL(W, P)                                                                                                                   \
-  hipLaunchKernelGGL((ffn_pipe_kernel<W, P>), dim3((unsigned)((rows + 32 * W - 1) / (32 * W))), dim3(64 * W), FPG<W>::LDS, h->stream, \
+#define FPL(W, P, U)                                                                                                                \
+  hipLaunchKernelGGL((ffn_pipe_kernel<W, P, U>), dim3((unsigned)((rows + 32 * W - 1) / (32 * W))), dim3(64 * W), FPG<W>::LDS, h->stream, \
                      (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F)
 #ifdef SL_DEBUG_HOOKS
-  if (packed) { if (waves == 8) FPL(8, true); else FPL(4, true); } else
+  if (packed) { if (waves == 8) FPL(8, true, false); else FPL(4, true, false); } else
 #endif
-  { if (waves == 8) FPL(8, false); else FPL(4, false); }
+  if (uniform) { if (waves == 8) FPL(8, false, true); else FPL(4, false, true); }
+  else { if (waves == 8) FPL(8, false, false); else FPL(4, false, false); }
 #undef FPL
 #ifdef SL_PROBE
   {
