@@ -54,7 +54,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # HBM traffic of the dominant kernels from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest round first
 ENCODER_TRAFFIC_FILES = ["r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
-CROSS_ATTN_TRAFFIC_FILES = ["r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
+CROSS_ATTN_TRAFFIC_FILES = ["r04_pmc_cross_attention_traffic.json", "r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
 PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # all classes of one launch sequence (round 1), tools/pmc_summary.py
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
 

@@ -90,9 +90,10 @@ int simulst_graph_enable(simulst_handle* h, int on);
  *   VALU_ATTENTION          1: bf16 Emformer attention through the fp32-VALU kernel instead of the MFMA one, bf16 decoder
  *                              self-attention through its workgroup kernel instead of the wave-per-head one
  *   UNFUSED_DECODE          1: simulst_mma_decode / simulst_mma_stream_steps with one launch per GEMM (no head-split block, no chains)
- *   FFN_WAVES               simulst_emformer_ffn: 0 the library's choice (the pipelined 4-wave form while F <= 2048); 4 / 8 the block form
+ *   FFN_WAVES               simulst_emformer_ffn: 0 the library's choice (the pipelined 4-wave form 43 while F <= 2048); 4 / 8 the block form
  *                           (GELU between the two products) with that many waves per workgroup; 41 / 81 the software-pipelined form
- *                           (GELU inside the matrix-core stream, csrc/ffn_pipe.hip) -- all bit-identical
+ *                           with the GELU behind the 16 fc1 MFMAs of a tile iteration, 43 / 83 behind all 32 MFMAs (csrc/ffn_pipe.hip)
+ *                           -- all bit-identical
  *   DEC_CHAIN               0: no row-local layer chains (csrc/dec_chain.hip) in the decode loops
  *   DEC_ATTN_CHAIN_MAX_ROWS rows up to which self-attention rides inside the projection chain (simulst_decoder_attn_proj_chain)
  *   DEC_ATTN_CHAIN_ROWS     rows per workgroup of that launch: 0 chosen from the row count, 4, 8, 16

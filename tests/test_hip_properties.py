@@ -77,9 +77,10 @@ def test_co_scheduled_rows_consistency_and_determinism(full_model):
         rng = torch.arange(n_pairs, device=idx.device).view(1, -1)
         assert bool(((idx >= width * rng) & (idx < width * rng + width)).all())    # every pair's index lies in its own range
 
-    # round 4 default: the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial pick), 8 column ranges
+    # round 4 default: the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial pick), 4 column ranges
+    # (csrc/handle.cpp dec_vocab_chain_split)
     t_chain, lg, _ = three_runs()
-    check_pairs(t_chain, lg, 8)
+    check_pairs(t_chain, lg, 4)
     model.ops.h.set_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT, 0)
     try:
         # ... the 64 x 64 tile GEMM with the per-tile maxima in its epilogue
@@ -97,7 +98,7 @@ def test_co_scheduled_rows_consistency_and_determinism(full_model):
         assert torch.isfinite(lg2).all()
     finally:
         model.ops.h.set_option(_lib.OPT_FUSED_ARGMAX, 1)
-        model.ops.h.set_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT, 8)
+        model.ops.h.set_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT, 4)
 
 
 def test_multi_stream_pass_repeats_bit_for_bit(full_model):
