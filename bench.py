@@ -219,8 +219,8 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="wait
         tile64 = Bs >= 256
         chains = Bs > 128 and dtype_name == "bf16"                # the chains' domain (csrc/handle.cpp dec_chain_min_rows)
         # the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial pick): feed-forward chain domain,
-        # split 8 by default (csrc/handle.cpp dec_vocab_chain_split, dec_chain.hip sl_dec_vocab_chain_split)
-        vsplit = 8 if (chains and Bs <= 1024 and V % 2048 == 0 and kind != "cif") else 0
+        # split 4 by default (csrc/handle.cpp dec_vocab_chain_split, dec_chain.hip sl_dec_vocab_chain_split); MMA and CIF decode loops
+        vsplit = 4 if (chains and Bs <= 1024 and V % 1024 == 0) else 0
 
         def alg(n, k):
             return (n * k + Bs * k + Bs * n) * esz

@@ -689,10 +689,12 @@ int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid, void* x, 
  * int32 bits in the second float) over columns [s V / split, (s + 1) V / split) of Wout LN(x), columns skip_a / skip_b (pad, a
  * masked eos; -1: none) excluded.  The fold over the `split` pairs of a row uses the same (value, lowest column) rule
  * (simulst_mma_decode's commit kernel).  wout_fm: [V][256] in fragment-major order; pairs [B][split][2] floats.
- * bf16, D == 256, V a multiple of 256 x split. */
+ * row_bias != NULL: row_bias[row] is added to the logit of column row_bias_col before the exclusions (simulst_cif_decode's per-row
+ * eos bias, simulst_cif_decoder_desc.eos_bias).  bf16, D == 256, V a multiple of 256 x split. */
 int simulst_decoder_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2,
                                 const float* ln_g, const float* ln_b, const void* wout_fm, float* pairs, int32_t B, int32_t D,
-                                int32_t F, int32_t V, int32_t split, int32_t skip_a, int32_t skip_b, int32_t dtype);
+                                int32_t F, int32_t V, int32_t split, int32_t skip_a, int32_t skip_b, const float* row_bias,
+                                int32_t row_bias_col, int32_t dtype);
 
 /* Self-attention INSIDE the projection chain (round 4): simulst_decoder_self_attention + simulst_decoder_proj_chain in ONE launch,
  * same results bit for bit.  qkv [B][3*256] = this step's q | k | v rows (fairseq MultiheadAttention in_proj of the decoder layer's

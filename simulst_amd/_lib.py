@@ -149,7 +149,7 @@ SIGNATURES = {
     "simulst_decoder_proj_chain": [_vp] * 13 + [_i32, _i32, _i32],
     "simulst_decoder_ffn_chain": [_vp] * 14 + [_i32, _i32, _i32, _i32],
     "simulst_decoder_slab_sum_qkv": [_vp] * 10 + [_i32, _i32, _i32, _i32],
-    "simulst_decoder_vocab_chain": [_vp] * 9 + [_i32] * 8,
+    "simulst_decoder_vocab_chain": [_vp] * 9 + [_i32] * 7 + [_vp, _i32, _i32],
     "simulst_decoder_attn_proj_chain": [_vp] * 17 + [_i32] * 7,
 }
 

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void cif_commit_kernel(const float* __restrict
                                                          const int* __restrict__ cif_len, KcPtrs Kc, T* __restrict__ kk,
                                                          const T* __restrict__ cif, T* __restrict__ cif_t, int L, int n_cap,
                                                          int V, int D, int B_, int pad_idx, int eos_idx, int mask_eos,
-                                                         float scale, float overshoot_w, CifCtl ctl) {
+                                                         float scale, float overshoot_w, CifCtl ctl,
+                                                         const float2* __restrict__ partial, int n_tiles) {
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int s_tok, s_np, s_clen;
@@ -77,6 +78,15 @@ __global__ __launch_bounds__(256) void cif_commit_kernel(const float* __restrict
     const float bias = eos_bias[b];
     float best = -INFINITY;
     int bi = 0x7fffffff;
+    if (partial) {
+      // the step's closing launch (dec_chain.hip dec_vocab_chain_kernel) left n_tiles (largest value, lowest column) pairs per row, the
+      // eos bias added and pad / masked eos excluded there: fold them with the same rule
+      for (int t = tid; t < n_tiles; t += 256) {
+        const float2 pr = partial[(long)b * n_tiles + t];
+        const int c = __float_as_int(pr.y);
+        if (pr.x > best || (pr.x == best && c < bi)) { best = pr.x; bi = c; }
+      }
+    } else
     if ((V & 3) == 0) {                                  // 16-byte loads: a thread's candidates still arrive in index order
       for (int c4 = tid; c4 < (V >> 2); c4 += 256) {
         const float4 q = *reinterpret_cast<const float4*>(row + 4 * c4);
@@ -201,12 +211,13 @@ int lin(simulst_handle* h, int dtype, int B, int N, int K, const void* A, const 
 
 template <typename T>
 int launch_commit(simulst_handle* h, const simulst_cif_decoder_desc* dd, const KcPtrs& kc, const float* logits, int64_t* tokens,
-                  int64_t* out_row, int mask_eos, const CifCtl& ctl) {
+                  int64_t* out_row, int mask_eos, const CifCtl& ctl, int n_pairs = 0) {
   KTimer t(h, logits ? SIMULST_K_ARGMAX : SIMULST_K_MISC);
   hipLaunchKernelGGL(cif_commit_kernel<T>, dim3(dd->B), dim3(256), 0, h->stream, logits, dd->eos_bias, (long*)tokens,
                      (long*)out_row, dd->n_prev, (const T*)dd->E, dd->pos_table, (T*)dd->x, dd->cif_len, kc, (T*)dd->kk,
                      (const T*)dd->cif, (T*)(dd->highway ? dd->cif_t : nullptr), dd->n_layers, dd->n_cap, dd->V, dd->D, dd->B,
-                     dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, dd->overshoot_weight, ctl);
+                     dd->pad_idx, dd->eos_idx, mask_eos, dd->embed_scale, dd->overshoot_weight, ctl,
+                     n_pairs ? reinterpret_cast<const float2*>(logits) : nullptr, n_pairs);
   return sl_launch_status(h, "simulst_cif_decode(commit)");
 }
 
@@ -273,6 +284,22 @@ int run_cif(simulst_handle* h, const simulst_cif_decoder_desc* dd, const simulst
       if ((rc = lin(h, dt, B, D, D, dd->q, L.c_wo, L.c_bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
       if ((rc = lin(h, dt, B, F, D, dd->x, L.fc1, L.b1, nullptr, dd->hidden, SIMULST_EPI_BIAS_GELU, L.ln3_g, L.ln3_b, pk))) return rc;
       if ((rc = lin(h, dt, B, D, F, dd->hidden, L.fc2, L.b2, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
+    }
+    // the step's closing launch (dec_chain.hip dec_vocab_chain_kernel: last layer's slab sum + final LayerNorm + output projection +
+    // eos bias + partial greedy pick) where the masks are known at launch time, as in simulst_mma_decode; not with the highway (the
+    // projection's input there is LN(x) + c)
+    const bool streaming = ctl.done != nullptr;
+    const bool masks_known = streaming || mask_eos || np_uniform >= 0;
+    const bool no_eos = !streaming && (mask_eos || (np_uniform >= 0 && np_uniform + s == 0));
+    const int vsplit = (chain_ffn && masks_known && h->fused_argmax && !dd->highway)
+                           ? sl_dec_vocab_chain_split(h, dt, B, V, D, pk != 0, true) : 0;
+    if (vsplit) {
+      if ((rc = sl_dec_vocab_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[dd->n_layers - 1].b2, dd->ln_g, dd->ln_b, dd->out_proj,
+                                   (float2*)dd->logits, B, F, V, vsplit, streaming ? -1 : dd->pad_idx, no_eos ? dd->eos_idx : -1,
+                                   dd->eos_bias, dd->eos_idx))) return rc;
+      int64_t* out_row_v = out_tokens ? out_tokens + (long)s * B : nullptr;
+      if ((rc = launch_commit<bf16>(h, dd, kc, dd->logits, tokens_io, out_row_v, mask_eos, ctl, vsplit))) return rc;
+      continue;
     }
     if (chain_ffn)                                  // the last layer's slabs
       if ((rc = sl_dec_qkv_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[dd->n_layers - 1].b2, nullptr, nullptr, nullptr,

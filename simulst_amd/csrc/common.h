@@ -290,7 +290,8 @@ bool sl_dec_attn_chain_ok(const simulst_handle* h, int dtype, int B, int H, int 
 // to use for this shape, 0 = not taken
 int sl_dec_vocab_chain_split(const simulst_handle* h, int dtype, int B, int V, int D, bool packed, bool has_ln);
 int sl_dec_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
-                       const float* ln_b, const void* Wout, float2* pairs, int B, int F, int V, int n_cb, int skip_a, int skip_b);
+                       const float* ln_b, const void* Wout, float2* pairs, int B, int F, int V, int n_cb, int skip_a, int skip_b,
+                       const float* row_bias = nullptr, int row_bias_col = -1);
 int sl_dec_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev, int np_uniform,
                            int cap, void* x, const void* Wo, const float* bo, const float* ln_g, const float* ln_b, const void* Wq,
                            const float* bq, void* q, const void* Wq2, const float* bq2, void* q2, int B, const void* kk_gelu = nullptr);

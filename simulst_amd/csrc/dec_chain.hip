@@ -535,12 +535,13 @@ __global__ __launch_bounds__(256, 2) void dec_qkv_chain_kernel(
 // normalises the tile once and walks VC / 256 weight blocks, wave w taking 64 columns of each block; a lane keeps the running
 // (value, column) of ITS row (strictly-greater keeps the lowest column: a lane meets its columns in ascending order), lanes of
 // a row and then the four waves are folded with the (value, column) rule of argmax_embed_kernel, which folds the n_cb pairs of a row.
-// Columns skip_a / skip_b (pad, masked eos; -1: none) never win.  No bias (the output projection has none).
+// Columns skip_a / skip_b (pad, masked eos; -1: none) never win.  No bias (the output projection has none); row_bias != nullptr adds
+// row_bias[row] to column row_bias_col before the masks (the CIF decoder's per-row eos bias).
 template <int XM>
 __global__ __launch_bounds__(256, 2) void dec_vocab_chain_kernel(
     const bf16* __restrict__ x_mid, bf16* __restrict__ x, const float* __restrict__ partial, const float* __restrict__ b2,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W, float2* __restrict__ pairs,
-    int M, int splits, int n_cb, int n_blk, int skip_a, int skip_b) {
+    int M, int splits, int n_cb, int n_blk, int skip_a, int skip_b, const float* __restrict__ row_bias, int row_bias_col) {
   constexpr int RT = 16;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // lds_bytes(1)
   unsigned short* bufA = lds;
@@ -572,6 +573,8 @@ __global__ __launch_bounds__(256, 2) void dec_vocab_chain_kernel(
   lds_barrier();
   float best = -INFINITY;
   int bi = 0x7fffffff;
+  // a per-row addend of ONE column (the CIF decoder's eos bias, agents/cif_agent.py tail handling): applied before the masks
+  const float rb = (row_bias && m0 + lr < M) ? row_bias[m0 + lr] : 0.f;
   for (int j = 0; j < n_blk; ++j) {
     f32x4 acc[1][4];
     zero_acc<1>(acc);
@@ -585,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void dec_vocab_chain_kernel(
       for (int e = 0; e < 4; ++e) {
         const int c = 16 * (tw + ct) + 4 * lg + e;
         float v = acc[0][ct][e];
+        if (row_bias && c == row_bias_col) v += rb;
         if (c == skip_a || c == skip_b) v = -INFINITY;
         if (v > best) { best = v; bi = c; }
       }
@@ -1125,14 +1129,15 @@ int sl_dec_vocab_chain_split(const simulst_handle* h, int dtype, int B, int V, i
   return V % (256 * n_cb) == 0 ? n_cb : 0;
 }
 int sl_dec_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
-                       const float* ln_b, const void* Wout, float2* pairs, int B, int F, int V, int n_cb, int skip_a, int skip_b) {
+                       const float* ln_b, const void* Wout, float2* pairs, int B, int F, int V, int n_cb, int skip_a, int skip_b,
+                       const float* row_bias, int row_bias_col) {
   if (int rc = raise_lds_limits(h)) return rc;
   KTimer t(h, SIMULST_K_DEC_VOCAB_CHAIN);
   const int splits = F / 256, n_blk = V / (256 * n_cb);
 #define VC(XM)                                                                                                         \
   hipLaunchKernelGGL((dec_vocab_chain_kernel<XM>), dim3(((B + 15) / 16) * n_cb), dim3(256), lds_request(h), h->stream, \
                      (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wout, pairs, B, splits, n_cb, \
-                     n_blk, skip_a, skip_b)
+                     n_blk, skip_a, skip_b, row_bias, row_bias_col)
   SL_XMODE(h, VC);
 #undef VC
   return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + vocabulary chain)");
@@ -1211,7 +1216,7 @@ extern "C" int simulst_decoder_slab_sum_qkv(simulst_handle* h, const void* x_mid
 extern "C" int simulst_decoder_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2,
                                            const float* ln_g, const float* ln_b, const void* wout_fm, float* pairs, int32_t B,
                                            int32_t D, int32_t F, int32_t V, int32_t split, int32_t skip_a, int32_t skip_b,
-                                           int32_t dtype) {
+                                           const float* row_bias, int32_t row_bias_col, int32_t dtype) {
   if (!h) return SIMULST_E_NULL;
   SL_CHECK_NULL(h, x_mid); SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, partial); SL_CHECK_NULL(h, b2); SL_CHECK_NULL(h, ln_g);
   SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, wout_fm); SL_CHECK_NULL(h, pairs);
@@ -1223,7 +1228,7 @@ extern "C" int simulst_decoder_vocab_chain(simulst_handle* h, const void* x_mid,
   SL_REQUIRE(h, x_mid != x, SIMULST_E_ARG, "simulst_decoder_vocab_chain: x_mid must not alias x");
   if (B == 0) return SIMULST_OK;
   return sl_dec_vocab_chain(h, x_mid, x, partial, b2, ln_g, ln_b, wout_fm, reinterpret_cast<float2*>(pairs), B, F, V, split, skip_a,
-                            skip_b);
+                            skip_b, row_bias, row_bias_col);
 }
 
 extern "C" int simulst_decoder_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache,

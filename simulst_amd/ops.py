@@ -372,14 +372,15 @@ class Ops:
                      "simulst_decoder_slab_sum_qkv")
         return qkv
 
-    def decoder_vocab_chain(self, x_mid, x, partial, b2, ln, wout_fm, V, split, skip_a=-1, skip_b=-1):
+    def decoder_vocab_chain(self, x_mid, x, partial, b2, ln, wout_fm, V, split, skip_a=-1, skip_b=-1, row_bias=None, row_bias_col=-1):
         """x <- x_mid + b2 + sum of the slabs; pairs[row][s] = (largest logit, its lowest column) of Wout LN(x) over the s-th of
         `split` column ranges (simulst_decoder_vocab_chain).  Returns (values [B, split] fp32, columns [B, split] int32)."""
         B, D = x.shape
         F = partial.shape[0] * 256
         pairs = torch.empty(B, split, 2, device=x.device, dtype=torch.float32)
         self.h.check(self.lib.simulst_decoder_vocab_chain(self.h.ptr, _p(x_mid), _p(x), _p(partial), _p(b2), _p(ln[0]), _p(ln[1]),
-                                                          _p(wout_fm), _p(pairs), B, D, F, V, split, skip_a, skip_b, dt(x)),
+                                                          _p(wout_fm), _p(pairs), B, D, F, V, split, skip_a, skip_b, _p(row_bias),
+                                                          row_bias_col, dt(x)),
                      "simulst_decoder_vocab_chain")
         return pairs[..., 0].contiguous(), pairs[..., 1].contiguous().view(torch.int32)
 

@@ -280,11 +280,18 @@ def test_vocab_chain_vs_slab_sum_and_torch(ops, B, V, split):
     x_ref = torch.full_like(xm, 7.0)
     ops.decoder_slab_sum_qkv(xm, x_ref, partial, b2.cuda())
     skip_a, skip_b = 1, int(torch.randint(0, V, (1,), generator=g))
+    # a per-row addend on one column (the CIF decoder's eos bias): large on every third row, so that the column wins there
+    bias_col = 7
+    row_bias = torch.where(torch.arange(B) % 3 == 0, torch.full((B,), 50.0), _rand((B,), g, 0.1))
     x = torch.full_like(xm, 3.0)
-    val, col = ops.decoder_vocab_chain(xm, x, partial, b2.cuda(), (lg.cuda(), lb.cuda()), Wfm, V, split, skip_a, skip_b)
+    val, col = ops.decoder_vocab_chain(xm, x, partial, b2.cuda(), (lg.cuda(), lb.cuda()), Wfm, V, split, skip_a, skip_b,
+                                       row_bias=row_bias.cuda(), row_bias_col=bias_col)
     torch.cuda.synchronize()
     assert torch.equal(x, x_ref)
     logits = _bf(_ln(x_ref.float().cpu(), lg, lb)) @ W.T
+    logits[:, bias_col] += row_bias
+    if skip_b != bias_col:
+        assert (col[::3, 0].cpu() == bias_col).all()
     logits[:, skip_a] = -float("inf"); logits[:, skip_b] = -float("inf")
     val, col = val.cpu(), col.cpu().long()
     VC = V // split
@@ -306,11 +313,12 @@ def test_vocab_chain_vs_slab_sum_and_torch(ops, B, V, split):
     assert (logits.max(dim=1).values - logits.gather(1, pick[:, None])[:, 0]).max() <= tol
     # deterministic
     for _ in range(3):
-        v2, c2 = ops.decoder_vocab_chain(xm, x, partial, b2.cuda(), (lg.cuda(), lb.cuda()), Wfm, V, split, skip_a, skip_b)
+        v2, c2 = ops.decoder_vocab_chain(xm, x, partial, b2.cuda(), (lg.cuda(), lb.cuda()), Wfm, V, split, skip_a, skip_b,
+                                         row_bias=row_bias.cuda(), row_bias_col=bias_col)
         assert torch.equal(v2.cpu(), val) and torch.equal(c2.cpu().long(), col)
 
 
-@pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback"])
+@pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback", "cif"])
 @pytest.mark.parametrize("mask_eos", [True, False])
 def test_decode_loop_with_the_vocabulary_chain(model_kind, mask_eos):
     """simulst_mma_decode with the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial pick, split 8
@@ -328,9 +336,19 @@ def test_decode_loop_with_the_vocabulary_chain(model_kind, mask_eos):
     for b in range(B):
         fb[b, L[b]:] = 0
     fb = fb.cuda().to(torch.bfloat16)
-    attn = "waitk_fixed_pre_decision" if model_kind == "waitk" else "infinite_lookback"
-    cfg = mma_model_s(encoder_layers=1, decoder_layers=3, simul_attn_type=attn, waitk_lagging=3)
-    w = init_model(cfg, seed=21)
+    if model_kind == "cif":
+        from simulst_amd.cif import CIFTransformerModel
+        from simulst_amd.config import cif_transformer_s
+        cfg = cif_transformer_s(encoder_layers=1, decoder_layers=3, cif_beta=1.0)
+        w = init_model(cfg, seed=21)
+        w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
+        w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.0
+        make = lambda o: CIFTransformerModel(cfg, w, dtype=torch.bfloat16, ops=o)
+    else:
+        attn = "waitk_fixed_pre_decision" if model_kind == "waitk" else "infinite_lookback"
+        cfg = mma_model_s(encoder_layers=1, decoder_layers=3, simul_attn_type=attn, waitk_lagging=3)
+        w = init_model(cfg, seed=21)
+        make = lambda o: SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=o)
     w["decoder.embed_tokens.weight"][cfg.eos] = 0
     w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(5)) \
         * cfg.embed_dim ** -0.5
@@ -338,7 +356,7 @@ def test_decode_loop_with_the_vocabulary_chain(model_kind, mask_eos):
     for split in (0, 8, 16):
         o = Ops()
         o.h.set_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT, split)
-        m = SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=o)
+        m = make(o)
         toks[split] = m.generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)[0].clone()
         o.h.timer_reset(); o.h.timer_enable(-1, True)
         m.generate_offline(fb, L, n_steps=2, mask_eos=mask_eos)
