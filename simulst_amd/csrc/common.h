@@ -58,6 +58,7 @@ struct simulst_handle {
   int dec_chain_xmode;         // how the chains' MFMAs get their activation fragments (dec_chain.hip mma_unit)
   int dec_attn_chain_max_rows; // rows up to which self-attention rides inside the projection chain (dec_attn_proj_chain_kernel)
   int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
+  int policy_lds_bytes;        // policy / cross-attention launch of co-scheduled batches: minimum dynamic LDS request (occupancy cap), 0: none
   int dec_vocab_chain_split;   // workgroups per row tile of the step's closing launch (dec_vocab_chain_kernel); 0: off
   bool fused_argmax;           // decode loops: per-tile (max, index) partials out of the vocabulary projection instead of fp32 logits
 };

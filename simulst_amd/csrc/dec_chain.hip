@@ -31,6 +31,13 @@
 
 namespace {
 
+// experiment hook (make EXTRA=-DSL_CHAIN_PRIO=n): wave priority of the chain kernels' waves against co-resident waves of other streams
+#ifdef SL_CHAIN_PRIO
+#define SL_CHAIN_SETPRIO() __builtin_amdgcn_s_setprio(SL_CHAIN_PRIO)
+#else
+#define SL_CHAIN_SETPRIO()
+#endif
+
 constexpr int CD = 256;            // model width
 constexpr int XS = CD + 16;        // LDS row stride in elements (544 B: rows shift by 8 banks)
 constexpr int NKS = CD / 32;       // k-steps of a 256-deep contraction
@@ -228,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // 2 * RT * XS elements
   unsigned short* bufA = lds;
   unsigned short* bufB = lds + RT * XS;
+  SL_CHAIN_SETPRIO();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * RT;
   const int tw = 4 * wave;                               // this wave's first column tile of every 256-column block
@@ -343,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void dec_ffn_chain_kernel(
   unsigned short* bufA = lds;
   unsigned short* bufB = lds + RT * XS;
   int* flag = reinterpret_cast<int*>(lds + 2 * RT * XS);
+  SL_CHAIN_SETPRIO();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
   // split index fastest: the 8 XCDs each see ONE split's slice of W1 / W2 (workgroup ids are dealt round-robin), so a
   // layer's 2 MB of feed-forward weights are 256 KB per XCD L2
@@ -481,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void dec_qkv_chain_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // lds_bytes(RTL)
   unsigned short* bufA = lds;
   unsigned short* bufB = lds + RT * XS;
+  SL_CHAIN_SETPRIO();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const int cb = blockIdx.x % n_cb, m0 = (blockIdx.x / n_cb) * RT;
   const int tw = 16 * cb + 4 * wave;
@@ -546,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void dec_vocab_chain_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // lds_bytes(1)
   unsigned short* bufA = lds;
   unsigned short* bufB = lds + RT * XS;
+  SL_CHAIN_SETPRIO();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const int cb = blockIdx.x % n_cb, m0 = (blockIdx.x / n_cb) * RT;
   int tw = 16 * (cb * n_blk) + 4 * wave;                          // this wave's four column tiles of the current block
@@ -736,6 +747,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_proj_chain_kernel(
   __shared__ __attribute__((aligned(16))) float vec[5 * 256];  // [bo | bq | bq2 | gamma | beta]
   unsigned short* bufA = lds;
   unsigned short* bufB = lds + 16 * XS;
+  SL_CHAIN_SETPRIO();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * VR;
   const int tw = 4 * wave;
@@ -903,6 +915,7 @@ __global__ __launch_bounds__(256, 1) void dec_proj_chain_probe_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* bufA = lds;
   unsigned short* bufB = lds + RT * XS;
+  SL_CHAIN_SETPRIO();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * RT;
   const int tw = 4 * wave;

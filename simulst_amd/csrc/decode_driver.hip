@@ -570,7 +570,10 @@ int launch_policy_cross(simulst_handle* h, const void* qm, const void* qs, const
                         int attn_type, int waitk_k, int online, int mass_pres, int n_hint, const void* xres,
                         const float* ln_g, const float* ln_b, const void* Wqm, const float* bqm, const void* Wqs,
                         const float* bqs, const StreamCtl& ctl, const HeadSplit& hs, const float* kpool, int P_cap) {
-  const size_t lds = (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
+  size_t lds = (size_t)(64 + attn::RED_FLOATS + (S_cap > 256 ? S_cap : 256) + 2 * S_cap + 1 + H * d + 64) * sizeof(float);
+  // occupancy cap of this launch (SIMULST_POLICY_LDS_BYTES: request at least that much dynamic LDS -- 42 KB = 3, 56 KB = 2 workgroups per
+  // compute unit instead of the 4 its registers allow): leaves register space for the 200-register chain workgroups of other streams
+  if ((size_t)h->policy_lds_bytes > lds && B >= h->dec_chain_min_rows) lds = (size_t)h->policy_lds_bytes;
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
   const int np = attn::lanes_per_row<T>(d);
   if (attn_type == SIMULST_ATTN_WAITK && S_cap > KB_KEYS && !xres && qs && Ks && np > 0 && !h->force_unfused_decode) {

@@ -59,6 +59,8 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   // 1.503, 16: 1.500; one sequence alone 50.2-50.4 ms with 4 or 8 against 50.6-50.7 ms
   h->dec_vocab_chain_split = 4;
   if (const char* e = getenv("SIMULST_DEC_VOCAB_CHAIN_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->dec_vocab_chain_split = v; }
+  h->policy_lds_bytes = 0;
+  if (const char* e = getenv("SIMULST_POLICY_LDS_BYTES")) { const int v = atoi(e); if (v >= 0 && v <= 64 * 1024) h->policy_lds_bytes = v; }
   h->fused_argmax = true;      // greedy pick's partial maxima in the vocabulary projection's epilogue (decode loops, bf16, co-scheduled rows)
   if (const char* e = getenv("SIMULST_FUSED_ARGMAX")) h->fused_argmax = atoi(e) != 0;
   if (const char* e = getenv("SIMULST_DEC_ATTN_CHAIN_ROWS")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->dec_attn_chain_rows = v; }
