@@ -275,6 +275,23 @@ def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev
         assert n_rec == want, (n_rec, want)
         from simulst_amd.offline_eval import max_steps
         caps_ok = all(n <= max_steps(lengths[i]) + 1 for i, n in zip(ids, ntok))
+        # untimed: what the offline encoder states change.  The chunked streaming encoder advances its rows in lockstep, so the sample is
+        # the first rows of the first launch sequence CUT to their shortest length; both forms decode it
+        sample = None
+        if batches and len(batches[0][0]) >= 2:
+            ns = min(8, len(batches[0][0]))
+            Lmin = min(int(x) for x in batches[0][3].tolist()[:ns])
+            fb_s = batches[0][1][:ns, :Lmin].contiguous()
+            with torch.no_grad(), torch.cuda.stream(pipe.streams[0]):
+                r_off = pipe.agents[0].run_batch(fb_s, self_paced=True, encoder="offline")
+                r_chk = pipe.agents[0].run_batch(fb_s, self_paced=True, encoder="chunked")
+            pipe.streams[0].synchronize()
+            same = [a["tokens"] == b["tokens"] and a["actions"] == b["actions"] and a["delays_ms"] == b["delays_ms"] for a, b in zip(r_off, r_chk)]
+            sample = {"utterances": ns, "frames": Lmin, "records_identical": int(sum(same)),
+                      "tokens_identical": int(sum(a["tokens"] == b["tokens"] for a, b in zip(r_off, r_chk))),
+                      "average_lagging_ms_mean": [round(sum(r["AL"] for r in rr) / ns, 2) for rr in (r_off, r_chk)],
+                      "note": "decoder over one offline forward's states vs over encoder.infer's chunked states, the same rows (the "
+                              "first of the shard, cut to their shortest length); %s rows can part at near ties" % args.dtype}
         emit({"workload": f"configs[4]: batched STREAMING eval, utterance-sharded ({args.policy}; decoder over the encoder states of ONE "
                           "OFFLINE forward per launch sequence, not the chunked streaming encoder)" +
                           (f" (rank {args.shard_rank} of {args.shard_of}: one rank's shard on one GPU)" if args.shard_of > 0 else ""),
@@ -284,6 +301,7 @@ def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev
               "average_lagging_ms_mean": round(al_sum / n_utt, 2), "reads_per_utterance": round(reads / n_utt, 2),
               "dtype": args.dtype, "utterances_per_sequence": args.batch, "streams": S,
               "encoder": "offline states (one padded forward per launch sequence)",
+              "chunked_vs_offline_states_on_a_sample": sample,
               "properties": {"one_record_per_utterance": len(set(ids)) == len(ids), "every_length_within_its_cap": bool(caps_ok)},
               "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk,
                                            "hard" if args.policy == "hard" else "waitk", True, n_tokens / total_s, world),
