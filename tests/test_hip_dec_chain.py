@@ -457,6 +457,7 @@ def test_chains_repeat_beside_other_streams(ops):
     qkv_in = bf(_rand((B, 3 * D), g))
     kc0, vc0 = bf(_rand((B, 4, 128, 64), g)), bf(_rand((B, 4, 128, 64), g))
     n_prev = torch.randint(0, 110, (B,), generator=g).to(torch.int32).cuda()
+    Wout = pk(_rand((4096, D), g, D ** -0.5))
 
     def chains():
         x = x0.clone()
@@ -466,8 +467,11 @@ def test_chains_repeat_beside_other_streams(ops):
         qkv = ops.decoder_slab_sum_qkv(x_mid, x2, partial, bD, ln, Wqkv, b3)
         x3, kc, vc = x0.clone(), kc0.clone(), vc0.clone()
         q3, _ = ops.decoder_attn_proj_chain(qkv_in, kc, vc, n_prev, x3, Wo, bD, ln, Wq, bD)
+        # ... and the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial greedy pick)
+        x4 = torch.empty_like(x)
+        pv, pc = ops.decoder_vocab_chain(x_mid, x4, partial, bD, ln, Wout, 4096, 4, 1, 2)
         torch.cuda.synchronize()
-        return x, q, x2, qkv, x3, q3
+        return x, q, x2, qkv, x3, q3, x4, pv, pc
 
     quiet = chains()
     for _ in range(20):
