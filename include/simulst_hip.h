@@ -102,10 +102,13 @@ int simulst_graph_enable(simulst_handle* h, int on);
  *   DEC_VOCAB_CHAIN_SPLIT   workgroups per 16-row tile of the decode step's closing launch (last layer's slab sum + final LayerNorm +
  *                              vocabulary projection + partial greedy pick, simulst_decoder_vocab_chain): 0 off (reduction launch +
  *                              64 x 64 tile GEMM), 1, 2, 4, 8, 16 (halved until V is a multiple of 256 x the split)
+ *   DEC_EMBED_QKV_CHAIN     0: every decode step ends with its own commit launch (default 1: in simulst_mma_decode over lockstep rows
+ *                              -- n_prev_uniform >= 0, more than 128 bf16 rows -- a step's commit and the new token's embedding are the
+ *                              prologue of the next step's first launch, layer 0's LayerNorm + QKV; the call's last step commits as before)
  * Returns SIMULST_E_ARG for an unknown option or a value outside its range. */
 enum { SIMULST_OPT_VALU_ATTENTION = 0, SIMULST_OPT_UNFUSED_DECODE = 1, SIMULST_OPT_FFN_WAVES = 2, SIMULST_OPT_DEC_CHAIN = 3,
        SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 4, SIMULST_OPT_DEC_ATTN_CHAIN_ROWS = 5, SIMULST_OPT_FUSED_ARGMAX = 6,
-       SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT = 7 };
+       SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT = 7, SIMULST_OPT_DEC_EMBED_QKV_CHAIN = 8 };
 int simulst_set_option(simulst_handle* h, int32_t option, int32_t value);
 
 #ifdef SIMULST_DEBUG_HOOKS

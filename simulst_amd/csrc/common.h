@@ -58,6 +58,7 @@ struct simulst_handle {
   int dec_chain_xmode;         // how the chains' MFMAs get their activation fragments (dec_chain.hip mma_unit)
   int dec_attn_chain_max_rows; // rows up to which self-attention rides inside the projection chain (dec_attn_proj_chain_kernel)
   int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
+  bool dec_embed_qkv_chain;    // offline lockstep decode: commit + embedding inside the next step's first launch (dec_embed_qkv_chain_kernel)
   int policy_lds_bytes;        // policy / cross-attention launch of co-scheduled batches: minimum dynamic LDS request (occupancy cap), 0: none
   int dec_vocab_chain_split;   // workgroups per row tile of the step's closing launch (dec_vocab_chain_kernel); 0: off
   bool fused_argmax;           // decode loops: per-tile (max, index) partials out of the vocabulary projection instead of fp32 logits
@@ -290,6 +291,9 @@ bool sl_dec_attn_chain_ok(const simulst_handle* h, int dtype, int B, int H, int 
 // the closing launch of a decode step (slab sum + final LayerNorm + vocabulary projection + partial greedy pick): the column split
 // to use for this shape, 0 = not taken
 int sl_dec_vocab_chain_split(const simulst_handle* h, int dtype, int B, int V, int D, bool packed, bool has_ln);
+int sl_dec_embed_qkv_chain(simulst_handle* h, const float2* pairs, int n_pairs, int64_t* tokens, int64_t* out_row, int32_t* n_prev,
+                           int np, const void* E, const float* pos, float scale, int pad_idx, void* x, const float* ln_g,
+                           const float* ln_b, const void* Wqkv, const float* bqkv, void* qkv, int B);
 int sl_dec_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
                        const float* ln_b, const void* Wout, float2* pairs, int B, int F, int V, int n_cb, int skip_a, int skip_b,
                        const float* row_bias = nullptr, int row_bias_col = -1);

@@ -535,6 +535,86 @@ __global__ __launch_bounds__(256, 2) void dec_qkv_chain_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The BEGINNING of a decode step as one launch (round 4): the second half of the previous step's greedy choice, its commit, the new
+// token's input embedding and layer 0's LayerNorm + q / k / v projections:
+//   tok[row] = fold of the row's n_pairs (value, column) pairs (dec_vocab_chain_kernel's output; (value, lowest column) rule)
+//   tokens[row] = out_row[row] = tok;  n_prev[row] = np + 1;  x[row] = bf16(scale E[tok] + pos[pad + 1 + np + 1])     (column block 0 writes)
+//   qkv[row, 256 cb ..] = W LN(x[row]) + b
+// i.e. argmax_embed_kernel (decode_driver.hip) + the LayerNorm-prologue GEMM of layer 0 for LOCKSTEP rows of an offline decode
+// (every row at the same position np, known on the host, no streaming control block): nothing a workgroup reads is written by
+// another workgroup of the launch (the three column blocks of a row tile fold the same pairs and build the same x; block 0 alone
+// writes tokens, n_prev and x).  Same expressions as the two launches replaced, LayerNorm through ln_rows like layers 1 ..
+template <int XM>
+__global__ __launch_bounds__(256, 2) void dec_embed_qkv_chain_kernel(
+    const float2* __restrict__ pairs, int n_pairs, long* __restrict__ tokens, long* __restrict__ out_row, int* __restrict__ n_prev,
+    int np, const bf16* __restrict__ E, const float* __restrict__ pos, float scale, int pad_idx, bf16* __restrict__ x,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W, const float* __restrict__ bias,
+    bf16* __restrict__ out, int M, int n_cb) {
+  SL_CHAIN_SETPRIO();
+  constexpr int RT = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];     // lds_bytes(1)
+  unsigned short* bufA = lds;
+  unsigned short* bufB = lds + RT * XS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int cb = blockIdx.x % n_cb, m0 = (blockIdx.x / n_cb) * RT;
+  const int tw = 16 * cb + 4 * wave;
+  WUnit u0, u1;
+  load_unit(u0, W, tw, NKS, 0, lane);
+  load_unit(u1, W, tw + 2, NKS, 0, lane);
+  float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS);     // [bias of this column block | gamma | beta] x 256
+  vec[tid] = bias[256 * cb + tid]; vec[256 + tid] = ln_g[tid]; vec[512 + tid] = ln_b[tid];
+  const long prow = (long)(pad_idx + 1 + np + 1) * CD;         // position row of the NEXT input token
+  const float4 pv = *reinterpret_cast<const float4*>(pos + prow + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave + 4 * i, g = m0 + row;
+    uint2 o = make_uint2(0, 0);
+    if (g < M) {
+      // fold: lanes 0 .. n_pairs - 1 hold one pair each (n_pairs <= 64), butterfly with the (value, lowest column) rule
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      if (lane < n_pairs) {
+        const float2 pr = pairs[(long)g * n_pairs + lane];
+        best = pr.x; bi = __float_as_int(pr.y);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      if (bi == 0x7fffffff) bi = 0;
+      const long tok = bi;
+      float e[4];
+      unpack4(*reinterpret_cast<const uint2*>(E + tok * CD + 4 * lane), e);
+      o = pack4(scale * e[0] + pv.x, scale * e[1] + pv.y, scale * e[2] + pv.z, scale * e[3] + pv.w);
+      if (cb == 0) {
+        *reinterpret_cast<uint2*>(x + (long)g * CD + 4 * lane) = o;
+        if (lane == 0) { tokens[g] = tok; out_row[g] = tok; n_prev[g] = np + 1; }
+      }
+    }
+    *reinterpret_cast<uint2*>(bufB + row * XS + 4 * lane) = o;
+  }
+  lds_barrier();
+  ln_rows<1, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 256 + 4 * lane),
+                 *reinterpret_cast<const float4*>(vec + 512 + 4 * lane), wave, lane);
+  lds_barrier();
+  f32x4 acc[1][4];
+  zero_acc<1>(acc);
+  mma_unit<1, 0, XM>(acc, u0, bufA, lr, lg);
+  mma_unit<1, 2, XM>(acc, u1, bufA, lr, lg);
+  const int nb = 64 * wave + 4 * lg;
+  const int g = m0 + lr;
+  if (g >= M) return;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
+    *reinterpret_cast<uint2*>(out + (long)g * (256 * n_cb) + 256 * cb + nb + 16 * ct) =
+        pack4(acc[0][ct][0] + bv.x, acc[0][ct][1] + bv.y, acc[0][ct][2] + bv.z, acc[0][ct][3] + bv.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The end of a decode step as ONE launch (round 4): the last layer's slab sum, the decoder's final LayerNorm and the vocabulary
 // projection with the greedy pick's partial maxima as its only output:
 //   x <- bf16(x' + b2 + slabs);  pairs[row][cb] = (largest logit, its lowest column) over columns [cb VC, (cb + 1) VC) of W_out LN(x)
@@ -1054,6 +1134,7 @@ static hipError_t raise_lds_limits_mode() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, false, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_vocab_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_embed_qkv_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   return e;
 }
 
@@ -1154,6 +1235,21 @@ int sl_dec_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const floa
   SL_XMODE(h, VC);
 #undef VC
   return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + vocabulary chain)");
+}
+
+// the beginning of a decode step in one launch (dec_embed_qkv_chain_kernel): lockstep offline rows, bf16, D = 256
+int sl_dec_embed_qkv_chain(simulst_handle* h, const float2* pairs, int n_pairs, int64_t* tokens, int64_t* out_row, int32_t* n_prev,
+                           int np, const void* E, const float* pos, float scale, int pad_idx, void* x, const float* ln_g,
+                           const float* ln_b, const void* Wqkv, const float* bqkv, void* qkv, int B) {
+  if (int rc = raise_lds_limits(h)) return rc;
+  KTimer t(h, SIMULST_K_DEC_QKV_CHAIN);
+#define EC(XM)                                                                                                         \
+  hipLaunchKernelGGL((dec_embed_qkv_chain_kernel<XM>), dim3(((B + 15) / 16) * 3), dim3(256), lds_request(h), h->stream, \
+                     pairs, n_pairs, (long*)tokens, (long*)out_row, n_prev, np, (const bf16*)E, pos, scale, pad_idx,    \
+                     (bf16*)x, ln_g, ln_b, (const uint4*)Wqkv, bqkv, (bf16*)qkv, B, 3)
+  SL_XMODE(h, EC);
+#undef EC
+  return sl_launch_status(h, "simulst_mma_decode(commit + embedding + LN + QKV chain)");
 }
 
 // self-attention + projection chain in one launch (dec_attn_proj_chain_kernel): bf16, 4 heads x 64, cache capacity <= 128

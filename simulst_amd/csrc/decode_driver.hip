@@ -808,11 +808,23 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   const bool chain_ffn = chain && B <= h->dec_chain_ffn_max_rows && dd->x_mid;
   // round 4: the self-attention of a layer inside its projection chain (4 launches per layer)
   const bool attn_chain = chain && sl_dec_attn_chain_ok(h, dt, B, H, d, dd->cap);
+  // round 4: a step's commit (fold of the greedy pick's pairs, token, position) + the new embedding ride in the NEXT step's first launch
+  // with layer 0's LayerNorm + QKV (dec_embed_qkv_chain_kernel) -- lockstep offline rows only; the last step of the call commits as before
+  const bool fuse_commit = chain_ffn && !ctlp && !device_indexed && np_uniform >= 0 && h->dec_embed_qkv_chain;
+  int pending_pairs = 0;                         // pairs of the previous step's projection that no launch has committed yet
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_dec_layer& L = layers[l];
       const void* xin = dd->x;                   // residual row entering the cross-attention block
       HeadSplit hs = {nullptr, nullptr, nullptr, pk};
+      if (l == 0 && pending_pairs > 0) {
+        if ((rc = sl_dec_embed_qkv_chain(h, (const float2*)dd->logits, pending_pairs, tokens_io, out_tokens + (long)(s - 1) * B,
+                                         dd->n_prev, np_uniform + s - 1, dd->E, dd->pos_table, dd->embed_scale, dd->pad_idx, dd->x,
+                                         L.ln1_g, L.ln1_b, L.wqkv, L.bqkv, dd->qkv, B))) return rc;
+        pending_pairs = 0;
+        if (!attn_chain)
+          if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform + s, dd->ctx, B, H, d, dd->cap, dt))) return rc;
+      } else
       if (split) {
         if ((rc = sl_self_attention_fused(h, dd->x, L.ln1_g, L.ln1_b, L.wqkv, L.bqkv, L.wo, L.k_cache, L.v_cache,
                                           dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s, dd->partial_self, B, H, d,
@@ -898,6 +910,11 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
                                        ctlp ? -1 : dd->pad_idx, no_eos ? dd->eos_idx : -1))) return rc;
     } else if ((rc = lin(h, dt, B, V, D, dd->x, dd->out_proj, nullptr, nullptr, dd->logits, SIMULST_EPI_BIAS_F32OUT, dd->ln_g,
                          dd->ln_b, pk))) return rc;
+    const int n_pairs_now = amax ? (vsplit ? vsplit : V / 64) : 0;
+    if (fuse_commit && n_pairs_now > 0 && n_pairs_now <= 64 && s + 1 < n_steps) {
+      pending_pairs = n_pairs_now;               // committed by the next step's first launch
+      continue;
+    }
     {
       const float2* part = amax ? (const float2*)dd->logits : nullptr;
       KTimer t(h, SIMULST_K_ARGMAX);

@@ -59,6 +59,8 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   // 1.503, 16: 1.500; one sequence alone 50.2-50.4 ms with 4 or 8 against 50.6-50.7 ms
   h->dec_vocab_chain_split = 4;
   if (const char* e = getenv("SIMULST_DEC_VOCAB_CHAIN_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->dec_vocab_chain_split = v; }
+  h->dec_embed_qkv_chain = true;
+  if (const char* e = getenv("SIMULST_DEC_EMBED_QKV_CHAIN")) h->dec_embed_qkv_chain = atoi(e) != 0;
   h->policy_lds_bytes = 0;
   if (const char* e = getenv("SIMULST_POLICY_LDS_BYTES")) { const int v = atoi(e); if (v >= 0 && v <= 64 * 1024) h->policy_lds_bytes = v; }
   h->fused_argmax = true;      // greedy pick's partial maxima in the vocabulary projection's epilogue (decode loops, bf16, co-scheduled rows)
@@ -169,6 +171,7 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
       SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG, "simulst_set_option(DEC_ATTN_CHAIN_ROWS): 0, 4, 8 or 16");
       h->dec_attn_chain_rows = value; return SIMULST_OK;
     case SIMULST_OPT_FUSED_ARGMAX: h->fused_argmax = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_DEC_EMBED_QKV_CHAIN: h->dec_embed_qkv_chain = value != 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT:
       SL_REQUIRE(h, value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG,
                  "simulst_set_option(DEC_VOCAB_CHAIN_SPLIT): 0 (off), 1, 2, 4, 8 or 16");

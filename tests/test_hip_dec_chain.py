@@ -373,6 +373,56 @@ def test_decode_loop_with_the_vocabulary_chain(model_kind, mask_eos):
     assert len(set(t8.flatten().tolist())) > 50
 
 
+@pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback"])
+@pytest.mark.parametrize("mask_eos", [True, False])
+def test_decode_loop_with_the_commit_in_the_next_steps_first_launch(model_kind, mask_eos):
+    """simulst_mma_decode over lockstep rows: a step's commit (fold of the pick's pairs, token, position) and the new embedding as the
+    prologue of the next step's first launch (dec_embed_qkv_chain_kernel) against the same loop with a commit launch per step.  The
+    first token of every row is computed before the first fused launch: identical.  From the second step on layer 0's LayerNorm
+    runs through the chains' ln_rows instead of the tile GEMM's prologue (another summation order): rows agree except at near ties.
+    The state the call leaves (n_prev, last token) is the same, one commit launch per call instead of one per step."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.ops import Ops
+    from simulst_amd.weights import init_model
+    B, T, U = 320, 240, 12
+    fb = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(8))
+    L = torch.randint(100, T + 1, (B,), generator=torch.Generator().manual_seed(9))
+    L[0] = T
+    for b in range(B):
+        fb[b, L[b]:] = 0
+    fb = fb.cuda().to(torch.bfloat16)
+    attn = "waitk_fixed_pre_decision" if model_kind == "waitk" else "infinite_lookback"
+    cfg = mma_model_s(encoder_layers=1, decoder_layers=3, simul_attn_type=attn, waitk_lagging=3)
+    w = init_model(cfg, seed=21)
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0
+    w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(5)) \
+        * cfg.embed_dim ** -0.5
+    res = {}
+    for on in (0, 1):
+        o = Ops()
+        o.h.set_option(_lib.OPT_DEC_EMBED_QKV_CHAIN, on)
+        m = SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=o)
+        t, info = m.generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)
+        st = info["state"]
+        res[on] = (t.clone(), st.n_prev.clone())
+        t_again = m.generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)[0]
+        assert torch.equal(t_again, res[on][0])                 # repeats bit for bit
+        o.h.timer_reset(); o.h.timer_enable(-1, True)
+        m.generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)
+        torch.cuda.synchronize()
+        o.h.timer_enable(-1, False)
+        assert o.h.timer_read(_lib.K_ARGMAX)[1] == (1 if on else U)  # commit launches of the call
+    (t0, n0), (t1, n1) = res[0], res[1]
+    t0 = t0 if t0.shape[0] == B else t0.t()
+    t1 = t1 if t1.shape[0] == B else t1.t()
+    assert torch.equal(n0, n1)
+    assert torch.equal(t0[:, 0], t1[:, 0])
+    same_rows = (t0 == t1).all(dim=1).float().mean().item()
+    assert same_rows >= 0.9, same_rows
+    assert len(set(t1.flatten().tolist())) > 50
+
+
 @pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback", "cif"])
 @pytest.mark.parametrize("mask_eos", [True, False])
 def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):
@@ -410,8 +460,9 @@ def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):
         * cfg.embed_dim ** -0.5
     o_new, o_old = Ops(), Ops()
     o_new.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 1024)      # off by default: measured slower (csrc/dec_chain.hip)
-    for o in (o_new, o_old):                               # the step's closing launch normalises in another order: own test above
+    for o in (o_new, o_old):                               # the step's closing / opening launches normalise in another order: own tests above
         o.h.set_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT, 0)
+        o.h.set_option(_lib.OPT_DEC_EMBED_QKV_CHAIN, 0)
     o_old.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 0)
     o_old.h.set_option(_lib.OPT_FUSED_ARGMAX, 0)
     t_new = make(o_new).generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)[0].clone()
