@@ -55,6 +55,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # HBM traffic of the dominant kernels from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest round first
 ENCODER_TRAFFIC_FILES = ["r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
 CROSS_ATTN_TRAFFIC_FILES = ["r04_pmc_cross_attention_traffic.json", "r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
+IN_SITU_STATS_FILE = "r04_c_k20_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of the driver-shaped command (tools/profile_r04.sh)
 PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # all classes of one launch sequence (round 1), tools/pmc_summary.py
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
 
@@ -939,6 +940,21 @@ def main(argv=None):
                                       "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / bpt),
                                       "frac": round(value / world / (HBM_PEAK_GBS * 1e9 / bpt), 5)}
         roofline["rows_per_sequence"] = Bs
+        # what the dominant kernel runs at INSIDE the timed region (several sequences sharing the chip), from the committed rocprofv3
+        # run of the driver-shaped command: `achieved` above comes from the serial instrumented replay of ONE sequence
+        try:
+            if roofline["kernel"] == "decoder_cross_attention" and args.dtype == "bf16" and Bs == 448 and streams_used == 3:
+                import csv
+                with open(os.path.join(ROOT, "profiles", IN_SITU_STATS_FILE)) as fcsv:
+                    row = next(r for r in csv.DictReader(fcsv) if "policy_cross_attn_kernel<__hip_bfloat16, 8, false>" in r["Name"])
+                us = float(row["AverageNs"]) / 1e3
+                ach = roofline["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9
+                roofline["in_the_timed_region"] = {
+                    "avg_launch_us": round(us, 2), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "source": f"profiles/{IN_SITU_STATS_FILE}: rocprofv3 --kernel-trace --stats of this command with three sequences on three "
+                              "streams (committed, not measured in this run)"}
+        except (OSError, StopIteration, KeyError, ValueError):
+            pass
         roofline["class_ms_per_sequence"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
         roofline["launches_per_sequence_all_classes"] = n_launch
         extra = {}

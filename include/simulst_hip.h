@@ -92,7 +92,8 @@ int simulst_graph_enable(simulst_handle* h, int on);
  *   UNFUSED_DECODE          1: simulst_mma_decode / simulst_mma_stream_steps with one launch per GEMM (no head-split block, no chains)
  *   FFN_WAVES               simulst_emformer_ffn: 0 the library's choice (the pipelined 4-wave form 43 while F <= 2048); 4 / 8 the block form
  *                           (GELU between the two products) with that many waves per workgroup; 41 / 81 the software-pipelined form
- *                           with the GELU behind the 16 fc1 MFMAs of a tile iteration, 43 / 83 behind all 32 MFMAs (csrc/ffn_pipe.hip)
+ *                           with the GELU behind the 16 fc1 MFMAs of a tile iteration, 43 / 83 behind all 32 MFMAs, 45 the same with
+ *                           64 rows per wave in one 4-wave workgroup per compute unit (measured slower; csrc/ffn_pipe.hip)
  *                           -- all bit-identical
  *   DEC_CHAIN               0: no row-local layer chains (csrc/dec_chain.hip) in the decode loops
  *   DEC_ATTN_CHAIN_MAX_ROWS rows up to which self-attention rides inside the projection chain (simulst_decoder_attn_proj_chain)

@@ -427,6 +427,217 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// WIDE form (round 4, third form): 64 rows per wave -- RT = 2 row tiles of 32 -- in ONE 4-wave workgroup per compute unit (one wave per
+// SIMD, 512 registers).  Every weight fragment a wave reads from LDS then feeds TWO MFMAs (one per row tile): the uniform form's third
+// budget, the LDS reads of the fragments (8 waves x 32 KB per compute unit and iteration), is halved, and so is the number of waves
+// sharing the SIMD's vector issue.  The schedule is the uniform one scaled by RT: per iteration 32 RT MFMAs
+//   fc1 of tile t + 1 (16 k-steps x RT)  |  fc2 k-step 0 of tile t (8 column tiles x RT)  |  fc2 k-step 1 of tile t (8 x RT)
+// each followed by a quarter of the GELU of one element pair of one row tile: pairs 2 .. 5 of tile t behind the fc1 MFMAs, pairs 6, 7
+// behind fc2's k-step 0, pairs 0, 1 of tile t + 1 behind k-step 1 (row tiles alternate inside a pair index).  With one wave per SIMD
+// nothing else hides a stall, so the weight rings are four slots deep and tiles are requested two iterations ahead (counted vmcnt).
+// fc2's accumulators (RT x 8 x 16 = 256 registers) live in the AGPR half of the file.  Arithmetic and rounding points unchanged.
+struct FWG {
+  static constexpr int THREADS = 256, NS = 4, AHEAD = 2, PIECES = FP_W / (THREADS * 16);
+  static constexpr int LDS = 2 * NS * FP_W + 3072 + 2048 * 4;
+};
+
+template <int RT>
+__global__ __launch_bounds__(256, 1) void ffn_wide_kernel(
+    const bf16* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const bf16* __restrict__ W1p,
+    const float* __restrict__ b1, const bf16* __restrict__ W2p, const float* __restrict__ b2, bf16* __restrict__ out, long M, int F) {
+  constexpr int NS = FWG::NS, AH = FWG::AHEAD;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* w1ring = lds;
+  char* w2ring = lds + NS * FP_W;
+  float* lng = reinterpret_cast<float*>(lds + 2 * NS * FP_W);
+  float* lnb = lng + FF_D;
+  float* b2s = lnb + FF_D;
+  float* b1s = b2s + FF_D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const long row0 = (long)blockIdx.x * (32 * RT * 4) + wave * (32 * RT);
+  const int nt = F / 32;
+  const unsigned voff = (unsigned)tid * 16u;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  stage_tile<4>(W1p, 0, w1ring, voff, wave_u);
+  stage_tile<4>(W2p, 0, w2ring, voff, wave_u);
+#pragma unroll
+  for (int a = 1; a <= AH; ++a) {
+    if (a < nt) stage_tile<4>(W1p, a, w1ring + (a % NS) * FP_W, voff, wave_u);
+    if (a < AH && a < nt) stage_tile<4>(W2p, a, w2ring + (a % NS) * FP_W, voff, wave_u);
+  }
+  for (int k = tid; k < FF_D; k += 256) { lng[k] = ln_g[k]; lnb[k] = ln_b[k]; b2s[k] = b2[k]; }
+  for (int k = tid; k < F; k += 256) b1s[k] = 0.5f * b1[k];                  // half the bias (gelu_q1)
+  uint4 xa[RT][16];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const long rr = row0 + r * 32 + lr;
+    const bool ok = rr < M;
+    const bf16* xr = X + (ok ? rr : 0) * FF_D + lh * 8;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const uint4 v = ld16(xr + s * 16);
+      xa[r][s] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) moments_mid(xa[r][s], s1, s2, bf16());
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float mean = s1 * (1.0f / FF_D);
+    const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / FF_D) - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xa[r][s] = ln_frag_mid(xa[r][s], mean, rstd, lng, lnb, s * 16 + lh * 8, bf16());
+  }
+  f32x16 y[RT][8];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) y[r][n][e] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 hcur[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) hcur[r][e] = 0.f;
+  {
+    const uint4* w1 = reinterpret_cast<const uint4*>(w1ring);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const uint4 wf = w1[s * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+        hcur[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wf),
+                                                          *reinterpret_cast<const bf16x8_t*>(&xa[r][s]), hcur[r], 0, 0, 0);
+    }
+  }
+  // packed GELU outputs (fc2's A operand) per row tile: [r][0] = elements 0 .. 7 (k-step 0), [r][1] = elements 8 .. 15
+  uint4 hbv[RT][2];
+  float4 bv_carry;
+  {
+    const float* bt0 = b1s + 4 * lh;
+    const float4 b0 = *reinterpret_cast<const float4*>(bt0);
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      unsigned int* hb = reinterpret_cast<unsigned int*>(hbv[r]);
+      GeluPair g0;
+      gelu_q1(g0, hcur[r][0], hcur[r][1], b0.x, b0.y); gelu_q2(g0); gelu_q3(g0); hb[0] = gelu_q4(g0);
+      gelu_q1(g0, hcur[r][2], hcur[r][3], b0.z, b0.w); gelu_q2(g0); gelu_q3(g0); hb[1] = gelu_q4(g0);
+    }
+    bv_carry = *reinterpret_cast<const float4*>(bt0 + 8);
+  }
+  auto iteration = [&](int t, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    if (t == 0 || t + AH + 1 > nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * FWG::PIECES) : "memory");
+    __syncthreads();
+    if (t + 1 + AH < nt) stage_tile<4>(W1p, t + 1 + AH, w1ring + ((t + 1 + AH) % NS) * FP_W, voff, wave_u);
+    if (t + AH < nt) stage_tile<4>(W2p, t + AH, w2ring + ((t + AH) % NS) * FP_W, voff, wave_u);
+    const uint4* w1 = reinterpret_cast<const uint4*>(w1ring + ((t + 1) % NS) * FP_W);    // fc1 weights of tile t + 1
+    const uint4* w2 = reinterpret_cast<const uint4*>(w2ring + (t % NS) * FP_W);          // fc2 weights of tile t
+    const float* bt = b1s + t * 32 + 4 * lh;
+    f32x16 hnext[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) hnext[r][e] = 0.f;
+    uint4 wfa[FF_PF];
+    if constexpr (MORE) {
+#pragma unroll
+      for (int i = 0; i < FF_PF; ++i) wfa[i] = w1[i * 64 + lane];
+    }
+    float4 bv = bv_carry;                                       // half-bias of elements 4 .. 7 (pairs 2, 3)
+    GeluPair gp;
+    // one quarter of job (pair, row tile) -- q 0 .. 3; src = the fc1 accumulator holding the pair; nxt = bias group to fetch afterwards
+    auto quarter = [&](int q, int pair, int r, const f32x16& src, const float* nxt_bias, float4& dst_bias, bool fetch) {
+      if (q == 0) gelu_q1(gp, src[2 * pair], src[2 * pair + 1], (pair & 1) ? bv.z : bv.x, (pair & 1) ? bv.w : bv.y);
+      else if (q == 1) { gelu_q2(gp); if (fetch) dst_bias = *reinterpret_cast<const float4*>(nxt_bias); }
+      else if (q == 2) gelu_q3(gp);
+      else reinterpret_cast<unsigned int*>(hbv[r])[pair] = gelu_q4(gp);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16 * RT; ++k) {                         // fc1 of tile t + 1
+      const int s = k / RT, r = k % RT;
+      if constexpr (MORE)
+        hnext[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wfa[s % FF_PF]),
+                                                           *reinterpret_cast<const bf16x8_t*>(&xa[r][s]), hnext[r], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) { if (r == RT - 1 && s + FF_PF < 16) wfa[s % FF_PF] = w1[(s + FF_PF) * 64 + lane]; }
+      const int j = k / 4, pair = 2 + j / RT, jr = j % RT;      // pairs 2 .. 5 of tile t
+      quarter(k % 4, pair, jr, hcur[jr], bt + 8 * ((pair + 1) >> 1), bv, (pair & 1) && jr == RT - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    uint4 wf[FF_PF];
+#pragma unroll
+    for (int i = 0; i < FF_PF; ++i) wf[i] = w2[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16 * RT; ++k) {                         // fc2 of tile t: k-step 0 (i < 8), then k-step 1
+      const int i = k / RT, r = k % RT;
+      y[r][i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&hbv[r][i >> 3]),
+                                                            *reinterpret_cast<const bf16x8_t*>(&wf[i % FF_PF]), y[r][i & 7], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r == RT - 1 && i + FF_PF < 16) wf[i % FF_PF] = w2[(i + FF_PF) * 64 + lane];
+      if (k < 8 * RT) {
+        const int j = k / 4, pair = 6 + j / RT, jr = j % RT;    // pairs 6, 7 of tile t; then the half-bias of tile t + 1, elements 0 .. 3
+        quarter(k % 4, pair, jr, hcur[jr], bt + 32, bv, MORE && pair == 7 && jr == RT - 1);
+      } else if constexpr (MORE) {
+        const int j = (k - 8 * RT) / 4, pair = j / RT, jr = j % RT;   // pairs 0, 1 of tile t + 1: their registers were read by k-step 0
+        quarter(k % 4, pair, jr, hnext[jr], bt + 32 + 8, bv_carry, pair == 1 && jr == RT - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (MORE) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) hcur[r] = hnext[r];
+    }
+  };
+  for (int t = 0; t + 1 < nt; ++t) iteration(t, std::true_type());
+  iteration(nt - 1, std::false_type());
+  // ---- epilogue: as ffn_pipe_kernel, 64 rows per wave (4 x 32 KB staging = the 2 * NS weight slots)
+  __syncthreads();
+  constexpr int RS = FF_D * 2;
+  char* st = lds + wave * (32 * RT * RS);
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const float bvv = b2s[n * 32 + lr];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rw = r * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        *reinterpret_cast<bf16*>(st + rw * RS + (n * 32 + lr) * 2) = __float2bfloat16(y[r][n][e] + bvv);
+      }
+    }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 16 * RT; ++it) {
+    const int rl = it * 2 + lh;
+    const long r = row0 + rl;
+    if (r >= M) continue;
+    const uint4 yv = *reinterpret_cast<const uint4*>(st + rl * RS + lr * 16);
+    const uint4 xv = ld16(X + r * FF_D + lr * 8);
+    const unsigned int yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
+    unsigned int ou[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      ou[q] = pack_bf16x2(__uint_as_float(yu[q] << 16) + __uint_as_float(xu[q] << 16),
+                          __uint_as_float(yu[q] & 0xffff0000u) + __uint_as_float(xu[q] & 0xffff0000u));
+    st_stream16(out + r * FF_D + lr * 8, make_uint4(ou[0], ou[1], ou[2], ou[3]));
+  }
+}
+
 }  // namespace
 
 int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
@@ -440,6 +651,7 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FWG::LDS);
 #ifdef SL_DEBUG_HOOKS
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
@@ -453,6 +665,10 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
 #ifdef SL_DEBUG_HOOKS
   if (packed) { if (waves == 8) FPL(8, true, false); else FPL(4, true, false); } else
 #endif
+  if (uniform == 2) {
+    hipLaunchKernelGGL((ffn_wide_kernel<2>), dim3((unsigned)((rows + 255) / 256)), dim3(256), FWG::LDS, h->stream, (const bf16*)x, ln_g, ln_b,
+                       (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F);
+  } else
   if (uniform) { if (waves == 8) FPL(8, false, true); else FPL(4, false, true); }
   else { if (waves == 8) FPL(8, false, false); else FPL(4, false, false); }
 #undef FPL

@@ -159,9 +159,9 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
     case SIMULST_OPT_VALU_ATTENTION: h->force_valu_attention = value != 0; return SIMULST_OK;
     case SIMULST_OPT_UNFUSED_DECODE: h->force_unfused_decode = value != 0; return SIMULST_OK;
     case SIMULST_OPT_FFN_WAVES:
-      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 41 || value == 42 || value == 43 || value == 81 || value == 82 || value == 83, SIMULST_E_ARG,
+      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 41 || value == 42 || value == 43 || value == 45 || value == 81 || value == 82 || value == 83, SIMULST_E_ARG,
                  "simulst_set_option(FFN_WAVES): 0 (the library's choice), 4 / 8 (GELU as a block between the products), 41 / 81 (GELU inside the "
-                 "MFMA stream, 4 / 8 waves; 42 / 82: packed GELU, DEBUG_HOOKS builds, else the scalar form; 43 / 83: GELU spread over all 32 MFMAs)");
+                 "MFMA stream, 4 / 8 waves; 42 / 82: packed GELU, DEBUG_HOOKS builds, else the scalar form; 43 / 83: GELU spread over all 32 MFMAs; 45: 64 rows per wave)");
       h->ffn_waves = value; return SIMULST_OK;
     case SIMULST_OPT_DEC_CHAIN: h->dec_chain_on = value != 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS:

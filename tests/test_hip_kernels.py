@@ -792,7 +792,7 @@ def test_emformer_ffn_pipelined_equals_the_block_form(ops, rows, F):
             gam, bet = 1 + 0.1 * torch.randn(D, generator=g_), 0.1 * torch.randn(D, generator=g_)
         args = (x.cuda(), gam.cuda(), bet.cuda(), ffn_pack_w1(W1.cuda()), b1.cuda(), ffn_pack_w2(W2.cuda()), b2.cuda())
         outs = {}
-        for waves in (0, 4, 8, 41, 81, 43, 83):
+        for waves in (0, 4, 8, 41, 81, 43, 83, 45):
             out = torch.full((rows, D), float("nan"), device="cuda", dtype=torch.bfloat16)
             ops.h.set_option(_lib.OPT_FFN_WAVES, waves)
             try:
@@ -803,7 +803,7 @@ def test_emformer_ffn_pipelined_equals_the_block_form(ops, rows, F):
         torch.cuda.synchronize()
         assert torch.isfinite(outs[41].float()).all()
         assert torch.equal(outs[4], outs[8])
-        for wv in (0, 41, 81, 43, 83):       # 43 / 83: the GELU spread over all 32 MFMAs of an iteration; 0: the default; 4 waves x 2 workgroups per CU (rings of 2 slots); 8 waves, one workgroup per CU (rings of 4, tiles two ahead)
+        for wv in (0, 41, 81, 43, 83, 45):       # 45: 64 rows per wave, one 4-wave workgroup per compute unit; 43 / 83: the GELU spread over all 32 MFMAs of an iteration; 0: the default; 4 waves x 2 workgroups per CU (rings of 2 slots); 8 waves, one workgroup per CU (rings of 4, tiles two ahead)
             assert torch.equal(outs[wv], outs[4]), (wv, exact, int((outs[wv] != outs[4]).sum()),
                                                     float((outs[wv].float() - outs[4].float()).abs().max()))
         if not exact:

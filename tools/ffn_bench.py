@@ -64,7 +64,8 @@ def main():
         fns = [("fused_default", fused), ("two_launch", two), ("fused_one_8wave_workgroup_per_cu", waves(8)),
                ("fused_two_4wave_workgroups_per_cu", waves(4)), ("pipelined_gelu_inside_the_mfma_stream", waves(41)),
                ("pipelined_8_waves_one_workgroup_per_cu", waves(81)),
-               ("pipelined_uniform_gelu_behind_all_32_mfmas", waves(43)), ("pipelined_uniform_8_waves", waves(83))]
+               ("pipelined_uniform_gelu_behind_all_32_mfmas", waves(43)), ("pipelined_uniform_8_waves", waves(83)),
+               ("wide_64_rows_per_wave_one_workgroup_per_cu", waves(45))]
         if hasattr(ops.lib, "simulst_debug_ffn_variant"):      # DEBUG_HOOKS build: the packed-GELU instantiations exist
             fns += [("pipelined_packed_gelu", waves(42)), ("pipelined_packed_gelu_8_waves", waves(82))]
         if hasattr(ops.lib, "simulst_debug_ffn_variant"):
