@@ -106,10 +106,13 @@ int simulst_graph_enable(simulst_handle* h, int on);
  *   DEC_EMBED_QKV_CHAIN     0: every decode step ends with its own commit launch (default 1: in simulst_mma_decode over lockstep rows
  *                              -- n_prev_uniform >= 0, more than 128 bf16 rows -- a step's commit and the new token's embedding are the
  *                              prologue of the next step's first launch, layer 0's LayerNorm + QKV; the call's last step commits as before)
+ *   PANEL_WIDE              0: simulst_linear keeps tall bias-only K = 256 projections (8192 rows and more: the encoder's QKV, the joint
+ *                              cross K / V projection) on the 32-rows-per-wave row panel (default 1: 64 rows per wave, LDS-DMA weights,
+ *                              csrc/gemm_panel.hip panel_wide_kernel; identical results)
  * Returns SIMULST_E_ARG for an unknown option or a value outside its range. */
 enum { SIMULST_OPT_VALU_ATTENTION = 0, SIMULST_OPT_UNFUSED_DECODE = 1, SIMULST_OPT_FFN_WAVES = 2, SIMULST_OPT_DEC_CHAIN = 3,
        SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 4, SIMULST_OPT_DEC_ATTN_CHAIN_ROWS = 5, SIMULST_OPT_FUSED_ARGMAX = 6,
-       SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT = 7, SIMULST_OPT_DEC_EMBED_QKV_CHAIN = 8 };
+       SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT = 7, SIMULST_OPT_DEC_EMBED_QKV_CHAIN = 8, SIMULST_OPT_PANEL_WIDE = 9 };
 int simulst_set_option(simulst_handle* h, int32_t option, int32_t value);
 
 #ifdef SIMULST_DEBUG_HOOKS

@@ -59,6 +59,8 @@ struct simulst_handle {
   int dec_attn_chain_max_rows; // rows up to which self-attention rides inside the projection chain (dec_attn_proj_chain_kernel)
   int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
   bool dec_embed_qkv_chain;    // offline lockstep decode: commit + embedding inside the next step's first launch (dec_embed_qkv_chain_kernel)
+  bool panel_wide_plain_stores;   // experiment: default-policy stores instead of streaming ones in panel_wide_kernel
+  bool panel_wide;             // tall bias-only K = 256 projections on the 64-rows-per-wave panel kernel (gemm_panel.hip panel_wide_kernel)
   int policy_lds_bytes;        // policy / cross-attention launch of co-scheduled batches: minimum dynamic LDS request (occupancy cap), 0: none
   int dec_vocab_chain_split;   // workgroups per row tile of the step's closing launch (dec_vocab_chain_kernel); 0: off
   bool fused_argmax;           // decode loops: per-tile (max, index) partials out of the vocabulary projection instead of fp32 logits

@@ -258,6 +258,167 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
   PROBE(5);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// WIDE row panels (round 4) for the bias-only projections with K = 256 (the encoder's QKV, the decoder's joint cross K / V projection).
+// The kernel above moves 448 KB through LDS per 2 x (128 rows x 64 columns) against 2 048 matrix-core cycles, requests a step's weights
+// ONE step ahead and waits for them with s_waitcnt vmcnt(0), which on gfx9 also waits for the step's own stores.  Here:
+//   * a wave keeps 64 rows (4 row tiles: 128 VGPRs of A fragments) and a column step is 32 columns: a 1 KB weight fragment read from LDS
+//     feeds FOUR MFMAs, fragments go through a ring of four register quads so that no MFMA waits for its own LDS read;
+//   * the weights reach LDS by LDS-DMA (global_load_lds) into a ring of THREE 16 KB slots, requested TWO steps ahead (timing ablations:
+//     at 441 600 rows x 768 columns the skeleton -- A loads, weight DMA, barriers, staging -- takes 100 us, the MFMAs add 97 us, the stores
+//     116 us, the whole 228-258 us: three phases of about equal length that two workgroups per compute unit overlap only partly; the
+//     weight stream through LDS-DMA alone, 16 KB per workgroup and step, is 660 MB per launch at the ~6.4 TB/s that path delivers);
+//   * wave 0 is the LOADER: it issues every DMA and the bias loads and never stores, so its vector-memory queue holds loads only and a
+//     COUNTED s_waitcnt vmcnt (loads complete in order) leaves the next step's request in flight.  Its staged output rows are written by
+//     waves 1 .. 3 beside their own; those waves issue no vector load inside the loop, so nothing ever waits for a store.  The bias of a
+//     step travels loader -> LDS -> everyone.  (Every wave issuing its share of the DMA with a counted wait over loads AND stores --
+//     gfx9 has one in-order counter -- measured 258 us at 441 600 rows against 228 us for this form; 512-row workgroups 243 us.)
+//   * the epilogue packs to bf16 BEFORE staging (bias only: one rounding, the value the fp32 staging gave), and a step's staged rows
+//     leave for memory at the start of the next step.
+// One workgroup barrier per step.  Results are identical to panel_kernel's (tests/test_hip_kernels.py::test_wide_row_panel_equals_the_row_panel).
+constexpr int PW_PF = 4;                                           // weight fragments in flight from LDS per wave
+constexpr int PW_M = 256, PW_N = 32, PW_SS = 40;                   // rows per workgroup, columns per step, staging row stride (bf16 elements)
+constexpr int PW_NS = 3;                                           // weight slots (requests run two steps ahead)
+typedef __attribute__((address_space(3))) void pw_lds_void;
+typedef const __attribute__((address_space(1))) void pw_gbl_void;
+
+__device__ __forceinline__ void pw_barrier() {                     // LDS hand-offs only: no vmcnt (a plain __syncthreads() drains the stores)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256, 2) void panel_wide_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Wp,
+                                                            const float* __restrict__ bias, bf16* __restrict__ C, LinArgs p) {
+  __shared__ __attribute__((aligned(16))) uint4 wl[PW_NS][2 * 8 * 64];           // [slot][(j, s)][lane]: 3 x 16 KB
+  __shared__ __attribute__((aligned(16))) unsigned short stage[5][64 * PW_SS];   // per wave [64 rows][32 columns] bf16; [0] and [4]: the loader's two
+  __shared__ __attribute__((aligned(16))) float bl[2][PW_N];                     // bias of the step (loader -> everyone)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * PW_M;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool loader = wave_u == 0;
+  const int n_steps = p.N / PW_N;
+  // ---- this wave's A fragments: 4 row tiles x 8 k-steps, loaded once (the loader's oldest loads)
+  uint4 fa[4][8];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int ar = m0 + wave * 64 + m * 16 + lr;
+    const bool aok = ar < p.M;
+    const int ab = aok ? ar / p.rpb : 0, ai = aok ? ar - ab * p.rpb : 0;
+    const bf16* arow = A + (long)ab * p.a_bs + (long)ai * p.a_rs;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const uint4 v = ld16(arow + s * PB_KS + lg * 8);
+      fa[m][s] = make_uint4(aok ? v.x : 0u, aok ? v.y : 0u, aok ? v.z : 0u, aok ? v.w : 0u);
+    }
+  }
+  // loader: request of a step = ONE bias load (lanes 0 .. 31) + the 16 fragments (j, s) of the step, 1 KB each at (column tile * 8 + s) KB
+  float breq[2] = {0.f, 0.f};                                      // bias words in flight, step t in breq[t & 1]
+  auto request = [&](int step, float& bdst) {
+    if (bias) bdst = bias[step * PW_N + (lane & (PW_N - 1))];      // one vector-memory instruction, counted below
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      const int j = f >> 3, s8 = f & 7;
+      const bf16* src = Wp + (((long)(step * 2 + j) * 8 + s8) * 64 + lane) * 8;
+      __builtin_amdgcn_global_load_lds((pw_gbl_void*)src, (pw_lds_void*)&wl[step % PW_NS][f * 64], 16, 0, 0);
+    }
+  };
+  if (loader) {
+    request(0, breq[0]);
+    if (n_steps > 1) request(1, breq[1]);
+  }
+  // the loader's staged rows are read by OTHER waves one step later, with no barrier before its next staging: two buffers by step parity
+  unsigned short* st = stage[wave];
+  // rows a lane writes to memory: its own wave's staged rows (row it * 16 + lane / 4) -- and, for waves 1 .. 3, their share of the
+  // loader's: wave 1 its row groups 0 and 1, wave 2 group 2, wave 3 group 3
+  int e_b[4], e_ii[4], x_b[2], x_ii[2];
+  bool e_ok[4], x_ok[2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = m0 + wave * 64 + it * 16 + (lane >> 2);
+    e_ok[it] = r < p.M && !loader;
+    e_b[it] = e_ok[it] ? r / p.rpb : 0;
+    e_ii[it] = e_ok[it] ? r - e_b[it] * p.rpb : 0;
+  }
+  const int xg0 = wave_u == 1 ? 0 : wave_u;                       // first loader row group of this wave
+  const int xn = loader ? 0 : (wave_u == 1 ? 2 : 1);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = m0 + (xg0 + q) * 16 + (lane >> 2);
+    x_ok[q] = q < xn && r < p.M;
+    x_b[q] = x_ok[q] ? r / p.rpb : 0;
+    x_ii[q] = x_ok[q] ? r - x_b[q] * p.rpb : 0;
+  }
+  auto put = [&](int b_, int ii_, int c, const uint4& v) {
+    if constexpr (NT) st_stream16(C + c_index(p, b_, ii_, c), v);
+    else *reinterpret_cast<uint4*>(C + c_index(p, b_, ii_, c)) = v;
+  };
+  auto flush = [&](int step) {
+    const int c = step * PW_N + (lane & 3) * 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (e_ok[it]) put(e_b[it], e_ii[it], c, *reinterpret_cast<const uint4*>(&st[(it * 16 + (lane >> 2)) * PW_SS + (lane & 3) * 8]));
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (x_ok[q]) put(x_b[q], x_ii[q], c, *reinterpret_cast<const uint4*>(&stage[(step & 1) * 4][((xg0 + q) * 16 + (lane >> 2)) * PW_SS + (lane & 3) * 8]));
+  };
+  for (int step = 0; step < n_steps; ++step) {
+    if (loader) {
+      // everything older than the NEXT step's request (1 bias load + 16 DMA pieces) has landed: loads complete in order
+      if (step + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (bias) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (lane < PW_N) bl[step & 1][lane] = breq[step & 1];
+    }
+    pw_barrier();                                                  // slot step % 3 and the step's bias are in LDS; every wave is past step - 1
+    if (loader && step + 2 < n_steps) request(step + 2, breq[step & 1]);
+    if (step > 0) flush(step - 1);
+    const uint4* wls = wl[step % PW_NS];
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4_t wf[PW_PF];
+#pragma unroll
+    for (int f = 0; f < PW_PF - 1; ++f) wf[f] = *reinterpret_cast<const u32x4_t*>(&wls[((f & 1) * 8 + (f >> 1)) * 64 + lane]);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {                                // fragment f = (k-step f / 2, column tile f % 2)
+      const int sK = f >> 1, j = f & 1;
+      if (f + PW_PF - 1 < 16) {
+        const int g2 = f + PW_PF - 1;
+        wf[g2 % PW_PF] = *reinterpret_cast<const u32x4_t*>(&wls[((g2 & 1) * 8 + (g2 >> 1)) * 64 + lane]);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[f % PW_PF]),
+                                                           *reinterpret_cast<const bf16x8_t*>(&fa[m][sK]), acc[m][j], 0, 0, 0);
+      // the fragment stays alive past the MFMAs that read it (panel_kernel explains the destination-on-source allocation)
+      asm volatile("" :: "v"(wf[f % PW_PF]), "v"(acc[0][j]), "v"(acc[1][j]), "v"(acc[2][j]), "v"(acc[3][j]));
+    }
+    // ---- wave-private staging: acc[m][j][e] = C[64 w + 16 m + lr][32 step + 16 j + 4 lg + e]; bias, ONE rounding to bf16
+    // (this wave's rows of the previous step were read by the flush above -- the loader's by waves 1 .. 3 after the barrier)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 bv = *reinterpret_cast<const float4*>(&bl[step & 1][j * 16 + 4 * lg]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const bf16 v4[4] = {__float2bfloat16(acc[m][j][0] + bv.x), __float2bfloat16(acc[m][j][1] + bv.y),
+                            __float2bfloat16(acc[m][j][2] + bv.z), __float2bfloat16(acc[m][j][3] + bv.w)};
+        uint2 pk;
+        __builtin_memcpy(&pk, v4, 8);
+        unsigned short* sw = loader ? stage[(step & 1) * 4] : st;
+        *reinterpret_cast<uint2*>(&sw[(m * 16 + lr) * PW_SS + j * 16 + 4 * lg]) = pk;
+      }
+    }
+  }
+  pw_barrier();                                                    // the loader's last staged rows are visible
+  flush(n_steps - 1);
+}
+
 }  // namespace
 
 // shapes the panel kernel takes: bf16, fragment-major weights, tall problems with a short contraction
@@ -272,8 +433,24 @@ bool sl_panel_wanted(int dtype, int epi, const LinArgs& p) {
          (epi == SIMULST_EPI_BIAS || epi == SIMULST_EPI_BIAS_GELU || epi == SIMULST_EPI_BIAS_RES || epi == SIMULST_EPI_EMF_OUT);
 }
 
+// the wide form: bias-only epilogue, K == 256, whole 32-column steps, 16-byte aligned output rows / heads
+static bool panel_wide_wanted(const simulst_handle* h, int epi, const LinArgs& p) {
+  return h->panel_wide && epi == SIMULST_EPI_BIAS && !p.ln_g && p.K == 256 && p.N % PW_N == 0 && p.M >= 8192 &&
+         ((p.c_rs | p.c_bs | p.c_hs | p.c_ts) & 7) == 0 && (p.c_hd == 0 || p.c_hd % 8 == 0) && (p.a_rs & 7) == 0 && (p.a_bs & 7) == 0;
+}
+
 int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
                     void* aux, const LinArgs& p) {
+  if (panel_wide_wanted(h, epi, p)) {
+    KTimer tw(h, SIMULST_K_LINEAR);
+    if (h->panel_wide_plain_stores)
+      hipLaunchKernelGGL(panel_wide_kernel<false>, dim3((p.M + PW_M - 1) / PW_M), dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias,
+                         (bf16*)C, p);
+    else
+      hipLaunchKernelGGL(panel_wide_kernel<true>, dim3((p.M + PW_M - 1) / PW_M), dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias,
+                         (bf16*)C, p);
+    return sl_launch_status(h, "simulst_linear(wide row panel)");
+  }
   dim3 grid((p.M + PB_M - 1) / PB_M);
   const int spb = (p.N + PB_N - 1) / PB_N;
   KTimer t(h, SIMULST_K_LINEAR);

@@ -61,6 +61,9 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_DEC_VOCAB_CHAIN_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->dec_vocab_chain_split = v; }
   h->dec_embed_qkv_chain = true;
   if (const char* e = getenv("SIMULST_DEC_EMBED_QKV_CHAIN")) h->dec_embed_qkv_chain = atoi(e) != 0;
+  h->panel_wide = true;
+  h->panel_wide_plain_stores = false;
+  if (const char* e = getenv("SIMULST_PANEL_WIDE")) { h->panel_wide = atoi(e) != 0; h->panel_wide_plain_stores = atoi(e) == 2; }
   h->policy_lds_bytes = 0;
   if (const char* e = getenv("SIMULST_POLICY_LDS_BYTES")) { const int v = atoi(e); if (v >= 0 && v <= 64 * 1024) h->policy_lds_bytes = v; }
   h->fused_argmax = true;      // greedy pick's partial maxima in the vocabulary projection's epilogue (decode loops, bf16, co-scheduled rows)
@@ -172,6 +175,7 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
       h->dec_attn_chain_rows = value; return SIMULST_OK;
     case SIMULST_OPT_FUSED_ARGMAX: h->fused_argmax = value != 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_EMBED_QKV_CHAIN: h->dec_embed_qkv_chain = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_PANEL_WIDE: h->panel_wide = value != 0; h->panel_wide_plain_stores = value == 2; return SIMULST_OK;
     case SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT:
       SL_REQUIRE(h, value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG,
                  "simulst_set_option(DEC_VOCAB_CHAIN_SPLIT): 0 (off), 1, 2, 4, 8 or 16");

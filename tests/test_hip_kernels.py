@@ -588,6 +588,86 @@ def test_decoder_self_attention_wave_kernel(ops):
         n_prev += 1
 
 
+@pytest.mark.parametrize("case", ["plain", "batched", "head_major", "tensor_heads"])
+def test_wide_row_panel_equals_the_row_panel(ops, case):
+    """Tall bias-only K = 256 projections (round 4): the 64-rows-per-wave panel (LDS-DMA weights, bf16 staging) against the
+    32-rows-per-wave one it replaces (SIMULST_OPT_PANEL_WIDE = 0) -- same MFMA shape, same accumulation order, one rounding: IDENTICAL
+    outputs; and against torch fp32.  Ragged M, batched rows with a row stride, head-major and several-tensor head-major stores."""
+    from simulst_amd._lib import EPI_BIAS
+    g = torch.Generator().manual_seed(77)
+    bf = torch.bfloat16
+    K = 256
+
+    def both(fn):
+        outs = []
+        for wide in (1, 0):
+            ops.h.set_option(_lib.OPT_PANEL_WIDE, wide)
+            try:
+                outs.append(fn())
+            finally:
+                ops.h.set_option(_lib.OPT_PANEL_WIDE, 1)
+        torch.cuda.synchronize()
+        return outs
+
+    if case == "plain":
+        for M, N in ((8192 + 37, 768), (20000, 3072), (8192, 32)):
+            x = torch.randn(M, K, generator=g).to(bf).cuda()
+            W = (torch.randn(N, K, generator=g) / K ** 0.5).to(bf).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            Wp = ops.pack_fragment_major(W)
+            y1, y0 = both(lambda: ops.linear(x, Wp, b, epilogue=EPI_BIAS, w_fragment_major=True))
+            assert torch.equal(y1, y0), (M, N, int((y1 != y0).sum()))
+            torch.testing.assert_close(y1.float(), x.float() @ W.float().t() + b, atol=6e-2, rtol=3e-2)
+            y2, y3 = both(lambda: ops.linear(x, Wp, None, epilogue=EPI_BIAS, w_fragment_major=True))     # no bias
+            assert torch.equal(y2, y3)
+    else:
+        Bq, n, N = 40, 333, 768                              # 13 320 rows, rows of a batch 272 elements apart
+        a_rs = K + 16
+        xb = torch.randn(Bq, n, a_rs, generator=g).to(bf).cuda()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(bf).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        Wp = ops.pack_fragment_major(W)
+        ref = xb[..., :K].float() @ W.float().t() + b
+        if case == "batched":
+            def run():
+                C = torch.full((Bq, n + 3, N), 9.0, device="cuda", dtype=bf)
+                ops.linear_raw(xb, Wp, b, C, M_batches=Bq, rows_per_batch=n, N=N, K=K, a_bs=n * a_rs, a_rs=a_rs,
+                               c_bs=(n + 3) * N, c_rs=N, epilogue=EPI_BIAS, w_fragment_major=True)
+                return C
+            y1, y0 = both(run)
+            assert torch.equal(y1, y0)
+            torch.testing.assert_close(y1[:, :n].float(), ref, atol=6e-2, rtol=3e-2)
+            assert float((y1[:, n:].float() - 9.0).abs().max()) == 0.0        # rows past a batch's end untouched
+        elif case == "head_major":
+            H, d, S_cap, r0 = N // 64, 64, n + 9, 4
+
+            def run():
+                dst = torch.zeros(Bq, H, S_cap, d, device="cuda", dtype=bf)
+                ops.linear_raw(xb, Wp, b, dst[:, :, r0:], M_batches=Bq, rows_per_batch=n, N=N, K=K, a_bs=n * a_rs, a_rs=a_rs,
+                               c_bs=H * S_cap * d, c_rs=d, epilogue=EPI_BIAS, c_head_dim=d, c_head_stride=S_cap * d,
+                               w_fragment_major=True)
+                return dst
+            y1, y0 = both(run)
+            assert torch.equal(y1, y0)
+            torch.testing.assert_close(y1[:, :, r0:r0 + n].float(), ref.view(Bq, n, H, d).permute(0, 2, 1, 3), atol=6e-2, rtol=3e-2)
+            assert float(y1[:, :, :r0].abs().max()) == 0.0 and float(y1[:, :, r0 + n:].abs().max()) == 0.0
+        else:
+            # three head-major tensors side by side (the joint cross K / V projection's store): 4 heads each
+            d, Ht, S_cap = 64, 4, n + 2
+            nt = N // (Ht * d)
+
+            def run():
+                dst = torch.zeros(nt, Bq, Ht, S_cap, d, device="cuda", dtype=bf)
+                ops.linear_raw(xb, Wp, b, dst, M_batches=Bq, rows_per_batch=n, N=N, K=K, a_bs=n * a_rs, a_rs=a_rs,
+                               c_bs=Ht * S_cap * d, c_rs=d, epilogue=EPI_BIAS, c_head_dim=d, c_head_stride=S_cap * d,
+                               c_tensor_heads=Ht, c_tensor_stride=Bq * Ht * S_cap * d, w_fragment_major=True)
+                return dst
+            y1, y0 = both(run)
+            assert torch.equal(y1, y0)
+            want = ref.view(Bq, n, nt, Ht, d).permute(2, 0, 3, 1, 4)
+            torch.testing.assert_close(y1[:, :, :, :n].float(), want, atol=6e-2, rtol=3e-2)
+
+
 @pytest.mark.parametrize("epi", ["bias", "gelu", "res", "emf_out", "head_major"])
 def test_row_panel_gemm(ops, epi):
     """The A-stationary row-panel kernel (tall bf16 problems, K <= 256, fragment-major weights) against the 128 x 128
