@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int PB_M = 128, PB_N = 64, PB_KS = 32;
+constexpr int PB_PF = 3;                 // weight fragments in flight from LDS per wave (register ring)
 
 #ifdef SL_PROBE
 __device__ long sl_probe_panel[16];
@@ -143,20 +144,26 @@ __global__ __launch_bounds__(256, 2) void panel_kernel(const bf16* __restrict__ 
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the 32 weight fragments of the step through a ring of PB_PF register quads, each requested PB_PF - 1 fragments before the two
+    // MFMAs that consume it (round 4: with ONE quad hipcc serialised read -> wait -> MFMAs -> read, the LDS latency 32 times per step)
+    u32x4_t wfr[PB_PF];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int f = 0; f < PB_PF - 1; ++f) wfr[f] = *reinterpret_cast<const u32x4_t*>(&wl[((f & 3) * 8 + (f >> 2)) * 64 + lane]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32x4_t wf = *reinterpret_cast<const u32x4_t*>(&wl[(j * 8 + s) * 64 + lane]);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf),
-                                                             *reinterpret_cast<const bf16x8_t*>(&fa[m][s]), acc[m][j], 0, 0, 0);
-        // the weight fragment stays alive past both MFMAs that read it: otherwise hipcc puts the second one's destination
-        // on the fragment's own registers ("v_mfma v[162:165], v[162:165], v[2:5], 0"), the allocation that made the layer
-        // chains irreproducible from run to run (dec_chain.hip)
-        asm volatile("" :: "v"(wf), "v"(acc[0][j]), "v"(acc[1][j]));
+    for (int f = 0; f < 32; ++f) {                              // fragment f = (k-step f / 4, column tile f % 4)
+      const int s = f >> 2, j = f & 3;
+      if (f + PB_PF - 1 < 32) {
+        const int g2 = f + PB_PF - 1;
+        wfr[g2 % PB_PF] = *reinterpret_cast<const u32x4_t*>(&wl[((g2 & 3) * 8 + (g2 >> 2)) * 64 + lane]);
       }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfr[f % PB_PF]),
+                                                           *reinterpret_cast<const bf16x8_t*>(&fa[m][s]), acc[m][j], 0, 0, 0);
+      // the weight fragment stays alive past both MFMAs that read it: otherwise hipcc puts the second one's destination
+      // on the fragment's own registers ("v_mfma v[162:165], v[162:165], v[2:5], 0"), the allocation that made the layer
+      // chains irreproducible from run to run (dec_chain.hip)
+      asm volatile("" :: "v"(wfr[f % PB_PF]), "v"(acc[0][j]), "v"(acc[1][j]));
     }
     if (step == step0) PROBE(3);                                // MFMAs of the first step issued
     // ---- wave-private epilogue.  The weights are the A operand of the MFMAs, so a lane holds 4 consecutive COLUMNS of one
