@@ -55,7 +55,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # HBM traffic of the dominant kernels from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest round first
 ENCODER_TRAFFIC_FILES = ["r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
 CROSS_ATTN_TRAFFIC_FILES = ["r04_pmc_cross_attention_traffic.json", "r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
-IN_SITU_STATS_FILE = "r04_c_k20_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of the driver-shaped command (tools/profile_r04.sh)
+IN_SITU_STATS_FILE = "r04_d_k20_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of the driver-shaped command (tools/profile_r04.sh)
 PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # all classes of one launch sequence (round 1), tools/pmc_summary.py
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
 
