@@ -630,7 +630,7 @@ def configs4_rank_shard_leg(dtype_name):
     if tools not in sys.path:
         sys.path.insert(0, tools)
     import eval_sharded
-    base = ["--utterances", "40000", "--shard-of", "8", "--shard-rank", "3", "--dtype", dtype_name, "--passes", "3"]
+    base = ["--utterances", "40000", "--shard-of", "8", "--shard-rank", "3", "--dtype", dtype_name, "--passes", "3", "--warmup-passes", "1"]
     out = {"workload": "configs[4]: one rank's shard (rank 3 of 8) of the 40 000-utterance set, lengths log-normal clipped to 100 .. 3000 "
                        "frames (seed 999), int(0.1 T + 10) tokens per utterance, wait-k 3",
            "note": "the other 7 shards are equally long (length-sorted snake deal, simulst_amd/sharding.py): an 8-GPU job is this x 8 plus one "

@@ -60,6 +60,9 @@ def main(argv=None, collect=None):
     ap.add_argument("--plan", default="work", choices=["work", "rows"],
                     help="work: sequence cuts by cost (offline_eval.plan_shard_by_work) and a queue, most expensive first; rows: equal row "
                          "counts dealt round-robin (round 2)")
+    ap.add_argument("--warmup-passes", type=int, default=0,
+                    help="whole untimed passes over the shard before the timed ones (allocator pools of every launch-sequence shape, like "
+                         "bench.py's warm-up steps); the default warm-up is one sequence per stream")
     ap.add_argument("--passes", type=int, default=1,
                     help="timed passes over the shard; the reported time is their MEDIAN (all are listed).  The pass includes the host's "
                          "assembly of the hypotheses, which is what varies on a shared box")
@@ -154,6 +157,8 @@ def main(argv=None, collect=None):
     if args.warmup:                      # one untimed sequence per stream: code objects, allocator pools
         run([[c] if c < len(batches) else [] for c in range(S)])
     pass_s = []
+    for _ in range(max(0, args.warmup_passes)):
+        run([list(range(c, len(batches), S)) for c in range(S)])
     for _ in range(max(1, args.passes)):
         ids, ntok, toks_all = [], [], []
         torch.cuda.synchronize()
@@ -237,6 +242,8 @@ def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev
     if dist is not None:
         dist.barrier()
     pass_s = []
+    for _ in range(max(0, args.warmup_passes)):
+        pipe.run(work)
     for _ in range(max(1, args.passes)):
         if pass_s:
             torch.cuda.synchronize()
