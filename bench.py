@@ -53,9 +53,8 @@ if ROOT not in sys.path:
 # Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # HBM traffic of the dominant kernels from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest round first
-ENCODER_TRAFFIC_FILES = ["r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
+ENCODER_TRAFFIC_FILES = ["r05_encoder_traffic.json", "r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
 CROSS_ATTN_TRAFFIC_FILES = ["r04_pmc_cross_attention_traffic.json", "r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
-IN_SITU_STATS_FILE = "r04_d_k20_kernel_stats.csv"   # rocprofv3 --kernel-trace --stats of the driver-shaped command (tools/profile_r04.sh)
 PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # all classes of one launch sequence (round 1), tools/pmc_summary.py
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
 
@@ -193,51 +192,57 @@ def algorithmic_work(cfg, B, T, U):
     return fl, dict(T1=T1, Te=Te, N=N, rows_x=rows_x, rows_z=rows_z, rows_c=rows_c)
 
 
-def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="waitk"):
-    """Roofline entry of one kernel class of a launch sequence of Bs rows: algorithmic bytes (HBM-bound classes) or
-    flops (the encoder-side contractions) of the class per sequence / its device time.  The decode-step GEMM groups are
-    scored against the L2 delivery rate: their operands (a layer's weights, a few hundred KB of activations) live in the
-    XCDs' L2s, what bounds them is operand delivery per workgroup and the dependent round trip, not HBM."""
+def decode_path_options(h, Bs, V, dtype_name):
+    """What the handle's decode loops run at Bs co-scheduled rows, read back from the handle (simulst_get_option) instead of re-modelled:
+    chains (row-local layer chains), vsplit (workgroups per row tile of the closing launch, 0 = off), embed_qkv (commit + embedding +
+    layer 0's QKV as the next step's first launch)."""
+    from simulst_amd import _lib
+    chains = bool(h.get_option(_lib.OPT_DEC_CHAIN)) and Bs > 128 and dtype_name == "bf16"      # csrc/handle.cpp dec_chain_min_rows
+    vs = h.get_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT) if (chains and Bs <= 1024) else 0        # feed-forward chain domain
+    while vs > 1 and V % (256 * vs):                                                           # dec_chain.hip sl_dec_vocab_chain_split
+        vs //= 2
+    if vs and V % 256:
+        vs = 0
+    return {"chains": chains, "vsplit": vs, "embed_qkv": bool(h.get_option(_lib.OPT_DEC_EMBED_QKV_CHAIN)) and chains}
+
+
+def class_work(name, cfg, Bs, dims, fl, dtype_name, kind="waitk", opts=None):
+    """Algorithmic work of one kernel class over ONE launch sequence of Bs rows (110 decode steps): (bound, work, informational L2 bytes).
+    work = flops for the encoder-side contractions (MFMA bound), bytes for everything else (HBM bound); None when the class has no model.
+    The decode-step GEMM groups are SCORED on algorithmic bytes -- every weight matrix of the launch once + its activations in and out
+    (+ the fp32 slabs, + cached K / V rows) -- against HBM, the only rate a better tiling cannot inflate; what the workgroups pull from L2
+    (the weights once per row tile) is reported beside it as information only."""
     esz = 2 if dtype_name == "bf16" else 4
     D, F, V, Ld, U = cfg.embed_dim, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, N_STEPS_DECODE
-    if ms <= 0 or n_launch <= 0:
-        return None
+    opts = opts or {"chains": Bs > 128 and dtype_name == "bf16", "vsplit": 4 if (Bs > 128 and Bs <= 1024 and dtype_name == "bf16" and V % 1024 == 0) else 0,
+                    "embed_qkv": Bs > 128 and dtype_name == "bf16"}
     if name == "linear":
-        # encoder-side contractions (conv GEMMs, QKV, out-proj, FFN, cross K/V projection): MFMA bound
-        flops = fl["conv"] + fl["enc_linear"] + fl["dec_cross_kv"]
-        peak = MFMA_PEAK_TFLOPS[dtype_name]
-        ach = flops / (ms * 1e-3) / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 5), "traffic": None, "launches_per_sequence": n_launch,
-                "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_flop_per_launch": round(flops / n_launch)}
+        return "mfma", fl["conv"] + fl["enc_linear"] + fl["dec_cross_kv"], None
     if name in ("linear_skinny", "linear_tile64", "dec_qkv_chain", "dec_proj_chain", "dec_ffn_chain", "dec_attn_proj_chain",
                 "dec_vocab_chain"):
-        # decode-step contractions: the launch-site groups of the per-GEMM kernels and, one class per kernel, the row-local layer
-        # chains (csrc/dec_chain.hip).  SCORED on algorithmic bytes -- every weight matrix of the launch once + its activations in
-        # and out (+ the cached K / V rows for the chain that carries the self-attention) -- against HBM, the only rate a
-        # better tiling cannot inflate; what the workgroups pull from L2 (the weights once per row tile) is reported beside it as
-        # information only (ADVICE r3: scoring the delivered bytes rewards redundant re-reads).
         tile64 = Bs >= 256
-        chains = Bs > 128 and dtype_name == "bf16"                # the chains' domain (csrc/handle.cpp dec_chain_min_rows)
-        # the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial pick): feed-forward chain domain,
-        # split 4 by default (csrc/handle.cpp dec_vocab_chain_split, dec_chain.hip sl_dec_vocab_chain_split); MMA and CIF decode loops
-        vsplit = 4 if (chains and Bs <= 1024 and V % 1024 == 0) else 0
+        chains, vsplit, embed_qkv = opts["chains"], opts["vsplit"], opts["embed_qkv"]
 
         def alg(n, k):
             return (n * k + Bs * k + Bs * n) * esz
 
         def delivered(n, k, rt):
             return (-(-Bs // rt) * n * k + Bs * k + Bs * n) * esz
-        per_step = {"qkv": (3 * D, D), "out": (D, D), "q": (D, D), "c_out": (D, D), "fc1": (F, D), "fc2": (D, F)}
+        slabs = (F // 256) * Bs * D * 4
+        # layer 0's LayerNorm + QKV: with embed_qkv every step but the call's first runs it inside dec_embed_qkv_chain_kernel (class
+        # dec_qkv_chain: the step's (value, index) pairs in, the embedding row + position gathered, x and qkv out); the first step's
+        # stays a plain GEMM launch in linear_tile64 / linear_skinny
+        l0_chain = (U - 1) if embed_qkv else 0
+        l0_plain = U - l0_chain
         if name == "dec_qkv_chain":
             # slab sum (F / 256 fp32 slabs in, x out) + LN1 + QKV; once more per step for the last layer's slabs
-            last = 0 if vsplit else (F // 256) * Bs * D * 4
-            byts = U * ((Ld - 1) * (alg(3 * D, D) + (F // 256) * Bs * D * 4) + last)
-            dl = U * (Ld - 1) * delivered(3 * D, D, 16)
+            last = 0 if vsplit else slabs
+            byts = U * ((Ld - 1) * (alg(3 * D, D) + slabs) + last) + l0_chain * (alg(3 * D, D) + 2 * Bs * D * esz + Bs * max(vsplit, 1) * 8)
+            dl = (U * (Ld - 1) + l0_chain) * delivered(3 * D, D, 16)
         elif name == "dec_vocab_chain":
             # the last layer's slabs + x' in, x out, the output projection once, `split` (value, index) pairs per row out
-            byts = U * ((F // 256) * Bs * D * 4 + 2 * Bs * D * esz + V * D * esz + Bs * vsplit * 8)
-            dl = U * ((F // 256) * Bs * D * 4 * vsplit + -(-Bs // 16) * V * D * esz)
+            byts = U * (slabs + 2 * Bs * D * esz + V * D * esz + Bs * vsplit * 8) if vsplit else 0
+            dl = U * (slabs * vsplit + -(-Bs // 16) * V * D * esz)
         elif name == "dec_proj_chain":
             byts = U * Ld * (alg(D, D) + alg(D, D))
             dl = U * Ld * 2 * delivered(D, D, 16)
@@ -246,36 +251,23 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="wait
             byts = U * Ld * (alg(D, D) + alg(D, D)) + Ld * kv
             dl = U * Ld * 2 * delivered(D, D, 4) + Ld * kv
         elif name == "dec_ffn_chain":
-            byts = U * Ld * (alg(D, D) + alg(F, D) + alg(D, F) + (F // 256) * Bs * D * 4)
+            byts = U * Ld * (alg(D, D) + alg(F, D) + alg(D, F) + slabs)
             dl = U * Ld * ((F // 256) * delivered(D, D, 16) + delivered(F, D, 16) + delivered(D, F, 16))
         else:
             rt = 64 if name == "linear_tile64" else 16
-            if chains:            # with the chains only layer 0's QKV and the vocabulary projection stay in these groups
-                shapes = [(3 * D, D)] * (name == "linear_tile64" and tile64) + \
-                         [(V, D)] * (name == "linear_tile64" and tile64 and not vsplit)
-                if name == "linear_skinny" and not tile64:
-                    shapes = [(3 * D, D)] + [(V, D)] * (not vsplit)
-                byts = U * sum(alg(n, k) for n, k in shapes)
-                dl = U * sum(delivered(n, k, rt) for n, k in shapes)
+            mine = (name == "linear_tile64") == tile64               # the group the plain GEMM launches of this row count fall in
+            if chains:            # with the chains only (some of) layer 0's QKV and, without the closing launch, the vocabulary projection
+                byts = (l0_plain * alg(3 * D, D) + (0 if vsplit else U * alg(V, D))) if mine else 0
+                dl = (l0_plain * delivered(3 * D, D, rt) + (0 if vsplit else U * delivered(V, D, rt))) if mine else 0
             else:
                 wide = [(3 * D, D), (F, D)]
                 narrow = [(D, D)] * 3 + [(D, F)]
                 sel = (wide if tile64 else []) if name == "linear_tile64" else (narrow if tile64 else wide + narrow)
-                extra_v = [(V, D)] if (name == "linear_tile64") == tile64 else []
+                extra_v = [(V, D)] if mine else []
                 byts = U * (Ld * sum(alg(n, k) for n, k in sel) + sum(alg(n, k) for n, k in extra_v))
                 dl = U * (Ld * sum(delivered(n, k, rt) for n, k in sel) + sum(delivered(n, k, rt) for n, k in extra_v))
-        if byts <= 0:
-            return None
-        ach = byts / (ms * 1e-3) / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "launches_per_sequence": n_launch,
-                "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_bytes_per_launch": round(byts / n_launch),
-                "informational_l2_delivered": {"bytes_per_launch": round(dl / n_launch), "GBps": round(dl / (ms * 1e-3) / 1e9, 1),
-                                               "frac_of_l2_peak": round(dl / (ms * 1e-3) / 1e9 / L2_PEAK_GBS, 5)},
-                "model": "algorithmic bytes: each weight matrix of the launch once + activations in / out (+ fp32 slabs, + cached K / V "
-                         "rows); these launches are latency-bound (28-224 workgroups, a dependent launch cannot finish under ~3 us), "
-                         "the fraction says how far from any rate they run"}
-    elif name == "emformer_attention":
+        return ("hbm", byts, dl) if byts > 0 else None
+    if name == "emformer_attention":
         byts = cfg.encoder_layers * Bs * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
     elif name == "decoder_cross_attention":
         if kind == "hard":
@@ -294,12 +286,41 @@ def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="wait
         byts = (cfg.encoder_layers * Bs * (dims["rows_x"] + dims["rows_z"]) * D + 2 * Bs * dims["rows_x"] * D) * esz
     else:
         return None
-    if byts <= 0:
+    return ("hbm", byts, None) if byts > 0 else None
+
+
+def roofline_entry(name, bound, work, dl, ms, n_launch, dtype_name):
+    """work / time of a class against its peak: the entry format of the `roofline` object"""
+    if ms <= 0 or n_launch <= 0 or work <= 0:
         return None
-    ach = byts / (ms * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "launches_per_sequence": n_launch,
-            "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_bytes_per_launch": round(byts / n_launch)}
+    if bound == "mfma":
+        peak = MFMA_PEAK_TFLOPS[dtype_name]
+        ach = work / (ms * 1e-3) / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 5), "traffic": None, "launches_per_sequence": n_launch,
+                "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_flop_per_launch": round(work / n_launch)}
+    ach = work / (ms * 1e-3) / 1e9
+    e = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "launches_per_sequence": n_launch,
+         "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_bytes_per_launch": round(work / n_launch)}
+    if dl:
+        e["informational_l2_delivered"] = {"bytes_per_launch": round(dl / n_launch), "GBps": round(dl / (ms * 1e-3) / 1e9, 1),
+                                           "frac_of_l2_peak": round(dl / (ms * 1e-3) / 1e9 / L2_PEAK_GBS, 5)}
+        e["model"] = ("algorithmic bytes: each weight matrix of the launch once + activations in / out (+ fp32 slabs, + cached K / V "
+                      "rows); these launches are latency-bound (28-224 workgroups, a dependent launch cannot finish under ~3 us), "
+                      "the fraction says how far from any rate they run")
+    return e
+
+
+def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="waitk", opts=None):
+    """Roofline entry of one kernel class of a launch sequence of Bs rows: algorithmic bytes (HBM-bound classes) or
+    flops (the encoder-side contractions) of the class per sequence / its device time."""
+    if ms <= 0 or n_launch <= 0:
+        return None
+    w = class_work(name, cfg, Bs, dims, fl, dtype_name, kind=kind, opts=opts)
+    if w is None:
+        return None
+    return roofline_entry(name, w[0], w[1], w[2], ms, n_launch, dtype_name)
 
 
 def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps, cores):
@@ -523,7 +544,10 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                 ovh = max(0.0, (replay_s - plain_s) * 1e3 / max(n_launch, 1))
                 per_class = {k: (max(0.0, v[0] - ovh * v[1]), v[1]) for k, v in raw.items()}
                 fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, U)
-                entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, dtn, kind=kind) for k, v in per_class.items()}
+                opts = decode_path_options(h, Bs, cfg.vocab, dtn)
+                if cif:
+                    opts["embed_qkv"] = False                 # simulst_cif_decode commits with its own launch
+                entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, dtn, kind=kind, opts=opts) for k, v in per_class.items()}
                 entries = {k: e for k, e in entries.items() if e is not None}
                 dom = max(entries, key=lambda k: per_class[k][0])     # every chain kernel is a class of its own: real device time
                 bpt = path_bytes_per_token(cfg, B, T_FRAMES, U, esz, 0, kind=kind)
@@ -654,9 +678,149 @@ def b1_latency_leg():
         sys.path.insert(0, tools)
     import b1_latency
     r = b1_latency.run()
-    log(f"configs0 B = 1 agent: per WRITE {r['hip_b1_agent']['per_write']['mean_ms']} ms, per READ {r['hip_b1_agent']['per_read']['mean_ms']} ms, "
-        f"AL_CA - AL {r['hip_b1_agent']['AL_CA_minus_AL_ms']} ms (oracle, 1 thread: {r['oracle_cpu']['AL_CA_minus_AL_ms']} ms)")
+    log(f"configs0 B = 1 agent: per WRITE {r['hip_b1_agent']['per_write']['median_ms']} ms, per READ {r['hip_b1_agent']['per_read']['median_ms']} ms "
+        f"(medians), median AL_CA - AL {r['hip_b1_agent']['AL_CA_minus_AL_ms_median']} ms (oracle, 1 thread: "
+        f"{r['oracle_cpu']['AL_CA_minus_AL_ms_median']} ms)")
     return r
+
+
+LEGS_FILE = "bench_legs.json"        # everything the line leaves out (per-row tables, per-utterance latency, census, notes)
+LINE_LIMIT = 8192                    # the driver parses the LAST stdout line; round 4's 32 KB line came back parsed: null
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _leg_summary(leg):
+    """ONE object of a few numbers per extra leg; the tables stay in bench_legs.json"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": str(leg["error"])[:160]}
+    o = {}
+    off, bs, par = leg.get("offline") or {}, leg.get("batched_streaming") or {}, leg.get("parity_on_sample") or {}
+    if off:
+        o["offline_tokens_per_s"] = off.get("tokens_per_s")
+    if bs:
+        o["streamed_tokens_per_s"] = bs.get("tokens_per_s")
+        o["streamed_self_paced_tokens_per_s"] = (bs.get("evaluation_form_self_paced_rows") or {}).get("tokens_per_s")
+        o["AL_ms_mean"] = bs.get("average_lagging_ms_mean")
+        o["rows"] = bs.get("rows")
+    if par:
+        o["fp32_streamed_records_identical_to_oracle"] = par.get("streaming_fp32_actions_tokens_delays_AL_identical_to_oracle")
+        if "offline_fp32_tokens_identical_to_oracle" in par:
+            o["fp32_offline_tokens_identical_to_oracle"] = par["offline_fp32_tokens_identical_to_oracle"]
+        for k, v in par.items():
+            if k.startswith("streaming_") and k.endswith("_rows_identical_to_oracle"):
+                o[k.replace("streaming_", "").replace("_rows_identical_to_oracle", "_streamed_rows_identical")] = \
+                    [v, par.get("streaming_sample_utterances")]
+    roof = leg.get("roofline") or {}
+    if roof:
+        o["dominant_class"] = [roof.get("kernel"), roof.get("frac")]
+        o["path_hbm_frac"] = (roof.get("path_hbm_model") or {}).get("frac_offline")
+    if "teacher_forced" in leg:
+        o["teacher_forced"] = leg["teacher_forced"]
+    return o
+
+
+def compact_line(full, legs_path=LEGS_FILE):
+    """The ONE stdout line of the contract from the full result: headline, `roofline`, `cpu_baseline` and one small object per leg.
+    Pure function of `full` (tests/test_bench_line.py drives it on a canned result)."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "ranks_seen", "per_rank_pass_ms_min_max")
+    out = {k: full.get(k) for k in head}
+    out["data"] = "synthetic N(0,1) 80-dim fbank, one distinct utterance per decoded row; random-init weights, seed 999"
+    out["timed_passes"] = _pick(full.get("timed_passes") or {}, "n", "ms", "tokens_per_s_min_median_max")
+    out["config"] = _pick(full.get("config") or {}, "workload", "batch_per_gpu", "frames", "decode_steps", "tokens_per_step",
+                          "sharding", "plan_batches_per_sequence", "streams", "rows_per_sequence", "warmup_steps_executed")
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        ro = _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_sequence", "avg_launch_us",
+                   "algorithmic_bytes_per_launch", "algorithmic_flop_per_launch", "rows_per_sequence", "measured")
+        if "in_the_timed_region" in r:
+            ro["in_the_timed_region"] = _pick(r["in_the_timed_region"], "avg_launch_us", "achieved", "frac", "launches", "streams",
+                                              "source")
+        if "path_hbm_model" in r:
+            ro["path_hbm_model"] = _pick(r["path_hbm_model"], "bytes_per_token", "tokens_per_s_at_peak", "frac")
+        if "other_bound_class" in r:
+            ro["other_bound_class"] = _pick(r["other_bound_class"], "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                            "avg_launch_us")
+        if "classes" in r:
+            ro["class_frac"] = {k: v.get("frac") for k, v in r["classes"].items()}
+        if "classes_in_the_timed_region" in r:
+            ro["class_frac_in_the_timed_region"] = {k: v.get("frac") for k, v in r["classes_in_the_timed_region"].items()}
+        if "class_ms_per_sequence" in r:
+            ro["class_ms_per_sequence"] = r["class_ms_per_sequence"]
+        out["roofline"] = ro
+    else:
+        out["roofline"] = None
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict):
+        co = _pick(c, "value", "unit", "cores", "kind", "sample")
+        if "single_thread" in c:
+            co["single_thread_value"] = c["single_thread"].get("value")
+        p = c.get("parity_on_sample") or {}
+        if p:
+            co["fp32_tokens_identical_to_oracle"] = p.get("fp32_tokens_identical_to_oracle")
+            t = p.get("timed_pass_rows_vs_oracle") or {}
+            co["timed_rows_identical_to_oracle"] = [t.get("rows_identical"), t.get("rows")]
+        out["cpu_baseline"] = co
+    else:
+        out["cpu_baseline"] = None
+    legs = {}
+    if "configs1_one_batch_of_64_alone" in full:
+        legs["configs1_one_batch_of_64_alone"] = full["configs1_one_batch_of_64_alone"]
+    if "one_sequence_alone" in full:
+        legs["one_sequence_alone"] = full["one_sequence_alone"]
+    for k in ("configs1_batched_streaming", "configs2_mma_hard", "configs3_cif"):
+        if k in full:
+            legs[k] = _leg_summary(full[k])
+    c4 = full.get("configs4_rank_shard")
+    if isinstance(c4, dict):
+        legs["configs4_rank_shard"] = ({"error": str(c4["error"])[:160]} if "error" in c4 else {
+            "offline_tokens_per_s": (c4.get("offline") or {}).get("tokens_per_s"),
+            "streamed_tokens_per_s": (c4.get("streaming_evaluation") or {}).get("tokens_per_s"),
+            "AL_ms_mean": (c4.get("streaming_evaluation") or {}).get("average_lagging_ms_mean"),
+            "utterances_decoded": (c4.get("offline") or {}).get("utterances_decoded"),
+            "path_hbm_frac": ((c4.get("offline") or {}).get("path_hbm_model") or {}).get("frac")})
+    c0 = full.get("configs0_b1_compute_aware_latency")
+    if isinstance(c0, dict):
+        hb = c0.get("hip_b1_agent") or {}
+        legs["configs0_b1_latency"] = ({"error": str(c0["error"])[:160]} if "error" in c0 else {
+            "records_identical_to_oracle": c0.get("records_identical_to_oracle"),
+            "per_write_ms_median": (hb.get("per_write") or {}).get("median_ms"),
+            "per_read_ms_median": (hb.get("per_read") or {}).get("median_ms"),
+            "AL_CA_minus_AL_ms_median": hb.get("AL_CA_minus_AL_ms_median"),
+            "oracle_1_thread_per_write_ms_median": ((c0.get("oracle_cpu") or {}).get("per_write") or {}).get("median_ms"),
+            "oracle_1_thread_per_read_ms_median": ((c0.get("oracle_cpu") or {}).get("per_read") or {}).get("median_ms")})
+    if legs:
+        out["legs"] = legs
+    if "average_lagging" in full:
+        out["average_lagging"] = full["average_lagging"]
+    out["details"] = legs_path
+    return out
+
+
+def emit(full, rank_dir=ROOT):
+    """Write the full result next to bench.py (and under gpurun_out/ when that exists: it travels back from the GPU box), return the
+    compact line.  A line above LINE_LIMIT is a bug the CPU test catches; at run time the legs are dropped rather than the headline."""
+    paths = [os.path.join(rank_dir, LEGS_FILE)]
+    if os.path.isdir(os.path.join(rank_dir, "gpurun_out")):
+        paths.append(os.path.join(rank_dir, "gpurun_out", LEGS_FILE))
+    for pth in paths:
+        try:
+            with open(pth, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError as e:
+            log(f"could not write {pth}: {e!r}")
+    line = json.dumps(compact_line(full), separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:
+        slim = compact_line(full)
+        slim.pop("legs", None)
+        slim["legs_dropped"] = f"line was {len(line)} bytes; see {LEGS_FILE}"
+        line = json.dumps(slim, separators=(",", ":"))
+    return line
 
 
 _T0 = time.perf_counter()
@@ -774,9 +938,9 @@ def main(argv=None):
             r0 += B * g
         return out
 
+    from simulst_amd.model import ConcurrentOffline
     pipe = None
     if args.concurrency > 1:
-        from simulst_amd.model import ConcurrentOffline
         pipe = ConcurrentOffline(model, weights, args.concurrency, graph=args.graph, stagger_encoders=args.stagger,
                                  joint_encoder_max_rows=args.joint_encoder_max_rows)
     elif not args.no_pipeline:
@@ -882,8 +1046,50 @@ def main(argv=None):
         log(f"instrumented replay of a {Bs}-row sequence: {replay_s * 1e3:.1f} ms vs {group_s * 1e3:.1f} ms plain, "
             f"{n_launch} launches, event record cost {ovh_ms * 1e3:.2f} us")
         fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, N_STEPS_DECODE)
-        entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, args.dtype) for k, v in per_class.items()}
+        opts = decode_path_options(h, Bs, cfg.vocab, args.dtype)
+        entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, args.dtype, opts=opts) for k, v in per_class.items()}
         entries = {k: e for k, e in entries.items() if e is not None}
+        # ---- the same classes INSIDE the multi-stream schedule of the timed region: one more, UNTIMED pass of the timed plan with the
+        #      event timers on in every stream's handle.  An interval between two events of a stream is the
+        #      dispatch-to-end time of a launch while the other streams' kernels share the chip -- the quantity rocprofv3 --kernel-trace
+        #      reports for the driver-shaped command (profiles/*_k20_kernel_stats.csv is the cross-check) -- plus one event record,
+        #      whose cost (measured above on the serial replay) is removed per launch.
+        in_situ = None
+        if isinstance(pipe, ConcurrentOffline) and len(plan) > 1:
+            hs = [m.ops.h for m in pipe.models]
+            with torch.no_grad():
+                for hh in hs:
+                    hh.timer_reset()
+                    hh.timer_enable(-1, True)
+                torch.cuda.synchronize()
+                ti0 = time.perf_counter()
+                pipe.run(sequences(plan), N_STEPS_DECODE, mask_eos=True)
+                torch.cuda.synchronize()
+                insitu_s = time.perf_counter() - ti0
+                for hh in hs:
+                    hh.timer_enable(-1, False)
+            tot = {}
+            for hh in hs:
+                for c in range(_lib.K_COUNT):
+                    ms_c, n_c = hh.timer_read(c)
+                    k = _lib.KERNEL_CLASS_NAMES[c]
+                    tot[k] = (tot.get(k, (0.0, 0))[0] + ms_c, tot.get(k, (0.0, 0))[1] + n_c)
+            tot = {k: (max(0.0, v[0] - ovh_ms * v[1]), v[1]) for k, v in tot.items() if v[1] > 0}
+            in_situ = {}
+            for k, (ms_c, n_c) in tot.items():
+                work, bound, dl = 0, None, 0
+                for g in plan:                           # every launch sequence of the plan at its own row count
+                    fl_g, dims_g = algorithmic_work(cfg, B * g, T_FRAMES, N_STEPS_DECODE)
+                    w = class_work(k, cfg, B * g, dims_g, fl_g, args.dtype, opts=decode_path_options(h, B * g, cfg.vocab, args.dtype))
+                    if w is not None:
+                        bound, work, dl = w[0], work + w[1], dl + (w[2] or 0)
+                e = roofline_entry(k, bound, work, dl, ms_c, n_c, args.dtype) if bound else None
+                if e is not None:
+                    e.pop("launches_per_sequence")
+                    e["launches"] = n_c
+                    in_situ[k] = e
+            log(f"instrumented multi-stream pass: {insitu_s * 1e3:.1f} ms (timed passes {elapsed * 1e3:.1f} ms), "
+                f"{sum(v[1] for v in tot.values())} launches on {len(hs)} handles")
         # the dominant kernel class by device time
         dom = max(entries, key=lambda k: per_class[k][0])
         roofline = dict(entries[dom])
@@ -893,8 +1099,12 @@ def main(argv=None):
         other = [k for k in sorted(entries, key=lambda k: -per_class[k][0]) if entries[k]["bound"] != roofline["bound"]]
         if other:
             roofline["other_bound_class"] = entries[other[0]]
+        roofline["measured"] = "one launch sequence alone on the GPU (serial instrumented replay); in_the_timed_region: all streams running"
         roofline["classes"] = {k: {kk: e[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_launch_us")}
                                for k, e in entries.items()}
+        if in_situ:
+            roofline["classes_in_the_timed_region"] = {k: {kk: e[kk] for kk in ("bound", "achieved", "unit", "frac", "avg_launch_us", "launches")}
+                                                       for k, e in in_situ.items()}
         # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
         # this command at 4096 rows per sequence; profiles/*_pmc_traffic.json says how it was corrected): scaled by rows,
         # and only attached when this run's dtype is the recorded one
@@ -940,21 +1150,15 @@ def main(argv=None):
                                       "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / bpt),
                                       "frac": round(value / world / (HBM_PEAK_GBS * 1e9 / bpt), 5)}
         roofline["rows_per_sequence"] = Bs
-        # what the dominant kernel runs at INSIDE the timed region (several sequences sharing the chip), from the committed rocprofv3
-        # run of the driver-shaped command: `achieved` above comes from the serial instrumented replay of ONE sequence
-        try:
-            if roofline["kernel"] == "decoder_cross_attention" and args.dtype == "bf16" and Bs == 448 and streams_used == 3:
-                import csv
-                with open(os.path.join(ROOT, "profiles", IN_SITU_STATS_FILE)) as fcsv:
-                    row = next(r for r in csv.DictReader(fcsv) if "policy_cross_attn_kernel<__hip_bfloat16, 8, false>" in r["Name"])
-                us = float(row["AverageNs"]) / 1e3
-                ach = roofline["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9
-                roofline["in_the_timed_region"] = {
-                    "avg_launch_us": round(us, 2), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "source": f"profiles/{IN_SITU_STATS_FILE}: rocprofv3 --kernel-trace --stats of this command with three sequences on three "
-                              "streams (committed, not measured in this run)"}
-        except (OSError, StopIteration, KeyError, ValueError):
-            pass
+        # what the dominant kernel runs at INSIDE the timed region, measured by THIS run (the instrumented multi-stream pass above);
+        # the committed rocprofv3 --kernel-trace --stats of the driver-shaped command is the cross-check (profiles/README.md)
+        if in_situ and roofline["kernel"] in in_situ:
+            e = in_situ[roofline["kernel"]]
+            roofline["in_the_timed_region"] = {
+                "avg_launch_us": e["avg_launch_us"], "achieved": e["achieved"], "frac": e["frac"], "launches": e["launches"],
+                "streams": streams_used,
+                "source": "this run: one untimed pass of the timed plan with HIP-event timers on in every stream's handle, event-record "
+                          "cost removed"}
         roofline["class_ms_per_sequence"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
         roofline["launches_per_sequence_all_classes"] = n_launch
         extra = {}
@@ -1061,7 +1265,7 @@ def main(argv=None):
                                 leg["parity_on_sample"]["streaming_fp32_actions_tokens_delays_AL_identical_to_oracle"]}
         if al:
             out["average_lagging"] = al
-        print(json.dumps(out))
+        print(emit(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -75,7 +75,7 @@ int simulst_create(simulst_handle** out, void* hip_stream);
 int simulst_destroy(simulst_handle* h);
 int simulst_set_stream(simulst_handle* h, void* hip_stream);
 const char* simulst_last_error(simulst_handle* h);
-int simulst_version(void);            /* 104 (round 4: kernel classes 11-15, simulst_set_option, simulst_decoder_attn_proj_chain, simulst_decoder_vocab_chain); a binding built for another value must not use the library */
+int simulst_version(void);            /* 105 (round 5: simulst_get_option); a binding built for another value must not use the library */
 /* per-kernel-class HIP-event timing on the handle's stream (off by default) */
 int simulst_timer_enable(simulst_handle* h, int kernel_class, int on);
 int simulst_timer_read(simulst_handle* h, int kernel_class, double* total_ms, int64_t* launches);
@@ -114,6 +114,8 @@ enum { SIMULST_OPT_VALU_ATTENTION = 0, SIMULST_OPT_UNFUSED_DECODE = 1, SIMULST_O
        SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 4, SIMULST_OPT_DEC_ATTN_CHAIN_ROWS = 5, SIMULST_OPT_FUSED_ARGMAX = 6,
        SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT = 7, SIMULST_OPT_DEC_EMBED_QKV_CHAIN = 8, SIMULST_OPT_PANEL_WIDE = 9 };
 int simulst_set_option(simulst_handle* h, int32_t option, int32_t value);
+/* the value a handle currently runs with (simulst_create's environment overrides included) */
+int simulst_get_option(simulst_handle* h, int32_t option, int32_t* value);
 
 #ifdef SIMULST_DEBUG_HOOKS
 /* ---- investigation hooks: compiled only by `make DEBUG_HOOKS=1` (csrc/Makefile); the shipped library does not export them ----

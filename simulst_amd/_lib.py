@@ -104,6 +104,7 @@ SIGNATURES = {
     "simulst_timer_reset": [_vp],
     "simulst_graph_enable": [_vp, C.c_int],
     "simulst_set_option": [_vp, _i32, _i32],
+    "simulst_get_option": [_vp, _i32, C.POINTER(_i32)],
     "simulst_pack_fragment_major": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
@@ -166,7 +167,7 @@ DEBUG_SIGNATURES = {
  OPT_FUSED_ARGMAX, OPT_DEC_VOCAB_CHAIN_SPLIT, OPT_DEC_EMBED_QKV_CHAIN, OPT_PANEL_WIDE) = range(10)
 
 _lib = None
-ABI_VERSION = 104          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
+ABI_VERSION = 105          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
 
 
 def load():
@@ -228,6 +229,11 @@ class Handle:
     def set_option(self, option, value):
         """simulst_set_option: path selection / tuning values of this handle (OPT_* above, include/simulst_hip.h)"""
         self.check(self.lib.simulst_set_option(self._h, int(option), int(value)), "simulst_set_option")
+
+    def get_option(self, option):
+        v = _i32(0)
+        self.check(self.lib.simulst_get_option(self._h, int(option), C.byref(v)), "simulst_get_option")
+        return v.value
 
     def timer_enable(self, kernel_class=-1, on=True):
         self.check(self.lib.simulst_timer_enable(self._h, kernel_class, int(on)), "simulst_timer_enable")

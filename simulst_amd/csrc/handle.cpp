@@ -4,9 +4,10 @@
 
 // 100: rounds 1-2.  103: round 3 -- simulst_linear_desc, simulst_stream_ctl and simulst_cif_stream_ctl grew at their ends
 // (c_tensor_heads / c_tensor_stride; the chunk schedules of self-paced rows), simulst_decoder_desc gained P_cap.
-// 104: round 4 -- kernel classes 11-14 (one per layer-chain kernel), simulst_set_option replaces the two path-selection hooks,
+// 104: round 4 -- kernel classes 11-15 (one per layer-chain kernel), simulst_set_option replaces the two path-selection hooks,
 // simulst_decoder_attn_proj_chain, the simulst_debug_* entry points only in DEBUG_HOOKS builds.
-extern "C" int simulst_version(void) { return 104; }
+// 105: round 5 -- simulst_get_option (what a handle actually runs with, for the roofline models of bench.py).
+extern "C" int simulst_version(void) { return 105; }
 
 extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (!out) return SIMULST_E_NULL;
@@ -183,5 +184,27 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
     default: break;
   }
   h->err = "simulst_set_option: unknown option";
+  return SIMULST_E_ARG;
+}
+
+// What the handle currently runs with (the environment overrides of simulst_create included): callers that MODEL the launches of a
+// decode step (bench.py's per-class byte counts) read the values back instead of re-deriving the library's defaults.
+extern "C" int simulst_get_option(simulst_handle* h, int32_t option, int32_t* value) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, value);
+  switch (option) {
+    case SIMULST_OPT_VALU_ATTENTION: *value = h->force_valu_attention; return SIMULST_OK;
+    case SIMULST_OPT_UNFUSED_DECODE: *value = h->force_unfused_decode; return SIMULST_OK;
+    case SIMULST_OPT_FFN_WAVES: *value = h->ffn_waves; return SIMULST_OK;
+    case SIMULST_OPT_DEC_CHAIN: *value = h->dec_chain_on; return SIMULST_OK;
+    case SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS: *value = h->dec_attn_chain_max_rows; return SIMULST_OK;
+    case SIMULST_OPT_DEC_ATTN_CHAIN_ROWS: *value = h->dec_attn_chain_rows; return SIMULST_OK;
+    case SIMULST_OPT_FUSED_ARGMAX: *value = h->fused_argmax; return SIMULST_OK;
+    case SIMULST_OPT_DEC_EMBED_QKV_CHAIN: *value = h->dec_embed_qkv_chain; return SIMULST_OK;
+    case SIMULST_OPT_PANEL_WIDE: *value = h->panel_wide ? (h->panel_wide_plain_stores ? 2 : 1) : 0; return SIMULST_OK;
+    case SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT: *value = h->dec_vocab_chain_split; return SIMULST_OK;
+    default: break;
+  }
+  h->err = "simulst_get_option: unknown option";
   return SIMULST_E_ARG;
 }
