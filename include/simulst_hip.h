@@ -576,6 +576,12 @@ typedef struct {
                                      position and source length, so the commit takes every chunk the row is going to ask for on the
                                      spot (position u can be written once the source holds u + k pooled keys) and no round is spent on
                                      asking; the caller starts every row at the first chunk that allows position 0 */
+  /* Parity audit of the learned policies (tools/teacher_forced_audit.py; NULL in production).  p_probe [n_layers][B][H][probe_P] receives
+   * the pooled step probabilities sigmoid(energy) every (layer, row, head) computed in the round (modules/monotonic_multihead_attention.py:
+   * 88-149 over the pooled keys of modules/fixed_pre_decision.py:97-131), step_probe [n_layers][B][H] the step its own search found
+   * (:196-257); a step_force [n_layers][B][H] entry >= 0 replaces the found step for head_step and the value aggregation, so a run can
+   * be driven along another implementation's trajectory (teacher forcing) while its own decisions are recorded. */
+  float* p_probe; int64_t* step_probe; const int64_t* step_force; int32_t probe_P;
 } simulst_stream_ctl;
 
 int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,

@@ -54,12 +54,15 @@ def _next_chunk_frames(ecfg):
     return ecfg.segment_length * ecfg.stride * SHIFT_MS // SHIFT_MS
 
 
-def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=False, timing=None):
+def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=False, timing=None, trace=None):
     """FairseqSimulSTAgent loop for wait-k / MMA (agents/default_agent.py:303-436).
     Returns dict(tokens, delays_ms, actions ('R'/'W' string), AL, n_enc).
     ``timing``: a dict that receives wall-clock seconds per READ (policy + source read + encoder update) and per WRITE (policy +
     predict) and, per committed token, the wall-clock milliseconds since the start of the utterance (computation-aware delays:
-    the *_CA metrics of docs/mma.md:44-56 are the latency metrics over delay + that)."""
+    the *_CA metrics of docs/mma.md:44-56 are the latency metrics over delay + that).
+    ``trace``: a list that receives one record per decoder call (policy()): {'enc_rows', 'frames', 'n_prev', 'last_token', 'online',
+    'layers' (decoder.mma_decoder_step trace), 'action', and for a WRITE 'logits' [V] fp32 + 'token'} -- the trajectory a
+    teacher-forced run of another implementation is driven along (tools/teacher_forced_audit.py)."""
     import time
     src = FrameSource(fbank)
     t_start = time.perf_counter()
@@ -102,10 +105,14 @@ def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=
         else:
             toks = torch.tensor([[dcfg.eos] + hyp])
             dec_state["online"] = not src.finished
+            ltrace = [] if trace is not None else None
             x, extra = dec.mma_decoder_step(w, "decoder", dcfg, toks,
                                             {"encoder_out": [enc_out], "encoder_padding_mask": []},
-                                            dec_state)
+                                            dec_state, trace=ltrace)
             action = extra["action"]
+            if trace is not None:
+                trace.append({"enc_rows": enc_out.size(0), "frames": src.pos, "n_prev": len(hyp), "last_token": int(toks[0, -1]),
+                              "online": bool(dec_state["online"]), "layers": ltrace, "action": int(action)})
             margin = float(extra["decision_margin"][0])
             if action == 0:
                 expected = _next_chunk_frames(ecfg)
@@ -130,6 +137,8 @@ def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=
         hyp.append(idx)
         token_gaps.append(float(top2[0] - top2[1]))
         delays.append(src.elapsed_ms())
+        if trace is not None:
+            trace[-1].update({"logits": x[0, -1].float().clone(), "token": idx, "top2_gap": float(top2[0] - top2[1])})
         if timing is not None:
             timing["write_s"].append(time.perf_counter() - t_act)
             timing["wall_ms_at_commit"].append((time.perf_counter() - t_start) * 1e3)
@@ -142,8 +151,13 @@ def simulate_mma(w, ecfg, dcfg, fbank, max_len_a=1.0, max_len_b=0, force_finish=
             "action_margins": action_margins, "token_gaps": token_gaps}
 
 
-def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot_weight=1.0):
-    """cif_agent.FairseqSimulSTAgent loop (agents/cif_agent.py:296-412)."""
+def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot_weight=1.0, trace=None):
+    """cif_agent.FairseqSimulSTAgent loop (agents/cif_agent.py:296-412).
+    ``trace``: a dict that receives 'updates' (per encoder update: frames, the accumulated weight of the CIF call 'alpha_sum', the
+    un-fired 'tail' weight, vectors released 'n_new', total 'cif_len', 'fire_margin') and 'writes' (per decoder call: n_prev,
+    last_token, cif_len, logits [V] fp32 with the overshoot bias, token, top2_gap) -- the trajectory of the teacher-forced audit."""
+    if trace is not None:
+        trace.update({"updates": [], "writes": []})
     src = FrameSource(fbank)
     enc_state = em.new_encoder_state()
     cif_state = cifm.new_cif_state()
@@ -167,6 +181,11 @@ def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot
                                torch.tensor([src.pos]), enc_state, finish=finish)
         c = cifm.cif_layer_infer(w, "encoder.cif_layer", beta, out["encoder_out"][0], cif_state, finish)
         fire_margin = float(c["fire_margin"][0][0])
+        if trace is not None:
+            tw = c["tail_weights"][0] if c["tail_weights"] else None
+            trace["updates"].append({"frames": src.pos, "finish": bool(finish), "alpha_sum": float(c["alpha_sum"][0][0]),
+                                     "tail": None if tw is None else float(tw.reshape(-1)[0]), "n_new": int(c["cif_lengths"][0]),
+                                     "fire_margin": fire_margin, "enc_rows_new": out["encoder_out"][0].size(0)})
         if states is None:
             states = {"cif_out": [c["cif_out"][0]], "cif_lengths": [c["cif_lengths"][0]]}
         else:
@@ -198,6 +217,10 @@ def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot
         lp = torch.log_softmax(x[:, -1:].float(), dim=-1)
         idx = int(lp.argmax(dim=-1)[0, 0])
         top2 = lp[0, 0].topk(2).values
+        if trace is not None:
+            trace["writes"].append({"n_prev": len(hyp), "last_token": int(toks[0, -1]), "cif_len": int(states["cif_lengths"][0]),
+                                    "frames": src.pos, "logits": x[0, -1].float().clone(), "token": idx,
+                                    "top2_gap": float(top2[0] - top2[1])})
         hyp.append(idx)
         token_gaps.append(float(top2[0] - top2[1]))
         delays.append(src.elapsed_ms())

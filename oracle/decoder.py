@@ -101,10 +101,12 @@ def clear_cache(state, end_id=None, has_mono=True):
         _prune(state["layers"][i], has_mono)
 
 
-def mma_decoder_step(w, p, cfg, prev_output_tokens, encoder_out, state, features_only=False):
+def mma_decoder_step(w, p, cfg, prev_output_tokens, encoder_out, state, features_only=False, trace=None):
     """MMADecoder.forward -> extract_features with incremental_state
     (mma_model.py:79-220) + fairseq output_layer. prev_output_tokens [B,u] int64
-    ([eos]+hyp). Returns (logits [B,1,V] | partial x, extra{'action', 'attn_list'})."""
+    ([eos]+hyp). Returns (logits [B,1,V] | partial x, extra{'action', 'attn_list'}).
+    ``trace``: a list that receives, per layer that ran, {'head_step_before' [B,H], 'head_step' [B,H], 'head_read' [B,H],
+    'pooled_p' [B,H,P] or None, 'margin' [B,H]} (teacher-forced audit; diagnostic only)."""
     B, u = prev_output_tokens.shape
     table = sinusoidal_table(cfg.padding_idx + 1 + max(u, 1) + 1, cfg.embed_dim, cfg.padding_idx)
     pos = table[cfg.padding_idx + u].expand(B, 1, -1)
@@ -125,9 +127,17 @@ def mma_decoder_step(w, p, cfg, prev_output_tokens, encoder_out, state, features
         h = _self_attn_step(w, lp + ".self_attn", cfg, _ln(w, lp + ".self_attn_layer_norm", x), lst)
         x = res + h
         res = x
+        hs_before = lst["mono"].get("head_step")
         h, attn = mono.attention_forward(w, lp + ".encoder_attn", cfg.attn,
                                          _ln(w, lp + ".encoder_attn_layer_norm", x), enc, enc,
                                          enc_pad, lst["mono"])
+        if trace is not None:
+            H = cfg.num_heads
+            pp = lst["mono"].get("pooled_p")
+            trace.append({"head_step_before": (torch.zeros(B, H, dtype=torch.long) if hs_before is None else hs_before.clone()),
+                          "head_step": lst["mono"]["head_step"].clone(), "head_read": lst["mono"]["head_read"].clone(),
+                          "pooled_p": None if pp is None else pp.float().reshape(B, H, -1).clone(),
+                          "margin": lst["mono"]["decision_margin"].clone() if "decision_margin" in lst["mono"] else None})
         x = res + h
         res = x
         h = _ln(w, lp + ".final_layer_norm", x)

@@ -216,6 +216,8 @@ def p_choose(w, prefix, cfg, query, key, key_padding_mask, state, incremental):
             if mask_pool is not None:
                 mask_pool = mask_pool[:, :-1]
     pp = _p_choose_from_qk(w, prefix, cfg, query, key_pool, mask_pool, state, incremental)
+    if incremental and state is not None:
+        state["pooled_p"] = pp            # diagnostic for the teacher-forced audit (not reference state): [B*H, 1, P]
     p = insert_zeros(pp, r)
     if p.size(-1) < src_len:
         p = torch.cat([p, p.new_zeros(p.size(0), tgt_len, src_len - p.size(-1))], dim=2)

@@ -89,7 +89,8 @@ class StreamCtl(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("active", "read_flag", "online", "done", "delays_ms", "hyp")] + \
                [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now", "n_chunks")] + \
                [(n, C.c_void_p) for n in ("sched_rows", "sched_ms", "sched_max_len", "chunk_idx", "enc_len", "tok_chunk", "row_chunks")] + \
-               [(n, C.c_int32) for n in ("ff_waitk", "ff_ratio")]
+               [(n, C.c_int32) for n in ("ff_waitk", "ff_ratio")] + \
+               [(n, C.c_void_p) for n in ("p_probe", "step_probe", "step_force")] + [("probe_P", C.c_int32)]
 
 
 # name -> argtypes (restype is int unless noted); mirrors include/simulst_hip.h one to one

@@ -107,7 +107,7 @@ class CIFLayer:
                 "cif": torch.zeros(B, n_cap, D, device=dev, dtype=self.dtype), "n_cap": n_cap,
                 "cif_len": torch.zeros(B, device=dev, dtype=torch.int32)}
 
-    def infer_batched(self, x_btd: torch.Tensor, st: dict, finish: bool = False):
+    def infer_batched(self, x_btd: torch.Tensor, st: dict, finish: bool = False, trace: Optional[list] = None):
         """CIFLayer.infer for B rows that receive the same number of new encoder frames (lockstep sources): per row exactly
         the B == 1 arithmetic -- weights of the new frames, the carried (weight, feature / beta) pseudo-frame in front
         (:217-226), one integrate-and-fire scan, the un-fired tail withheld and carried unless ``finish`` (:235-255).  The new
@@ -125,8 +125,10 @@ class CIFLayer:
         st["first"] = False
         if x.size(1) == 0:
             return
-        out, n, _, tail_w, _ = self.ops.cif_integrate(x.contiguous(), alpha, beta=self.beta,
-                                                      tail_thres=self.tail_thres if finish else 0.0)
+        out, n, _, tail_w, asum = self.ops.cif_integrate(x.contiguous(), alpha, beta=self.beta,
+                                                         tail_thres=self.tail_thres if finish else 0.0)
+        if trace is not None:         # parity audit (tools/teacher_forced_audit.py): what this call's scan accumulated and released
+            trace.append({"alpha_sum": asum.clone(), "n": n.clone(), "tail": tail_w.clone(), "finish": finish})
         self.ops.cif_stream_append(out, n, tail_w, st["cif"], st["cif_len"], st["prev_feat"], st["prev_weight"],
                                    beta=self.beta, finish=finish)
 

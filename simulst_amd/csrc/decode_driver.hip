@@ -36,6 +36,12 @@ struct StreamCtl {
   int* chunk_idx; int* enc_len; int* tok_chunk;
   int n_chunks;
   int ff_waitk, ff_ratio;                                                // wait-k rows: lagging and signed pre-decision ratio (0: off)
+  // parity audit (tools/teacher_forced_audit.py; all null in production -- one uniform branch each): what the learned policies computed,
+  // and the step to continue with instead of the one found (teacher forcing along the CPU oracle's trajectory)
+  float* p_probe;            // [n_layers][B][H][probe_P] out: pooled step probabilities
+  long* step_probe;          // [n_layers][B][H] out: the step this kernel's own search found
+  const long* step_force;    // [n_layers][B][H] in: a value >= 0 replaces the found step (head_step, value aggregation)
+  int probe_P;
 };
 
 // head-split projections around the policy kernel (all null: separate GEMM launches do the projections)
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void 
         for (int i = 0; i < W; ++i) en = fmaf(accv[i] / (float)(f1 - f0), q_s[c + i], en);
       }
       pp[j] = 1.0f / (1.0f + expf(-(en + energy_bias)));
+      if (ctl.p_probe && j < ctl.probe_P) ctl.p_probe[((long)(ctl.layer - 1) * gridDim.y * H + r) * ctl.probe_P + j] = pp[j];
     }
   }
   __syncthreads();
@@ -285,6 +292,8 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void 
       if (m) found = j0 + __ffsll((long long)m) - 1;
     }
     if (found < 0) found = 0;
+    if (ctl.step_probe && lane == 0) ctl.step_probe[(long)(ctl.layer - 1) * gridDim.y * H + r] = found;
+    if (ctl.step_force) { const long f = ctl.step_force[(long)(ctl.layer - 1) * gridDim.y * H + r]; if (f >= 0) found = (int)f; }
     if (lane == 0) {
       const int clampi = min(max(found, 0), len - 1);
       const bool hr = found == max_steps && pl[clampi] < 0.5f;
@@ -948,6 +957,8 @@ extern "C" int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder
   ctl.chunk_idx = c->chunk_idx; ctl.enc_len = c->enc_len; ctl.tok_chunk = c->tok_chunk; ctl.n_chunks = c->n_chunks;
   ctl.row_chunks = c->row_chunks;
   ctl.ff_waitk = c->sched_rows ? c->ff_waitk : 0; ctl.ff_ratio = c->ff_ratio;
+  ctl.p_probe = c->p_probe; ctl.step_probe = (long*)c->step_probe; ctl.step_force = (const long*)c->step_force; ctl.probe_P = c->probe_P;
+  SL_REQUIRE(h, !c->p_probe || c->probe_P > 0, SIMULST_E_SHAPE, "simulst_mma_stream_steps: p_probe needs probe_P");
   if (c->sched_rows) {
     SL_REQUIRE(h, c->ff_waitk == 0 || (dd && dd->attn_type == SIMULST_ATTN_WAITK && c->ff_waitk == dd->waitk_k && c->ff_ratio == dd->ratio),
                SIMULST_E_ARG, "simulst_mma_stream_steps: ff_waitk / ff_ratio must be the descriptor's wait-k lagging and ratio");
