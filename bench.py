@@ -96,6 +96,7 @@ def parse_args(argv=None):
                     help="timed passes of the K-step plan; value = the MEDIAN pass, all of them are reported")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] streaming / configs[2] / configs[3] legs")
     ap.add_argument("--extra-rows", type=int, default=448, help="rows of the batched streaming runs of the extra legs")
+    ap.add_argument("--no-teacher-forced", action="store_true", help="skip the teacher-forced bf16 audits of the configs[2] / configs[3] legs")
     ap.add_argument("--cpu-sample", type=int, default=64)
     ap.add_argument("--cpu-sample-1thread", type=int, default=4,
                     help="utterances of the one-thread CPU baseline sample (the oracle at one thread is ~8x slower)")
@@ -621,8 +622,36 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                 parity.update({"offline_fp32_tokens_identical_to_oracle": bool(torch.equal(t32, ref)), "offline_sample_utterances": n_off,
                                f"offline_{dtn}_timed_rows_identical_to_oracle": int(sum(torch.equal(h16[r], ref[r]) for r in range(n_off))),
                                f"offline_{dtn}_oracle_top2_gap_at_first_divergence": sorted(gaps)})
+        forced = None
+        if not waitk and not args.no_teacher_forced:
+            # numerical bf16 parity along the ORACLE's trajectory (tools/teacher_forced_audit.py): the streaming entry points driven with
+            # the oracle's tokens / READ schedule / head steps, every probability, accumulated weight and decision compared
+            tools = os.path.join(ROOT, "tools")
+            if tools not in sys.path:
+                sys.path.insert(0, tools)
+            import teacher_forced_audit as tfa
+            del pipe, model, m32
+            pipe = model = m32 = None
+            torch.cuda.empty_cache()
+            utts = [fb_cpu[i] for i in range(min(8, n_off))]
+            with torch.no_grad():
+                a = (tfa.audit_cif if cif else tfa.audit_mma_hard)(cfg, w, utts, copies=17, dtype=dtype, device=dev)
+            forced = {"rows": a["rows"], "utterances": a["utterances"], "layer_chains": a["layer_chains"],
+                      "tokens_differ": [a["tokens"]["differ"], a["tokens"]["writes"]],
+                      "logit_abs_err_max": round(a["logits"]["abs_err"]["max"], 5)}
+            if cif:
+                forced.update({"accumulated_weight_abs_err_max": round(a["accumulated_weight_abs_err"]["max"], 5),
+                               "released_counts_differ": [a["fired_counts"]["updates_where_the_released_count_differs"], a["updates"]],
+                               "unexplained": a["fired_counts"]["not_explained_by_the_weight_error"]})
+            else:
+                forced.update({"p_abs_err_max": round(a["p_abs_err"]["max"], 5),
+                               "step_searches_differ": [a["decisions"]["own_search_differs_from_oracle"], a["decisions"]["searches"]],
+                               "unexplained": a["decisions"]["not_explained_by_the_p_error"]})
+            out_full_audit[key] = a
         out[key] = {"workload": workload + f"; {T_FRAMES}-frame utterances, {dtn}", "batched_streaming": streaming,
                     "parity_on_sample": parity, "seconds_spent": round(time.perf_counter() - t_leg, 1)}
+        if forced is not None:
+            out[key]["teacher_forced"] = forced
         if not waitk:
             out[key].update({"offline": offline, "roofline": roof})
         log(f"{key}: " + ("" if waitk else f"offline {offline['tokens_per_s']:.0f} tokens/s, ") +
@@ -634,6 +663,7 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
         del pipe, model, m32
         torch.cuda.empty_cache()
 
+    out_full_audit = {}
     for key in ("configs1_batched_streaming", "configs2_mma_hard", "configs3_cif"):
         try:
             one_leg(key)
@@ -642,6 +672,8 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
             out[key] = {"error": repr(e), "traceback_tail": traceback.format_exc().strip().splitlines()[-3:]}
             log(f"{key}: FAILED {e!r}")
             torch.cuda.empty_cache()
+    if out_full_audit:
+        out["teacher_forced_audit_full"] = out_full_audit            # bench_legs.json only (compact_line leaves it out)
     return out
 
 

@@ -27,9 +27,7 @@ def shard_utterances(lengths: Sequence[int], world_size: int, rank: int) -> List
 
 def gather_hypotheses(tokens: torch.Tensor, dist, group=None) -> torch.Tensor:
     """all_gather of equally-shaped token tensors [B, U] -> [world*B, U] (rank-major)."""
-    world = dist.get_world_size(group)
-    if world == 1:
-        return tokens
+    world = dist.get_world_size(group)      # a one-rank group takes the collective too (the RCCL call is what a one-GPU box can test)
     tokens = tokens.contiguous()
     out = torch.empty((world,) + tuple(tokens.shape), device=tokens.device, dtype=tokens.dtype)
     dist.all_gather_into_tensor(out.view(world * tokens.shape[0], *tokens.shape[1:]), tokens, group=group)

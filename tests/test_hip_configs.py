@@ -143,95 +143,59 @@ def _parity_args(**kw):
     return SimpleNamespace(**base)
 
 
-# ---- bf16 READ / WRITE parity.  "Average Lagging identical to the CPU reference" is asserted in fp32; the bf16
-#      runs the bench times leave the oracle's action strings on some rows.  A streamed row may leave the oracle's record only where the
-#      ORACLE'S OWN decision was a near tie: the policy compares p with 0.5 (modules/monotonic_multihead_attention.py:230-237) /
-#      the CIF agent compares the number of released vectors with the hypothesis length (agents/cif_agent.py:385-389: the
-#      accumulated weight against multiples of beta), the token pick compares the two best log-probabilities.
-#      oracle.agent.simulate_* record those margins per action / per token, oracle.agent.first_divergence finds the cause.
-POLICY_BOUND = {"mma_hard": 0.06, "cif": 0.12}   # |p - 0.5| ; |accumulated weight - k beta| (a sum over up to 250 bf16 frame weights)
-TOKEN_GAP_BOUND = 0.12                           # top-2 log-probability gap: streamed bf16 rows measured up to 0.085 on MI355X
-                                                 # (gpurun_out r04_d; the offline audit above, 110-step rows, stays below 0.01)
-
-
+# ---- bf16 READ / WRITE parity.  "Average Lagging identical to the CPU reference" is asserted in fp32; a free-running bf16 row equals
+#      the oracle's record until the first decision the ORACLE took at a near tie and is unrelated to it afterwards.  How near is
+#      "near" comes from the teacher-forced audit (tests/test_hip_teacher_forced.py; bounds in tools/bf16_trajectory_margins.py):
+#      the policy compares p with 0.5 (modules/monotonic_multihead_attention.py:230-237) / the CIF agent compares the number of released
+#      vectors with the hypothesis length (agents/cif_agent.py:385-389), the token pick compares the two best log-probabilities.
 @pytest.mark.parametrize("kind", ["mma_hard", "cif"])
 def test_bf16_streamed_rows_leave_the_oracle_only_at_near_ties(kind):
-    from oracle import agent as oag
-    from oracle.configs import from_model_config
-    from simulst_amd.agent import BatchedStreamingAgent
-    from simulst_amd.cif import BatchedCIFStreamingAgent, CIFTransformerModel
-    from simulst_amd.config import cif_transformer_s, mma_model_s
-    from simulst_amd.model import SimulSTModel
-    from simulst_amd.weights import init_model
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    n = 16
-    fb = torch.stack([torch.randn(1000, 80, generator=torch.Generator().manual_seed(999 + i)) for i in range(n)])
-    if kind == "cif":                               # the bench legs' tensors (bench.py extra_config_legs)
-        cfg = cif_transformer_s(cif_beta=1.0)
-        w = init_model(cfg, seed=999)
-        w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
-        w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.5
-    else:
-        cfg = mma_model_s(simul_attn_type="hard_aligned_fixed_pre_decision", fixed_pre_decision_ratio=8, mass_preservation=True)
-        w = init_model(cfg, seed=999)
-        for l in range(cfg.decoder_layers):
-            k = f"decoder.layers.{l}.encoder_attn.q_proj.weight"
-            w[k] = w[k] * 8
-    w["decoder.embed_tokens.weight"][cfg.eos] = 0
-    ecfg, dcfg = from_model_config(cfg)
-    with torch.no_grad():
-        if kind == "cif":
-            refs = [oag.simulate_cif(w, ecfg, dcfg, cfg.cif_beta, fb[i], max_len_a=0.1, max_len_b=10) for i in range(n)]
-            m16 = CIFTransformerModel(cfg, w, dtype=torch.bfloat16)
-            m32 = CIFTransformerModel(cfg, w, dtype=torch.float32)
-            mk = lambda m: BatchedCIFStreamingAgent(m, max_len_a=0.1, max_len_b=10)
-        else:
-            refs = [oag.simulate_mma(w, ecfg, dcfg, fb[i], max_len_a=0.1, max_len_b=10) for i in range(n)]
-            m16 = SimulSTModel(cfg, w, dtype=torch.bfloat16)
-            m32 = SimulSTModel(cfg, w, dtype=torch.float32)
-            mk = lambda m: BatchedStreamingAgent(m, max_len_a=0.1, max_len_b=10, steps_per_call=8)
-        got32 = mk(m32).run_batch(fb.cuda())
-        got16 = mk(m16).run_batch(fb.cuda().to(torch.bfloat16))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bf16_trajectory_margins as btm
+    r = btm.trajectory_table(kind, n=16, frames=1000)
     # fp32: every row IS the oracle's record (16 utterances; the claim the Average Lagging statement rests on)
-    for r, g in zip(refs, got32):
-        assert g["actions"] == r["actions"] and g["tokens"] == r["tokens"] and g["delays_ms"] == r["delays_ms"] and g["AL"] == r["AL"]
-    # bf16: identical, or parted at a near tie of the oracle
-    pb = POLICY_BOUND[kind]
-    causes, identical, safe_rows = [], 0, 0
-    table = []
-    for i, (r, g) in enumerate(zip(refs, got16)):
-        d = oag.first_divergence(r, g)
-        row_safe = min(r["action_margins"]) > pb and min(r["token_gaps"]) > TOKEN_GAP_BOUND
-        safe_rows += int(row_safe)
-        table.append({"row": i, "first_divergence": d, "oracle_min_policy_margin": round(min(r["action_margins"]), 6),
-                      "oracle_min_token_gap": round(min(r["token_gaps"]), 6), "AL_ms_bf16_vs_oracle": [g["AL"], r["AL"]]})
-        if d is None:
-            identical += 1
-            continue
-        causes.append((i, d["cause"], d["policy_margin"], d["token_gap"], d["policy_margin_of_the_call_that_wrote_the_token"]))
-    # the measured table travels back from the GPU box (gpurun merges gpurun_out/; profiles/r04_bf16_parity_margins_*.json is a copy)
-    import json
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump({"kind": kind, "policy_bound": pb, "token_gap_bound": TOKEN_GAP_BOUND, "rows_identical": identical, "rows": n, "table": table},
-              open(os.path.join(ROOT, "gpurun_out", f"bf16_parity_margins_{kind}.json"), "w"), indent=1)
-    for e in table:
+    assert r["fp32_rows_identical"] == 16
+    pb, gb = r["policy_bound"], r["token_gap_bound"]
+    causes = []
+    for e in r["table"]:
         d, i = e["first_divergence"], e["row"]
         if d is None:
             continue
-        row_safe = e["oracle_min_policy_margin"] > pb and e["oracle_min_token_gap"] > TOKEN_GAP_BOUND
-        assert not row_safe, (i, d)               # a row whose every decision had room must not move
+        assert not e["safe"], (i, d)              # a row whose every decision had room must not move
+        causes.append((i, d["cause"], d["policy_margin"], d["token_gap"], d["policy_margin_of_the_call_that_wrote_the_token"]))
         if d["cause"] == "action":
             assert d["policy_margin"] is not None and d["policy_margin"] <= pb, (i, d)
         else:
             # a token leaves the oracle's at a near tie of the two best log-probabilities -- or, with hard monotonic attention, where
             # a head's step search in THAT decoder call sat on a near tie: the head then looks at another encoder frame (same READ /
-            # WRITE action), which moves the logits by far more than rounding (measured: first tokens with top-2 gaps of 0.08-0.23)
-            near_tie = d["token_gap"] is not None and d["token_gap"] <= TOKEN_GAP_BOUND
+            # WRITE action), which moves the logits by far more than rounding (measured: first tokens with top-2 gaps of 0.08-0.47)
+            near_tie = d["token_gap"] is not None and d["token_gap"] <= gb
             moved_head = kind == "mma_hard" and d["policy_margin_of_the_call_that_wrote_the_token"] is not None and \
                 d["policy_margin_of_the_call_that_wrote_the_token"] <= pb
             assert near_tie or moved_head, (i, d)
-    print(f"{kind}: {identical} of {n} bf16 streamed rows identical to the oracle; {safe_rows} rows had every margin above the bounds; "
-          f"first divergences (row, cause, oracle |policy margin|, oracle top-2 gap): {causes}")
+    print(f"{kind}: {r['bf16_rows_identical']} of 16 bf16 streamed rows identical to the oracle; {r['safe_rows']} rows had every margin above "
+          f"the bounds; first divergences (row, cause, oracle |policy margin|, oracle top-2 gap, margin of the writing call): {causes}")
+
+
+def test_bf16_rows_with_room_at_every_decision_equal_the_oracle_records():
+    """The row-level statement bf16 supports: a streamed row whose EVERY oracle decision has more room than the worst error the
+    teacher-forced audit measured must be record-identical (READ / WRITE string, tokens, delays, Average Lagging).  Population: 320
+    CIF utterances of 160 frames -- 8 such rows (asserted: the check must not be vacuous), and they are identical; of all 320 rows
+    312 are.  No such population exists for MMA-hard with random-init weights: a row's smallest |p - 0.5| over its ~700 comparisons
+    is 0.001 in the median even for 160-frame sources (against |p - p_oracle| up to 0.022), so there the statement is the
+    per-decision one of tests/test_hip_teacher_forced.py: zero unexplained decisions in 32 496 step searches."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bf16_trajectory_margins as btm
+    r = btm.trajectory_table("cif", n=320, frames=160, bounds="cif_160")
+    assert r["fp32_rows_identical"] == 320
+    assert r["safe_rows"] >= 8, r["safe_rows"]
+    assert r["safe_rows_identical"] == r["safe_rows"], [e for e in r["table"] if e["safe"] and e["first_divergence"]]
+    assert r["bf16_rows_identical"] >= 300, r["bf16_rows_identical"]
+    for e in r["table"]:                          # and every row that did move left at a decision without room
+        d = e["first_divergence"]
+        if d is not None:
+            m = d["policy_margin"] if d["cause"] == "action" else d["token_gap"]
+            assert m is not None and m <= (r["policy_bound"] if d["cause"] == "action" else r["token_gap_bound"]), (e["row"], d)
 
 
 @pytest.fixture()

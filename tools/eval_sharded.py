@@ -80,8 +80,10 @@ def main(argv=None, collect=None):
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1 and collect is None:
+    # SIMULST_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1: the RCCL path (barriers, reductions, record gather) on a one-GPU box
+    if (world > 1 or os.environ.get("SIMULST_BENCH_FORCE_DIST") == "1") and collect is None:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from simulst_amd.config import mma_model_s
@@ -197,17 +199,26 @@ def main(argv=None, collect=None):
         want = args.utterances if args.shard_of <= 0 else n_shard
         assert len(recs) == want, (len(recs), want)
         from simulst_amd.offline_eval import max_steps
-        caps_ok = all(int(n) <= max_steps(lengths[i]) for i, n in zip(ids, torch.cat(ntok).tolist())) if ntok else True
+        if dist is not None:
+            # a multi-rank job reports the WHOLE job: the gathered records of every rank (rank 0's shard alone under-reported
+            # utterances/s by the world size and checked the properties of 1 / world of the hypotheses)
+            n_done = len(recs)
+            caps_ok = all(len(r["tokens"]) <= max_steps(lengths[i]) for i, r in recs.items())
+            one_each = n_done == args.utterances and set(recs) == set(range(args.utterances))
+        else:
+            n_done = n_shard
+            caps_ok = all(int(n) <= max_steps(lengths[i]) for i, n in zip(ids, torch.cat(ntok).tolist())) if ntok else True
+            one_each = len(set(ids)) == n_shard
         emit({"workload": "configs[4]: batched offline eval, utterance-sharded" +
                           (f" (rank {args.shard_rank} of {args.shard_of}: one rank's shard on one GPU)" if args.shard_of > 0 else ""),
-              "utterances": args.utterances, "utterances_decoded": n_shard,
+              "utterances": args.utterances, "utterances_decoded": n_done,
               "n_gpus": world, "tokens": total_tokens, "seconds": round(total_s, 3),
               "passes_s_this_rank": [round(x, 3) for x in pass_s],
               "tokens_per_s": round(total_tokens / total_s, 1),
-              "utterances_per_s": round(n_shard / total_s, 1), "dtype": args.dtype,
+              "utterances_per_s": round(n_done / total_s, 1), "dtype": args.dtype,
               "utterances_per_sequence": args.batch, "streams": args.streams, "plan": args.plan,
               "rows_per_sequence": [len(b[0]) for b in batches],
-              "properties": {"one_hypothesis_per_utterance": len(set(ids)) == n_shard, "every_length_within_its_cap": bool(caps_ok)},
+              "properties": {"one_hypothesis_per_utterance": bool(one_each), "every_length_within_its_cap": bool(caps_ok)},
               "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk, "waitk", False,
                                            total_tokens / total_s, world),
               "timed": "decode of every launch sequence + D2H + hypothesis trimming" +
@@ -281,7 +292,14 @@ def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev
         want = args.utterances if args.shard_of <= 0 else len(ids)
         assert n_rec == want, (n_rec, want)
         from simulst_amd.offline_eval import max_steps
-        caps_ok = all(n <= max_steps(lengths[i]) + 1 for i, n in zip(ids, ntok))
+        if dist is not None:          # the whole job: every rank's gathered records (see the offline path)
+            n_done = n_rec
+            caps_ok = all(len(r["tokens"]) <= max_steps(lengths[i]) + 1 for i, r in recs.items())
+            one_each = n_rec == args.utterances and set(recs) == set(range(args.utterances))
+        else:
+            n_done = len(ids)
+            caps_ok = all(n <= max_steps(lengths[i]) + 1 for i, n in zip(ids, ntok))
+            one_each = len(set(ids)) == len(ids)
         # untimed: what the offline encoder states change.  The chunked streaming encoder advances its rows in lockstep, so the sample is
         # the first rows of the first launch sequence CUT to their shortest length; both forms decode it
         sample = None
@@ -302,14 +320,14 @@ def streaming_eval(args, model, weights, cfg, batches, S, dist, rank, world, dev
         emit({"workload": f"configs[4]: batched STREAMING eval, utterance-sharded ({args.policy}; decoder over the encoder states of ONE "
                           "OFFLINE forward per launch sequence, not the chunked streaming encoder)" +
                           (f" (rank {args.shard_rank} of {args.shard_of}: one rank's shard on one GPU)" if args.shard_of > 0 else ""),
-              "utterances": args.utterances, "utterances_decoded": len(ids),
+              "utterances": args.utterances, "utterances_decoded": n_done,
               "n_gpus": world, "tokens": int(n_tokens), "seconds": round(total_s, 3), "passes_s_this_rank": [round(x, 3) for x in pass_s],
-              "tokens_per_s": round(n_tokens / total_s, 1), "utterances_per_s": round(len(ids) / total_s, 1),
+              "tokens_per_s": round(n_tokens / total_s, 1), "utterances_per_s": round(n_done / total_s, 1),
               "average_lagging_ms_mean": round(al_sum / n_utt, 2), "reads_per_utterance": round(reads / n_utt, 2),
               "dtype": args.dtype, "utterances_per_sequence": args.batch, "streams": S,
               "encoder": "offline states (one padded forward per launch sequence)",
               "chunked_vs_offline_states_on_a_sample": sample,
-              "properties": {"one_record_per_utterance": len(set(ids)) == len(ids), "every_length_within_its_cap": bool(caps_ok)},
+              "properties": {"one_record_per_utterance": bool(one_each), "every_length_within_its_cap": bool(caps_ok)},
               "path_hbm_model": path_model(cfg, lengths, [b[0] for b in batches], dtype, args.waitk,
                                            "hard" if args.policy == "hard" else "waitk", True, n_tokens / total_s, world),
               "form": "self-paced rows, encoder states of one padded offline forward per launch sequence, every row on the "

@@ -202,7 +202,9 @@ def _mma_pass(cfg, model, dec, enc, agent, fb, recs, traces, n_utt, copies, T, w
                     if int(sp_d[l, u, h]) != int(lay["head_step"][0, h]):
                         flips.append({"utterance": u, "call": k, "layer": l, "head": h, "oracle_step": int(lay["head_step"][0, h]),
                                       "hip_step": int(sp_d[l, u, h]), "oracle_margin": round(float(lay["margin"][0, h]), 6),
-                                      "p_abs_err_of_the_head": round(float(e[h]), 6)})
+                                      "p_abs_err_of_the_head": round(float(e[h]), 6),
+                                      # a comparison with 0.5 can flip only if the probability moved by at least the oracle's margin
+                                      "explained_by_the_p_error": bool(float(e[h]) >= float(lay["margin"][0, h]) - 1e-6)})
                 hs_run[u][l] = lay["head_step"][0]
             if c["action"] == 1:
                 tok_checked += 1
@@ -214,6 +216,7 @@ def _mma_pass(cfg, model, dec, enc, agent, fb, recs, traces, n_utt, copies, T, w
                 reads_checked += 1
     return {"p_abs_err": _summ(p_err), "p_abs_err_max_by_layer": [max(x) if x else None for x in p_err_by_layer],
             "decisions": {"searches": len(p_err), "own_search_differs_from_oracle": len(flips),
+                          "not_explained_by_the_p_error": sum(1 for f in flips if not f["explained_by_the_p_error"]),
                           "oracle_margin_at_those": _summ([f["oracle_margin"] for f in flips]),
                           "worst": sorted(flips, key=lambda f: -f["oracle_margin"])[:8]},
             "tokens": {"writes": tok_checked, "differ": len(tok_bad),
@@ -263,7 +266,7 @@ def audit_cif(cfg, w, utts, copies=9, dtype=torch.bfloat16, device="cuda:0", log
             assert r0 + o.size(1) == plan_rows[i]
             r0 = plan_rows[i]
             enc.cif_layer.infer_batched(o.contiguous(), cst, i == len(positions) - 1, trace=ctrace)
-    asum_err, cum_err, count_diffs, copy_mismatch = [], [], [], 0
+    cum_err, cum_signed, count_diffs, copy_mismatch = [], [], [], 0
     got_counts = torch.stack([(c["n"] - (0 if c["finish"] else 1)).cpu() for c in ctrace], 1)           # [B][chunks] vectors released per update
     got_asum = torch.stack([c["alpha_sum"].cpu() for c in ctrace], 1)
     got_tail = torch.stack([c["tail"].cpu() for c in ctrace], 1)
@@ -274,24 +277,32 @@ def audit_cif(cfg, w, utts, copies=9, dtype=torch.bfloat16, device="cuda:0", log
             b = cp * n_utt + u
             if not (torch.equal(got_counts[b], got_counts[u]) and torch.equal(got_asum[b], got_asum[u])):
                 copy_mismatch += 1
+        # What the agent's READ rule looks at is the number of vectors released SO FAR (agents/cif_agent.py:385-389): cumulative
+        # counts and the weight integrated so far over the whole source (a call's accumulation minus the carried tail it started
+        # from).  A release that flips at one update is compensated at the next (the carried tail differs by beta), so per-update
+        # counts differ in pairs while the cumulative ones differ only where the accumulated weight sits near a multiple of beta.
         cum_o = cum_g = 0.0
+        cnt_o = cnt_g = 0
         for c, x in enumerate(ups):
-            asum_err.append(abs(float(got_asum[u, c]) - x["alpha_sum"]))
-            # weight integrated so far over the whole source: this call's accumulation minus the carried tail it started from
             cum_o += x["alpha_sum"] - (ups[c - 1]["tail"] if c > 0 else 0.0)
             cum_g += float(got_asum[u, c]) - (float(got_tail[u, c - 1]) if c > 0 else 0.0)
-            cum_err.append(abs(cum_g - cum_o))
-            if int(got_counts[u, c]) != x["n_new"]:
-                count_diffs.append({"utterance": u, "chunk": c, "oracle_released": x["n_new"], "hip_released": int(got_counts[u, c]),
-                                    "oracle_fire_margin": round(x["fire_margin"], 6),
-                                    "alpha_sum_abs_err": round(abs(float(got_asum[u, c]) - x["alpha_sum"]), 6)})
+            cnt_o += x["n_new"]
+            cnt_g += int(got_counts[u, c])
+            cum_err.append(abs(cum_g - cum_o)); cum_signed.append(cum_g - cum_o)
+            if cnt_g != cnt_o:
+                count_diffs.append({"utterance": u, "chunk": c, "oracle_released_so_far": cnt_o, "hip_released_so_far": cnt_g,
+                                    "oracle_fire_margin": round(x["fire_margin"], 6), "finish": x["finish"],
+                                    "accumulated_weight_abs_err": round(abs(cum_g - cum_o), 6),
+                                    # a count can differ only if the error of the accumulated weight reaches the oracle's margin
+                                    "explained_by_the_weight_error": bool(abs(cum_g - cum_o) >= x["fire_margin"] - 1e-6)})
     total_g = cst["cif_len"].cpu()
     res = {"policy": "cif", "dtype": str(dtype).replace("torch.", ""), "utterances": n_utt, "copies": copies, "rows": B, "frames": T,
            "layer_chains": bool(B > 128 and dtype == torch.bfloat16), "chunks": len(positions),
            "oracle_actions": [r["actions"] for r in recs],
-           "alpha_sum_abs_err_per_update": _summ(asum_err), "accumulated_weight_abs_err_over_the_source": _summ(cum_err),
-           "updates": len(asum_err),
-           "fired_counts": {"updates_where_the_count_differs": len(count_diffs),
+           "accumulated_weight_abs_err": _summ(cum_err), "accumulated_weight_mean_signed_err": sum(cum_signed) / max(len(cum_signed), 1),
+           "updates": len(cum_err),
+           "fired_counts": {"updates_where_the_released_count_differs": len(count_diffs),
+                            "not_explained_by_the_weight_error": sum(1 for c in count_diffs if not c["explained_by_the_weight_error"]),
                             "oracle_fire_margin_at_those": _summ([c["oracle_fire_margin"] for c in count_diffs]),
                             "worst": sorted(count_diffs, key=lambda c: -c["oracle_fire_margin"])[:8],
                             "total_vectors_oracle": [r["n_cif"] for r in recs], "total_vectors_hip": total_g[:n_utt].tolist()},
@@ -352,7 +363,6 @@ def _cif_decoder_pass(cfg, model, dec, cst, traces, n_utt, copies, cap, n_cap, w
             dec.stream_steps(st, ctl, 1, 1.0)
         tok_d = st["tok"].cpu()
         lg_d = st["ws"]["logits"].cpu() if want_logits else None
-        eb_d = st["ws"]["eos_bias"].cpu() if want_logits else None
         for u in live:
             c = traces[u]["writes"][k]
             for cp in range(1, copies):
@@ -363,7 +373,8 @@ def _cif_decoder_pass(cfg, model, dec, cst, traces, n_utt, copies, cap, n_cap, w
                 tok_bad.append({"utterance": u, "write": k, "oracle_top2_gap": round(c["top2_gap"], 5)})
             if want_logits:
                 lg = lg_d[u].clone()
-                lg[cfg.eos] += eb_d[u]                         # the oracle's logits carry the overshoot bias on EOS (:716-722)
+                # the oracle's logits carry the overshoot bias on EOS (:716-722); the device adds it inside the pick
+                lg[cfg.eos] += float(max(0, c["n_prev"] + 1 - c["cif_len"]))
                 logit_err.append(float((lg - c["logits"]).abs().max()))
     return {"tokens": {"writes": tok_checked, "differ": len(tok_bad), "writes_skipped_last_vector_missing": skipped,
                        "oracle_top2_gap_at_those": _summ([t["oracle_top2_gap"] for t in tok_bad]),
@@ -396,7 +407,10 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         open(a.out, "w").write(s)
     for k, v in r.items():
-        brief = {kk: v[kk] for kk in ("p_abs_err", "alpha_sum_abs_err_per_update", "accumulated_weight_abs_err_over_the_source") if kk in v}
+        brief = {kk: v[kk] for kk in ("p_abs_err", "decisions", "accumulated_weight_abs_err", "accumulated_weight_mean_signed_err", "fired_counts") if kk in v}
+        for kk in ("decisions", "fired_counts"):
+            if kk in brief:
+                brief[kk] = {a: b for a, b in brief[kk].items() if a != "worst" and not a.startswith("total_")}
         print(k, json.dumps(brief), "tokens differ", v["tokens"]["differ"], "of", v["tokens"]["writes"],
               "logit err", (v.get("logits") or {}).get("abs_err"))
 
