@@ -92,6 +92,10 @@ def parse_args(argv=None):
     ap.add_argument("--joint-encoder-max-rows", type=int, default=2048,
                     help="plans with at most this many utterances in all run ONE encoder pass for every launch sequence before the "
                          "sequences decode side by side (0: an encoder pass per sequence)")
+    ap.add_argument("--partition", type=int, default=0, metavar="CUS",
+                    help="encoder beside decode on disjoint compute units (model.PartitionedOffline): this many compute units of every "
+                         "XCD (of 32) for the decode streams, the rest for the encoder of the later launch sequences; 0: off")
+    ap.add_argument("--partition-phase-a", type=int, default=0, help="--partition: launch sequences encoded in the first, whole-chip phase (0: half)")
     ap.add_argument("--passes", type=int, default=3,
                     help="timed passes of the K-step plan; value = the MEDIAN pass, all of them are reported")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[1] streaming / configs[2] / configs[3] legs")
@@ -972,7 +976,12 @@ def main(argv=None):
 
     from simulst_amd.model import ConcurrentOffline
     pipe = None
-    if args.concurrency > 1:
+    if args.partition > 0 and args.concurrency > 1:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from partitioned_offline import PartitionedOffline      # experiment, measured negative (profiles/r05_cu_partition_sweep.txt)
+        pipe = PartitionedOffline(model, weights, args.concurrency, decode_cus_per_xcd=args.partition,
+                                  phase_a=args.partition_phase_a or None)
+    elif args.concurrency > 1:
         pipe = ConcurrentOffline(model, weights, args.concurrency, graph=args.graph, stagger_encoders=args.stagger,
                                  joint_encoder_max_rows=args.joint_encoder_max_rows)
     elif not args.no_pipeline:

@@ -76,6 +76,13 @@ int simulst_destroy(simulst_handle* h);
 int simulst_set_stream(simulst_handle* h, void* hip_stream);
 const char* simulst_last_error(simulst_handle* h);
 int simulst_version(void);            /* 105 (round 5: simulst_get_option); a binding built for another value must not use the library */
+/* HIP streams with a compute-unit mask (hipExtStreamCreateWithCUMask) or a priority, for hosts whose framework cannot create them.
+ * cu_mask: mask_words 32-bit words; on MI355X bit i is compute unit (i / 8) of XCD (i % 8) (tools/microbench_cumask.hip), every XCD
+ * must keep at least one unit; NULL / 0: no mask.  priority: 0 default, > 0 greatest, < 0 least (ignored with a mask).  Used by
+ * tools/partitioned_offline.py: the encoder of the next utterances beside the decode loops of the previous ones on DISJOINT
+ * compute units (the offline evaluation loop of eval/generate.py:187-209 over independent batches). */
+int simulst_stream_create(void** out_stream, int32_t priority, const uint32_t* cu_mask, int32_t mask_words);
+int simulst_stream_destroy(void* stream);
 /* per-kernel-class HIP-event timing on the handle's stream (off by default) */
 int simulst_timer_enable(simulst_handle* h, int kernel_class, int on);
 int simulst_timer_read(simulst_handle* h, int kernel_class, double* total_ms, int64_t* launches);

@@ -106,6 +106,8 @@ SIGNATURES = {
     "simulst_graph_enable": [_vp, C.c_int],
     "simulst_set_option": [_vp, _i32, _i32],
     "simulst_get_option": [_vp, _i32, C.POINTER(_i32)],
+    "simulst_stream_create": [C.POINTER(_vp), _i32, _vp, _i32],
+    "simulst_stream_destroy": [_vp],
     "simulst_pack_fragment_major": [_vp, _vp, _vp, _i32, _i32, _i32],
     "simulst_linear": [_vp, C.POINTER(LinearDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "simulst_conv_pos": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32],
@@ -197,6 +199,31 @@ def load():
                            f"{ABI_VERSION} -- rebuild the library (make -C simulst_amd/csrc)")
     _lib = lib
     return lib
+
+
+def cu_mask_words(cus_per_xcd, n_xcd=8, cus_total_per_xcd=32, take_high=False):
+    """Mask words for simulst_stream_create: `cus_per_xcd` compute units of EVERY XCD (bit i = unit i // 8 of XCD i % 8 on MI355X) --
+    the low-numbered units, or with take_high the high-numbered ones (the complement of the low cus_total_per_xcd - cus_per_xcd)."""
+    lo, hi = (cus_total_per_xcd - cus_per_xcd, cus_total_per_xcd) if take_high else (0, cus_per_xcd)
+    words = [0] * (n_xcd * cus_total_per_xcd // 32)
+    for cu in range(lo, hi):
+        for x in range(n_xcd):
+            i = cu * n_xcd + x
+            words[i >> 5] |= 1 << (i & 31)
+    return words
+
+
+def create_stream(device=None, cu_mask=None, priority=0):
+    """A torch stream over a HIP stream made by simulst_stream_create (compute-unit mask words or a priority).  The HIP stream lives
+    as long as the process (a handful per pipeline object)."""
+    import torch
+    lib = load()
+    arr = (C.c_uint32 * len(cu_mask))(*cu_mask) if cu_mask else None
+    out = _vp()
+    rc = lib.simulst_stream_create(C.byref(out), int(priority), arr, len(cu_mask) if cu_mask else 0)
+    if rc != 0:
+        raise RuntimeError(f"simulst_stream_create failed (status {rc})")
+    return torch.cuda.ExternalStream(out.value, device=device)
 
 
 class Handle:

@@ -208,3 +208,31 @@ extern "C" int simulst_get_option(simulst_handle* h, int32_t option, int32_t* va
   h->err = "simulst_get_option: unknown option";
   return SIMULST_E_ARG;
 }
+
+// HIP streams with a compute-unit mask and / or a priority, for callers whose framework cannot create them (torch wraps the returned
+// pointer as an external stream).  cu_mask: mask_words 32-bit words, bit i = compute unit (i / 8) of XCD (i % 8) on MI355X (measured:
+// tools/microbench_cumask.hip; every XCD must keep at least one unit or the runtime ignores the mask); nullptr / 0: no mask.
+// priority: 0 default, > 0 the device's greatest, < 0 its least (ignored with a mask: the extension takes none).
+extern "C" int simulst_stream_create(void** out_stream, int32_t priority, const uint32_t* cu_mask, int32_t mask_words) {
+  if (!out_stream) return SIMULST_E_NULL;
+  hipStream_t s = nullptr;
+  hipError_t e;
+  if (cu_mask && mask_words > 0) {
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask);
+  } else if (priority != 0) {
+    int least = 0, greatest = 0;
+    e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority > 0 ? greatest : least);
+  } else {
+    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  }
+  if (e != hipSuccess) return (int)e;
+  *out_stream = (void*)s;
+  return SIMULST_OK;
+}
+
+extern "C" int simulst_stream_destroy(void* stream) {
+  if (!stream) return SIMULST_E_NULL;
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? SIMULST_OK : (int)e;
+}
