@@ -59,7 +59,7 @@ def main():
     ops = Ops()
     lib, h = ops.lib, ops.h
     if not hasattr(lib, "simulst_debug_chain_probe"):
-        sys.exit("tools/chain_race_probe.py needs the investigation hooks: rebuild with `make -C simulst_amd/csrc clean all DEBUG_HOOKS=1`")
+        sys.exit("tools/chain_race_probe.py needs the investigation hooks: build them with `make -C simulst_amd/csrc DEBUG_HOOKS=1` (the library lands in csrc/build_dbg/) and run with SIMULST_LIB_PATH=simulst_amd/csrc/build_dbg/libsimulst_hip.so")
     B = args.rows
     n_wg = (B + 15) // 16
     g = torch.Generator().manual_seed(12)
