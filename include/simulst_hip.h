@@ -96,15 +96,14 @@ int simulst_graph_enable(simulst_handle* h, int on);
  * parity tests run both -- and the tuning values simulst_create reads from the environment (csrc/handle.cpp).
  *   VALU_ATTENTION          1: bf16 Emformer attention through the fp32-VALU kernel instead of the MFMA one, bf16 decoder
  *                              self-attention through its workgroup kernel instead of the wave-per-head one
- *   UNFUSED_DECODE          1: simulst_mma_decode / simulst_mma_stream_steps with one launch per GEMM (no head-split block, no chains)
- *   FFN_WAVES               simulst_emformer_ffn: 0 the library's choice (the pipelined 4-wave form 43 while F <= 2048); 4 / 8 the block form
- *                           (GELU between the two products) with that many waves per workgroup; 41 / 81 the software-pipelined form
- *                           with the GELU behind the 16 fc1 MFMAs of a tile iteration, 43 / 83 behind all 32 MFMAs, 45 the same with
- *                           64 rows per wave in one 4-wave workgroup per compute unit (measured slower; csrc/ffn_pipe.hip)
- *                           -- all bit-identical
+ *   UNFUSED_DECODE          1: simulst_mma_decode / simulst_mma_stream_steps with one launch per GEMM (no layer chains)
+ *   FFN_WAVES               simulst_emformer_ffn: 0 the library's choice (43 while F <= 2048, else the block form); 43 the software-pipelined
+ *                           form (4 waves, GELU behind the 32 MFMAs of a tile iteration, csrc/ffn_pipe.hip); 4 / 8 the block form (GELU
+ *                           between the two products) with that many waves per workgroup -- all bit-identical.  EXPERIMENTS builds also
+ *                           take 41 / 81 / 83 / 45 (GELU behind the 16 fc1 MFMAs; 8 waves; 64 rows per wave: measured slower)
  *   DEC_CHAIN               0: no row-local layer chains (csrc/dec_chain.hip) in the decode loops
- *   DEC_ATTN_CHAIN_MAX_ROWS rows up to which self-attention rides inside the projection chain (simulst_decoder_attn_proj_chain)
- *   DEC_ATTN_CHAIN_ROWS     rows per workgroup of that launch: 0 chosen from the row count, 4, 8, 16
+ *   DEC_ATTN_CHAIN_MAX_ROWS EXPERIMENTS builds only (E_ARG otherwise): rows up to which self-attention rides inside the projection chain
+ *   DEC_ATTN_CHAIN_ROWS     EXPERIMENTS builds only: rows per workgroup of that launch: 0 chosen from the row count, 4, 8, 16
  *   FUSED_ARGMAX            0: the decode loops write fp32 logits and pick from them (default 1: partial maxima out of the
  *                              vocabulary projection's epilogue where the shapes allow)
  *   DEC_VOCAB_CHAIN_SPLIT   workgroups per 16-row tile of the decode step's closing launch (last layer's slab sum + final LayerNorm +
@@ -115,7 +114,7 @@ int simulst_graph_enable(simulst_handle* h, int on);
  *                              prologue of the next step's first launch, layer 0's LayerNorm + QKV; the call's last step commits as before)
  *   PANEL_WIDE              0: simulst_linear keeps tall bias-only K = 256 projections (8192 rows and more: the encoder's QKV, the joint
  *                              cross K / V projection) on the 32-rows-per-wave row panel (default 1: 64 rows per wave, LDS-DMA weights,
- *                              csrc/gemm_panel.hip panel_wide_kernel; identical results)
+ *                              csrc/gemm_panel.hip panel_wide_kernel; identical results; 2, EXPERIMENTS builds: the same with plain stores)
  * Returns SIMULST_E_ARG for an unknown option or a value outside its range. */
 enum { SIMULST_OPT_VALU_ATTENTION = 0, SIMULST_OPT_UNFUSED_DECODE = 1, SIMULST_OPT_FFN_WAVES = 2, SIMULST_OPT_DEC_CHAIN = 3,
        SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 4, SIMULST_OPT_DEC_ATTN_CHAIN_ROWS = 5, SIMULST_OPT_FUSED_ARGMAX = 6,
@@ -123,6 +122,8 @@ enum { SIMULST_OPT_VALU_ATTENTION = 0, SIMULST_OPT_UNFUSED_DECODE = 1, SIMULST_O
 int simulst_set_option(simulst_handle* h, int32_t option, int32_t value);
 /* the value a handle currently runs with (simulst_create's environment overrides included) */
 int simulst_get_option(simulst_handle* h, int32_t option, int32_t* value);
+/* 1 in a `make EXPERIMENTS=1` build of the library (csrc/Makefile: the measured-slower kernel families and their option values), else 0 */
+int simulst_has_experiments(void);
 
 #ifdef SIMULST_DEBUG_HOOKS
 /* ---- investigation hooks: compiled only by `make DEBUG_HOOKS=1` (csrc/Makefile); the shipped library does not export them ----
@@ -718,6 +719,8 @@ int simulst_decoder_vocab_chain(simulst_handle* h, const void* x_mid, void* x, c
                                 int32_t F, int32_t V, int32_t split, int32_t skip_a, int32_t skip_b, const float* row_bias,
                                 int32_t row_bias_col, int32_t dtype);
 
+#ifdef SIMULST_EXPERIMENTS
+/* ---- `make EXPERIMENTS=1` builds only (measured slower than what ships; kept for the A/B record) ---- */
 /* Self-attention INSIDE the projection chain (round 4): simulst_decoder_self_attention + simulst_decoder_proj_chain in ONE launch,
  * same results bit for bit.  qkv [B][3*256] = this step's q | k | v rows (fairseq MultiheadAttention in_proj of the decoder layer's
  * self-attention; witness models/cif_transformer.py:405-470), k_cache / v_cache [B][4][cap][64] updated in place at position
@@ -732,6 +735,7 @@ int simulst_decoder_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_
                                     const void* wq_fm, const float* bq, void* q, const void* wq2_fm, const float* bq2, void* q2,
                                     const void* kk_gelu, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t n_prev_uniform,
                                     int32_t rows_per_workgroup, int32_t dtype);
+#endif  /* SIMULST_EXPERIMENTS */
 
 /* Pooled monotonic keys for fixed pre-decision with 'average' pooling (modules/fixed_pre_decision.py:23-29,104-110): for the
  * windows j in [j_lo, j_hi) that are complete for row b ((j + 1) * ratio <= key_len[b]), Kpool[b][h][j][:] = mean of frames

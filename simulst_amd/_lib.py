@@ -154,6 +154,11 @@ SIGNATURES = {
     "simulst_decoder_ffn_chain": [_vp] * 14 + [_i32, _i32, _i32, _i32],
     "simulst_decoder_slab_sum_qkv": [_vp] * 10 + [_i32, _i32, _i32, _i32],
     "simulst_decoder_vocab_chain": [_vp] * 9 + [_i32] * 7 + [_vp, _i32, _i32],
+    "simulst_has_experiments": [],
+}
+
+# entry points of a `make EXPERIMENTS=1` build (include/simulst_hip.h, SIMULST_EXPERIMENTS): measured-slower kernel families kept for A/B
+EXPERIMENT_SIGNATURES = {
     "simulst_decoder_attn_proj_chain": [_vp] * 17 + [_i32] * 7,
 }
 
@@ -189,6 +194,11 @@ def load():
         fn.restype = (C.c_char_p if name == "simulst_last_error"
                       else C.c_int64 if name == "simulst_ctc_best_alignment_scratch_bytes"
                       else C.c_int)
+    for name, argtypes in EXPERIMENT_SIGNATURES.items():     # only an EXPERIMENTS build has them
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
     for name, argtypes in DEBUG_SIGNATURES.items():          # only a DEBUG_HOOKS build has them
         fn = getattr(lib, name, None)
         if fn is not None:
@@ -199,6 +209,11 @@ def load():
                            f"{ABI_VERSION} -- rebuild the library (make -C simulst_amd/csrc)")
     _lib = lib
     return lib
+
+
+def has_experiments():
+    """True when the loaded library is a `make EXPERIMENTS=1` build (tests of the measured-slower kernel families skip otherwise)"""
+    return bool(load().simulst_has_experiments())
 
 
 def cu_mask_words(cus_per_xcd, n_xcd=8, cus_total_per_xcd=32, take_high=False):

@@ -705,6 +705,7 @@ __global__ __launch_bounds__(256, 2) void dec_vocab_chain_kernel(
   }
 }
 
+#ifdef SL_EXPERIMENTS     // measured slower than self-attention + projection chain as two launches at every cache length: `make EXPERIMENTS=1`
 // ---------------------------------------------------------------------------------------------------------------------
 // Self-attention INSIDE the projection chain (round 4):
 //   qkv [M][768], K / V caches [M][4][cap][64] --attention--> ctx (LDS only) --Wo, bo, + x--> x --LN--> --Wq, bq--> q (q2 / kk as above)
@@ -949,6 +950,7 @@ __global__ __launch_bounds__(256, 1) void dec_attn_proj_chain_kernel(
   }
 }
 
+#endif  // SL_EXPERIMENTS
 #ifdef SL_DEBUG_HOOKS
 // ---------------------------------------------------------------------------------------------------------------------
 // PROBE form of dec_proj_chain_kernel (Wq2 == nullptr) for tools/chain_race_probe.py: the same instruction sequence, with every
@@ -1252,6 +1254,7 @@ int sl_dec_embed_qkv_chain(simulst_handle* h, const float2* pairs, int n_pairs, 
   return sl_launch_status(h, "simulst_mma_decode(commit + embedding + LN + QKV chain)");
 }
 
+#ifdef SL_EXPERIMENTS
 // self-attention + projection chain in one launch (dec_attn_proj_chain_kernel): bf16, 4 heads x 64, cache capacity <= 128
 bool sl_dec_attn_chain_ok(const simulst_handle* h, int dtype, int B, int H, int d, int cap) {
   return dtype == SIMULST_BF16 && H == 4 && d == 64 && cap <= 128 && !h->force_valu_attention && B <= h->dec_attn_chain_max_rows;
@@ -1275,6 +1278,15 @@ int sl_dec_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, vo
 #undef AC
   return sl_launch_status(h, "simulst_mma_decode(self-attention + out-proj + LN + q-proj chain)");
 }
+#else
+// the one-launch self-attention + projection chain is an EXPERIMENTS build's (measured slower); the decode loops never take it here
+bool sl_dec_attn_chain_ok(const simulst_handle*, int, int, int, int, int) { return false; }
+int sl_dec_attn_proj_chain(simulst_handle* h, const void*, void*, void*, const int32_t*, int, int, void*, const void*, const float*, const float*,
+                           const float*, const void*, const float*, void*, const void*, const float*, void*, int, const void*) {
+  h->err = "self-attention inside the projection chain: an EXPERIMENTS build only";
+  return SIMULST_E_ARG;
+}
+#endif
 
 // C-ABI entry points of the two chains (the decode loop calls the internal forms above; these exist so that each chain
 // can be checked against a plain fp32 reference on its own, tests/test_hip_dec_chain.py)
@@ -1340,6 +1352,7 @@ extern "C" int simulst_decoder_vocab_chain(simulst_handle* h, const void* x_mid,
                             skip_b, row_bias, row_bias_col);
 }
 
+#ifdef SL_EXPERIMENTS
 extern "C" int simulst_decoder_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache,
                                                const int32_t* n_prev, void* x, const void* wo_fm, const float* bo,
                                                const float* ln_g, const float* ln_b, const void* wq_fm, const float* bq, void* q,
@@ -1366,6 +1379,7 @@ extern "C" int simulst_decoder_attn_proj_chain(simulst_handle* h, const void* qk
   h->dec_attn_chain_rows = keep;
   return rc;
 }
+#endif  // SL_EXPERIMENTS
 
 #ifdef SL_DEBUG_HOOKS
 // ---- debug hooks of the reproducibility investigation (tools/chain_race_probe.py) ----------------

@@ -803,8 +803,12 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
              "simulst_mma_decode: fragment-major weights need D, F multiples of 64, V and head_dim of 16");
   // head-split self-attention block (decode_fused.hip): 5 launches per layer instead of 7 when the host supplied the
   // partial buffer, the weights are fragment-major and the shapes fit (cached target positions <= 256)
+#ifdef SL_EXPERIMENTS
   const bool split = pk && dd->x_mid && dd->partial_self && !h->force_unfused_decode &&
                      sl_self_attention_fused_ok(H, d, dd->cap) && B <= 128 && (dt == SIMULST_BF16 ? D <= 512 : D <= 256);
+#else
+  const bool split = false;          // decode_fused.hip: measured slower, EXPERIMENTS builds only
+#endif
   // LN2 + query projection inside the policy/cross-attention launch (few rows: one launch less on the dependent
   // chain) or as its own GEMM (many rows: no per-workgroup re-read of the projection weights)
   const bool fuse_q = split || B <= h->fuse_q_max_rows;

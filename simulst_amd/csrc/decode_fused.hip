@@ -10,7 +10,10 @@
 // consumer (policy_cross_attn_kernel) adds the H partials in head order, the bias and the residual, and
 // rounds once -- deterministic, no atomics, same rounding points as the unfused path
 // (reference: fairseq TransformerDecoderLayer self-attention block as used by models/mma_model.py:99-135).
+// EXPERIMENTS builds only (make EXPERIMENTS=1): with the layer chains taking every batch above 128 rows and this block measuring slower
+// than the seven-launch layer below that (404 k vs 527 k tokens/s at 128 rows, simulst_amd/decoder.py head_split), nothing shipped runs it.
 #include "attn_core.h"
+#ifdef SL_EXPERIMENTS
 #include "gemv_mfma.h"
 
 namespace {
@@ -186,3 +189,11 @@ int sl_self_attention_fused(simulst_handle* h, const void* x, const float* ln_g,
   return sl_launch_status(h, "simulst_mma_decode(self-attention block)");
 }
 
+
+#else
+int sl_self_attention_fused(simulst_handle* h, const void*, const float*, const float*, const void*, const float*, const void*, void*, void*,
+                            const int32_t*, int, float*, int32_t, int32_t, int32_t, int32_t, int32_t) {
+  h->err = "head-split self-attention block: an EXPERIMENTS build only";
+  return SIMULST_E_ARG;
+}
+#endif  // SL_EXPERIMENTS

@@ -428,6 +428,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
 }
 
 
+#ifdef SL_EXPERIMENTS     // 64 rows per wave, one 4-wave workgroup per compute unit: 0.52-0.54 PFLOP/s against 0.87 (profiles/r04_ffn_bench_wide.json)
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // WIDE form (round 4, third form): 64 rows per wave -- RT = 2 row tiles of 32 -- in ONE 4-wave workgroup per compute unit (one wave per
 // SIMD, 512 registers).  Every weight fragment a wave reads from LDS then feeds TWO MFMAs (one per row tile): the uniform form's third
@@ -638,6 +639,8 @@ __global__ __launch_bounds__(256, 1) void ffn_wide_kernel(
   }
 }
 
+#endif  // SL_EXPERIMENTS
+
 }  // namespace
 
 int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
@@ -646,12 +649,19 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
 #ifndef SL_DEBUG_HOOKS
   packed = 0;
 #endif
+  // the shipped form: 4 waves, a quarter of an element pair's GELU behind each of the 32 MFMAs of an iteration (SIMULST_OPT_FFN_WAVES 43);
+  // the 8-wave, phase and 64-rows-per-wave forms measured slower and exist in EXPERIMENTS builds (41 / 45 / 81 / 83; 42 / 82 DEBUG_HOOKS)
+#ifndef SL_EXPERIMENTS
+  waves = 4; uniform = 1;
+#endif
   if (!h->ffn_pipe_lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+#ifdef SL_EXPERIMENTS
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FWG::LDS);
+#endif
 #ifdef SL_DEBUG_HOOKS
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
@@ -665,12 +675,16 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
 #ifdef SL_DEBUG_HOOKS
   if (packed) { if (waves == 8) FPL(8, true, false); else FPL(4, true, false); } else
 #endif
+#ifdef SL_EXPERIMENTS
   if (uniform == 2) {
     hipLaunchKernelGGL((ffn_wide_kernel<2>), dim3((unsigned)((rows + 255) / 256)), dim3(256), FWG::LDS, h->stream, (const bf16*)x, ln_g, ln_b,
                        (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F);
   } else
   if (uniform) { if (waves == 8) FPL(8, false, true); else FPL(4, false, true); }
   else { if (waves == 8) FPL(8, false, false); else FPL(4, false, false); }
+#else
+  FPL(4, false, true);
+#endif
 #undef FPL
 #ifdef SL_PROBE
   {

@@ -450,10 +450,12 @@ int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, co
                     void* aux, const LinArgs& p) {
   if (panel_wide_wanted(h, epi, p)) {
     KTimer tw(h, SIMULST_K_LINEAR);
+#ifdef SL_EXPERIMENTS      // default-policy stores instead of streaming ones (SIMULST_OPT_PANEL_WIDE = 2): measured slower
     if (h->panel_wide_plain_stores)
       hipLaunchKernelGGL(panel_wide_kernel<false>, dim3((p.M + PW_M - 1) / PW_M), dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias,
                          (bf16*)C, p);
     else
+#endif
       hipLaunchKernelGGL(panel_wide_kernel<true>, dim3((p.M + PW_M - 1) / PW_M), dim3(256), 0, h->stream, (const bf16*)A, (const bf16*)W, bias,
                          (bf16*)C, p);
     return sl_launch_status(h, "simulst_linear(wide row panel)");

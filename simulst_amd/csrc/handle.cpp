@@ -53,7 +53,9 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_DEC_CHAIN_LDS_BYTES")) { const int v = atoi(e); if (v >= 0 && v <= 160 * 1024) h->dec_chain_lds_bytes = v; }
 #endif
   h->dec_attn_chain_max_rows = 0;      // OFF: measured slower than the two launches at every cache length (dec_chain.hip)
+#ifdef SL_EXPERIMENTS
   if (const char* e = getenv("SIMULST_DEC_ATTN_CHAIN_MAX_ROWS")) h->dec_attn_chain_max_rows = atoi(e);
+#endif
   h->dec_attn_chain_rows = 0;
   // the decode step's closing launch (dec_chain.hip dec_vocab_chain_kernel), workgroups per 16-row tile.  Driver form at 448-row sequences
   // (bench.py --steps 20, two rounds each): off 1.490 / 1.497 M tokens/s, 1: 1.474, 2: 1.500 / 1.492, 4: 1.515 / 1.514 / 1.504, 8: 1.498 / 1.504 /
@@ -64,7 +66,12 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_DEC_EMBED_QKV_CHAIN")) h->dec_embed_qkv_chain = atoi(e) != 0;
   h->panel_wide = true;
   h->panel_wide_plain_stores = false;
-  if (const char* e = getenv("SIMULST_PANEL_WIDE")) { h->panel_wide = atoi(e) != 0; h->panel_wide_plain_stores = atoi(e) == 2; }
+  if (const char* e = getenv("SIMULST_PANEL_WIDE")) {
+    h->panel_wide = atoi(e) != 0;
+#ifdef SL_EXPERIMENTS
+    h->panel_wide_plain_stores = atoi(e) == 2;
+#endif
+  }
   h->policy_lds_bytes = 0;
   if (const char* e = getenv("SIMULST_POLICY_LDS_BYTES")) { const int v = atoi(e); if (v >= 0 && v <= 64 * 1024) h->policy_lds_bytes = v; }
   h->fused_argmax = true;      // greedy pick's partial maxima in the vocabulary projection's epilogue (decode loops, bf16, co-scheduled rows)
@@ -163,20 +170,43 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
     case SIMULST_OPT_VALU_ATTENTION: h->force_valu_attention = value != 0; return SIMULST_OK;
     case SIMULST_OPT_UNFUSED_DECODE: h->force_unfused_decode = value != 0; return SIMULST_OK;
     case SIMULST_OPT_FFN_WAVES:
-      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 41 || value == 42 || value == 43 || value == 45 || value == 81 || value == 82 || value == 83, SIMULST_E_ARG,
+#ifdef SL_EXPERIMENTS
+      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 41 || value == 43 || value == 45 || value == 81 || value == 83
+#ifdef SL_DEBUG_HOOKS
+                        || value == 42 || value == 82
+#endif
+                 , SIMULST_E_ARG,
                  "simulst_set_option(FFN_WAVES): 0 (the library's choice), 4 / 8 (GELU as a block between the products), 41 / 81 (GELU inside the "
-                 "MFMA stream, 4 / 8 waves; 42 / 82: packed GELU, DEBUG_HOOKS builds, else the scalar form; 43 / 83: GELU spread over all 32 MFMAs; 45: 64 rows per wave)");
+                 "MFMA stream, 4 / 8 waves; 42 / 82: packed GELU, DEBUG_HOOKS builds only), 43 / 83 (GELU spread over all 32 MFMAs), 45 (64 rows per wave)");
+#else
+      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 43, SIMULST_E_ARG,
+                 "simulst_set_option(FFN_WAVES): 0 (the library's choice: 43 while F <= 2048), 43 (GELU inside the MFMA stream), 4 / 8 (the block form "
+                 "with that many waves: GELU between the two products); the measured-slower forms exist in EXPERIMENTS builds");
+#endif
       h->ffn_waves = value; return SIMULST_OK;
     case SIMULST_OPT_DEC_CHAIN: h->dec_chain_on = value != 0; return SIMULST_OK;
+#ifdef SL_EXPERIMENTS
     case SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS:
       SL_REQUIRE(h, value >= 0, SIMULST_E_ARG, "simulst_set_option(DEC_ATTN_CHAIN_MAX_ROWS): >= 0");
       h->dec_attn_chain_max_rows = value; return SIMULST_OK;
     case SIMULST_OPT_DEC_ATTN_CHAIN_ROWS:
       SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG, "simulst_set_option(DEC_ATTN_CHAIN_ROWS): 0, 4, 8 or 16");
       h->dec_attn_chain_rows = value; return SIMULST_OK;
+#else
+    case SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS:
+    case SIMULST_OPT_DEC_ATTN_CHAIN_ROWS:
+      h->err = "simulst_set_option: self-attention inside the projection chain exists in EXPERIMENTS builds only (measured slower)";
+      return SIMULST_E_ARG;
+#endif
     case SIMULST_OPT_FUSED_ARGMAX: h->fused_argmax = value != 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_EMBED_QKV_CHAIN: h->dec_embed_qkv_chain = value != 0; return SIMULST_OK;
-    case SIMULST_OPT_PANEL_WIDE: h->panel_wide = value != 0; h->panel_wide_plain_stores = value == 2; return SIMULST_OK;
+    case SIMULST_OPT_PANEL_WIDE:
+#ifdef SL_EXPERIMENTS
+      SL_REQUIRE(h, value >= 0 && value <= 2, SIMULST_E_ARG, "simulst_set_option(PANEL_WIDE): 0, 1, 2 (plain stores)");
+#else
+      SL_REQUIRE(h, value == 0 || value == 1, SIMULST_E_ARG, "simulst_set_option(PANEL_WIDE): 0 or 1 (2, plain stores: EXPERIMENTS builds)");
+#endif
+      h->panel_wide = value != 0; h->panel_wide_plain_stores = value == 2; return SIMULST_OK;
     case SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT:
       SL_REQUIRE(h, value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG,
                  "simulst_set_option(DEC_VOCAB_CHAIN_SPLIT): 0 (off), 1, 2, 4, 8 or 16");
@@ -235,4 +265,13 @@ extern "C" int simulst_stream_destroy(void* stream) {
   if (!stream) return SIMULST_E_NULL;
   hipError_t e = hipStreamDestroy((hipStream_t)stream);
   return e == hipSuccess ? SIMULST_OK : (int)e;
+}
+
+// 1 in a `make EXPERIMENTS=1` build (the measured-slower kernel families and their option values are compiled in), else 0
+extern "C" int simulst_has_experiments(void) {
+#ifdef SL_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
 }

@@ -227,7 +227,7 @@ class MMADecoder:
         # 64-row sequence (211 k vs 204 k tokens/s) but every (head, row) workgroup re-streams its 128 KB of
         # weights, so it loses as soon as independent work shares the chip (352 k vs 404 k with 3 streams,
         # 404 k vs 527 k at 128 rows) => off by default, SIMULST_HEAD_SPLIT=1 / .head_split = True turns it on.
-        self.head_split = os.environ.get("SIMULST_HEAD_SPLIT", "0") == "1"
+        self.head_split = os.environ.get("SIMULST_HEAD_SPLIT", "0") == "1" and _lib.has_experiments()   # EXPERIMENTS builds only
         # row-local layer chains (csrc/dec_chain.hip) for co-scheduled bf16 batches: the library takes them from
         # SIMULST_DEC_CHAIN_MIN_ROWS rows on when the slab workspace below is passed
         self.layer_chains = os.environ.get("SIMULST_LAYER_CHAINS", "1") == "1"

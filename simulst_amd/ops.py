@@ -338,6 +338,8 @@ class Ops:
             q = torch.empty_like(x)
         if wq2_fm is not None and q2 is None:
             q2 = torch.empty_like(x)
+        if not hasattr(self.lib, "simulst_decoder_attn_proj_chain") or not _lib.has_experiments():
+            raise RuntimeError("simulst_decoder_attn_proj_chain: an EXPERIMENTS build of the library only (measured slower than the two launches)")
         self.h.check(self.lib.simulst_decoder_attn_proj_chain(self.h.ptr, _p(qkv), _p(k_cache), _p(v_cache), _p(n_prev), _p(x),
                                                               _p(wo_fm), _p(bo), _p(ln[0]), _p(ln[1]), _p(wq_fm), _p(bq), _p(q),
                                                               _p(wq2_fm), _p(bq2), _p(q2), _p(kk_gelu), B, H, d, cap,

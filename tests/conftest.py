@@ -13,6 +13,25 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments: parity tests of the measured-slower kernel families; they run against a "
+                                       "`make -C simulst_amd/csrc EXPERIMENTS=1` build (SIMULST_LIB_PATH=simulst_amd/csrc/build_exp/libsimulst_hip.so) "
+                                       "and skip against the shipped library")
+
+
+def pytest_collection_modifyitems(config, items):
+    """the shipped library does not hold the experiment kernels: the GPU suite tests what ships (prune)"""
+    exp = [it for it in items if it.get_closest_marker("experiments")]
+    if not exp:
+        return
+    from simulst_amd import _lib
+    try:
+        have = _lib.has_experiments()
+    except Exception:
+        have = False
+    if not have:
+        skip = pytest.mark.skip(reason="needs an EXPERIMENTS build of the library (make -C simulst_amd/csrc EXPERIMENTS=1 + SIMULST_LIB_PATH)")
+        for it in exp:
+            it.add_marker(skip)
 
 
 @pytest.fixture(autouse=True)

@@ -9,11 +9,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions(debug_hooks=False):
+def header_functions(debug_hooks=False, experiments=False):
     src = open(os.path.join(ROOT, "include", "simulst_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     if not debug_hooks:        # the investigation hooks exist only in a `make DEBUG_HOOKS=1` build (hygiene)
         src = re.sub(r"#ifdef SIMULST_DEBUG_HOOKS.*?#endif", "", src, flags=re.S)
+    if not experiments:        # the measured-slower kernel families only in a `make EXPERIMENTS=1` build (prune)
+        src = re.sub(r"#ifdef SIMULST_EXPERIMENTS.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(simulst_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -53,6 +55,15 @@ def test_shipped_library_has_no_debug_hooks():
     assert lib.simulst_create(ctypes.byref(h), None) == 0
     assert lib.simulst_set_option(h, _lib.OPT_FFN_WAVES, 4) == 0
     assert lib.simulst_set_option(h, _lib.OPT_FFN_WAVES, 5) == -4 and b"FFN_WAVES" in lib.simulst_last_error(h)
+    # ... and no experiment: the measured-slower kernel families, their entry point and their option values are an EXPERIMENTS build's
+    assert lib.simulst_has_experiments() == 0
+    exp = sorted(set(header_functions(experiments=True)) - set(header_functions()))
+    assert exp == sorted(_lib.EXPERIMENT_SIGNATURES) and all(not hasattr(lib, n) for n in exp)
+    for opt, val in ((_lib.OPT_FFN_WAVES, 81), (_lib.OPT_FFN_WAVES, 45), (_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 1024), (_lib.OPT_PANEL_WIDE, 2)):
+        assert lib.simulst_set_option(h, opt, val) == -4, (opt, val)
+    v = ctypes.c_int32(-1)
+    assert lib.simulst_get_option(h, _lib.OPT_DEC_VOCAB_CHAIN_SPLIT, ctypes.byref(v)) == 0 and v.value == 4
+    assert lib.simulst_get_option(h, 99, ctypes.byref(v)) == -4
     assert lib.simulst_set_option(h, 99, 1) == -4
     assert lib.simulst_destroy(h) == 0
 

@@ -111,6 +111,7 @@ def test_ffn_chain_vs_torch(ops, B, F):
             assert qkv is None
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("B,rows", [(1, 4), (5, 4), (130, 4), (448, 4), (448, 8), (448, 16), (700, 0), (1100, 8)])
 @pytest.mark.parametrize("variant", ["plain", "soft", "cif"])
 @pytest.mark.parametrize("uniform", [-1, 0, 7, 63, 64, 109])
@@ -459,11 +460,13 @@ def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):
     w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(5)) \
         * cfg.embed_dim ** -0.5
     o_new, o_old = Ops(), Ops()
-    o_new.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 1024)      # off by default: measured slower (csrc/dec_chain.hip)
+    if _lib.has_experiments():                             # self-attention inside the projection chain: an EXPERIMENTS build's
+        o_new.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 1024)
     for o in (o_new, o_old):                               # the step's closing / opening launches normalise in another order: own tests above
         o.h.set_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT, 0)
         o.h.set_option(_lib.OPT_DEC_EMBED_QKV_CHAIN, 0)
-    o_old.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 0)
+    if _lib.has_experiments():
+        o_old.h.set_option(_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 0)
     o_old.h.set_option(_lib.OPT_FUSED_ARGMAX, 0)
     t_new = make(o_new).generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)[0].clone()
     t_old = make(o_old).generate_offline(fb, L, n_steps=U, mask_eos=mask_eos)[0].clone()
@@ -517,7 +520,9 @@ def test_chains_repeat_beside_other_streams(ops):
         ops.decoder_ffn_chain(ctx, x, Wco, bD, ln, W1, bF, W2, bD, partial=partial, x_mid=x_mid)
         qkv = ops.decoder_slab_sum_qkv(x_mid, x2, partial, bD, ln, Wqkv, b3)
         x3, kc, vc = x0.clone(), kc0.clone(), vc0.clone()
-        q3, _ = ops.decoder_attn_proj_chain(qkv_in, kc, vc, n_prev, x3, Wo, bD, ln, Wq, bD)
+        q3 = x3
+        if _lib.has_experiments():
+            q3, _ = ops.decoder_attn_proj_chain(qkv_in, kc, vc, n_prev, x3, Wo, bD, ln, Wq, bD)
         # ... and the step's closing launch (slab sum + final LayerNorm + vocabulary projection + partial greedy pick)
         x4 = torch.empty_like(x)
         pv, pc = ops.decoder_vocab_chain(x_mid, x4, partial, bD, ln, Wout, 4096, 4, 1, 2)

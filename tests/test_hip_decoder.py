@@ -211,6 +211,7 @@ def test_concurrent_batches_equal_serial(ops):
         assert torch.equal(a, b)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("attn", ["waitk_fixed_pre_decision", "hard_aligned_fixed_pre_decision",
                                   "infinite_lookback_fixed_pre_decision"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
