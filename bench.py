@@ -95,6 +95,7 @@ def parse_args(argv=None):
     ap.add_argument("--partition", type=int, default=0, metavar="CUS",
                     help="encoder beside decode on disjoint compute units (model.PartitionedOffline): this many compute units of every "
                          "XCD (of 32) for the decode streams, the rest for the encoder of the later launch sequences; 0: off")
+    ap.add_argument("--plan", default="", help="explicit batches per launch sequence, e.g. 8,8,4 (must sum to --steps); default: plan_launch_sequences")
     ap.add_argument("--partition-phase-a", type=int, default=0, help="--partition: launch sequences encoded in the first, whole-chip phase (0: half)")
     ap.add_argument("--passes", type=int, default=3,
                     help="timed passes of the K-step plan; value = the MEDIAN pass, all of them are reported")
@@ -949,6 +950,10 @@ def main(argv=None):
     G = max(1, args.group)
     # the plan that is executed: batches per launch sequence, sequences dealt round-robin to the streams
     plan = plan_launch_sequences(args.steps, G, args.concurrency, min_per_sequence=args.min_per_sequence)
+    if args.plan:
+        plan = [int(x) for x in args.plan.split(",")]
+        if sum(plan) != args.steps or min(plan) <= 0:
+            raise SystemExit(f"--plan {args.plan}: positive batch counts that sum to --steps {args.steps}")
     g_max = max(plan) if plan else 1
     streams_used = min(args.concurrency, len(plan)) if args.concurrency > 1 else 1
     # synthetic fbank resident in HBM before the clock starts, one DISTINCT utterance per decoded row (B * sum(plan) of them):

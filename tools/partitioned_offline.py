@@ -42,14 +42,24 @@ class PartitionedOffline:
         with torch.cuda.stream(self.s_enc_full):
             self.enc_ops = Ops(_lib.Handle(self.s_enc_full.cuda_stream))
             self.enc_model = SimulSTModel(model.cfg, weights, device=dev, dtype=model.dtype, ops=self.enc_ops, share_with=model)
-        self.models, self.s_masked, self.s_plain = [], [], []
+        # decode replicas: one per launch sequence; their streams are made on first use (a masked one for a sequence of the first
+        # phase, a plain one for the others) so that no more HIP streams exist than run -- the device keeps a handful of hardware queues
+        # and streams that share one serialise
+        self.models, self._streams = [], {}
+        self._mask_d, self._weights = mask_d, weights
         for _ in range(concurrency):
-            sm, sp = _lib.create_stream(dev, cu_mask=mask_d), torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(sm):
-                ops = Ops(_lib.Handle(sm.cuda_stream))
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                ops = Ops(_lib.Handle(st.cuda_stream))
                 self.models.append(SimulSTModel(model.cfg, weights, device=dev, dtype=model.dtype, ops=ops, share_with=model))
-            self.s_masked.append(sm)
-            self.s_plain.append(sp)
+            self._streams[(len(self.models) - 1, False)] = st
+
+    def _stream(self, i, masked):
+        from simulst_amd import _lib
+        key = (i, bool(masked))
+        if key not in self._streams:
+            self._streams[key] = _lib.create_stream(self.model.device, cu_mask=self._mask_d) if masked else torch.cuda.Stream(device=self.model.device)
+        return self._streams[key]
 
     def _encode(self, batches, stream, after=None):
         """ONE encoder pass over the stacked rows of `batches` on `stream` -> per batch (encoder rows, lengths), the event, the dict"""
@@ -86,7 +96,8 @@ class PartitionedOffline:
             raise ValueError("PartitionedOffline stacks the sequences' rows for the encoder: equal frame counts needed")
         k_a = min(k, self.phase_a if self.phase_a else (k + 1) // 2)
         cur = torch.cuda.current_stream()
-        for st in [self.s_enc_full, self.s_enc_part] + self.s_masked + self.s_plain:
+        used = [self.s_enc_full, self.s_enc_part] + [self._stream(i, i < k_a) for i in range(k)]
+        for st in used:
             st.wait_stream(cur)
         keep = []
         parts_a, ev_a, enc_a = self._encode(batches[:k_a], self.s_enc_full)
@@ -104,7 +115,7 @@ class PartitionedOffline:
             try:
                 if dev_index is not None:
                     torch.cuda.set_device(dev_index)
-                st = self.s_masked[i] if i < k_a else self.s_plain[i]
+                st = self._stream(i, i < k_a)
                 m = self.models[i]
                 m.ops.h.set_stream(st.cuda_stream)
                 with torch.no_grad(), torch.cuda.stream(st):
@@ -119,7 +130,7 @@ class PartitionedOffline:
             t.start()
         for t in threads:
             t.join()
-        for st in [self.s_enc_full, self.s_enc_part] + self.s_masked + self.s_plain:      # host-side join (see ConcurrentOffline.run)
+        for st in used:      # host-side join (see ConcurrentOffline.run)
             st.synchronize()
         del keep
         if errs:
