@@ -75,7 +75,11 @@ __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restr
   const int b = pair / H, h = pair - b * H;
   const int D = H * d;
   const int np = np_uniform >= 0 ? np_uniform : n_prev[b];
+#ifdef SL_ABLATE_SELF       // timing ablation (results invalid): one cached row instead of np + 1 -- what the launch costs without its bytes
+  const int n = 1;
+#else
   const int n = np + 1;
+#endif
   const bf16* row = qkv + (long)b * 3 * D;
   bf16* Kh = kc + ((long)b * H + h) * cap * d;
   bf16* Vh = vc + ((long)b * H + h) * cap * d;

@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void 
   const int tg = tgt_idx ? tgt_idx[b] : 0;    // scalar inputs of the policy: issued with the prefetch
   const long hs = head_step[r];
   if (n_hint < 0) n_hint = attn_type == SIMULST_ATTN_WAITK ? (tg + waitk_k) * ratio : S_cap;
+#ifdef SL_ABLATE_CROSS      // timing ablation (results invalid): 8 key / value rows instead of the visible source
+  n_hint = 8;
+#endif
   const bool fusedq = FQ && xres != nullptr;
   const int n_pref = min(S_cap, n_hint);
   if constexpr (NP > 0) {
