@@ -487,6 +487,30 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                           "average_lagging_ms_mean": round(sum(r["AL"] for rb in recs_c for r in rb) / rows_c, 2),
                           "form": "self-paced rows, encoder states of one offline forward per launch sequence (agent.ConcurrentStreamingEval): "
                                   "the utterances and the schedule of this config's offline leg, decoded with the simultaneous policy"}
+            # the microphone form with SEVERAL groups of live streams side by side: a group's masked steps cost their
+            # launch latency whatever the row count (~38 of 448 rows write in an average step), so what raises the device's live capacity
+            # is more groups on more HIP streams, not fewer idle rows per group
+            groups = min(args.concurrency, 3)
+            # group g takes rows_s consecutive utterances starting at an even spread of offsets (groups may share utterances: every row is
+            # an independent live stream either way; group 0 = the single-group run's rows)
+            span = max(fb_all.size(0) - rows_s, 0)
+            live = [(fb_all[(g_ * span) // max(groups - 1, 1):(g_ * span) // max(groups - 1, 1) + rows_s], None) for g_ in range(groups)] if span > 0 else []
+            mic_groups = None
+            if len(live) > 1:
+                cse.run(live, self_paced=False)
+                ts_m, recs_m = [], None
+                for _ in range(max(1, args.passes)):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    recs_m = cse.run(live, self_paced=False)
+                    torch.cuda.synchronize()
+                    ts_m.append(time.perf_counter() - t0)
+                n_m = sum(len(r["tokens"]) for rb in recs_m for r in rb)
+                mic_groups = {"tokens_per_s": round(n_m / sorted(ts_m)[len(ts_m) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts_m],
+                              "groups": len(live), "rows_per_group": rows_s, "live_streams": len(live) * rows_s, "tokens_per_pass": n_m,
+                              "first_group_rows_identical_to_the_single_group_run":
+                                  sum(all(a[k] == b[k] for k in ("actions", "tokens", "delays_ms")) for a, b in zip(recs_m[0], recs)),
+                              "form": "microphone form (lockstep sources, one host round trip per chunk), one group of live streams per HIP stream"}
             del cse
             keys3 = ("actions", "tokens", "delays_ms")
             paced["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_p, recs))
@@ -520,6 +544,7 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                                            "(agents/default_agent.py:367,407); sources advance in lockstep, the host feeds one chunk at a time",
                               "evaluation_form_self_paced_rows": paced, "evaluation_form_offline_encoder_states": paced_off,
                               "evaluation_form_whole_plan_on_streams": whole_plan,
+                              "microphone_form_groups_side_by_side": mic_groups,
                               "evaluation_form": "sources already on the device (SimulEval reading files): every chunk encoded first, then "
                                                  "one device loop in which a row takes its next chunk itself when its policy says READ "
                                                  "(simulst_stream_ctl / simulst_cif_stream_ctl schedules); same READ / WRITE strings, "
@@ -742,6 +767,9 @@ def _leg_summary(leg):
     if bs:
         o["streamed_tokens_per_s"] = bs.get("tokens_per_s")
         o["streamed_self_paced_tokens_per_s"] = (bs.get("evaluation_form_self_paced_rows") or {}).get("tokens_per_s")
+        mg = bs.get("microphone_form_groups_side_by_side") or {}
+        if mg:
+            o["streamed_groups_tokens_per_s"] = [mg.get("tokens_per_s"), mg.get("live_streams")]
         o["AL_ms_mean"] = bs.get("average_lagging_ms_mean")
         o["rows"] = bs.get("rows")
     if par:

@@ -409,10 +409,13 @@ class ConcurrentStreamingEval:
                 self.agents.append(agent_factory(m) if agent_factory is not None else BatchedStreamingAgent(m))
             self.streams.append(st)
 
-    def run(self, batches, encoder: str = "offline"):
+    def run(self, batches, encoder: str = "offline", self_paced: bool = True):
         """batches: (fbank [B, T, 80], lengths or None) pairs, already on the device.  Returns one list of records per batch.
         The streams take the batches from a queue in the given order (a run ends with a read-back, so a free host thread means a
-        free stream): put the expensive ones first."""
+        free stream): put the expensive ones first.
+        self_paced=False: every batch in the MICROPHONE form (sources advance in lockstep, one host round trip per chunk and per group
+        of masked steps; equal lengths, the streaming encoder): several groups of live streams side by side -- a group's masked steps
+        are latency-bound whatever its row count, so groups on different HIP streams overlap."""
         import threading
         batches = list(batches)
         out, errs = [None] * len(batches), []
@@ -433,7 +436,8 @@ class ConcurrentStreamingEval:
                                 break
                             i = queue.pop(0)
                         fb, lengths = batches[i]
-                        out[i] = self.agents[c].run_batch(fb, self_paced=True, encoder=encoder, lengths=lengths)
+                        out[i] = (self.agents[c].run_batch(fb, self_paced=True, encoder=encoder, lengths=lengths) if self_paced
+                                  else self.agents[c].run_batch(fb))
             except Exception as e:          # surfaced to the caller below
                 errs.append(e)
 
