@@ -473,8 +473,9 @@ def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):
     torch.cuda.synchronize()
     assert torch.equal(t_new, t_old), (t_new != t_old).sum().item()
     assert len(set(t_new.flatten().tolist())) > 50         # not a degenerate hypothesis
-    # ... and the fused launches really ran: the attention-chain kernel class has launches on the new handle only
-    for o, want in ((o_new, True), (o_old, False)):
+    # ... and the fused launches really ran: the attention-chain kernel class has launches on the new handle only (EXPERIMENTS builds:
+    # the shipped library has no such kernel, there the comparison above is about the greedy pick's partial maxima alone)
+    for o, want in ((o_new, _lib.has_experiments()), (o_old, False)):
         o.h.timer_reset(); o.h.timer_enable(-1, True)
         make(o).generate_offline(fb, L, n_steps=2, mask_eos=mask_eos)
         torch.cuda.synchronize()
