@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void panel_wide_kernel(const bf16* __restri
                                                             const float* __restrict__ bias, bf16* __restrict__ C, LinArgs p) {
   __shared__ __attribute__((aligned(16))) uint4 wl[PW_NS][2 * 8 * 64];           // [slot][(j, s)][lane]: 3 x 16 KB
   __shared__ __attribute__((aligned(16))) unsigned short stage[5][64 * PW_SS];   // per wave [64 rows][32 columns] bf16; [0] and [4]: the loader's two
-  __shared__ __attribute__((aligned(16))) float bl[2][PW_N];                     // bias of the step (loader -> everyone)
+  __shared__ __attribute__((aligned(16))) float bl[PW_NS][64];                   // bias of a step, by LDS-DMA like its weights (32 used)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * PW_M;
@@ -322,10 +322,12 @@ __global__ __launch_bounds__(256, 2) void panel_wide_kernel(const bf16* __restri
       fa[m][s] = make_uint4(aok ? v.x : 0u, aok ? v.y : 0u, aok ? v.z : 0u, aok ? v.w : 0u);
     }
   }
-  // loader: request of a step = ONE bias load (lanes 0 .. 31) + the 16 fragments (j, s) of the step, 1 KB each at (column tile * 8 + s) KB
-  float breq[2] = {0.f, 0.f};                                      // bias words in flight, step t in breq[t & 1]
-  auto request = [&](int step, float& bdst) {
-    if (bias) bdst = bias[step * PW_N + (lane & (PW_N - 1))];      // one vector-memory instruction, counted below
+  // loader: request of a step = ONE 4-byte-per-lane DMA of its bias + the 16 fragments (j, s) of the step, 1 KB each at (column tile * 8 + s)
+  // KB -- 17 LDS-DMA instructions and nothing else (the bias used to be an ordinary load into a register, whose place in the
+  // instruction stream the compiler was free to choose while the s_waitcnt below counted on it)
+  auto request = [&](int step) {
+    if (bias)
+      __builtin_amdgcn_global_load_lds((pw_gbl_void*)(bias + step * PW_N + (lane & (PW_N - 1))), (pw_lds_void*)&bl[step % PW_NS][0], 4, 0, 0);
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
       const int j = f >> 3, s8 = f & 7;
@@ -333,9 +335,10 @@ __global__ __launch_bounds__(256, 2) void panel_wide_kernel(const bf16* __restri
       __builtin_amdgcn_global_load_lds((pw_gbl_void*)src, (pw_lds_void*)&wl[step % PW_NS][f * 64], 16, 0, 0);
     }
   };
+  if (!bias && tid < PW_NS * 64) (&bl[0][0])[tid] = 0.f;             // no bias: zeros, written once (the first barrier publishes them)
   if (loader) {
-    request(0, breq[0]);
-    if (n_steps > 1) request(1, breq[1]);
+    request(0);
+    if (n_steps > 1) request(1);
   }
   // the loader's staged rows are read by OTHER waves one step later, with no barrier before its next staging: two buffers by step parity
   unsigned short* st = stage[wave];
@@ -374,14 +377,13 @@ __global__ __launch_bounds__(256, 2) void panel_wide_kernel(const bf16* __restri
   };
   for (int step = 0; step < n_steps; ++step) {
     if (loader) {
-      // everything older than the NEXT step's request (1 bias load + 16 DMA pieces) has landed: loads complete in order
+      // everything older than the NEXT step's request (17 DMA instructions with a bias, 16 without) has landed: loads complete in order
       if (step + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (bias) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      if (lane < PW_N) bl[step & 1][lane] = breq[step & 1];
     }
     pw_barrier();                                                  // slot step % 3 and the step's bias are in LDS; every wave is past step - 1
-    if (loader && step + 2 < n_steps) request(step + 2, breq[step & 1]);
+    if (loader && step + 2 < n_steps) request(step + 2);
     if (step > 0) flush(step - 1);
     const uint4* wls = wl[step % PW_NS];
     f32x4 acc[4][2];
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void panel_wide_kernel(const bf16* __restri
     // (this wave's rows of the previous step were read by the flush above -- the loader's by waves 1 .. 3 after the barrier)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float4 bv = *reinterpret_cast<const float4*>(&bl[step & 1][j * 16 + 4 * lg]);
+      const float4 bv = *reinterpret_cast<const float4*>(&bl[step % PW_NS][j * 16 + 4 * lg]);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const bf16 v4[4] = {__float2bfloat16(acc[m][j][0] + bv.x), __float2bfloat16(acc[m][j][1] + bv.y),
@@ -441,14 +443,17 @@ bool sl_panel_wanted(int dtype, int epi, const LinArgs& p) {
 }
 
 // the wide form: bias-only epilogue, K == 256, whole 32-column steps, 16-byte aligned output rows / heads
-static bool panel_wide_wanted(const simulst_handle* h, int epi, const LinArgs& p) {
+static bool panel_wide_wanted(const simulst_handle* h, int epi, const LinArgs& p, const void* A, const void* C, const float* bias) {
+  // 16-byte loads of A rows and 16-byte streaming stores of C rows: the base pointers must be aligned like the strides;
+  // the bias travels by 4-byte DMA
+  if ((((uintptr_t)A | (uintptr_t)C) & 15) != 0 || ((uintptr_t)bias & 3) != 0) return false;
   return h->panel_wide && epi == SIMULST_EPI_BIAS && !p.ln_g && p.K == 256 && p.N % PW_N == 0 && p.M >= 8192 &&
          ((p.c_rs | p.c_bs | p.c_hs | p.c_ts) & 7) == 0 && (p.c_hd == 0 || p.c_hd % 8 == 0) && (p.a_rs & 7) == 0 && (p.a_bs & 7) == 0;
 }
 
 int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
                     void* aux, const LinArgs& p) {
-  if (panel_wide_wanted(h, epi, p)) {
+  if (panel_wide_wanted(h, epi, p, A, C, bias)) {
     KTimer tw(h, SIMULST_K_LINEAR);
 #ifdef SL_EXPERIMENTS      // default-policy stores instead of streaming ones (SIMULST_OPT_PANEL_WIDE = 2): measured slower
     if (h->panel_wide_plain_stores)
