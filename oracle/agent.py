@@ -233,7 +233,7 @@ def simulate_cif(w, ecfg, dcfg, beta, fbank, max_len_a=1, max_len_b=0, overshoot
 
 
 def greedy_offline(w, ecfg, dcfg, src_tokens, src_lengths, n_steps=None, mask_eos=False,
-                   max_len_a=0.1, max_len_b=10, margins=None):
+                   max_len_a=0.1, max_len_b=10, margins=None, logits_out=None):
     """Offline batched greedy decode: eval/generate.py:187-209 ->
     task.inference_step -> SequenceGenerator(beam=1) semantics restated:
     encoder._forward once, then decoder steps with 'online' unset (never READs,
@@ -241,7 +241,8 @@ def greedy_offline(w, ecfg, dcfg, src_tokens, src_lengths, n_steps=None, mask_eo
     With ``mask_eos`` EOS is never chosen, so exactly n_steps tokens/utterance
     (bench config 2: 110). Returns tokens [B, n] (eos-padded after finish), lengths [B], encoder dict.
     ``margins``: a list that receives, per step, the gap between the best and the second-best admissible
-    log-probability of every row [B] (how close each greedy decision is to flipping under bf16 rounding)."""
+    log-probability of every row [B] (how close each greedy decision is to flipping under bf16 rounding).
+    ``logits_out``: a list that receives the raw fp32 logits [B, V] of every step (teacher-forced audit of the offline loop)."""
     B = src_tokens.size(0)
     enc = em.encoder_forward(w, "encoder", ecfg, src_tokens, src_lengths)
     pad = enc["encoder_padding_mask"][0]
@@ -255,6 +256,8 @@ def greedy_offline(w, ecfg, dcfg, src_tokens, src_lengths, n_steps=None, mask_eo
     lengths = torch.zeros(B, dtype=torch.long)
     for step in range(n_steps):
         logits, _ = dec.mma_decoder_step(w, "decoder", dcfg, toks, enc_in, st)
+        if logits_out is not None:
+            logits_out.append(logits[:, -1].float().clone())
         lp = torch.log_softmax(logits[:, -1].float(), dim=-1)
         lp[:, dcfg.padding_idx] = -float("inf")
         if mask_eos or step == 0:

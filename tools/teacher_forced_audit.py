@@ -382,11 +382,74 @@ def _cif_decoder_pass(cfg, model, dec, cst, traces, n_utt, copies, cap, n_cap, w
             "logits": {"abs_err": _summ(logit_err)} if want_logits else None, "copy_mismatch": copy_mismatch}
 
 
+# ------------------------------------------------------------------------------------------------------------ wait-k, offline loop
+def audit_waitk_offline(utts, copies=9, dtype=torch.bfloat16, device="cuda:0", n_steps=110, waitk=5):
+    """The headline configuration (BASELINE configs[1]: Emformer + wait-k 5, offline loop of eval/generate.py:187-209, EOS masked): the
+    device loop simulst_mma_decode driven ONE step per call with the oracle's previous token forced, fp32 logits read back every step
+    (the policy is a closed form of the position: nothing to audit there).  Returns max |logit - logit_oracle|, the tokens the device
+    would have picked against the oracle's, and the oracle's top-2 gap where they differ."""
+    from oracle import agent as oag
+    from oracle.configs import from_model_config
+    from simulst_amd import _lib
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=waitk, fixed_pre_decision_ratio=8)
+    w = init_model(cfg, seed=999)
+    ecfg, dcfg = from_model_config(cfg)
+    n_utt, T = len(utts), utts[0].size(0)
+    fb_cpu = torch.stack(utts)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    margins, lg_ref = [], []
+    with torch.no_grad():
+        ref, _, _ = oag.greedy_offline(w, ecfg, dcfg, fb_cpu, torch.full((n_utt,), T), n_steps=n_steps, mask_eos=True, margins=margins,
+                                       logits_out=lg_ref)
+    model = SimulSTModel(cfg, w, device=device, dtype=dtype)
+    dec = model.decoder
+    B = n_utt * copies
+    fb = fb_cpu.repeat(copies, 1, 1).to(device=device, dtype=dtype)
+    model.ops.h.set_option(_lib.OPT_FUSED_ARGMAX, 0)          # fp32 logits in the workspace instead of partial maxima
+    model.ops.h.set_option(_lib.OPT_DEC_EMBED_QKV_CHAIN, 0)   # every call commits its own step (one step per call here)
+    err, bad, checked, copy_mismatch = [], [], 0, 0
+    try:
+        with torch.no_grad():
+            enc = model.encoder.forward(fb, torch.full((B,), T, device=device))
+            st = dec.new_state(B, cap=n_steps + 2, S_cap=max(enc["encoder_out_btd"].size(1), 1))
+            st.online = False
+            dec.append_encoder_out(st, enc["encoder_out_btd"], enc["encoder_lengths"])
+            toks = torch.full((B,), cfg.eos, device=device, dtype=torch.int64)
+            for s_ in range(n_steps):
+                if s_ > 0:
+                    toks.copy_(ref[:, s_ - 1].repeat(copies).to(device))           # the ORACLE's previous token
+                out = dec.decode_steps(st, toks, 1, True)
+                lg = st.ws["logits"].cpu()
+                pick = out[0].cpu()
+                for u in range(n_utt):
+                    for cp in range(1, copies):
+                        if pick[cp * n_utt + u] != pick[u] or not torch.equal(lg[cp * n_utt + u], lg[u]):
+                            copy_mismatch += 1
+                    err.append(float((lg[u] - lg_ref[s_][u]).abs().max()))
+                    checked += 1
+                    if int(pick[u]) != int(ref[u, s_]):
+                        bad.append({"utterance": u, "step": s_, "oracle_top2_gap": round(float(margins[s_][u]), 5)})
+    finally:
+        model.ops.h.set_option(_lib.OPT_FUSED_ARGMAX, 1)
+        model.ops.h.set_option(_lib.OPT_DEC_EMBED_QKV_CHAIN, 1)
+    return {"policy": f"waitk{waitk}_offline", "dtype": str(dtype).replace("torch.", ""), "utterances": n_utt, "copies": copies, "rows": B,
+            "frames": T, "steps": n_steps, "layer_chains": bool(B > 128 and dtype == torch.bfloat16),
+            "logits": {"abs_err": _summ(err)},
+            "tokens": {"writes": checked, "differ": len(bad), "oracle_top2_gap_at_those": _summ([b_["oracle_top2_gap"] for b_ in bad]),
+                       "worst": sorted(bad, key=lambda t: -t["oracle_top2_gap"])[:8]},
+            "copies_that_disagree_with_their_original": copy_mismatch}
+
+
 def run(n_utt=16, copies=9, frames=1000, dtype="bf16", logits_pass=True):
     dt = torch.bfloat16 if dtype == "bf16" else torch.float32
     utts = _utterances(n_utt, frames)
+    out = {"waitk5_offline": audit_waitk_offline(utts, copies=copies, dtype=dt)}
+    torch.cuda.empty_cache()
     cfg, w = mma_hard_setup()
-    out = {"mma_hard": audit_mma_hard(cfg, w, utts, copies=copies, dtype=dt, logits_pass=logits_pass)}
+    out["mma_hard"] = audit_mma_hard(cfg, w, utts, copies=copies, dtype=dt, logits_pass=logits_pass)
     torch.cuda.empty_cache()
     cfg, w = cif_setup()
     out["cif"] = audit_cif(cfg, w, utts, copies=copies, dtype=dt, logits_pass=logits_pass)
@@ -411,7 +474,7 @@ def main():
         for kk in ("decisions", "fired_counts"):
             if kk in brief:
                 brief[kk] = {a: b for a, b in brief[kk].items() if a != "worst" and not a.startswith("total_")}
-        print(k, json.dumps(brief), "tokens differ", v["tokens"]["differ"], "of", v["tokens"]["writes"],
+        print(k, json.dumps(brief), "tokens differ", v["tokens"]["differ"], "of", v["tokens"]["writes"], v["tokens"]["oracle_top2_gap_at_those"],
               "logit err", (v.get("logits") or {}).get("abs_err"))
 
 
