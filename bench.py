@@ -830,6 +830,8 @@ def compact_line(full, legs_path=LEGS_FILE):
             co["fp32_tokens_identical_to_oracle"] = p.get("fp32_tokens_identical_to_oracle")
             t = p.get("timed_pass_rows_vs_oracle") or {}
             co["timed_rows_identical_to_oracle"] = [t.get("rows_identical"), t.get("rows")]
+        if "teacher_forced" in c:
+            co["teacher_forced"] = c["teacher_forced"]
         out["cpu_baseline"] = co
     else:
         out["cpu_baseline"] = None
@@ -1292,6 +1294,21 @@ def main(argv=None):
                 "timed_pass_rows_vs_oracle": divergence(hyp_timed[:n_t].cpu()),
                 f"{args.dtype}_batch_of_{n_s}_alone_vs_oracle": divergence(t16.cpu())}
             log(f"parity on the cpu sample: {cpu_base['parity_on_sample']}")
+            if not args.no_teacher_forced and args.dtype == "bf16":
+                # the timed configuration's own numerical bound: the offline loop driven one step per call along the ORACLE's tokens
+                tools = os.path.join(ROOT, "tools")
+                if tools not in sys.path:
+                    sys.path.insert(0, tools)
+                import teacher_forced_audit as tfa
+                try:
+                    with torch.no_grad():
+                        a = tfa.audit_waitk_offline([ref_fb[i] for i in range(min(8, ref_fb.size(0)))], copies=17, dtype=dtype, device=dev,
+                                                    n_steps=N_STEPS_DECODE, waitk=WAITK)
+                    cpu_base["teacher_forced"] = {"rows": a["rows"], "steps": a["steps"], "logit_abs_err_max": round(a["logits"]["abs_err"]["max"], 5),
+                                                  "tokens_differ": [a["tokens"]["differ"], a["tokens"]["writes"]]}
+                    log(f"teacher-forced wait-k audit: {cpu_base['teacher_forced']}")
+                except Exception as e:
+                    cpu_base["teacher_forced"] = {"error": repr(e)[:160]}
         sched = (f"{sum(plan)} batches of {B} as {len(plan)} launch sequence(s) of {sorted(set(plan), reverse=True)} stacked "
                  f"batches on {streams_used} HIP stream(s)" +
                  ("" if args.concurrency > 1 or args.no_pipeline else ", encoder(i+1) overlapped with decode(i)"))
