@@ -64,6 +64,9 @@ struct simulst_handle {
   int policy_lds_bytes;        // policy / cross-attention launch of co-scheduled batches: minimum dynamic LDS request (occupancy cap), 0: none
   int dec_vocab_chain_split;   // workgroups per row tile of the step's closing launch (dec_vocab_chain_kernel); 0: off
   bool fused_argmax;           // decode loops: per-tile (max, index) partials out of the vocabulary projection instead of fp32 logits
+  bool dec_fuse_proj_cross;    // experiment: projection chain + wait-k cross-attention of a layer in ONE launch (dec_chain.hip)
+  int* fuse_flags;             // its tile flags (1024 words: [1023] = the bounded spin ran out), made on first use
+  int fuse_epoch;              // one per fused launch, monotonic
 };
 
 #define SL_CHECK_NULL(h, p)                                   \
@@ -302,6 +305,12 @@ int sl_dec_vocab_chain(simulst_handle* h, const void* x_mid, void* x, const floa
 int sl_dec_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev, int np_uniform,
                            int cap, void* x, const void* Wo, const float* bo, const float* ln_g, const float* ln_b, const void* Wq,
                            const float* bq, void* q, const void* Wq2, const float* bq2, void* q2, int B, const void* kk_gelu = nullptr);
+bool sl_dec_proj_cross_fused_ok(const simulst_handle* h, int dtype, int B, int H, int d, int S_cap, int attn_type, bool lockstep_offline,
+                                bool separate_soft);
+int sl_dec_proj_cross_fused(simulst_handle* h, const void* ctx_in, void* x, const void* Wo, const float* bo, const float* ln_g,
+                            const float* ln_b, const void* Wq, const float* bq, void* q, const void* Ks, const void* Vc,
+                            const int32_t* key_len, const int32_t* tgt_idx, int64_t* head_step, uint8_t* head_read, void* ctx_out, int B,
+                            int H, int S_cap, int ratio, int waitk_k, int online, int mass_pres, int n_hint);
 int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
                      const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
                      int32_t* sem, void* x_mid, int B, int F);

@@ -28,6 +28,7 @@
 // agent-scope release fence + ticket; last arriver: agent-scope acquire fence, barrier, plain loads): placement-
 // independent, no waiting anywhere (nothing can hang), deterministic (fixed split order in one workgroup).
 #include "gemm_args.h"
+#include "attn_core.h"
 
 namespace {
 
@@ -224,11 +225,11 @@ __device__ __forceinline__ uint2 add_slabs(const float (&r)[4], float4 b2, const
 // ---------------------------------------------------------------------------------------------------------------------
 // ctx [M][256] --Wo, bo, + x--> x (in place) --LN--> --Wq, bq--> q   (--Wq2, bq2--> q2 when Wq2 != nullptr)
 template <int RTL, int XM>
-__global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
+__device__ __forceinline__ void proj_chain_body(
     const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ Wq,
     const float* __restrict__ bq, bf16* __restrict__ q, const uint4* __restrict__ Wq2, const float* __restrict__ bq2,
-    bf16* __restrict__ q2, int M, unsigned short* __restrict__ dbg, const bf16* __restrict__ kk) {
+    bf16* __restrict__ q2, int M, unsigned short* __restrict__ dbg, const bf16* __restrict__ kk, const int tile) {
   // kk != nullptr (CIF decoder, models/cif_transformer.py:357-362): q = gelu(Wq LN(x) + bq + kk) with kk [M][256] the k_proj of the
   // integrated vector each row looks at -- FakeCrossAttn's activation(q_proj(query) + k_proj(key)); Wq2 is unused then
   constexpr int RT = 16 * RTL;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
   unsigned short* bufB = lds + RT * XS;
   SL_CHAIN_SETPRIO();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.x * RT;
+  const int m0 = tile * RT;
   const int tw = 4 * wave;                               // this wave's first column tile of every 256-column block
   WUnit u0, u1;
   load_unit(u0, Wo, tw, NKS, 0, lane);
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
     }
   }
   if (dbg) {   // investigation tail (simulst_debug_chain_tail): what the two row buffers hold when the kernel ends
-    unsigned short* Dg = dbg + (long)blockIdx.x * (2 * RT * CD);
+    unsigned short* Dg = dbg + (long)tile * (2 * RT * CD);
 #pragma unroll
     for (int i = 0; i < 4 * RTL; ++i) {
       const int row = wave + 4 * i;
@@ -334,6 +335,112 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
     }
   }
 }
+
+template <int RTL, int XM>
+__global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
+    const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ Wq,
+    const float* __restrict__ bq, bf16* __restrict__ q, const uint4* __restrict__ Wq2, const float* __restrict__ bq2,
+    bf16* __restrict__ q2, int M, unsigned short* __restrict__ dbg, const bf16* __restrict__ kk) {
+  proj_chain_body<RTL, XM>(ctx, x, Wo, bo, ln_g, ln_b, Wq, bq, q, Wq2, bq2, q2, M, dbg, kk, (int)blockIdx.x);
+}
+
+#ifdef SL_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 5; `make EXPERIMENTS=1`, SIMULST_OPT_DEC_FUSE_PROJ_CROSS; measured SLOWER: 36.1 us per launch against 27.6 us for the two
+// launches alone, 106.6 against 91.7 ms in the driver's form -- DESIGN.md section 3): the projection chain and the wait-k cross-attention of a
+// decoder layer in ONE launch with two kinds of workgroups.  Workgroups 0 .. n_tiles-1 run the projection chain of their 16 rows and
+// then PUBLISH the tile (stores drained, workgroup barrier, one agent-scope release, a flag word = the launch's epoch); the other
+// H x rows workgroups are the cross-attention of one (head, row): they request every visible K / V row FIRST -- those loads do not
+// depend on the query -- and only then wait for their row's tile (one lane polls with s_sleep, one agent-scope acquire, barrier), read
+// their 64 query channels and finish.  What it buys over two launches: the K / V stream of the resident attention workgroups runs
+// UNDER the chain's 7-9 us of latency, and one launch boundary goes.  Same arithmetic in the same order as dec_proj_chain_kernel +
+// policy_cross_attn_kernel's wait-k branch (decode_driver.hip): results are bit-identical (tests/test_hip_dec_chain.py).
+// The chain workgroups have the lowest ids, so they are dispatched before any waiting workgroup can occupy their place; a bounded
+// spin turns a broken assumption into an error word instead of a hang.
+template <int XM>
+__global__ __launch_bounds__(256, 2) void dec_proj_cross_fused_kernel(
+    const bf16* __restrict__ ctx_in, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ Wq, const float* __restrict__ bq,
+    bf16* __restrict__ q, int M, int n_tiles, int* __restrict__ flags, int epoch,
+    const bf16* __restrict__ Ks, const bf16* __restrict__ Vc, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
+    long* __restrict__ head_step, unsigned char* __restrict__ head_read, bf16* __restrict__ ctx_out, int H, int S_cap, int ratio,
+    int waitk_k, int online, int mass_pres, int n_hint) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds_f[];
+  if ((int)blockIdx.x < n_tiles) {
+    proj_chain_body<1, XM>(ctx_in, x, Wo, bo, ln_g, ln_b, Wq, bq, q, nullptr, nullptr, nullptr, M, nullptr, nullptr, (int)blockIdx.x);
+    // publish: every storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope and sets the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  constexpr int d = 64, NP = 8;
+  const int id = (int)blockIdx.x - n_tiles;
+  const int h = id % H, b = id / H, tid = threadIdx.x;
+  const int D = H * d;
+  float* red = reinterpret_cast<float*>(lds_f) + 64;
+  const int len = key_len ? key_len[b] : S_cap;
+  const int r = b * H + h;
+  const bool pool_last = ratio < 0;
+  ratio = ratio < 0 ? -ratio : ratio;
+  const int P = pooled_count(len, ratio, true, pool_last);
+  const long hb = ((long)b * H + h) * S_cap * d;
+  const bf16* Vh = Vc + hb;
+  const bf16* Kh = Ks + hb;
+  const int tg = tgt_idx ? tgt_idx[b] : 0;
+  const long hs = head_step[r];
+  if (n_hint < 0) n_hint = (tg + waitk_k) * ratio;
+  const int n_pref = min(S_cap, n_hint);
+  attn::Regs2<bf16, NP> rg2;
+  attn::prefetch2<bf16, NP>(rg2, nullptr, Kh, d, Vh, d, n_pref, -1, nullptr, nullptr);        // K / V only: the query does not exist yet
+  // wait-k policy in closed form, as policy_cross_attn_kernel (decode_driver.hip)
+  long st;
+  {
+    int wk = tg + waitk_k - 1;
+    if (!online) wk = min(wk, P - 1);
+    int s1 = -1, s2 = -1;
+    if (wk < P) {
+      const int c1 = (wk + 1) * ratio - 1;
+      if (c1 < len) s1 = c1;
+      if (wk == P - 1 && P * ratio >= len) s2 = len - 1;
+    }
+    const int max_steps = mass_pres ? len - 1 : len;
+    int found = max_steps;
+    if (s1 >= 0 && (long)s1 >= hs) found = min(found, s1);
+    if (s2 >= 0 && (long)s2 >= hs) found = min(found, s2);
+    if (found < 0) found = 0;
+    if (tid == 0) {
+      const int clampi = min(max(found, 0), len - 1);
+      const bool one = clampi >= 0 && (clampi == s1 || clampi == s2);
+      head_step[r] = found;
+      head_read[r] = (found == max_steps && !one) ? 1 : 0;
+    }
+    st = found;
+  }
+  // ---- the row's query: wait for its tile of the projection chain
+  if (tid == 0) {
+    const int* f = flags + (b >> 4);
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1 << 22)) { __hip_atomic_store(flags + 1023, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  rg2.q = *reinterpret_cast<const uint4*>(q + (long)b * D + h * d + (tid % NP) * 8);
+  float o = 0.f;
+  const int n = (int)(st < len - 1 ? st : len - 1) + 1;
+  if (st > 0 && n > 0) o = attn::finish3<bf16, NP>(rg2, n, n_pref, rsqrtf((float)d), red, nullptr, nullptr);
+  if (tid < d) ctx_out[(long)b * D + h * d + tid] = from_f32<bf16>(o);
+}
+#endif  // SL_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------------------
 // x <- x' + fc2(gelu(fc1(LN(x')))) + b2  with  x' = x + Wco . ctx + bco;   grid = row tiles x splits, split sp owns hidden
@@ -1180,6 +1287,46 @@ int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* W
 #undef PC
   return sl_launch_status(h, "simulst_mma_decode(out-proj + LN + q-proj chain)");
 }
+
+#ifdef SL_EXPERIMENTS
+// EXPERIMENT: projection chain + wait-k cross-attention of a layer in one launch (dec_proj_cross_fused_kernel)
+bool sl_dec_proj_cross_fused_ok(const simulst_handle* h, int dtype, int B, int H, int d, int S_cap, int attn_type, bool lockstep_offline,
+                                bool separate_soft) {
+  return h->dec_fuse_proj_cross && dtype == SIMULST_BF16 && H * d == CD && d == 64 && S_cap <= 256 && attn_type == SIMULST_ATTN_WAITK &&
+         lockstep_offline && !separate_soft && (B + 15) / 16 <= 1000;
+}
+
+int sl_dec_proj_cross_fused(simulst_handle* h, const void* ctx_in, void* x, const void* Wo, const float* bo, const float* ln_g,
+                            const float* ln_b, const void* Wq, const float* bq, void* q, const void* Ks, const void* Vc,
+                            const int32_t* key_len, const int32_t* tgt_idx, int64_t* head_step, uint8_t* head_read, void* ctx_out, int B,
+                            int H, int S_cap, int ratio, int waitk_k, int online, int mass_pres, int n_hint) {
+  if (int rc = raise_lds_limits(h)) return rc;
+  if (!h->fuse_flags) {
+    hipError_t e = hipMalloc((void**)&h->fuse_flags, 1024 * sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(h->fuse_flags, 0, 1024 * sizeof(int), h->stream);
+    if (e != hipSuccess) { h->err = "simulst_mma_decode: flag words of the fused projection / cross-attention launch"; return (int)e; }
+    h->fuse_epoch = 0;
+  }
+  const int n_tiles = (B + 15) / 16;
+  const int epoch = ++h->fuse_epoch;
+  KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
+  // dynamic LDS: the chain's row buffers (lds_request) cover the attention's reduction scratch (64 + RED_FLOATS floats)
+  const int lds = lds_request(h) > (int)((64 + attn::RED_FLOATS) * sizeof(float)) ? lds_request(h) : (int)((64 + attn::RED_FLOATS) * sizeof(float));
+  hipLaunchKernelGGL((dec_proj_cross_fused_kernel<3>), dim3(n_tiles + H * B), dim3(256), lds, h->stream, (const bf16*)ctx_in, (bf16*)x,
+                     (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q, B, n_tiles, h->fuse_flags, epoch, (const bf16*)Ks,
+                     (const bf16*)Vc, key_len, tgt_idx, (long*)head_step, head_read, (bf16*)ctx_out, H, S_cap, ratio, waitk_k, online,
+                     mass_pres, n_hint);
+  return sl_launch_status(h, "simulst_mma_decode(projection chain + wait-k cross-attention, one launch)");
+}
+#else
+bool sl_dec_proj_cross_fused_ok(const simulst_handle*, int, int, int, int, int, int, bool, bool) { return false; }
+int sl_dec_proj_cross_fused(simulst_handle* h, const void*, void*, const void*, const float*, const float*, const float*, const void*,
+                            const float*, void*, const void*, const void*, const int32_t*, const int32_t*, int64_t*, uint8_t*, void*, int, int,
+                            int, int, int, int, int, int) {
+  h->err = "projection chain + cross-attention in one launch: an EXPERIMENTS build only";
+  return SIMULST_E_ARG;
+}
+#endif  // SL_EXPERIMENTS
 
 int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
                      const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,

@@ -880,6 +880,13 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
           if ((rc = sl_dec_attn_proj_chain(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
                                            dd->cap, dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, L.c_bq, dd->q, L.c_wq_soft,
                                            L.c_bq_soft, dd->q2, B))) return rc;
+        } else if (chain && sl_dec_proj_cross_fused_ok(h, dt, B, H, d, dd->S_cap, dd->attn_type, !ctlp && !device_indexed && np_uniform >= 0,
+                                                       L.c_wq_soft != nullptr)) {
+          // experiment: the chain and the wait-k cross-attention in one launch (dec_chain.hip dec_proj_cross_fused_kernel)
+          if ((rc = sl_dec_proj_cross_fused(h, dd->ctx, dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, L.c_bq, dd->q, L.Ksoft ? L.Ksoft : L.Kmono,
+                                            L.V, dd->enc_len, dd->n_prev, L.head_step, L.head_read, dd->ctx, B, H, dd->S_cap, dd->ratio,
+                                            dd->waitk_k, dd->online, dd->mass_preservation, n_hint))) return rc;
+          goto cross_done;
         } else if (chain) {
           if ((rc = sl_dec_proj_chain(h, dd->ctx, dd->x, L.wo, L.bo, L.ln2_g, L.ln2_b, L.c_wq, L.c_bq, dd->q, L.c_wq_soft,
                                       L.c_bq_soft, dd->q2, B))) return rc;
@@ -893,6 +900,7 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
                                dd->attn_type, dd->waitk_k, dd->online, dd->mass_preservation, dt, n_hint, nullptr, nullptr,
                                nullptr, nullptr, nullptr, nullptr, nullptr, ctlp ? &ctl : nullptr, nullptr, L.Kpool, dd->P_cap))) return rc;
       }
+    cross_done:
       if (chain_ffn) {
         if ((rc = sl_dec_ffn_chain(h, dd->ctx, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2,
                                    dd->ffn_partial, dd->ffn_sem, dd->x_mid, B, F))) return rc;

@@ -77,6 +77,12 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->fused_argmax = true;      // greedy pick's partial maxima in the vocabulary projection's epilogue (decode loops, bf16, co-scheduled rows)
   if (const char* e = getenv("SIMULST_FUSED_ARGMAX")) h->fused_argmax = atoi(e) != 0;
   if (const char* e = getenv("SIMULST_DEC_ATTN_CHAIN_ROWS")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->dec_attn_chain_rows = v; }
+  h->dec_fuse_proj_cross = false;      // experiment, off
+#ifdef SL_EXPERIMENTS
+  if (const char* e = getenv("SIMULST_DEC_FUSE_PROJ_CROSS")) h->dec_fuse_proj_cross = atoi(e) != 0;
+#endif
+  h->fuse_flags = nullptr;
+  h->fuse_epoch = 0;
   h->graph_exec = nullptr;
   h->ctc_lds_attr_set = false;
   h->conv_pos_lds_attr_set = false;
@@ -96,6 +102,7 @@ extern "C" int simulst_destroy(simulst_handle* h) {
   if (!h) return SIMULST_E_NULL;
   for (auto& p : h->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (h->ws) (void)hipFree(h->ws);
+  if (h->fuse_flags) (void)hipFree(h->fuse_flags);
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   delete h;
   return SIMULST_OK;
@@ -207,6 +214,13 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
       SL_REQUIRE(h, value == 0 || value == 1, SIMULST_E_ARG, "simulst_set_option(PANEL_WIDE): 0 or 1 (2, plain stores: EXPERIMENTS builds)");
 #endif
       h->panel_wide = value != 0; h->panel_wide_plain_stores = value == 2; return SIMULST_OK;
+    case SIMULST_OPT_DEC_FUSE_PROJ_CROSS:
+#ifdef SL_EXPERIMENTS
+      h->dec_fuse_proj_cross = value != 0; return SIMULST_OK;
+#else
+      h->err = "simulst_set_option: the one-launch projection chain + cross-attention exists in EXPERIMENTS builds only (measured slower)";
+      return SIMULST_E_ARG;
+#endif
     case SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT:
       SL_REQUIRE(h, value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16, SIMULST_E_ARG,
                  "simulst_set_option(DEC_VOCAB_CHAIN_SPLIT): 0 (off), 1, 2, 4, 8 or 16");
@@ -233,6 +247,16 @@ extern "C" int simulst_get_option(simulst_handle* h, int32_t option, int32_t* va
     case SIMULST_OPT_DEC_EMBED_QKV_CHAIN: *value = h->dec_embed_qkv_chain; return SIMULST_OK;
     case SIMULST_OPT_PANEL_WIDE: *value = h->panel_wide ? (h->panel_wide_plain_stores ? 2 : 1) : 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT: *value = h->dec_vocab_chain_split; return SIMULST_OK;
+    case SIMULST_OPT_DEC_FUSE_PROJ_CROSS: {
+      // bit 0: on; bit 1: a waiting workgroup's bounded spin ran out at some point (synchronises the stream: tests only)
+      int err = 0;
+      if (h->fuse_flags) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipMemcpy(&err, h->fuse_flags + 1023, sizeof(int), hipMemcpyDeviceToHost);
+      }
+      *value = (h->dec_fuse_proj_cross ? 1 : 0) | (err ? 2 : 0);
+      return SIMULST_OK;
+    }
     default: break;
   }
   h->err = "simulst_get_option: unknown option";

@@ -586,3 +586,41 @@ def test_chains_repeat_beside_other_streams(ops):
         for t in threads:
             t.join()
     assert bad == 0, f"{bad} of 150 repeats differ from the quiet result"
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("B,T,U", [(320, 240, 24), (448, 1000, 40), (150, 400, 12)])
+def test_projection_chain_and_waitk_cross_attention_in_one_launch_change_no_token(B, T, U):
+    """Round-5 experiment (EXPERIMENTS builds, SIMULST_OPT_DEC_FUSE_PROJ_CROSS; measured slower): the projection chain and the wait-k cross-attention of a
+    layer as ONE launch with two kinds of workgroups (attention workgroups request their K / V rows, then wait for their row's tile of
+    the chain behind an agent-scope release / acquire) against the two launches: same arithmetic in the same order, so every token of
+    every row is IDENTICAL (bf16, ragged rows, lockstep offline decode), and no waiting workgroup's bounded spin ran out."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.ops import Ops
+    from simulst_amd.weights import init_model
+    fb = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(8))
+    L = torch.randint(100, T + 1, (B,), generator=torch.Generator().manual_seed(9))
+    L[0] = T
+    for b in range(B):
+        fb[b, L[b]:] = 0
+    fb = fb.cuda().to(torch.bfloat16)
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=6, simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=3)
+    w = init_model(cfg, seed=21)
+    w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(5)) \
+        * cfg.embed_dim ** -0.5
+    o_new, o_old = Ops(), Ops()
+    o_new.h.set_option(_lib.OPT_DEC_FUSE_PROJ_CROSS, 1)
+    t_new = SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=o_new).generate_offline(fb, L, n_steps=U, mask_eos=True)[0].clone()
+    t_old = SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=o_old).generate_offline(fb, L, n_steps=U, mask_eos=True)[0].clone()
+    torch.cuda.synchronize()
+    assert o_new.h.get_option(_lib.OPT_DEC_FUSE_PROJ_CROSS) == 1, "a waiting workgroup gave up: the chain workgroups did not run first"
+    assert torch.equal(t_new, t_old), (t_new != t_old).sum().item()
+    assert len(set(t_new.flatten().tolist())) > 50
+    # the fused launch really ran: no projection-chain launches on the new handle
+    for o, want in ((o_new, 0), (o_old, 1)):
+        o.h.timer_reset(); o.h.timer_enable(-1, True)
+        SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=o).generate_offline(fb, L, n_steps=2, mask_eos=True)
+        torch.cuda.synchronize()
+        o.h.timer_enable(-1, False)
+        assert (o.h.timer_read(_lib.K_DEC_PROJ_CHAIN)[1] > 0) == bool(want)
