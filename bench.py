@@ -785,7 +785,7 @@ def _leg_summary(leg):
         o["dominant_class"] = [roof.get("kernel"), roof.get("frac")]
         o["path_hbm_frac"] = (roof.get("path_hbm_model") or {}).get("frac_offline")
     if "teacher_forced" in leg:
-        o["teacher_forced"] = leg["teacher_forced"]
+        o["teacher_forced"] = {k: v for k, v in leg["teacher_forced"].items() if k not in ("utterances", "layer_chains")}
     return o
 
 

@@ -37,7 +37,7 @@ def test_line_is_small_and_complete(path):
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     # one small object per leg, no tables
     for name, leg in out.get("legs", {}).items():
-        assert len(json.dumps(leg)) < 600, (name, len(json.dumps(leg)))
+        assert len(json.dumps(leg)) < 700, (name, len(json.dumps(leg)))
         assert not any(isinstance(v, list) and len(v) > 4 for v in leg.values()), name
     assert out["details"] == bench.LEGS_FILE
 
