@@ -99,3 +99,19 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_cu_mask_words_keep_every_xcd_populated():
+    """simulst_stream_create's mask layout (bit i = compute unit i // 8 of XCD i % 8 on MI355X, tools/microbench_cumask.hip): the helper
+    gives every XCD the same number of units -- a mask that empties an XCD is ignored by the runtime -- and the decode / encoder masks of a
+    partition are disjoint and complete"""
+    from simulst_amd._lib import cu_mask_words
+    for d in (1, 12, 16, 20, 31):
+        lo, hi = cu_mask_words(d), cu_mask_words(32 - d, take_high=True)
+        assert len(lo) == len(hi) == 8
+        bits_lo = {i for i in range(256) if lo[i >> 5] >> (i & 31) & 1}
+        bits_hi = {i for i in range(256) if hi[i >> 5] >> (i & 31) & 1}
+        assert len(bits_lo) == 8 * d and len(bits_hi) == 8 * (32 - d)
+        assert not (bits_lo & bits_hi) and len(bits_lo | bits_hi) == 256
+        for x in range(8):
+            assert sum(1 for i in bits_lo if i % 8 == x) == d and sum(1 for i in bits_hi if i % 8 == x) == 32 - d
