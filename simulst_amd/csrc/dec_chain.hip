@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
 
 #ifdef SL_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 5; `make EXPERIMENTS=1`, SIMULST_OPT_DEC_FUSE_PROJ_CROSS; measured SLOWER: 36.1 us per launch against 27.6 us for the two
-// launches alone, 106.6 against 91.7 ms in the driver's form -- DESIGN.md section 3): the projection chain and the wait-k cross-attention of a
+// EXPERIMENT (round 5; `make EXPERIMENTS=1`, SIMULST_OPT_DEC_FUSE_PROJ_CROSS; measured SLOWER: 36-37 us per launch against 27.6 us for the two
+// launches alone, 107-113 against 91.7 ms in the driver's form -- DESIGN.md section 3): the projection chain and the wait-k cross-attention of a
 // decoder layer in ONE launch with two kinds of workgroups.  Workgroups 0 .. n_tiles-1 run the projection chain of their 16 rows and
 // then PUBLISH the tile (stores drained, workgroup barrier, one agent-scope release, a flag word = the launch's epoch); the other
 // H x rows workgroups are the cross-attention of one (head, row): they request every visible K / V row FIRST -- those loads do not
@@ -379,67 +379,86 @@ __global__ __launch_bounds__(256, 2) void dec_proj_cross_fused_kernel(
     }
     return;
   }
+  // ---- PERSISTENT attention workgroups: this one takes the (head, row) problems id, id + G, id + 2 G, ... with TWO of them in flight (two
+  //      register sets of K / V rows): while the chain runs, a resident workgroup has requested the rows of its first two problems; after
+  //      that every problem's query read and softmax run under the next problem's loads.  (One problem per workgroup: 36 us per launch
+  //      against 27.6 for two launches -- only 2 workgroups fit a compute unit beside the chain's 210 registers)
   constexpr int d = 64, NP = 8;
-  const int id = (int)blockIdx.x - n_tiles;
-  const int h = id % H, b = id / H, tid = threadIdx.x;
+  const int id = (int)blockIdx.x - n_tiles, G = (int)gridDim.x - n_tiles, nprob = H * M;
+  const int tid = threadIdx.x;
   const int D = H * d;
   float* red = reinterpret_cast<float*>(lds_f) + 64;
-  const int len = key_len ? key_len[b] : S_cap;
-  const int r = b * H + h;
   const bool pool_last = ratio < 0;
   ratio = ratio < 0 ? -ratio : ratio;
-  const int P = pooled_count(len, ratio, true, pool_last);
-  const long hb = ((long)b * H + h) * S_cap * d;
-  const bf16* Vh = Vc + hb;
-  const bf16* Kh = Ks + hb;
-  const int tg = tgt_idx ? tgt_idx[b] : 0;
-  const long hs = head_step[r];
-  if (n_hint < 0) n_hint = (tg + waitk_k) * ratio;
-  const int n_pref = min(S_cap, n_hint);
-  attn::Regs2<bf16, NP> rg2;
-  attn::prefetch2<bf16, NP>(rg2, nullptr, Kh, d, Vh, d, n_pref, -1, nullptr, nullptr);        // K / V only: the query does not exist yet
-  // wait-k policy in closed form, as policy_cross_attn_kernel (decode_driver.hip)
-  long st;
-  {
+  struct Prob { int h, b, len, n_pref; long st; };
+  auto issue = [&](attn::Regs2<bf16, NP>& rg, Prob& pr, int p) {
+    pr.b = p / H; pr.h = p - pr.b * H;
+    pr.len = key_len ? key_len[pr.b] : S_cap;
+    const int P = pooled_count(pr.len, ratio, true, pool_last);
+    const long hb = ((long)pr.b * H + pr.h) * S_cap * d;
+    const int tg = tgt_idx ? tgt_idx[pr.b] : 0;
+    const long hs = head_step[p];
+    const int nh = n_hint < 0 ? (tg + waitk_k) * ratio : n_hint;
+    pr.n_pref = min(S_cap, nh);
+    attn::prefetch2<bf16, NP>(rg, nullptr, Ks + hb, d, Vc + hb, d, pr.n_pref, -1, nullptr, nullptr);   // K / V only: no query yet
+    // wait-k policy in closed form, as policy_cross_attn_kernel (decode_driver.hip)
     int wk = tg + waitk_k - 1;
     if (!online) wk = min(wk, P - 1);
     int s1 = -1, s2 = -1;
     if (wk < P) {
       const int c1 = (wk + 1) * ratio - 1;
-      if (c1 < len) s1 = c1;
-      if (wk == P - 1 && P * ratio >= len) s2 = len - 1;
+      if (c1 < pr.len) s1 = c1;
+      if (wk == P - 1 && P * ratio >= pr.len) s2 = pr.len - 1;
     }
-    const int max_steps = mass_pres ? len - 1 : len;
+    const int max_steps = mass_pres ? pr.len - 1 : pr.len;
     int found = max_steps;
     if (s1 >= 0 && (long)s1 >= hs) found = min(found, s1);
     if (s2 >= 0 && (long)s2 >= hs) found = min(found, s2);
     if (found < 0) found = 0;
     if (tid == 0) {
-      const int clampi = min(max(found, 0), len - 1);
+      const int clampi = min(max(found, 0), pr.len - 1);
       const bool one = clampi >= 0 && (clampi == s1 || clampi == s2);
-      head_step[r] = found;
-      head_read[r] = (found == max_steps && !one) ? 1 : 0;
+      head_step[p] = found;
+      head_read[p] = (found == max_steps && !one) ? 1 : 0;
     }
-    st = found;
-  }
-  // ---- the row's query: wait for its tile of the projection chain
-  if (tid == 0) {
-    const int* f = flags + (b >> 4);
-    int spins = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1 << 22)) { __hip_atomic_store(flags + 1023, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    pr.st = found;
+  };
+  auto consume = [&](attn::Regs2<bf16, NP>& rg, const Prob& pr) {
+    // the row's query: wait for its tile of the projection chain (one lane polls; acquire; the workgroup meets)
+    if (tid == 0) {
+      const int* f = flags + (pr.b >> 4);
+      int spins = 0;
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 22)) { __hip_atomic_store(flags + 1023, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    rg.q = *reinterpret_cast<const uint4*>(q + (long)pr.b * D + pr.h * d + (tid % NP) * 8);
+    float o = 0.f;
+    const int n = (int)(pr.st < pr.len - 1 ? pr.st : pr.len - 1) + 1;
+    if (pr.st > 0 && n > 0) o = attn::finish3<bf16, NP>(rg, n, pr.n_pref, rsqrtf((float)d), red, nullptr, nullptr);
+    if (tid < d) ctx_out[(long)pr.b * D + pr.h * d + tid] = from_f32<bf16>(o);
+  };
+  attn::Regs2<bf16, NP> ra, rb;
+  Prob qa, qb;
+  int pA = id, pB = id + G;
+  if (pA < nprob) issue(ra, qa, pA);
+  if (pB < nprob) issue(rb, qb, pB);
+  for (;;) {
+    if (pA >= nprob) break;
+    consume(ra, qa);
+    pA += 2 * G;
+    if (pA < nprob) issue(ra, qa, pA);
+    if (pB >= nprob) break;
+    consume(rb, qb);
+    pB += 2 * G;
+    if (pB < nprob) issue(rb, qb, pB);
   }
-  __syncthreads();
-  rg2.q = *reinterpret_cast<const uint4*>(q + (long)b * D + h * d + (tid % NP) * 8);
-  float o = 0.f;
-  const int n = (int)(st < len - 1 ? st : len - 1) + 1;
-  if (st > 0 && n > 0) o = attn::finish3<bf16, NP>(rg2, n, n_pref, rsqrtf((float)d), red, nullptr, nullptr);
-  if (tid < d) ctx_out[(long)b * D + h * d + tid] = from_f32<bf16>(o);
 }
+
 #endif  // SL_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1312,7 +1331,12 @@ int sl_dec_proj_cross_fused(simulst_handle* h, const void* ctx_in, void* x, cons
   KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
   // dynamic LDS: the chain's row buffers (lds_request) cover the attention's reduction scratch (64 + RED_FLOATS floats)
   const int lds = lds_request(h) > (int)((64 + attn::RED_FLOATS) * sizeof(float)) ? lds_request(h) : (int)((64 + attn::RED_FLOATS) * sizeof(float));
-  hipLaunchKernelGGL((dec_proj_cross_fused_kernel<3>), dim3(n_tiles + H * B), dim3(256), lds, h->stream, (const bf16*)ctx_in, (bf16*)x,
+  // the attention workgroups are persistent: as many as stay resident beside the chain (2 per compute unit), each walks its problems
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  const int slots = 2 * cus - n_tiles;
+  const int n_attn = H * B < slots ? H * B : (slots > 64 ? slots : 64);
+  hipLaunchKernelGGL((dec_proj_cross_fused_kernel<3>), dim3(n_tiles + n_attn), dim3(256), lds, h->stream, (const bf16*)ctx_in, (bf16*)x,
                      (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q, B, n_tiles, h->fuse_flags, epoch, (const bf16*)Ks,
                      (const bf16*)Vc, key_len, tgt_idx, (long*)head_step, head_read, (bf16*)ctx_out, H, S_cap, ratio, waitk_k, online,
                      mass_pres, n_hint);
