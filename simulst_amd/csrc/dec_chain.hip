@@ -1235,7 +1235,7 @@ bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bo
 }
 
 // Dynamic LDS requested per workgroup: the 23 KB the kernels use, so two chain workgroups share a compute unit.  History (DESIGN.md
-// section 3, "Reproducibility"): round 2 reserved the CU's whole 160 KB because the chains did not repeat bit for bit beside an
+// N5 "Reproducibility", docs/DESIGN_NOTES.md): round 2 reserved the CU's whole 160 KB because the chains did not repeat bit for bit beside an
 // LDS-holding, matrix-core-heavy workgroup of another stream.  Round 3 isolated the trigger -- the SLP vectoriser's packed
 // `v_pk_add_f32 ... op_sel` form of the LayerNorm's x - mean -- and removed it (ln_apply's opaque registers, -fno-slp-vectorize for this
 // translation unit, tools/check_isa.py as a build step); the mechanism inside the hardware is unconfirmed (the stand-alone

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Localise the run-to-run differences of the decoder's row-local projection chain (csrc/dec_chain.hip) beside an LDS-holding,
-matrix-core-heavy neighbour on the same compute unit ("Reproducibility of the layer chains").
+matrix-core-heavy neighbour on the same compute unit (docs/DESIGN_NOTES.md N5, "Reproducibility of the layer chains").
 
 One stream repeats the chain in its PROBE form (simulst_debug_chain_probe: production instruction sequence + a dump, after the
 last contraction, of every value that crossed an LDS hand-off); another stream keeps the neighbour resident.  Every repeat is
