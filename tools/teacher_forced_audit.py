@@ -100,7 +100,7 @@ def audit_mma_hard(cfg, w, utts, copies=9, dtype=torch.bfloat16, device="cuda:0"
             recs.append(oag.simulate_mma(w, ecfg, dcfg, u, max_len_a=MAX_LEN_A, max_len_b=MAX_LEN_B, trace=tr))
             traces.append(tr)
     n_utt, T = len(utts), utts[0].size(0)
-    B, H, Ld, V = n_utt * copies, cfg.num_heads, cfg.decoder_layers, cfg.vocab
+    B = n_utt * copies
     model = SimulSTModel(cfg, w, device=device, dtype=dtype, ops=ops)
     dec, enc = model.decoder, model.encoder
     agent = BatchedStreamingAgent(model, max_len_a=MAX_LEN_A, max_len_b=MAX_LEN_B)
@@ -127,7 +127,6 @@ def audit_mma_hard(cfg, w, utts, copies=9, dtype=torch.bfloat16, device="cuda:0"
 
 def _mma_pass(cfg, model, dec, enc, agent, fb, recs, traces, n_utt, copies, T, want_logits):
     from simulst_amd import _lib
-    from simulst_amd.agent import SHIFT_SIZE, WINDOW_SIZE  # noqa: F401
     dev = model.device
     B, H, Ld, V = fb.size(0), cfg.num_heads, cfg.decoder_layers, cfg.vocab
     positions = agent._chunk_positions(T)
