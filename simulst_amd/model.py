@@ -282,12 +282,14 @@ class ConcurrentOffline:
         adjacent = all(t.is_contiguous() and t.shape[1:] == toks[0].shape[1:] for t in toks) and all(
             toks[i].data_ptr() + toks[i].numel() * esz == toks[i + 1].data_ptr() for i in range(len(toks) - 1))
         total = sum(t.size(0) for t in toks)
-        if adjacent and toks[0].untyped_storage().data_ptr() == toks[-1].untyped_storage().data_ptr():
-            allt = toks[0].as_strided((total,) + tuple(toks[0].shape[1:]), toks[0].stride())     # the batches are slices of one tensor
-        else:
-            allt = torch.cat(toks, 0)
-        lens = torch.cat([b[1].to(allt.device) for b in batches], 0)
+        # the gathers are enqueued on stream 0 too: it has waited for the caller's stream (run), the caller's stream has NOT
+        # been told to wait for anything, and a concatenation left on it would race the encoder's first reads
         with torch.no_grad(), torch.cuda.stream(self.streams[0]):
+            if adjacent and toks[0].untyped_storage().data_ptr() == toks[-1].untyped_storage().data_ptr():
+                allt = toks[0].as_strided((total,) + tuple(toks[0].shape[1:]), toks[0].stride())     # the batches are slices of one tensor
+            else:
+                allt = torch.cat(toks, 0)
+            lens = torch.cat([b[1].to(allt.device) for b in batches], 0)
             enc = self.models[0].encoder.forward(allt, lens)
             ev = torch.cuda.Event()
             ev.record(self.streams[0])

@@ -68,15 +68,15 @@ class PartitionedOffline:
         adjacent = all(t.is_contiguous() and t.shape[1:] == toks[0].shape[1:] for t in toks) and all(
             toks[i].data_ptr() + toks[i].numel() * esz == toks[i + 1].data_ptr() for i in range(len(toks) - 1))
         total = sum(t.size(0) for t in toks)
-        if adjacent and toks[0].untyped_storage().data_ptr() == toks[-1].untyped_storage().data_ptr():
-            allt = toks[0].as_strided((total,) + tuple(toks[0].shape[1:]), toks[0].stride())
-        else:
-            allt = torch.cat(toks, 0)
-        lens = torch.cat([b[1].to(allt.device) for b in batches], 0)
         self.enc_ops.h.set_stream(stream.cuda_stream)
-        with torch.no_grad(), torch.cuda.stream(stream):
+        with torch.no_grad(), torch.cuda.stream(stream):           # the gathers on the encoder's stream (model.ConcurrentOffline._joint_encoder)
             if after is not None:
                 stream.wait_event(after)
+            if adjacent and toks[0].untyped_storage().data_ptr() == toks[-1].untyped_storage().data_ptr():
+                allt = toks[0].as_strided((total,) + tuple(toks[0].shape[1:]), toks[0].stride())
+            else:
+                allt = torch.cat(toks, 0)
+            lens = torch.cat([b[1].to(allt.device) for b in batches], 0)
             enc = self.enc_model.encoder.forward(allt, lens)
             ev = torch.cuda.Event()
             ev.record(stream)
