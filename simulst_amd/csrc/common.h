@@ -60,6 +60,9 @@ struct simulst_handle {
   int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
   bool dec_embed_qkv_chain;    // offline lockstep decode: commit + embedding inside the next step's first launch (dec_embed_qkv_chain_kernel)
   bool panel_wide_plain_stores;   // experiment: default-policy stores instead of streaming ones in panel_wide_kernel
+  bool wstat;                  // tall K = 256 projections of the encoder on the weight-stationary kernel (gemm_wstat.hip)
+  bool wstat_lds_attr_set;
+  int n_cus;                   // compute units of the device (persistent one-workgroup-per-CU launches)
   bool panel_wide;             // tall bias-only K = 256 projections on the 64-rows-per-wave panel kernel (gemm_panel.hip panel_wide_kernel)
   int policy_lds_bytes;        // policy / cross-attention launch of co-scheduled batches: minimum dynamic LDS request (occupancy cap), 0: none
   int dec_vocab_chain_split;   // workgroups per row tile of the step's closing launch (dec_vocab_chain_kernel); 0: off

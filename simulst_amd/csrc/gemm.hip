@@ -39,6 +39,13 @@ __device__ __forceinline__ void lds_store(bf16* s, int m, int kq, uint4 v) {
   *reinterpret_cast<uint4*>(&s[m * (Tile<bf16>::BK + 8) + kq * 8]) = v;
 }
 
+#ifdef SL_PROBE
+__device__ long sl_probe_tile[16];
+#define TPROBE(i) do { if (EPI == SIMULST_EPI_GLU && blockIdx.x == 4003 && threadIdx.x == 0) sl_probe_tile[i] = wall_clock64(); } while (0)
+#else
+#define TPROBE(i)
+#endif
+
 template <typename TA, typename TC, int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, const TA* __restrict__ W,
                                                      const float* __restrict__ bias,
@@ -121,8 +128,10 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
   };
 
   const int nk = (p.K + BK - 1) / BK;
+  TPROBE(0);
   gload(0);
   for (int t = 0; t < nk; ++t) {
+    if (t < 6) TPROBE(1 + t);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) lds_store<BM>(As, lr + 32 * i, kq, ra[i]);
@@ -166,9 +175,47 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
     }
   }
 
+  TPROBE(8);
   // ---- epilogue: acc[i][j][e] is C[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
   const int lcol = lane & 31, lhi = lane >> 5;
-  if constexpr (EPI == SIMULST_EPI_GLU) {
+  if constexpr (EPI == SIMULST_EPI_GLU && std::is_same<TC, bf16>::value && std::is_same<TA, bf16>::value) {
+    // bf16 GLU (the subsampler's two convolutions): value * sigmoid(gate) in registers, the BM x BN/2 output tile staged through LDS
+    // (the operand buffers are free now) and written as 16-byte row segments with ONE row split per segment.  The accumulator-layout
+    // form below -- a division and a two-byte store per element -- took 10-14 us of a workgroup's 22 (conv 1) / 90 us (conv 2).
+    static_assert(TN == 2, "GLU epilogue pairs the two 32-column tiles of a wave");
+    constexpr int CS = BN / 2 + 8;                   // bf16 elements per staged row
+    static_assert(BM * CS <= LDS_A + LDS_W, "staging tile must fit in the operand buffers");
+    bf16* Cs = smem;
+    const int nv = n0 + wc * WN + lcol, ng = nv + 32;
+    const bool cok = ng < p.N;
+    const float bv = (bias && cok) ? bias[nv] : 0.f, bg = (bias && cok) ? bias[ng] : 0.f;
+    const int ocl = (wc * WN) / 2 + lcol;            // output column inside the tile
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wr * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+        const float v = (acc[i][0][e] + bv) * sigmoidf_(acc[i][1][e] + bg) * p.scale;
+        Cs[rl * CS + ocl] = from_f32<TC>(v);
+      }
+    __syncthreads();
+    constexpr int CHUNKS = BM * (BN / 2) / 8;
+    const int half_n = p.N / 2;
+    for (int ch = tid; ch < CHUNKS; ch += 256) {
+      const int rl = ch / (BN / 16), c8 = (ch % (BN / 16)) * 8;
+      const int r = m0 + rl, c = n0 / 2 + c8;
+      if (r >= p.M || c >= half_n) continue;
+      const int b = r / p.rpb, ii = r - b * p.rpb;
+      TC* dst = C + (long)b * p.c_bs + (long)ii * p.c_rs + c;
+      if (c + 8 <= half_n && ((p.c_rs | p.c_bs) & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&Cs[rl * CS + c8]);
+      } else {
+        for (int q = 0; q < 8 && c + q < half_n; ++q) dst[q] = Cs[rl * CS + c8 + q];
+      }
+    }
+    TPROBE(9);
+  } else if constexpr (EPI == SIMULST_EPI_GLU) {
     static_assert(TN == 2, "GLU epilogue pairs the two 32-column tiles of a wave");
     const int nv = n0 + wc * WN + lcol;          // value column in the prepacked W
     const int ng = nv + 32;                      // gate column
@@ -186,6 +233,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const TA* __restrict__ A, c
           C[(long)b * p.c_bs + (long)ii * p.c_rs + oc] = from_f32<TC>(v);
         }
       }
+    TPROBE(9);
   } else if constexpr ((EPI == SIMULST_EPI_BIAS || EPI == SIMULST_EPI_BIAS_GELU) && std::is_same<TC, bf16>::value &&
                        std::is_same<TA, bf16>::value) {
     // bf16 output without residual (QKV, FFN1): bias / GELU in registers, tile staged through LDS (the operand
@@ -333,6 +381,16 @@ void launch(simulst_handle* h, const void* A, const void* W, const float* bias, 
   dim3 grid(nbm * nbn);
   hipLaunchKernelGGL((linear_kernel<TA, TC, BM, BN, EPI>), grid, dim3(256), 0, h->stream,
                      (const TA*)A, (const TA*)W, bias, (const TA*)R, (TC*)C, (TA*)aux, p);
+#ifdef SL_PROBE
+  if (EPI == SIMULST_EPI_GLU && p.M > 100000) {
+    (void)hipStreamSynchronize(h->stream);
+    long t[16];
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(sl_probe_tile), sizeof t);
+    fprintf(stderr, "[probe tile GLU] M=%d N=%d K=%d: first load->tile0 %.2f | tiles", p.M, p.N, p.K, (t[1] - t[0]) * 0.01);
+    for (int i = 1; i < 6; ++i) fprintf(stderr, " %.2f", (t[i + 1] - t[i]) * 0.01);
+    fprintf(stderr, " | loop total %.2f  epilogue %.2f us\n", (t[8] - t[0]) * 0.01, (t[9] - t[8]) * 0.01);
+  }
+#endif
 }
 
 template <typename TA, typename TC, int EPI>

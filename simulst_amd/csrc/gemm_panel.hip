@@ -453,6 +453,7 @@ static bool panel_wide_wanted(const simulst_handle* h, int epi, const LinArgs& p
 
 int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
                     void* aux, const LinArgs& p) {
+  if (sl_wstat_wanted(h, SIMULST_BF16, epi, p, A, C, R)) return sl_launch_wstat(h, epi, A, W, bias, R, C, aux, p);
   if (panel_wide_wanted(h, epi, p, A, C, bias)) {
     KTimer tw(h, SIMULST_K_LINEAR);
 #ifdef SL_EXPERIMENTS      // default-policy stores instead of streaming ones (SIMULST_OPT_PANEL_WIDE = 2): measured slower

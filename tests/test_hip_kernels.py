@@ -90,6 +90,30 @@ def test_g1_subsampler_as_overlapping_gemm(ops, dtype):
     assert torch.equal(enc.out_lengths(a["lengths"], 2), a["out_lengths"])
 
 
+def test_subsampler_bf16_glu_tiles_vs_fp32(ops):
+    """The bf16 GLU epilogue of the 128 x 128 tile kernel (round 5: value * sigmoid(gate) staged through LDS, 16-byte row segments)
+    on the subsampler's two convolutions at the model's widths -- 3 x 999 frames: 1 500 and 750 output rows, ragged last tiles, rows
+    of three utterances in one tile -- against the fp32 kernel (accumulator-layout epilogue) on the same bf16-rounded operands."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.encoder import S2TEmformerEncoder
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s()
+    w = init_model(cfg, seed=5)
+    w16 = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in w.items()}
+    e16 = S2TEmformerEncoder(cfg, w16, dtype=torch.bfloat16, ops=ops)
+    e32 = S2TEmformerEncoder(cfg, w16, dtype=torch.float32, ops=ops)
+    x = torch.randn(3, 999, 80, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16).cuda()
+    y16 = e16._subsample(x, lead=True)
+    y32 = e32._subsample(x.float(), lead=True)
+    assert y16.shape == y32.shape == (3, 250, cfg.embed_dim)
+    torch.testing.assert_close(y16.float(), y32, atol=6e-2, rtol=5e-2)
+    # streaming form (no zero lead, k - 1 context frames in front): the same epilogue on a short call
+    xs = x[:, :84].contiguous()
+    z16 = e16._subsample(xs, lead=False)
+    z32 = e32._subsample(xs.float(), lead=False)
+    torch.testing.assert_close(z16.float(), z32, atol=6e-2, rtol=5e-2)
+
+
 # ------------------------------------------------------------------ row ops
 @pytest.mark.parametrize("D", [32, 256, 1024])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -602,10 +626,12 @@ def test_wide_row_panel_equals_the_row_panel(ops, case):
         outs = []
         for wide in (1, 0):
             ops.h.set_option(_lib.OPT_PANEL_WIDE, wide)
+            ops.h.set_option(_lib.OPT_WEIGHT_STATIONARY, 0)          # (the weight-stationary kernel would take the plain-output shapes first)
             try:
                 outs.append(fn())
             finally:
                 ops.h.set_option(_lib.OPT_PANEL_WIDE, 1)
+                ops.h.set_option(_lib.OPT_WEIGHT_STATIONARY, 1)
         torch.cuda.synchronize()
         return outs
 
@@ -666,6 +692,85 @@ def test_wide_row_panel_equals_the_row_panel(ops, case):
             assert torch.equal(y1, y0)
             want = ref.view(Bq, n, nt, Ht, d).permute(2, 0, 3, 1, 4)
             torch.testing.assert_close(y1[:, :, :, :n].float(), want, atol=6e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("case", ["qkv", "two_slices", "one_slice", "batched", "emf_out"])
+def test_weight_stationary_rows_equal_the_row_panels(ops, case):
+    """The encoder's tall K = 256 projections on the weight-stationary kernel (round 5, csrc/gemm_wstat.hip: a slice of the packed
+    weights resident in LDS, permuted column tiles, 16-byte stores from registers) against the row-panel kernels it replaces
+    (SIMULST_OPT_WEIGHT_STATIONARY = 0): same MFMA shape and operand roles, same k order, same epilogue arithmetic -- IDENTICAL
+    outputs; and against torch fp32.  Ragged last tile, widths of 4 x 192 / 2 x 256 / 1 x 256 / 1 x 192 columns, batched rows with
+    row strides, and the Emformer out-proj epilogue (residual on the main rows, tanh of the summary rows into the memory bank)."""
+    from simulst_amd._lib import EPI_BIAS, EPI_EMF_OUT
+    g = torch.Generator().manual_seed(78)
+    bf = torch.bfloat16
+    K = 256
+
+    def both(fn):
+        outs = []
+        for on in (1, 0):
+            ops.h.set_option(_lib.OPT_WEIGHT_STATIONARY, on)
+            try:
+                outs.append(fn())
+            finally:
+                ops.h.set_option(_lib.OPT_WEIGHT_STATIONARY, 1)
+        torch.cuda.synchronize()
+        return outs
+
+    assert ops.h.get_option(_lib.OPT_WEIGHT_STATIONARY) == 1
+    if case in ("qkv", "two_slices", "one_slice"):
+        shapes = {"qkv": ((8192 + 37, 768), (70000, 768)), "two_slices": ((9000, 512),), "one_slice": ((8200, 256), (8200, 192))}[case]
+        for M, N in shapes:
+            x = torch.randn(M, K, generator=g).to(bf).cuda()
+            W = (torch.randn(N, K, generator=g) / K ** 0.5).to(bf).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            Wp = ops.pack_fragment_major(W)
+            y1, y0 = both(lambda: ops.linear(x, Wp, b, epilogue=EPI_BIAS, w_fragment_major=True))
+            assert torch.equal(y1, y0), (M, N, int((y1 != y0).sum()))
+            torch.testing.assert_close(y1.float(), x.float() @ W.float().t() + b, atol=6e-2, rtol=3e-2)
+            y2, y3 = both(lambda: ops.linear(x, Wp, None, epilogue=EPI_BIAS, w_fragment_major=True))     # no bias
+            assert torch.equal(y2, y3)
+    elif case == "batched":
+        Bq, n, N = 40, 333, 768                              # 13 320 rows, rows of a batch 272 elements apart
+        a_rs = K + 16
+        xb = torch.randn(Bq, n, a_rs, generator=g).to(bf).cuda()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(bf).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        Wp = ops.pack_fragment_major(W)
+        ref = xb[..., :K].float() @ W.float().t() + b
+
+        def run():
+            C = torch.full((Bq, n + 3, N + 8), 9.0, device="cuda", dtype=bf)
+            ops.linear_raw(xb, Wp, b, C, M_batches=Bq, rows_per_batch=n, N=N, K=K, a_bs=n * a_rs, a_rs=a_rs,
+                           c_bs=(n + 3) * (N + 8), c_rs=N + 8, epilogue=EPI_BIAS, w_fragment_major=True)
+            return C
+        y1, y0 = both(run)
+        assert torch.equal(y1, y0)
+        torch.testing.assert_close(y1[:, :n, :N].float(), ref, atol=6e-2, rtol=3e-2)
+        assert float((y1[:, n:].float() - 9.0).abs().max()) == 0.0 and float((y1[:, :, N:].float() - 9.0).abs().max()) == 0.0
+    else:
+        # the encoder's shapes: rows_c = n_rc + T + n_sum rows per utterance in, n_main = n_rc + T out, n_sum - 1 memory rows
+        Bq, n_main, n_sum, N = 24, 378, 16, 256
+        rows_c, rows_z, n_mem = n_main + n_sum, 15 + n_main + n_sum, 15
+        ctx = torch.randn(Bq, rows_c, K, generator=g).to(bf).cuda()
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(bf).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        Wp = ops.pack_fragment_major(W)
+        res = torch.randn(Bq, n_main, N, generator=g).to(bf).cuda()
+
+        def run():
+            X1 = torch.full((Bq, n_main, N), 7.0, device="cuda", dtype=bf)
+            Zn = torch.full((Bq, rows_z, N), 5.0, device="cuda", dtype=bf)
+            ops.linear_raw(ctx, Wp, b, X1, M_batches=Bq, rows_per_batch=rows_c, N=N, K=K, a_bs=rows_c * K, a_rs=K,
+                           c_bs=n_main * N, c_rs=N, epilogue=EPI_EMF_OUT, R=res, r_bs=n_main * N, r_rs=N, n_main=n_main,
+                           aux=Zn, aux_rows=n_mem, aux_bs=rows_z * N, w_fragment_major=True)
+            return X1, Zn
+        (x1, z1), (x0, z0) = both(run)
+        assert torch.equal(x1, x0) and torch.equal(z1, z0)
+        y = ctx.float() @ W.float().t() + b
+        torch.testing.assert_close(x1.float(), y[:, :n_main] + res.float(), atol=6e-2, rtol=3e-2)
+        torch.testing.assert_close(z1[:, :n_mem].float(), torch.tanh(y[:, n_main:n_main + n_mem]), atol=2e-2, rtol=2e-2)
+        assert float((z1[:, n_mem:].float() - 5.0).abs().max()) == 0.0        # the last summary row is dropped, other rows untouched
 
 
 @pytest.mark.parametrize("epi", ["bias", "gelu", "res", "emf_out", "head_major"])
