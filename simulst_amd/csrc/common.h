@@ -60,6 +60,8 @@ struct simulst_handle {
   int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
   bool dec_embed_qkv_chain;    // offline lockstep decode: commit + embedding inside the next step's first launch (dec_embed_qkv_chain_kernel)
   bool panel_wide_plain_stores;   // experiment: default-policy stores instead of streaming ones in panel_wide_kernel
+  bool tile256;                // bf16 GLU contractions (the subsampler) on 256 x 256 tiles, one 8-wave workgroup per CU (gemm_tile256.hip)
+  bool tile256_lds_attr_set;
   bool wstat;                  // tall K = 256 projections of the encoder on the weight-stationary kernel (gemm_wstat.hip)
   bool wstat_lds_attr_set;
   int n_cus;                   // compute units of the device (persistent one-workgroup-per-CU launches)

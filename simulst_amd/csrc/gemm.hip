@@ -482,6 +482,7 @@ extern "C" int simulst_linear(simulst_handle* h, const simulst_linear_desc* d, c
                "N % 16 == 0 and K % (64 bytes) == 0");
   if (skinny_ok) return sl_launch_skinny(h, d->dtype, d->epilogue, A, W, bias, R, C, p);
   SL_REQUIRE(h, !p.ln_g, SIMULST_E_SHAPE, "simulst_linear: LN prologue needs a decode-step shape");
+  if (sl_tile256_wanted(h, d->dtype, d->epilogue, p, C)) return sl_launch_tile256(h, A, W, bias, C, p);
   KTimer t(h, SIMULST_K_LINEAR);
   int rc = d->dtype == SIMULST_F32 ? dispatch<float>(h, d->epilogue, A, W, bias, R, C, aux, p)
                                    : dispatch<bf16>(h, d->epilogue, A, W, bias, R, C, aux, p);

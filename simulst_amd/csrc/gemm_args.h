@@ -84,6 +84,9 @@ int sl_launch_skinny(simulst_handle* h, int dtype, int epilogue, const void* A, 
 bool sl_panel_wanted(int dtype, int epi, const LinArgs& p);
 int sl_launch_panel(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C,
                     void* aux, const LinArgs& p);
+// 256 x 256 tiles with the GLU epilogue for the subsampler's convolutions, defined in gemm_tile256.hip
+bool sl_tile256_wanted(const simulst_handle* h, int dtype, int epi, const LinArgs& p, const void* C);
+int sl_launch_tile256(simulst_handle* h, const void* A, const void* W, const float* bias, void* C, const LinArgs& p);
 // weight-stationary persistent kernel for the encoder's tall K = 256 projections (QKV, out-proj), defined in gemm_wstat.hip
 bool sl_wstat_wanted(const simulst_handle* h, int dtype, int epi, const LinArgs& p, const void* A, const void* C, const void* R);
 int sl_launch_wstat(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C, void* aux,

@@ -64,6 +64,9 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_DEC_VOCAB_CHAIN_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->dec_vocab_chain_split = v; }
   h->dec_embed_qkv_chain = true;
   if (const char* e = getenv("SIMULST_DEC_EMBED_QKV_CHAIN")) h->dec_embed_qkv_chain = atoi(e) != 0;
+  h->tile256 = true;
+  if (const char* e = getenv("SIMULST_CONV_TILE256")) h->tile256 = atoi(e) != 0;
+  h->tile256_lds_attr_set = false;
   h->wstat = true;
   if (const char* e = getenv("SIMULST_WEIGHT_STATIONARY")) h->wstat = atoi(e) != 0;
   h->wstat_lds_attr_set = false;
@@ -216,6 +219,7 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
     case SIMULST_OPT_FUSED_ARGMAX: h->fused_argmax = value != 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_EMBED_QKV_CHAIN: h->dec_embed_qkv_chain = value != 0; return SIMULST_OK;
     case SIMULST_OPT_WEIGHT_STATIONARY: h->wstat = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_CONV_TILE256: h->tile256 = value != 0; return SIMULST_OK;
     case SIMULST_OPT_PANEL_WIDE:
 #ifdef SL_EXPERIMENTS
       SL_REQUIRE(h, value >= 0 && value <= 2, SIMULST_E_ARG, "simulst_set_option(PANEL_WIDE): 0, 1, 2 (plain stores)");
@@ -257,6 +261,7 @@ extern "C" int simulst_get_option(simulst_handle* h, int32_t option, int32_t* va
     case SIMULST_OPT_PANEL_WIDE: *value = h->panel_wide ? (h->panel_wide_plain_stores ? 2 : 1) : 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT: *value = h->dec_vocab_chain_split; return SIMULST_OK;
     case SIMULST_OPT_WEIGHT_STATIONARY: *value = h->wstat; return SIMULST_OK;
+    case SIMULST_OPT_CONV_TILE256: *value = h->tile256; return SIMULST_OK;
     case SIMULST_OPT_DEC_FUSE_PROJ_CROSS: {
       // bit 0: on; bit 1: a waiting workgroup's bounded spin ran out at some point (synchronises the stream: tests only)
       int err = 0;
