@@ -53,7 +53,7 @@ if ROOT not in sys.path:
 # Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # HBM traffic of the dominant kernels from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest round first
-ENCODER_TRAFFIC_FILES = ["r05_encoder_traffic.json", "r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
+ENCODER_TRAFFIC_FILES = ["r05_c_encoder_traffic.json", "r05_encoder_traffic.json", "r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
 CROSS_ATTN_TRAFFIC_FILES = ["r05_pmc_cross_attention_traffic.json", "r04_pmc_cross_attention_traffic.json", "r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
 PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # all classes of one launch sequence (round 1), tools/pmc_summary.py
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
@@ -1208,7 +1208,8 @@ def main(argv=None):
                     # FETCH_SIZE / WRITE_SIZE passes of one encoder pass (tools/encoder_traffic.py)
                     ENCODER_TRAFFIC_FILE, enc = first_profile(ENCODER_TRAFFIC_FILES)
                     gemm = sum(v["hbm_bytes_per_pass"] for k, v in enc["per_kernel"].items()
-                               if k.startswith(("ffn_fused_kernel", "ffn_pipe_kernel", "panel_kernel", "panel_wide_kernel", "linear_kernel")))
+                               if k.startswith(("ffn_fused_kernel", "ffn_pipe_kernel", "panel_kernel", "panel_wide_kernel", "linear_kernel", "wstat_kernel",
+                                                "tile256_glu_kernel")))
                     e["traffic"] = round(gemm / enc["utterances"] * Bs / e["launches_per_sequence"])
                     e["traffic_source"] = (f"profiles/{ENCODER_TRAFFIC_FILE}: FETCH_SIZE / WRITE_SIZE passes of one encoder pass over "
                                            f"{enc['utterances']} utterances (encoder total {enc['encoder_hbm_MB_per_utterance']} MB per "

@@ -4,7 +4,7 @@
 # command (main leg only), FETCH_SIZE / WRITE_SIZE passes of one encoder pass (tools/encoder_traffic.py, 256 utterances) and of the
 # dominant kernel (tools/kernel_bench.py cross_attn), a SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE pass of the main leg.
 # Counter passes carry --kernel-trace only; the program itself follows `--` (no wrapper).
-TAG=${1:-r05_a}
+TAG=${1:-r05_c}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
