@@ -163,8 +163,12 @@ __global__ __launch_bounds__(512, 1) void tile256_glu_kernel(const bf16* __restr
 // bf16 GLU contractions of tall problems whose width is a multiple of 256 (the subsampler at the model's widths), 16-byte aligned
 // output rows
 bool sl_tile256_wanted(const simulst_handle* h, int dtype, int epi, const LinArgs& p, const void* C) {
+  // the kernel addresses its operands with 32-bit element offsets: both must span fewer than 2^31 elements (a 5 000-utterance batch of
+  // the second convolution does not -- it stays on the 128 x 128 kernel's 64-bit pointers)
+  const long a_span = (long)((p.M + p.rpb - 1) / p.rpb) * p.a_bs + (long)p.rpb * p.a_rs + p.K, w_span = (long)p.N * p.K;
   return h->tile256 && dtype == SIMULST_BF16 && epi == SIMULST_EPI_GLU && p.M >= 8192 && p.N % TB == 0 && p.K % 8 == 0 &&
-         ((p.c_rs | p.c_bs) & 7) == 0 && ((uintptr_t)C & 15) == 0 && !p.w_packed && !p.ln_g;
+         ((p.c_rs | p.c_bs) & 7) == 0 && ((uintptr_t)C & 15) == 0 && !p.w_packed && !p.ln_g && a_span < (1L << 31) && w_span < (1L << 31) &&
+         p.a_bs >= 0 && p.a_rs >= 0;
 }
 
 int sl_launch_tile256(simulst_handle* h, const void* A, const void* W, const float* bias, void* C, const LinArgs& p) {
