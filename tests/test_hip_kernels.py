@@ -137,6 +137,15 @@ def test_subsampler_big_tiles_equal_the_128_tiles(ops):
     assert outs[0].shape == (40, 250, cfg.embed_dim)
     assert torch.equal(outs[0], outs[1]), int((outs[0] != outs[1]).sum())
     assert float(outs[0].float().abs().mean()) > 0.1
+    # no zero lead (the streaming form's addressing: k - 1 context frames in front) at the same row counts
+    outs = []
+    for on in (1, 0):
+        ops.h.set_option(_lib.OPT_CONV_TILE256, on)
+        try:
+            outs.append(enc._subsample(x, lead=False).clone())
+        finally:
+            ops.h.set_option(_lib.OPT_CONV_TILE256, 1)
+    assert torch.equal(outs[0], outs[1]) and outs[0].shape[1] == 247
 
 
 # ------------------------------------------------------------------ row ops
@@ -796,6 +805,18 @@ def test_weight_stationary_rows_equal_the_row_panels(ops, case):
         torch.testing.assert_close(x1.float(), y[:, :n_main] + res.float(), atol=6e-2, rtol=3e-2)
         torch.testing.assert_close(z1[:, :n_mem].float(), torch.tanh(y[:, n_main:n_main + n_mem]), atol=2e-2, rtol=2e-2)
         assert float((z1[:, n_mem:].float() - 5.0).abs().max()) == 0.0        # the last summary row is dropped, other rows untouched
+        # no memory (max_memory_size = 0): every input row is a main row, nothing goes to the bank
+        ctx2 = ctx[:, :n_main].contiguous()
+
+        def run2():
+            X1 = torch.full((Bq, n_main, N), 7.0, device="cuda", dtype=bf)
+            Zn = torch.full((Bq, 1, N), 5.0, device="cuda", dtype=bf)
+            ops.linear_raw(ctx2, Wp, b, X1, M_batches=Bq, rows_per_batch=n_main, N=N, K=K, a_bs=n_main * K, a_rs=K,
+                           c_bs=n_main * N, c_rs=N, epilogue=EPI_EMF_OUT, R=res, r_bs=n_main * N, r_rs=N, n_main=n_main,
+                           aux=Zn, aux_rows=0, aux_bs=N, w_fragment_major=True)
+            return X1, Zn
+        (x3, z3), (x2, z2) = both(run2)
+        assert torch.equal(x3, x2) and torch.equal(x3, x1) and float((z3.float() - 5.0).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("epi", ["bias", "gelu", "res", "emf_out", "head_major"])
