@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256, 3) void emformer_attn_mfma_kernel(
   const int u_hi = min(t1, max(len, 0));
   const int n_uk = max(0, u_hi - u_lo);
   const int nk = n_memk + a.R + n_lck + n_uk;            // <= 64 (checked on the host)
+  const int nk1 = max(nk - 1, 0);                        // absent keys read key nk - 1 (key 0 of an empty set: a valid row, fully masked)
   const int nq = a.R + (t1 - t0) + (a.use_summary ? 1 : 0);   // <= 32
   const bf16* Zb = QKV + (long)b * a.rows_z * D3;
   bf16* Cb = CTX + (long)b * a.rows_c * a.D;
@@ -104,9 +105,9 @@ __global__ __launch_bounds__(256, 3) void emformer_attn_mfma_kernel(
   };
   // -> element offset of key j's row from Zb (its K channels start at + D, its V channels at + 2 D); streaming: pointers, because
   //    the left-context keys live in the carried buffers
-  auto key_off = [&](int j) { return (unsigned)(key_row(min(j, nk - 1)) * D3); };
+  auto key_off = [&](int j) { return (unsigned)(key_row(min(j, nk1)) * D3); };
   auto key_ptrs = [&](int j, const bf16*& kp, const bf16*& vp) {
-    const int jc = min(j, nk - 1);
+    const int jc = min(j, nk1);
     const bf16* row = Zb + (unsigned)(key_row(jc) * D3);
     kp = row + a.D; vp = row + 2 * a.D;
     const int jl = jc - n_memk - a.R;
