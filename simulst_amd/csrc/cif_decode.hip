@@ -249,11 +249,16 @@ int run_cif(simulst_handle* h, const simulst_cif_decoder_desc* dd, const simulst
   const bool chain = dd->ffn_partial && dd->x_mid && sl_dec_chain_ok(h, dt, B, D, F, pk != 0);
   const bool chain_ffn = chain && B <= h->dec_chain_ffn_max_rows;
   const bool attn_chain = chain && sl_dec_attn_chain_ok(h, dt, B, H, d, dd->cap);
+  // round 5: the feed-forward chain of layer l with the slab sum + LN1 + QKV of layer l + 1 in one launch (as simulst_mma_decode)
+  const bool fuse_ffn_qkv = chain_ffn && !attn_chain && sl_dec_ffn_qkv_chain_ok(h, B, F);
+  bool qkv_done = false;
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_cif_dec_layer& L = layers[l];
       const void* kk_l = (const char*)dd->kk + (size_t)l * B * D * (dt == SIMULST_F32 ? 4 : 2);
-      if (chain_ffn && l > 0) {                     // the previous layer's feed-forward slabs are added here, then LN1 + QKV
+      if (qkv_done) {
+        qkv_done = false;                           // (x and qkv of this layer were written by the previous layer's launch)
+      } else if (chain_ffn && l > 0) {                     // the previous layer's feed-forward slabs are added here, then LN1 + QKV
         if ((rc = sl_dec_qkv_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[l - 1].b2, L.ln1_g, L.ln1_b, L.wqkv, L.bqkv,
                                    dd->qkv, B, F))) return rc;
       } else {
@@ -277,6 +282,13 @@ int run_cif(simulst_handle* h, const simulst_cif_decoder_desc* dd, const simulst
         }
       }
       if (chain_ffn) {
+        if (fuse_ffn_qkv && l + 1 < dd->n_layers) {
+          const simulst_cif_dec_layer& Ln = layers[l + 1];
+          if ((rc = sl_dec_ffn_qkv_chain(h, dd->q, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2, dd->ffn_partial, B, F,
+                                         Ln.ln1_g, Ln.ln1_b, Ln.wqkv, Ln.bqkv, dd->qkv))) return rc;
+          qkv_done = true;
+          continue;
+        }
         if ((rc = sl_dec_ffn_chain(h, dd->q, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2, dd->ffn_partial,
                                    nullptr, dd->x_mid, B, F))) return rc;
         continue;

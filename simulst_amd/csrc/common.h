@@ -60,6 +60,9 @@ struct simulst_handle {
   int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
   bool dec_embed_qkv_chain;    // offline lockstep decode: commit + embedding inside the next step's first launch (dec_embed_qkv_chain_kernel)
   bool panel_wide_plain_stores;   // experiment: default-policy stores instead of streaming ones in panel_wide_kernel
+  bool dec_fuse_ffn_qkv;       // decode loops: feed-forward chain of layer l + LN / QKV of layer l + 1 in one launch (dec_chain.hip, round 5)
+  int* chain_sem;              // its ticket words (one per row tile), device memory, lazily allocated
+  int chain_sem_splits;
   bool tile256;                // bf16 GLU contractions (the subsampler) on 256 x 256 tiles, one 8-wave workgroup per CU (gemm_tile256.hip)
   bool tile256_lds_attr_set;
   bool wstat;                  // tall K = 256 projections of the encoder on the weight-stationary kernel (gemm_wstat.hip)
@@ -319,6 +322,10 @@ int sl_dec_proj_cross_fused(simulst_handle* h, const void* ctx_in, void* x, cons
 int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
                      const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
                      int32_t* sem, void* x_mid, int B, int F);
+bool sl_dec_ffn_qkv_chain_ok(const simulst_handle* h, int B, int F);
+int sl_dec_ffn_qkv_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
+                         const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial, int B,
+                         int F, const float* nln_g, const float* nln_b, const void* nWqkv, const float* nbqkv, void* qkv);
 int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
                      const float* ln_b, const void* Wqkv, const float* bqkv, void* qkv, int B, int F);
 int sl_self_attention_fused(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* Wqkv,

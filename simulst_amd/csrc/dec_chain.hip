@@ -602,6 +602,211 @@ __global__ __launch_bounds__(256, 2) void dec_ffn_chain_kernel(
   if (tid == 0) __hip_atomic_store(sem + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
+#ifdef SL_EXPERIMENTS
+// Device-coherent 16-byte accesses for data handed from one workgroup to another INSIDE a launch.  MI355X has one L2 per XCD and the
+// splits of a row tile sit on eight different XCDs: an agent-scope release / acquire fence is `buffer_wbl2 sc1` / `buffer_inv sc1`,
+// i.e. the producer writes back its XCD's whole L2 and the consumer drops its own -- measured: the fused launch below took ~25 us
+// longer than the two launches it replaces (105 ms against 91 ms per pass).  With sc1 on the accesses themselves the slabs are written
+// through to memory and read from there, and no cache is flushed or invalidated for them.
+__device__ __forceinline__ void st16_sc1(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 ld16_sc1(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// add_slabs with device-coherent slab reads (same summation order)
+__device__ __forceinline__ uint2 add_slabs_sc1(const float (&r)[4], float4 b2, const float* partial, int splits, int M, int g, int lane) {
+  float4 s = float4{b2.x + r[0], b2.y + r[1], b2.z + r[2], b2.w + r[3]};
+  for (int k0 = 0; k0 < splits; k0 += 8) {
+    f32x4 p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = ld16_sc1(partial + ((long)min(k0 + j, splits - 1) * M + g) * CD + 4 * lane);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float m = k0 + j < splits ? 1.f : 0.f;
+      s.x = fmaf(p[j].x, m, s.x); s.y = fmaf(p[j].y, m, s.y); s.z = fmaf(p[j].z, m, s.z); s.w = fmaf(p[j].w, m, s.w);
+    }
+  }
+  return pack4(s.x, s.y, s.z, s.w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the feed-forward chain of layer l AND the slab sum + LayerNorm + QKV projection of layer l + 1 in ONE launch.
+// In the three-stream pass a launch boundary between two dependent chain launches costs ~8 us of a stream's time (62 ms of decode wall
+// for 34 ms of kernel time over 3 410 launches); inside a launch the same hand-off is a ticket counter.  Every split workgroup of a row
+// tile computes its slab exactly as dec_ffn_chain_kernel does and draws a ticket; workgroups sp = 0 .. n_cb - 1 then WAIT until all
+// `splits` slabs of the tile are published and run dec_qkv_chain_kernel's body for column block cb = sp -- x' is still in their LDS
+// (every split builds it), so no x_mid round trip; the others exit.  Same expressions in the same order as the two launches: identical
+// results (tests/test_hip_dec_chain.py).
+// Tickets: sem[tile] only ever counts up; a workgroup's ticket t tells the launch's target (t / splits + 1) * splits, because every
+// earlier launch on the stream completed all `splits` arrivals of the tile.  No deadlock: workgroups are dispatched in id order and
+// the splits of a tile have consecutive ids, so a waiting workgroup only ever waits for workgroups that are resident or next in line,
+// and every complete tile in front of them finishes without waiting on anything later.
+// MEASURED (driver form, same box): 93.4-94.0 ms per pass against 90.4-90.6 ms for the two launches (105 ms with agent-scope fences
+// instead of sc1 accesses, see above) although the pass has 16 % fewer launches: what separates two dependent chain launches in the
+// three-stream pass is not a fixed launch cost but queueing behind the other streams' workgroups, which a waiting workgroup does not
+// escape -- it only holds its slot longer.  EXPERIMENTS builds only, off by default.
+template <int RTL, int XM>
+__global__ __launch_bounds__(256, 2) void dec_ffn_qkv_chain_kernel(
+    const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wco, const float* __restrict__ bco,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W1,
+    const float* __restrict__ b1, const uint4* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ partial,
+    int* __restrict__ sem, int M, int F, int splits, const float* __restrict__ nln_g, const float* __restrict__ nln_b,
+    const uint4* __restrict__ nW, const float* __restrict__ nbias, bf16* __restrict__ qkv, int n_cb) {
+  constexpr bool HANDOFF = true;
+  (void)HANDOFF;
+  constexpr int RT = 16 * RTL;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];           // 2 * RT * XS + 8 elements: ONE LDS object
+  unsigned short* bufA = lds;
+  unsigned short* bufB = lds + RT * XS;
+  int* flag = reinterpret_cast<int*>(lds + 2 * RT * XS);
+  SL_CHAIN_SETPRIO();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  // split index fastest: the 8 XCDs each see ONE split's slice of W1 / W2 (workgroup ids are dealt round-robin), so a
+  // layer's 2 MB of feed-forward weights are 256 KB per XCD L2
+  const int sp = blockIdx.x % splits, tile = blockIdx.x / splits;
+  const int m0 = tile * RT;
+  PROBE(0);
+  const int tw = 4 * wave;                               // this wave's first column tile of every 256-column block
+  const int nks2 = F / 32;                               // k-steps of a whole fc2 row
+  WUnit u0, u1;
+  load_unit(u0, Wco, tw, NKS, 0, lane);
+  rows_to_lds<RTL>(ctx, bufA, m0, M, tid);
+  load_unit(u1, Wco, tw + 2, NKS, 0, lane);
+  const int nb = 64 * wave + 4 * lg;
+  float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS + 8);  // [bco | b1 of this split | b2 | gamma | beta] x 256
+  vec[tid] = bco[tid]; vec[256 + tid] = b1[256 * sp + tid]; vec[512 + tid] = b2[tid];
+  vec[768 + tid] = ln_g[tid]; vec[1024 + tid] = ln_b[tid];
+  uint2 res[RTL][4];
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int g = m0 + rt * 16 + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      res[rt][ct] = *reinterpret_cast<const uint2*>(x + (long)(g < M ? g : 0) * CD + nb + 16 * ct);
+  }
+  lds_barrier();
+  PROBE(1);
+  f32x4 acc[RTL][4];
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
+  load_unit(u0, W1, 16 * sp + tw, NKS, 0, lane);         // fc1 rows (hidden units) of this split, this wave's 64
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
+  load_unit(u1, W1, 16 * sp + tw + 2, NKS, 0, lane);
+  PROBE(2);
+  // x' = bf16(x + Wco . ctx + bco) -> bufB (kept to the end: the residual of the reduction)
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int row = rt * 16 + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float r[4];
+      unpack4(res[rt][ct], r);
+      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
+      const uint2 o = pack4(acc[rt][ct][0] + bv.x + r[0], acc[rt][ct][1] + bv.y + r[1], acc[rt][ct][2] + bv.z + r[2],
+                            acc[rt][ct][3] + bv.w + r[3]);
+      *reinterpret_cast<uint2*>(bufB + row * XS + nb + 16 * ct) = o;
+    }
+  }
+  lds_barrier();
+  ln_rows<RTL, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
+               *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane), wave, lane);
+  lds_barrier();
+  PROBE(3);
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
+  load_unit(u0, W2, tw, nks2, NKS * sp, lane);           // fc2 columns of this wave, k-steps (hidden units) of this split
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
+  load_unit(u1, W2, tw + 2, nks2, NKS * sp, lane);
+  PROBE(4);
+  lds_barrier();                                               // every wave is done reading LN(x') from bufA
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int row = rt * 16 + lr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const float4 bv = *reinterpret_cast<const float4*>(vec + 256 + nb + 16 * ct);
+      const f32x2 h0 = gelu_fast2(f32x2{acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y});
+      const f32x2 h1 = gelu_fast2(f32x2{acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w});
+      *reinterpret_cast<uint2*>(bufA + row * XS + nb + 16 * ct) = pack4(h0.x, h0.y, h1.x, h1.y);
+    }
+  }
+  lds_barrier();
+  PROBE(5);
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
+  PROBE(6);
+  float* slab = partial + (long)sp * M * CD;
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int g = m0 + rt * 16 + lr;
+    if (g >= M) continue;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      st16_sc1(slab + (long)g * CD + nb + 16 * ct, acc[rt][ct]);
+  }
+  // ---- hand-off: publish the slab, draw a ticket
+  if (sp >= n_cb) {                                              // nothing more to do here: publish and leave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(sem + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (slabs: written through, above)
+    return;
+  }
+  // column block cb = sp of the next layer's QKV: its weights and vectors are requested BEFORE the wait
+  const int cb = sp;
+  const int tq = 16 * cb + 4 * wave;
+  load_unit(u0, nW, tq, NKS, 0, lane);
+  load_unit(u1, nW, tq + 2, NKS, 0, lane);
+  const float4 b24 = *reinterpret_cast<const float4*>(vec + 512 + 4 * lane);
+  lds_barrier();                                                 // every wave is past its last read of the old vectors (b1: GELU epilogue)
+  vec[tid] = nbias[256 * cb + tid]; vec[768 + tid] = nln_g[tid]; vec[1024 + tid] = nln_b[tid];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (also waits for the prefetched fragments: they hit L2)
+  __syncthreads();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(sem + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int target = (t / splits + 1) * splits;
+    while (__hip_atomic_load(sem + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  // ---- dec_qkv_chain_kernel's body: x <- bf16(x' + b2 + slabs) (x' from bufB), LN, 256 columns of the projection
+#pragma unroll
+  for (int i = 0; i < 4 * RTL; ++i) {
+    const int row = wave + 4 * i, g = m0 + row;
+    uint2 o = make_uint2(0, 0);
+    if (g < M) {
+      float r[4];
+      unpack4(*reinterpret_cast<const uint2*>(bufB + row * XS + 4 * lane), r);
+      o = add_slabs_sc1(r, b24, partial, splits, M, g, lane);
+      if (cb == 0) *reinterpret_cast<uint2*>(x + (long)g * CD + 4 * lane) = o;
+    }
+    *reinterpret_cast<uint2*>(bufB + row * XS + 4 * lane) = o;
+  }
+  lds_barrier();
+  ln_rows<RTL, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
+               *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane), wave, lane);
+  lds_barrier();
+  zero_acc<RTL>(acc);
+  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
+  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
+#pragma unroll
+  for (int rt = 0; rt < RTL; ++rt) {
+    const int g = m0 + rt * 16 + lr;
+    if (g >= M) continue;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
+      *reinterpret_cast<uint2*>(qkv + (long)g * (256 * n_cb) + 256 * cb + nb + 16 * ct) =
+          pack4(acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w);
+    }
+  }
+}
+
+#endif  // SL_EXPERIMENTS (dec_ffn_qkv_chain_kernel)
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The launch after a feed-forward chain without hand-off:  x <- bf16(x' + b2 + slabs)  (x' from x_mid), then, unless
 // W == nullptr, qkv[:, 256 cb .. 256 cb + 255] = W LN(x) + b for column block cb = blockIdx.x % n_cb  (LN1 + QKV of the next
@@ -1260,6 +1465,9 @@ static hipError_t raise_lds_limits_mode() {
   hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, true, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, false, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+#ifdef SL_EXPERIMENTS
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_qkv_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+#endif
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_vocab_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_embed_qkv_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
@@ -1371,6 +1579,49 @@ int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wc
 #undef FC
   return sl_launch_status(h, "simulst_mma_decode(feed-forward chain)");
 }
+
+#ifdef SL_EXPERIMENTS     // EXPERIMENT, measured slower
+// feed-forward chain of a layer + slab sum, LayerNorm and QKV projection of the NEXT layer in one launch (dec_ffn_qkv_chain_kernel)
+constexpr int CHAIN_SEM_TILES = 4096;
+bool sl_dec_ffn_qkv_chain_ok(const simulst_handle* h, int B, int F) {
+  return h->dec_fuse_ffn_qkv && F / 256 >= 3 && (B + 15) / 16 <= CHAIN_SEM_TILES;
+}
+
+int sl_dec_ffn_qkv_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
+                         const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial, int B,
+                         int F, const float* nln_g, const float* nln_b, const void* nWqkv, const float* nbqkv, void* qkv) {
+  if (int rc = raise_lds_limits(h)) return rc;
+  const int splits = F / 256;
+  if (!h->chain_sem) {
+    hipError_t e = hipMalloc((void**)&h->chain_sem, CHAIN_SEM_TILES * sizeof(int));
+    if (e != hipSuccess) { h->err = "simulst_mma_decode: ticket words of the feed-forward + QKV launch"; return (int)e; }
+    h->chain_sem_splits = 0;
+  }
+  if (h->chain_sem_splits != splits) {                           // the tickets count in units of `splits`: restart them in stream order
+    const hipError_t e = hipMemsetAsync(h->chain_sem, 0, CHAIN_SEM_TILES * sizeof(int), h->stream);
+    if (e != hipSuccess) { h->err = "simulst_mma_decode: ticket words of the feed-forward + QKV launch"; return (int)e; }
+    h->chain_sem_splits = splits;
+  }
+  KTimer t(h, SIMULST_K_DEC_FFN_CHAIN);
+#define FQ(XM)                                                                                                         \
+  hipLaunchKernelGGL((dec_ffn_qkv_chain_kernel<1, XM>), dim3(((B + 15) / 16) * splits), dim3(256), lds_request(h),     \
+                     h->stream, (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,  \
+                     (const uint4*)W2, b2, partial, h->chain_sem, B, F, splits, nln_g, nln_b, (const uint4*)nWqkv, nbqkv, \
+                     (bf16*)qkv, 3)
+  SL_XMODE(h, FQ);
+#undef FQ
+  return sl_launch_status(h, "simulst_mma_decode(feed-forward chain + next layer's LN + QKV)");
+}
+
+#else
+bool sl_dec_ffn_qkv_chain_ok(const simulst_handle*, int, int) { return false; }
+int sl_dec_ffn_qkv_chain(simulst_handle* h, const void*, void*, const void*, const float*, const float*, const float*, const void*,
+                         const float*, const void*, const float*, float*, int, int, const float*, const float*, const void*, const float*,
+                         void*) {
+  h->err = "feed-forward chain + next layer's QKV in one launch: an EXPERIMENTS build only";
+  return SIMULST_E_ARG;
+}
+#endif  // SL_EXPERIMENTS
 
 // x <- x_mid + b2 + slabs; qkv = Wqkv LN(x) + bqkv (Wqkv == nullptr: the reduction only)
 int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,

@@ -827,6 +827,9 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   // round 4: a step's commit (fold of the greedy pick's pairs, token, position) + the new embedding ride in the NEXT step's first launch
   // with layer 0's LayerNorm + QKV (dec_embed_qkv_chain_kernel) -- lockstep offline rows only; the last step of the call commits as before
   const bool fuse_commit = chain_ffn && !ctlp && !device_indexed && np_uniform >= 0 && h->dec_embed_qkv_chain;
+  // round 5: the feed-forward chain of layer l with the slab sum + LN1 + QKV of layer l + 1 in one launch (dec_ffn_qkv_chain_kernel)
+  const bool fuse_ffn_qkv = chain_ffn && !attn_chain && sl_dec_ffn_qkv_chain_ok(h, B, F);
+  bool qkv_done = false;                         // this layer's QKV came out of the previous layer's feed-forward launch
   int pending_pairs = 0;                         // pairs of the previous step's projection that no launch has committed yet
   for (int s = 0; s < n_steps; ++s) {
     for (int l = 0; l < dd->n_layers; ++l) {
@@ -848,7 +851,9 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         hs.po = dd->partial_self; hs.bo = L.bo; hs.x_mid = dd->x_mid;
         xin = dd->x_mid;
       } else {
-        if (chain_ffn && l > 0) {                // the previous layer's feed-forward slabs are added here, then LN1 + QKV
+        if (qkv_done) {
+          qkv_done = false;                      // (x and qkv of this layer were written by the previous layer's launch)
+        } else if (chain_ffn && l > 0) {         // the previous layer's feed-forward slabs are added here, then LN1 + QKV
           if ((rc = sl_dec_qkv_chain(h, dd->x_mid, dd->x, dd->ffn_partial, layers[l - 1].b2, L.ln1_g, L.ln1_b, L.wqkv, L.bqkv,
                                      dd->qkv, B, F))) return rc;
         } else {
@@ -902,6 +907,13 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
       }
     cross_done:
       if (chain_ffn) {
+        if (fuse_ffn_qkv && l + 1 < dd->n_layers) {
+          const simulst_dec_layer& Ln = layers[l + 1];
+          if ((rc = sl_dec_ffn_qkv_chain(h, dd->ctx, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2, dd->ffn_partial,
+                                         B, F, Ln.ln1_g, Ln.ln1_b, Ln.wqkv, Ln.bqkv, dd->qkv))) return rc;
+          qkv_done = true;
+          continue;
+        }
         if ((rc = sl_dec_ffn_chain(h, dd->ctx, dd->x, L.c_wo, L.c_bo, L.ln3_g, L.ln3_b, L.fc1, L.b1, L.fc2, L.b2,
                                    dd->ffn_partial, dd->ffn_sem, dd->x_mid, B, F))) return rc;
         continue;

@@ -483,6 +483,66 @@ def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):
         assert (o.h.timer_read(_lib.K_DEC_ATTN_CHAIN)[1] > 0) == want
 
 
+@pytest.mark.experiments
+@pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback", "cif"])
+def test_feed_forward_and_next_qkv_in_one_launch_change_no_token(model_kind):
+    """Round 5 experiment (measured slower, EXPERIMENTS builds, off by default): the feed-forward chain of layer l and the slab sum +
+    LayerNorm + QKV of layer l + 1 as ONE launch (the hand-off a ticket counter per row tile and device-coherent slab accesses,
+    dec_ffn_qkv_chain_kernel; SIMULST_OPT_DEC_FUSE_FFN_QKV) against the two launches: the same
+    expressions in the same order, so every token of every row is IDENTICAL -- bf16, 320 ragged rows (a ragged last row tile), 24 steps,
+    4 decoder layers (three fused boundaries per step), twice on the same handle (the tickets only ever count up) and on a second row
+    count (the ticket words are shared by row tiles of every call); and the fused launches really ran (one launch class fewer)."""
+    from simulst_amd.cif import CIFTransformerModel
+    from simulst_amd.config import cif_transformer_s, mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.ops import Ops
+    from simulst_amd.weights import init_model
+    B, T, U = 320, 240, 24
+    fb = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(18))
+    L = torch.randint(100, T + 1, (B,), generator=torch.Generator().manual_seed(19))
+    L[0] = T
+    for b in range(B):
+        fb[b, L[b]:] = 0
+    fb = fb.cuda().to(torch.bfloat16)
+    if model_kind == "cif":
+        cfg = cif_transformer_s(encoder_layers=1, decoder_layers=4, cif_beta=1.0)
+        w = init_model(cfg, seed=22)
+        w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
+        w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.0
+        make = lambda ops: CIFTransformerModel(cfg, w, dtype=torch.bfloat16, ops=ops)
+    else:
+        attn = "waitk_fixed_pre_decision" if model_kind == "waitk" else "infinite_lookback"
+        cfg = mma_model_s(encoder_layers=1, decoder_layers=4, simul_attn_type=attn, waitk_lagging=3)
+        w = init_model(cfg, seed=22)
+        make = lambda ops: SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=ops)
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0          # free decoding must not stop at once
+    w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(6)) \
+        * cfg.embed_dim ** -0.5
+    o_new, o_old = Ops(), Ops()
+    assert o_new.h.get_option(_lib.OPT_DEC_FUSE_FFN_QKV) == 0 and o_old.h.get_option(_lib.OPT_DEC_FUSE_FFN_QKV) == 0
+    o_new.h.set_option(_lib.OPT_DEC_FUSE_FFN_QKV, 1)
+    m_new, m_old = make(o_new), make(o_old)
+    t_old = m_old.generate_offline(fb, L, n_steps=U, mask_eos=True)[0].clone()
+    for rep in range(2):
+        t_new = m_new.generate_offline(fb, L, n_steps=U, mask_eos=True)[0].clone()
+        torch.cuda.synchronize()
+        assert torch.equal(t_new, t_old), (rep, (t_new != t_old).sum().item())
+    assert len(set(t_old.flatten().tolist())) > 50         # not a degenerate hypothesis
+    t_new = m_new.generate_offline(fb[:200], L[:200], n_steps=8, mask_eos=True)[0].clone()
+    t_ref = m_old.generate_offline(fb[:200], L[:200], n_steps=8, mask_eos=True)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(t_new, t_ref)
+    # the QKV chain class: one launch per layer boundary without the fusion, none with it (layer 0 opens with its own launch)
+    counts = []
+    for o, m in ((o_new, m_new), (o_old, m_old)):
+        o.h.timer_reset(); o.h.timer_enable(-1, True)
+        m.generate_offline(fb, L, n_steps=2, mask_eos=True)
+        torch.cuda.synchronize()
+        o.h.timer_enable(-1, False)
+        counts.append(o.h.timer_read(_lib.K_DEC_QKV_CHAIN)[1])
+    assert counts[1] - counts[0] == 2 * 3, counts
+
+
 def test_chains_repeat_beside_other_streams(ops):
     """The three chains while four OTHER streams keep matrix-core-heavy kernels resident on the same compute units (the fused
     Emformer feed-forward with two 75 KB workgroups per CU, the Emformer block attention with three of 50 KB, the 128 x 128 tile

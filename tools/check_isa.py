@@ -121,7 +121,7 @@ def main():
     for name, n, ex in bad:
         print(f"  SWIZZLED packed fp32 in {name}: {n}, e.g. '{ex}'")
         rc = 1
-    chains = {k: b for k, b in kernels.items() if re.search(r"dec_(proj|ffn|qkv|attn_proj|vocab|embed_qkv)_chain_kernel", k)}
+    chains = {k: b for k, b in kernels.items() if re.search(r"dec_(proj|ffn|ffn_qkv|qkv|attn_proj|vocab|embed_qkv)_chain_kernel", k)}
     if not chains:
         print("the layer-chain kernels are missing from the library", file=sys.stderr)
         return 2
