@@ -369,14 +369,22 @@ __global__ __launch_bounds__(256, 2) void dec_proj_cross_fused_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_f[];
   if ((int)blockIdx.x < n_tiles) {
     proj_chain_body<1, XM>(ctx_in, x, Wo, bo, ln_g, ln_b, Wq, bq, q, nullptr, nullptr, nullptr, M, nullptr, nullptr, (int)blockIdx.x);
-    // publish: every storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope and sets the flag
+    // publish WITHOUT cache maintenance (an agent-scope release is buffer_wbl2 of this XCD's whole L2, the consumers' acquire a
+    // buffer_inv of theirs -- the feed-forward + QKV experiment below measured 11 ms per pass for that): the tile's 8 KB of query rows
+    // are re-stored device-coherently (sc1: written through to memory), then the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      const int row = threadIdx.x >> 4, g = (int)blockIdx.x * 16 + row;          // 16 rows x 16 chunks of 32 bytes
+      if (g < M) {
+        bf16* qp = q + (long)g * CD + (threadIdx.x & 15) * 16;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 8);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(qp), "v"(v0), "v"(v1) : "memory");
+      }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   // ---- PERSISTENT attention workgroups: this one takes the (head, row) problems id, id + G, id + 2 G, ... with TWO of them in flight (two
@@ -432,11 +440,14 @@ __global__ __launch_bounds__(256, 2) void dec_proj_cross_fused_kernel(
         __builtin_amdgcn_s_sleep(4);
         if (++spins > (1 << 22)) { __hip_atomic_store(flags + 1023, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    rg.q = *reinterpret_cast<const uint4*>(q + (long)pr.b * D + pr.h * d + (tid % NP) * 8);
+    {                                                              // device-coherent read of the 16 query bytes (no acquire fence: see the publish)
+      f32x4 qv;
+      const bf16* qp = q + (long)pr.b * D + pr.h * d + (tid % NP) * 8;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(qv) : "v"(qp) : "memory");
+      rg.q = __builtin_bit_cast(uint4, qv);
+    }
     float o = 0.f;
     const int n = (int)(pr.st < pr.len - 1 ? pr.st : pr.len - 1) + 1;
     if (pr.st > 0 && n > 0) o = attn::finish3<bf16, NP>(rg, n, pr.n_pref, rsqrtf((float)d), red, nullptr, nullptr);
