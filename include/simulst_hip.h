@@ -130,11 +130,14 @@ int simulst_graph_enable(simulst_handle* h, int on);
  *                              chain of layer l and the slab sum + LayerNorm + QKV projection of layer l + 1 run as ONE launch, the hand-off
  *                              a ticket counter per row tile and device-coherent (sc1) slab accesses (csrc/dec_chain.hip
  *                              dec_ffn_qkv_chain_kernel; identical results)
+ *   DEC_CHAIN_ROWS32        EXPERIMENTS builds only, measured slower; 1 (default 0): the projection / feed-forward / QKV chains of the decode
+ *                              loops take 32-row tiles from 256 rows on (a weight fragment serves two row tiles; the 16 MFMAs of a unit
+ *                              and row tile are one asm statement, csrc/dec_chain.hip mfma_block; identical results)
  * Returns SIMULST_E_ARG for an unknown option or a value outside its range. */
 enum { SIMULST_OPT_VALU_ATTENTION = 0, SIMULST_OPT_UNFUSED_DECODE = 1, SIMULST_OPT_FFN_WAVES = 2, SIMULST_OPT_DEC_CHAIN = 3,
        SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 4, SIMULST_OPT_DEC_ATTN_CHAIN_ROWS = 5, SIMULST_OPT_FUSED_ARGMAX = 6,
        SIMULST_OPT_DEC_VOCAB_CHAIN_SPLIT = 7, SIMULST_OPT_DEC_EMBED_QKV_CHAIN = 8, SIMULST_OPT_PANEL_WIDE = 9,
-       SIMULST_OPT_DEC_FUSE_PROJ_CROSS = 10, SIMULST_OPT_WEIGHT_STATIONARY = 11, SIMULST_OPT_CONV_TILE256 = 12, SIMULST_OPT_DEC_FUSE_FFN_QKV = 13 };
+       SIMULST_OPT_DEC_FUSE_PROJ_CROSS = 10, SIMULST_OPT_WEIGHT_STATIONARY = 11, SIMULST_OPT_CONV_TILE256 = 12, SIMULST_OPT_DEC_FUSE_FFN_QKV = 13, SIMULST_OPT_DEC_CHAIN_ROWS32 = 14 };
 int simulst_set_option(simulst_handle* h, int32_t option, int32_t value);
 /* the value a handle currently runs with (simulst_create's environment overrides included) */
 int simulst_get_option(simulst_handle* h, int32_t option, int32_t* value);

@@ -173,7 +173,7 @@ DEBUG_SIGNATURES = {
 }
 (OPT_VALU_ATTENTION, OPT_UNFUSED_DECODE, OPT_FFN_WAVES, OPT_DEC_CHAIN, OPT_DEC_ATTN_CHAIN_MAX_ROWS, OPT_DEC_ATTN_CHAIN_ROWS,
  OPT_FUSED_ARGMAX, OPT_DEC_VOCAB_CHAIN_SPLIT, OPT_DEC_EMBED_QKV_CHAIN, OPT_PANEL_WIDE, OPT_DEC_FUSE_PROJ_CROSS,
- OPT_WEIGHT_STATIONARY, OPT_CONV_TILE256, OPT_DEC_FUSE_FFN_QKV) = range(14)
+ OPT_WEIGHT_STATIONARY, OPT_CONV_TILE256, OPT_DEC_FUSE_FFN_QKV, OPT_DEC_CHAIN_ROWS32) = range(15)
 
 _lib = None
 ABI_VERSION = 105          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)

@@ -60,6 +60,8 @@ struct simulst_handle {
   int dec_attn_chain_rows;     // rows per workgroup of that launch (0: chosen from the row count)
   bool dec_embed_qkv_chain;    // offline lockstep decode: commit + embedding inside the next step's first launch (dec_embed_qkv_chain_kernel)
   bool panel_wide_plain_stores;   // experiment: default-policy stores instead of streaming ones in panel_wide_kernel
+  bool dec_chain_rows32;       // projection / feed-forward / QKV chains on 32-row tiles (dec_chain.hip mfma_block, round 5)
+  int dec_chain_rows32_min;    //   ... from this many rows on
   bool dec_fuse_ffn_qkv;       // decode loops: feed-forward chain of layer l + LN / QKV of layer l + 1 in one launch (dec_chain.hip, round 5)
   int* chain_sem;              // its ticket words (one per row tile), device memory, lazily allocated
   int chain_sem_splits;

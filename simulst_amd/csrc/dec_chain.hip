@@ -99,9 +99,41 @@ __device__ __forceinline__ void mfma_tied(f32x4& acc, const u32x4_t& w, const u3
 //                quad, i.e. each read is issued right behind the two MFMAs that consume that quad as their B operand
 //   bit 0 set    all 8 reads issued first into 8 distinct quads (32 VGPRs), then the 16 MFMAs
 //   bit 1        selects the wave reduction of ln_rows (see there)
+// The 16 MFMAs of one unit against ONE 16-row tile as a SINGLE asm statement (round 5, 32-row tiles): between two asm statements
+// the register allocator may move an accumulator, and it cannot see that the statements are MFMAs whose results need wait states --
+// with one tile per workgroup it never did, with two it started to (the old static_assert).  Inside one statement nothing can be
+// inserted; the leading s_nop covers a VALU write (zero-initialisation or such a move) feeding srcC / A / B, the closing ones the
+// 8-pass result before anything reads it.  Same instruction order as the 16 single statements: acc0 / acc1 alternate, k ascending.
+__device__ __forceinline__ void mfma_block(f32x4& a0, f32x4& a1, const WUnit& u, const u32x4_t (&xf)[NKS]) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "v_mfma_f32_16x16x32_bf16 %0, %2, %18, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %10, %18, %1\n\t"
+      "v_mfma_f32_16x16x32_bf16 %0, %3, %19, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %11, %19, %1\n\t"
+      "v_mfma_f32_16x16x32_bf16 %0, %4, %20, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %12, %20, %1\n\t"
+      "v_mfma_f32_16x16x32_bf16 %0, %5, %21, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %13, %21, %1\n\t"
+      "v_mfma_f32_16x16x32_bf16 %0, %6, %22, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %14, %22, %1\n\t"
+      "v_mfma_f32_16x16x32_bf16 %0, %7, %23, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %15, %23, %1\n\t"
+      "v_mfma_f32_16x16x32_bf16 %0, %8, %24, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %16, %24, %1\n\t"
+      "v_mfma_f32_16x16x32_bf16 %0, %9, %25, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %17, %25, %1\n\t"
+      "s_nop 15\n\ts_nop 7"
+      : "+v"(a0), "+v"(a1)
+      : "v"(u.f[0][0]), "v"(u.f[0][1]), "v"(u.f[0][2]), "v"(u.f[0][3]), "v"(u.f[0][4]), "v"(u.f[0][5]), "v"(u.f[0][6]), "v"(u.f[0][7]),
+        "v"(u.f[1][0]), "v"(u.f[1][1]), "v"(u.f[1][2]), "v"(u.f[1][3]), "v"(u.f[1][4]), "v"(u.f[1][5]), "v"(u.f[1][6]), "v"(u.f[1][7]),
+        "v"(xf[0]), "v"(xf[1]), "v"(xf[2]), "v"(xf[3]), "v"(xf[4]), "v"(xf[5]), "v"(xf[6]), "v"(xf[7]));
+}
+
 template <int RTL, int C0, int XM>
 __device__ __forceinline__ void mma_unit(f32x4 (&acc)[RTL][4], const WUnit& u, const unsigned short* xs, int lr, int lg) {
-  static_assert(RTL == 1, "one 16-row tile per workgroup");
+  if constexpr (RTL > 1) {                                       // 32-row tiles: a weight unit serves two row tiles, one block each
+#pragma unroll
+    for (int rt = 0; rt < RTL; ++rt) {
+      u32x4_t xf[NKS];
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) xf[s] = *reinterpret_cast<const u32x4_t*>(xs + (rt * 16 + lr) * XS + 32 * s + 8 * lg);
+      mfma_block(acc[rt][C0], acc[rt][C0 + 1], u, xf);
+    }
+    return;
+  }
   if constexpr ((XM & 1) != 0) {
     u32x4_t xf[NKS];
 #pragma unroll
@@ -1461,15 +1493,26 @@ bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bo
 constexpr int lds_used_bytes(int rtl) { return (2 * 16 * rtl * XS + 8) * 2 + 5 * 256 * 4; }   // row buffers, flag, 5 vectors
 constexpr int LDS_WHOLE_CU = 160 * 1024;
 
-static int lds_request(const simulst_handle* h) {
+static int lds_request(const simulst_handle* h, int rtl = 1) {
 #ifdef SL_DEBUG_HOOKS
-  const int want = h->dec_chain_lds_bytes > 0 ? h->dec_chain_lds_bytes : lds_used_bytes(1);     // default: what the kernels use
-  return want < lds_used_bytes(1) ? lds_used_bytes(1) : (want > LDS_WHOLE_CU ? LDS_WHOLE_CU : want);
+  const int want = h->dec_chain_lds_bytes > 0 ? h->dec_chain_lds_bytes : lds_used_bytes(rtl);     // default: what the kernels use
+  return want < lds_used_bytes(rtl) ? lds_used_bytes(rtl) : (want > LDS_WHOLE_CU ? LDS_WHOLE_CU : want);
 #else
   (void)h;
-  return lds_used_bytes(1);
+  return lds_used_bytes(rtl);
 #endif
 }
+
+// row tiles per workgroup of the projection / feed-forward / QKV chains: 2 (32 rows, round 5: a weight fragment serves two row tiles, half
+// the L2 -> CU weight stream these launches are bound by) from dec_chain_rows32_min rows on, else 1
+// MEASURED (driver form, same box): 96.8 ms per pass against 91.2 -- a chain workgroup is paced by ITS OWN weight stream (the per-CU
+// L2 -> CU rate, ~50 GB/s: 256 KB of the projection chain in ~5 us), not by the chip-wide one, so half as many workgroups doing twice
+// the rows each stream as long and finish later.  EXPERIMENTS builds only, off.
+#ifdef SL_EXPERIMENTS
+static int chain_rtl(const simulst_handle* h, int B) { return h->dec_chain_rows32 && B >= h->dec_chain_rows32_min ? 2 : 1; }
+#else
+static int chain_rtl(const simulst_handle*, int) { return 1; }
+#endif
 
 template <int XM>
 static hipError_t raise_lds_limits_mode() {
@@ -1482,6 +1525,11 @@ static hipError_t raise_lds_limits_mode() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_vocab_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_embed_qkv_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+#ifdef SL_EXPERIMENTS
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<2, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<2, false, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<2, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
+#endif
   return e;
 }
 
@@ -1521,8 +1569,16 @@ int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* W
   hipLaunchKernelGGL((dec_proj_chain_kernel<1, XM>), dim3((B + 15) / 16), dim3(256), lds_request(h), h->stream,        \
                      (const bf16*)ctx, (bf16*)x, (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q,     \
                      (const uint4*)Wq2, bq2, (bf16*)q2, B, SL_CHAIN_TAIL(h), (const bf16*)kk_gelu)
+#define PC2(XM)                                                                                                        \
+  hipLaunchKernelGGL((dec_proj_chain_kernel<2, XM>), dim3((B + 31) / 32), dim3(256), lds_request(h, 2), h->stream,     \
+                     (const bf16*)ctx, (bf16*)x, (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q,     \
+                     (const uint4*)Wq2, bq2, (bf16*)q2, B, SL_CHAIN_TAIL(h), (const bf16*)kk_gelu)
+#ifdef SL_EXPERIMENTS
+  if (chain_rtl(h, B) == 2 && !SL_CHAIN_TAIL(h)) SL_XMODE(h, PC2); else
+#endif
   SL_XMODE(h, PC);
 #undef PC
+#undef PC2
   return sl_launch_status(h, "simulst_mma_decode(out-proj + LN + q-proj chain)");
 }
 
@@ -1584,9 +1640,17 @@ int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wc
                      (const uint4*)W2, b2, partial, sem, (bf16*)x_mid, B, F, splits)
 #define FC0(XM) FC(false, XM)
 #define FC1(XM) FC(true, XM)
+#define FC2(XM)                                                                                                        \
+  hipLaunchKernelGGL((dec_ffn_chain_kernel<2, false, XM>), dim3(((B + 31) / 32) * splits), dim3(256), lds_request(h, 2), \
+                     h->stream, (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,  \
+                     (const uint4*)W2, b2, partial, sem, (bf16*)x_mid, B, F, splits)
+#ifdef SL_EXPERIMENTS
+  if (x_mid && chain_rtl(h, B) == 2) SL_XMODE(h, FC2); else
+#endif
   if (x_mid) SL_XMODE(h, FC0); else SL_XMODE(h, FC1);
 #undef FC0
 #undef FC1
+#undef FC2
 #undef FC
   return sl_launch_status(h, "simulst_mma_decode(feed-forward chain)");
 }
@@ -1644,8 +1708,16 @@ int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float*
   hipLaunchKernelGGL((dec_qkv_chain_kernel<1, XM>), dim3(((B + 15) / 16) * n_cb), dim3(256), lds_request(h),           \
                      h->stream, (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wqkv, bqkv,       \
                      (bf16*)qkv, B, splits, n_cb)
+#define QC2(XM)                                                                                                        \
+  hipLaunchKernelGGL((dec_qkv_chain_kernel<2, XM>), dim3(((B + 31) / 32) * n_cb), dim3(256), lds_request(h, 2),        \
+                     h->stream, (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wqkv, bqkv,       \
+                     (bf16*)qkv, B, splits, n_cb)
+#ifdef SL_EXPERIMENTS
+  if (Wqkv && chain_rtl(h, B) == 2) SL_XMODE(h, QC2); else
+#endif
   SL_XMODE(h, QC);
 #undef QC
+#undef QC2
   return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + QKV chain)");
 }
 

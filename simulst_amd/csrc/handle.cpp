@@ -64,6 +64,12 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_DEC_VOCAB_CHAIN_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->dec_vocab_chain_split = v; }
   h->dec_embed_qkv_chain = true;
   if (const char* e = getenv("SIMULST_DEC_EMBED_QKV_CHAIN")) h->dec_embed_qkv_chain = atoi(e) != 0;
+  h->dec_chain_rows32 = false;        // experiment, off (dec_chain.hip chain_rtl)
+  h->dec_chain_rows32_min = 256;
+#ifdef SL_EXPERIMENTS
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_ROWS32")) h->dec_chain_rows32 = atoi(e) != 0;
+  if (const char* e = getenv("SIMULST_DEC_CHAIN_ROWS32_MIN")) h->dec_chain_rows32_min = atoi(e);
+#endif
   h->dec_fuse_ffn_qkv = false;        // experiment, off
 #ifdef SL_EXPERIMENTS
   if (const char* e = getenv("SIMULST_DEC_FUSE_FFN_QKV")) h->dec_fuse_ffn_qkv = atoi(e) != 0;
@@ -227,6 +233,13 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
     case SIMULST_OPT_DEC_EMBED_QKV_CHAIN: h->dec_embed_qkv_chain = value != 0; return SIMULST_OK;
     case SIMULST_OPT_WEIGHT_STATIONARY: h->wstat = value != 0; return SIMULST_OK;
     case SIMULST_OPT_CONV_TILE256: h->tile256 = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_DEC_CHAIN_ROWS32:
+#ifdef SL_EXPERIMENTS
+      h->dec_chain_rows32 = value != 0; return SIMULST_OK;
+#else
+      h->err = "simulst_set_option: the layer chains on 32-row tiles exist in EXPERIMENTS builds only (measured slower)";
+      return SIMULST_E_ARG;
+#endif
     case SIMULST_OPT_DEC_FUSE_FFN_QKV:
 #ifdef SL_EXPERIMENTS
       h->dec_fuse_ffn_qkv = value != 0; return SIMULST_OK;
@@ -277,6 +290,7 @@ extern "C" int simulst_get_option(simulst_handle* h, int32_t option, int32_t* va
     case SIMULST_OPT_WEIGHT_STATIONARY: *value = h->wstat; return SIMULST_OK;
     case SIMULST_OPT_CONV_TILE256: *value = h->tile256; return SIMULST_OK;
     case SIMULST_OPT_DEC_FUSE_FFN_QKV: *value = h->dec_fuse_ffn_qkv; return SIMULST_OK;
+    case SIMULST_OPT_DEC_CHAIN_ROWS32: *value = h->dec_chain_rows32; return SIMULST_OK;
     case SIMULST_OPT_DEC_FUSE_PROJ_CROSS: {
       // bit 0: on; bit 1: a waiting workgroup's bounded spin ran out at some point (synchronises the stream: tests only)
       int err = 0;

@@ -60,7 +60,7 @@ def test_shipped_library_has_no_debug_hooks():
     exp = sorted(set(header_functions(experiments=True)) - set(header_functions()))
     assert exp == sorted(_lib.EXPERIMENT_SIGNATURES) and all(not hasattr(lib, n) for n in exp)
     for opt, val in ((_lib.OPT_FFN_WAVES, 81), (_lib.OPT_FFN_WAVES, 45), (_lib.OPT_DEC_ATTN_CHAIN_MAX_ROWS, 1024), (_lib.OPT_PANEL_WIDE, 2),
-                     (_lib.OPT_DEC_FUSE_PROJ_CROSS, 1), (_lib.OPT_DEC_FUSE_FFN_QKV, 1)):
+                     (_lib.OPT_DEC_FUSE_PROJ_CROSS, 1), (_lib.OPT_DEC_FUSE_FFN_QKV, 1), (_lib.OPT_DEC_CHAIN_ROWS32, 1)):
         assert lib.simulst_set_option(h, opt, val) == -4, (opt, val)
     v = ctypes.c_int32(-1)
     assert lib.simulst_get_option(h, _lib.OPT_DEC_VOCAB_CHAIN_SPLIT, ctypes.byref(v)) == 0 and v.value == 4

@@ -485,6 +485,56 @@ def test_round4_launch_fusions_change_no_token(model_kind, mask_eos):
 
 @pytest.mark.experiments
 @pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback", "cif"])
+def test_chains_on_32_row_tiles_change_no_token(model_kind):
+    """Round 5 experiment (measured slower, EXPERIMENTS builds, off by default): the projection / feed-forward / QKV chains with TWO
+    16-row tiles per workgroup (a weight fragment serves both; the 16 MFMAs of a unit and row tile are one asm statement, dec_chain.hip
+    mfma_block; SIMULST_OPT_DEC_CHAIN_ROWS32, from 256 rows) against one tile per workgroup: the same products in the same order per
+    row, so every token of every row is IDENTICAL -- bf16, 330 ragged rows (a ragged last 32-row tile: 10 rows), 24 steps, 4 decoder
+    layers, twice; and 200 rows (below the threshold: both handles run 16-row tiles)."""
+    from simulst_amd.cif import CIFTransformerModel
+    from simulst_amd.config import cif_transformer_s, mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.ops import Ops
+    from simulst_amd.weights import init_model
+    B, T, U = 330, 240, 24
+    fb = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(28))
+    L = torch.randint(100, T + 1, (B,), generator=torch.Generator().manual_seed(29))
+    L[0] = T
+    for b in range(B):
+        fb[b, L[b]:] = 0
+    fb = fb.cuda().to(torch.bfloat16)
+    if model_kind == "cif":
+        cfg = cif_transformer_s(encoder_layers=1, decoder_layers=4, cif_beta=1.0)
+        w = init_model(cfg, seed=23)
+        w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
+        w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.0
+        make = lambda ops: CIFTransformerModel(cfg, w, dtype=torch.bfloat16, ops=ops)
+    else:
+        attn = "waitk_fixed_pre_decision" if model_kind == "waitk" else "infinite_lookback"
+        cfg = mma_model_s(encoder_layers=1, decoder_layers=4, simul_attn_type=attn, waitk_lagging=3)
+        w = init_model(cfg, seed=23)
+        make = lambda ops: SimulSTModel(cfg, w, dtype=torch.bfloat16, ops=ops)
+    w["decoder.embed_tokens.weight"][cfg.eos] = 0          # free decoding must not stop at once
+    w["decoder.output_projection.weight"] = torch.randn(cfg.vocab, cfg.embed_dim, generator=torch.Generator().manual_seed(7)) \
+        * cfg.embed_dim ** -0.5
+    o_new, o_old = Ops(), Ops()
+    assert o_new.h.get_option(_lib.OPT_DEC_CHAIN_ROWS32) == 0 and o_old.h.get_option(_lib.OPT_DEC_CHAIN_ROWS32) == 0
+    o_new.h.set_option(_lib.OPT_DEC_CHAIN_ROWS32, 1)
+    m_new, m_old = make(o_new), make(o_old)
+    t_old = m_old.generate_offline(fb, L, n_steps=U, mask_eos=True)[0].clone()
+    for rep in range(2):
+        t_new = m_new.generate_offline(fb, L, n_steps=U, mask_eos=True)[0].clone()
+        torch.cuda.synchronize()
+        assert torch.equal(t_new, t_old), (rep, (t_new != t_old).sum().item())
+    assert len(set(t_old.flatten().tolist())) > 50         # not a degenerate hypothesis
+    t_new = m_new.generate_offline(fb[:200], L[:200], n_steps=8, mask_eos=True)[0].clone()
+    t_ref = m_old.generate_offline(fb[:200], L[:200], n_steps=8, mask_eos=True)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(t_new, t_ref)
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("model_kind", ["waitk", "infinite_lookback", "cif"])
 def test_feed_forward_and_next_qkv_in_one_launch_change_no_token(model_kind):
     """Round 5 experiment (measured slower, EXPERIMENTS builds, off by default): the feed-forward chain of layer l and the slab sum +
     LayerNorm + QKV of layer l + 1 as ONE launch (the hand-off a ticket counter per row tile and device-coherent slab accesses,
