@@ -100,7 +100,9 @@ int simulst_graph_enable(simulst_handle* h, int on);
  *   FFN_WAVES               simulst_emformer_ffn: 0 the library's choice (43 while F <= 2048, else the block form); 43 the software-pipelined
  *                           form (4 waves, GELU behind the 32 MFMAs of a tile iteration, csrc/ffn_pipe.hip); 4 / 8 the block form (GELU
  *                           between the two products) with that many waves per workgroup -- all bit-identical.  EXPERIMENTS builds also
- *                           take 41 / 81 / 83 / 45 (GELU behind the 16 fc1 MFMAs; 8 waves; 64 rows per wave: measured slower)
+ *                           take 41 / 81 / 83 / 45 (GELU behind the 16 fc1 MFMAs; 8 waves; 64 rows per wave: measured slower) and
+ *                           47 / 87 (round 6: the tile's LDS-DMA pieces as one burst behind the barrier -- 43 issues one per MFMA gap --
+ *                           and the 8-wave form with the pieces spread)
  *   DEC_CHAIN               0: no row-local layer chains (csrc/dec_chain.hip) in the decode loops
  *   DEC_ATTN_CHAIN_MAX_ROWS EXPERIMENTS builds only (E_ARG otherwise): rows up to which self-attention rides inside the projection chain
  *   DEC_ATTN_CHAIN_ROWS     EXPERIMENTS builds only: rows per workgroup of that launch: 0 chosen from the row count, 4, 8, 16

@@ -262,10 +262,10 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
   KTimer t(h, SIMULST_K_LINEAR);
   // the software-pipelined form (ffn_pipe.hip: GELU inside the matrix-core stream): 128 rows per workgroup, two workgroups per CU
   // SIMULST_OPT_FFN_WAVES 41 / 81: scalar GELU, 4 / 8 waves; 42 / 82: packed GELU
-  if (((h->ffn_waves >= 41 && h->ffn_waves <= 45) || (h->ffn_waves >= 81 && h->ffn_waves <= 83) || (h->ffn_waves == 0 && FF_DEFAULT_PIPELINED)) && F <= 2048)
+  if (((h->ffn_waves >= 41 && h->ffn_waves <= 47) || (h->ffn_waves >= 81 && h->ffn_waves <= 87) || (h->ffn_waves == 0 && FF_DEFAULT_PIPELINED)) && F <= 2048)
     return sl_launch_ffn_pipe(h, x, ln_gamma, ln_beta, w1_packed, b1, w2_packed, b2, out, rows, F, h->ffn_waves >= 81 ? 8 : 4,
                               h->ffn_waves == 0 ? FF_PIPELINED_PACKED : (h->ffn_waves % 10) == 2,
-                              h->ffn_waves == 0 ? FF_PIPELINED_UNIFORM : (h->ffn_waves == 45 ? 2 : (h->ffn_waves % 10) == 3));
+                              h->ffn_waves == 0 ? FF_PIPELINED_UNIFORM : (h->ffn_waves == 45 ? 2 : (h->ffn_waves % 10) == 7 ? 3 : (h->ffn_waves % 10) == 3));
 #define FFN(V, W)                                                                                                  \
   hipLaunchKernelGGL((ffn_fused_kernel<V, W>), dim3((unsigned)((rows + FFG<W>::ROWS - 1) / FFG<W>::ROWS)),         \
                      dim3(FFG<W>::THREADS), FFG<W>::LDS, h->stream, (const bf16*)x, ln_gamma, ln_beta,             \

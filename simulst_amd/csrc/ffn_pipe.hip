@@ -117,13 +117,29 @@ template <int WAVES> struct FPG {
   static constexpr int LDS = 2 * NS * FP_W + 3072 + 2048 * 4;
 };
 
+// One 1 KiB LDS-DMA piece, issued from inline assembly (round 6).  Through __builtin_amdgcn_global_load_lds hipcc books the piece as a
+// pending LDS WRITE on the vector-memory counter and puts `s_waitcnt vmcnt(0)` in front of the next ds_read of the SAME iteration
+// (it cannot tell the ring's slots apart inside one dynamic __shared__ array): every wave then sat out the full issue -> landed time
+// of the tile it had just requested (~1 us under load) once per iteration, and the ring's depth bought nothing -- the "37 % of the
+// cycles in s_waitcnt / s_barrier" of profiles/r04_pmc_ffn.json.  An asm piece is outside that bookkeeping
+// (cdna_hip_programming.md section 7, "What hipcc does not do"): the kernel's own counted vmcnt in front of the barrier of the
+// iteration that first reads the slot is the only wait.  M0 is written and restored inside the statement.
+__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void*)p);
+}
+
 template <int WAVES>
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ wp, int tile, char* dst, unsigned voff, int wave) {
   const char* g = reinterpret_cast<const char*>(wp) + (long)tile * FP_W;
+  const unsigned d0 = lds_addr(dst) + (unsigned)wave * 1024u;
 #pragma unroll
   for (int q = 0; q < FPG<WAVES>::PIECES; ++q)
-    __builtin_amdgcn_global_load_lds((gbl_void*)(g + (unsigned)(voff + q * FPG<WAVES>::THREADS * 16)),
-                                     (lds_void*)(dst + q * FPG<WAVES>::THREADS * 16 + wave * 1024), 16, 0, 0);
+    glds16(g + (unsigned)(voff + q * FPG<WAVES>::THREADS * 16), d0 + (unsigned)(q * FPG<WAVES>::THREADS * 16));
 }
 
 // UNI (round 4, second form): the GELU of a tile spread over ALL 32 MFMAs of an iteration instead of the 16 of phase A -- a quarter
@@ -135,7 +151,16 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ wp, int tile
 //   MFMAs 16 .. 23   fc2 k-step 0 of t     with elements 12 .. 15 of tile t
 //   MFMAs 24 .. 31   fc2 k-step 1 of t     with elements 0 .. 3 of tile t + 1 (its registers were freed by MFMAs 16 .. 23)
 // No extra registers: the packed elements are written into the halves of hb that the fc2 MFMAs have already read.
-template <int WAVES, bool PK, bool UNI>
+template <int WAVES>
+__device__ __forceinline__ void stage_piece(const bf16* __restrict__ wp, int tile, char* dst, unsigned voff, int wave, int q) {
+  const char* g = reinterpret_cast<const char*>(wp) + (long)tile * FP_W;
+  glds16(g + (unsigned)(voff + q * FPG<WAVES>::THREADS * 16), lds_addr(dst) + (unsigned)wave * 1024u + (unsigned)(q * FPG<WAVES>::THREADS * 16));
+}
+
+// SPREAD (round 6, uniform schedule only): the 2 * PIECES LDS-DMA pieces of an iteration are issued ONE PER MFMA GAP behind the first
+// fc1 MFMAs instead of as a burst behind the barrier, where all waves of both resident workgroups issue theirs at the same moment
+// (MI355X_MICROARCH.md: a piece costs its wave 100-185 cycles inside a phase already carrying 8 pieces, 25-60 in a later gap).
+template <int WAVES, bool PK, bool UNI, bool SPREAD = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kernel(
     const bf16* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const bf16* __restrict__ W1p,
     const float* __restrict__ b1, const bf16* __restrict__ W2p, const float* __restrict__ b2, bf16* __restrict__ out, long M, int F) {
@@ -225,8 +250,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
 #endif
   // one iteration of the pipeline; MORE = false only for the last tile (no tile t + 1 to start: phase A is the GELU alone), as a
   // compile-time flag: a run-time test around the MFMAs would split the basic block and let hipcc regroup the instructions
-  auto iteration = [&](int t, auto more_tag) {
+  // S1 / S2: tile t + 1 + AH of W1 / tile t + AH of W2 exist and are requested in this iteration -- compile-time flags as well (the last
+  // AH + 1 iterations are peeled below), so no run-time branch splits the pinned instruction stream
+  auto iteration = [&](int t, auto more_tag, auto s1_tag, auto s2_tag) {
     constexpr bool MORE = decltype(more_tag)::value;
+    constexpr bool S1 = decltype(s1_tag)::value, S2 = decltype(s2_tag)::value;
+    constexpr int NP = G::PIECES;
     // every wave is past iteration t - 1: the slots of W1(t) and W2(t - 1) are free; W1(t + 1) and W2(t) were requested AH iterations
     // ago.  AH = 1: everything in flight must have landed.  AH = 2: the requests of iteration t - 1 (2 * PIECES instructions of
     // this wave, the newest in its in-order queue) may stay in flight -- a counted wait; near the end, where an iteration requested
@@ -235,13 +264,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
     unsigned long long p0, p1, p2, p3, p4;
     FP_STAMP(p0);
 #endif
-    if (AH == 1 || t == 0 || t + AH + 1 > nt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (AH == 1 || t == 0 || !S2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // !S2: iteration t - 1 requested fewer than 2 * PIECES
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * G::PIECES) : "memory");
     FP_STAMP(p1);
     __syncthreads();
     FP_STAMP(p2);
-    if (t + 1 + AH < nt) stage_tile<WAVES>(W1p, t + 1 + AH, w1ring + ((t + 1 + AH) % NS) * FP_W, voff, wave_u);
-    if (t + AH < nt) stage_tile<WAVES>(W2p, t + AH, w2ring + ((t + AH) % NS) * FP_W, voff, wave_u);
+    char* const s1dst = w1ring + ((t + 1 + AH) % NS) * FP_W;
+    char* const s2dst = w2ring + ((t + AH) % NS) * FP_W;
+    if constexpr (!(SPREAD && UNI)) {
+      if constexpr (S1) stage_tile<WAVES>(W1p, t + 1 + AH, s1dst, voff, wave_u);
+      if constexpr (S2) stage_tile<WAVES>(W2p, t + AH, s2dst, voff, wave_u);
+    }
     const uint4* w1 = reinterpret_cast<const uint4*>(w1ring + ((t + 1) % NS) * FP_W);    // fc1 weights of tile t + 1
     const uint4* w2 = reinterpret_cast<const uint4*>(w2ring + (t % NS) * FP_W);          // fc2 weights of tile t
     const float* bt = b1s + t * 32 + 4 * lh;
@@ -266,6 +299,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
           hnext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&wfa[s % FF_PF]),
                                                           *reinterpret_cast<const bf16x8_t*>(&xa[s]), hnext, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SPREAD) {                                 // one LDS-DMA piece per gap: W1's pieces, then W2's
+          if constexpr (S1) { if (s < NP) stage_piece<WAVES>(W1p, t + 1 + AH, s1dst, voff, wave_u, s); }
+          if constexpr (S2) { if (s >= NP && s < 2 * NP) stage_piece<WAVES>(W2p, t + AH, s2dst, voff, wave_u, s - NP); }
+        }
         if constexpr (MORE) { if (s + FF_PF < 16) wfa[s % FF_PF] = w1[(s + FF_PF) * 64 + lane]; }
         const int pr = 2 + (s >> 2);                            // pairs 2 .. 5 = elements 4 .. 11 of tile t
         if ((s & 3) == 0) gelu_q1(gp, hcur[2 * pr], hcur[2 * pr + 1], (pr & 1) ? bv.z : bv.x, (pr & 1) ? bv.w : bv.y);
@@ -387,8 +424,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
 #endif
     if constexpr (MORE) hcur = hnext;
   };
-  for (int t = 0; t + 1 < nt; ++t) iteration(t, std::true_type());
-  iteration(nt - 1, std::false_type());
+  {
+    using TT = std::true_type; using FF = std::false_type;
+    int t = 0;
+    for (; t + 1 + AH < nt; ++t) iteration(t, TT(), TT(), TT());            // steady state: both tiles requested
+    for (; t + AH < nt && t + 1 < nt; ++t) iteration(t, TT(), FF(), TT());  // W1 has run out
+    for (; t + 1 < nt; ++t) iteration(t, TT(), FF(), FF());                 // (AH == 2) nothing left to request
+    iteration(nt - 1, FF(), FF(), FF());
+  }
 #ifdef SL_PROBE
   if (lane == 0 && blockIdx.x < 4096) {
     long* d = sl_probe_ffn + ((long)blockIdx.x * 8 + wave) * 4;
@@ -655,12 +698,14 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
   waves = 4; uniform = 1;
 #endif
   if (!h->ffn_pipe_lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
 #ifdef SL_EXPERIMENTS
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FWG::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<8, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<8>::LDS);
 #endif
 #ifdef SL_DEBUG_HOOKS
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
@@ -669,8 +714,8 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
     if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit (pipelined form)"; return (int)e; }
     h->ffn_pipe_lds_attr_set = true;
   }
-#define FPL(W, P, U)                                                                                                                \
-  hipLaunchKernelGGL((ffn_pipe_kernel<W, P, U>), dim3((unsigned)((rows + 32 * W - 1) / (32 * W))), dim3(64 * W), FPG<W>::LDS, h->stream, \
+#define FPL(W, P, U, ...)                                                                                                           \
+  hipLaunchKernelGGL((ffn_pipe_kernel<W, P, U, ##__VA_ARGS__>), dim3((unsigned)((rows + 32 * W - 1) / (32 * W))), dim3(64 * W), FPG<W>::LDS, h->stream, \
                      (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F)
 #ifdef SL_DEBUG_HOOKS
   if (packed) { if (waves == 8) FPL(8, true, false); else FPL(4, true, false); } else
@@ -680,10 +725,13 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
     hipLaunchKernelGGL((ffn_wide_kernel<2>), dim3((unsigned)((rows + 255) / 256)), dim3(256), FWG::LDS, h->stream, (const bf16*)x, ln_g, ln_b,
                        (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F);
   } else
-  if (uniform) { if (waves == 8) FPL(8, false, true); else FPL(4, false, true); }
+  // 43: the shipped form (uniform GELU, LDS-DMA pieces one per MFMA gap); 47: the same with the pieces as a burst behind the barrier;
+  // 83 / 87: 8 waves, burst / spread
+  if (uniform == 3) { if (waves == 8) FPL(8, false, true, true); else FPL(4, false, true, false); }
+  else if (uniform) { if (waves == 8) FPL(8, false, true, false); else FPL(4, false, true, true); }
   else { if (waves == 8) FPL(8, false, false); else FPL(4, false, false); }
 #else
-  FPL(4, false, true);
+  FPL(4, false, true, true);
 #endif
 #undef FPL
 #ifdef SL_PROBE

@@ -15,6 +15,10 @@
 //     segments straight from registers (the panel kernels stage every tile through LDS to get there)
 //   * a projection wider than one slice (QKV: 768 = 4 x 192) is split over the 32 CUs of an XCD in groups of n_slices workgroups that
 //     walk the SAME row tiles at the same time: the first reader of a tile brings it into the XCD's L2, the others hit
+// Round 6, measured and NOT kept: the next tile's A rows requested before the current tile's sweep (so that the wait for them is a counted
+// vmcnt that leaves the tile's stores in flight instead of vmcnt(0)) with the sweep unrolled: QKV 317 us -> 317 us at 1 280 utterances,
+// out-proj 170 -> 165.  The per-tile store acknowledgement is not what paces the launch; the memory system's rate for this 1 : 3
+// read : write mix in 64-byte row pieces is.
 // Arithmetic: the products, their order (k-steps 0..7, weights as the A operand) and the epilogue (fp32 bias, fp32 residual add, one
 // rounding) are those of panel_kernel / panel_wide_kernel: results are bit-identical (tests/test_hip_kernels.py).
 #include "gemm_args.h"

@@ -202,7 +202,7 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
     case SIMULST_OPT_UNFUSED_DECODE: h->force_unfused_decode = value != 0; return SIMULST_OK;
     case SIMULST_OPT_FFN_WAVES:
 #ifdef SL_EXPERIMENTS
-      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 41 || value == 43 || value == 45 || value == 81 || value == 83
+      SL_REQUIRE(h, value == 0 || value == 4 || value == 8 || value == 41 || value == 43 || value == 45 || value == 47 || value == 81 || value == 83 || value == 87
 #ifdef SL_DEBUG_HOOKS
                         || value == 42 || value == 82
 #endif

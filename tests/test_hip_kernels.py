@@ -1023,7 +1023,7 @@ def test_emformer_ffn_pipelined_equals_the_block_form(ops, rows, F):
             gam, bet = 1 + 0.1 * torch.randn(D, generator=g_), 0.1 * torch.randn(D, generator=g_)
         args = (x.cuda(), gam.cuda(), bet.cuda(), ffn_pack_w1(W1.cuda()), b1.cuda(), ffn_pack_w2(W2.cuda()), b2.cuda())
         outs = {}
-        exp = (41, 81, 83, 45) if _lib.has_experiments() else ()       # the measured-slower forms: EXPERIMENTS builds
+        exp = (41, 81, 83, 45, 47, 87) if _lib.has_experiments() else ()       # the measured-slower forms: EXPERIMENTS builds (47 / 87: round 6, LDS-DMA pieces as a burst / 8 waves with the pieces spread)
         for waves in (0, 4, 8, 43) + exp:
             out = torch.full((rows, D), float("nan"), device="cuda", dtype=torch.bfloat16)
             ops.h.set_option(_lib.OPT_FFN_WAVES, waves)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rows-per-utt", type=int, default=378)
     ap.add_argument("--utterances", type=int, nargs="+", default=[64, 128, 256, 512, 1280, 4096])
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--quick", action="store_true", help="skip the two-launch path and the 8-wave block form")
     args = ap.parse_args()
     from simulst_amd.encoder import ffn_pack_w1, ffn_pack_w2
     from simulst_amd.ops import EPI_BIAS_GELU, EPI_BIAS_RES, Ops
@@ -61,11 +62,19 @@ def main():
                 ops.lib.simulst_debug_ffn_variant(ops.h.ptr, 0)
             return run
 
-        fns = [("fused_default", fused), ("two_launch", two), ("fused_one_8wave_workgroup_per_cu", waves(8)),
-               ("fused_two_4wave_workgroups_per_cu", waves(4)), ("pipelined_gelu_inside_the_mfma_stream", waves(41)),
-               ("pipelined_8_waves_one_workgroup_per_cu", waves(81)),
-               ("pipelined_uniform_gelu_behind_all_32_mfmas", waves(43)), ("pipelined_uniform_8_waves", waves(83)),
-               ("wide_64_rows_per_wave_one_workgroup_per_cu", waves(45))]
+        fns = [("fused_default", fused), ("fused_two_4wave_workgroups_per_cu", waves(4)),
+               ("pipelined_uniform_gelu_behind_all_32_mfmas", waves(43))]
+        if not args.quick:
+            fns += [("two_launch", two), ("fused_one_8wave_workgroup_per_cu", waves(8))]
+        if _lib.has_experiments():       # the forms that measured slower than what ships: `make EXPERIMENTS=1` builds (SIMULST_LIB_PATH)
+            fns += [("pipelined_gelu_inside_the_mfma_stream", waves(41)), ("pipelined_8_waves_one_workgroup_per_cu", waves(81)),
+                    ("pipelined_uniform_8_waves", waves(83)), ("wide_64_rows_per_wave_one_workgroup_per_cu", waves(45))]
+            try:                         # round 6: LDS-DMA pieces spread over the MFMA gaps
+                ops.h.set_option(_lib.OPT_FFN_WAVES, 47)
+                ops.h.set_option(_lib.OPT_FFN_WAVES, 0)
+                fns += [("pipelined_uniform_dma_spread", waves(47)), ("pipelined_uniform_8_waves_dma_spread", waves(87))]
+            except RuntimeError:
+                pass
         if hasattr(ops.lib, "simulst_debug_ffn_variant"):      # DEBUG_HOOKS build: the packed-GELU instantiations exist
             fns += [("pipelined_packed_gelu", waves(42)), ("pipelined_packed_gelu_8_waves", waves(82))]
         if hasattr(ops.lib, "simulst_debug_ffn_variant"):
