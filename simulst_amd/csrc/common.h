@@ -230,27 +230,31 @@ __device__ __forceinline__ float wave_last(float v) {        // lane 63's value 
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// GELU for bf16 outputs, two elements per call so that every multiply-add issues on the packed fp32 pipe
-// (v_pk_fma_f32): x*Phi(x) = h + |h| - |h| * erfc(|x|/sqrt2), h = x/2, with erfc(z) = (1 + a1 z + ... + a6 z^6)^-16
-// (Abramowitz-Stegun 7.1.28, |error| <= 3e-7: absolute error of the result < 1e-6, two orders below bf16
-// resolution; no cancellation on the negative side).  13 packed ops + 2 v_rcp per pair, against ~22 issue slots per
-// element for the exp-based 7.1.26 form it replaces (the GELU epilogue was 21 % of the fc1 launch).
+// GELU for bf16 outputs: x*Phi(x) = h + |h| - |h| * erfc(|x|/sqrt2), h = x/2 (no cancellation on the negative side), with
+//   erfc(|h| sqrt2) = exp2(Q(|h|)),  Q(a) = a (c1 + a (c2 + a (c3 + a (c4 + a c5))))
+// Round 6: Q is a weighted minimax fit of log2 erfc (weight = the error's effect on the RESULT, |h| erfc ln 2; tools/fit_gelu.py):
+// |error of the result| <= 5.4e-7 in exact arithmetic, 7.1e-7 in fp32 -- the class of the form it replaces (Abramowitz-Stegun 7.1.28,
+// (1 + a1 z + ... + a6 z^6)^-16: 4.9e-7), two orders below bf16 resolution -- at 11 instructions per element (bias fma, abs, 4 fma, mul,
+// v_exp_f32, add, fma) instead of 16: the fused feed-forward launch is bound by the ISSUE of exactly these instructions (phase probe,
+// DESIGN.md section 3).  c5 < 0: Q falls monotonically to -inf, exp2 flushes to 0, the result is h + |h| for any magnitude.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define SL_GELU_C1 (-2.3020009994506836f)
+#define SL_GELU_C2 (-1.838383436203003f)
+#define SL_GELU_C3 (-0.4171730577945709f)
+#define SL_GELU_C4 (0.11517949402332306f)
+#define SL_GELU_C5 (-0.015619269572198391f)
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
   const f32x2 h = x * 0.5f;
-  const f32x2 ha = __builtin_elementwise_abs(h);
-  const f32x2 z = ha * 1.41421356237309504880f;
-  f32x2 q = z * 0.0000430638f + 0.0002765672f;
-  q = q * z + 0.0001520143f;
-  q = q * z + 0.0092705272f;
-  q = q * z + 0.0422820123f;
-  q = q * z + 0.0705230784f;
-  q = q * z + 1.0f;
-  q = q * q; q = q * q; q = q * q; q = q * q;     // overflow to +inf for |x| > ~25 gives erfc = 0, as it should
-  f32x2 r;
-  r.x = __builtin_amdgcn_rcpf(q.x);
-  r.y = __builtin_amdgcn_rcpf(q.y);
-  return (h + ha) - ha * r;
+  const f32x2 a = __builtin_elementwise_abs(h);
+  f32x2 q = a * SL_GELU_C5 + SL_GELU_C4;
+  q = q * a + SL_GELU_C3;
+  q = q * a + SL_GELU_C2;
+  q = q * a + SL_GELU_C1;
+  q = q * a;
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(q.x);
+  e.y = __builtin_amdgcn_exp2f(q.y);
+  return (h + a) - a * e;
 }
 __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(f32x2{x, x}).x; }
 // 16-byte streaming load (global_load_dwordx4 ... nt) for data read once per launch whose working set cannot survive

@@ -42,54 +42,46 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 // 4-wave geometry of ffn_fused.hip): at the start of iteration t every wave has finished iteration t - 1, the DMA of W1(t + 2) goes to the slot
 // W1(t) left and that of W2(t + 1) to the slot W2(t - 1) left; both land during iteration t.
 __device__ __forceinline__ float gelu_fast1(float x) {
-  // gelu_fast2, one element: the same operations in the same order (h = x / 2, z = |h| sqrt2, Horner, four squarings, rcp, (h + |h|) - |h| r)
+  // gelu_fast2 (common.h), one element: the same operations in the same order
   const float h = x * 0.5f;
-  const float ha = __builtin_fabsf(h);
-  const float z = ha * 1.41421356237309504880f;
-  float q = __builtin_fmaf(z, 0.0000430638f, 0.0002765672f);
-  q = __builtin_fmaf(q, z, 0.0001520143f);
-  q = __builtin_fmaf(q, z, 0.0092705272f);
-  q = __builtin_fmaf(q, z, 0.0422820123f);
-  q = __builtin_fmaf(q, z, 0.0705230784f);
-  q = __builtin_fmaf(q, z, 1.0f);
-  q = q * q; q = q * q; q = q * q; q = q * q;
-  const float r = __builtin_amdgcn_rcpf(q);
-  return __builtin_fmaf(-ha, r, h + ha);
+  const float a = __builtin_fabsf(h);
+  float q = __builtin_fmaf(a, SL_GELU_C5, SL_GELU_C4);
+  q = __builtin_fmaf(q, a, SL_GELU_C3);
+  q = __builtin_fmaf(q, a, SL_GELU_C2);
+  q = __builtin_fmaf(q, a, SL_GELU_C1);
+  q = q * a;
+  const float e = __builtin_amdgcn_exp2f(q);
+  return __builtin_fmaf(-a, e, h + a);
 }
 
 // The same arithmetic for the uniform schedule.  It takes the fc1 accumulator and HALF the bias: fma(acc, 0.5, b / 2) == (acc + b) * 0.5
 // bit for bit (halving is exact and commutes with the rounding of the sum), which saves the separate bias add.
-struct GeluPair { float h[2], z[2], q[2]; };
+struct GeluPair { float h[2], a[2], q[2]; };
 // the GELU of an element PAIR in four quarters (two independent dependency chains per quarter: a dependent fp32 chain issues at ~1.66 x
-// the cost of independent instructions, MI355X_MICROARCH.md constants table), gelu_fast2's operations in gelu_fast2's order per element
+// the cost of independent instructions, MI355X_MICROARCH.md constants table), gelu_fast2's operations in gelu_fast2's order per element:
+// 6 + 6 + 4 (two of them v_exp_f32, 8 cycles each) + 5 instructions
 __device__ __forceinline__ void gelu_q1(GeluPair& g, float acc0, float acc1, float hb0, float hb1) {
   g.h[0] = __builtin_fmaf(acc0, 0.5f, hb0);                 g.h[1] = __builtin_fmaf(acc1, 0.5f, hb1);
-  g.z[0] = __builtin_fabsf(g.h[0]) * 1.41421356237309504880f; g.z[1] = __builtin_fabsf(g.h[1]) * 1.41421356237309504880f;
-  g.q[0] = __builtin_fmaf(g.z[0], 0.0000430638f, 0.0002765672f); g.q[1] = __builtin_fmaf(g.z[1], 0.0000430638f, 0.0002765672f);
-  g.q[0] = __builtin_fmaf(g.q[0], g.z[0], 0.0001520143f);   g.q[1] = __builtin_fmaf(g.q[1], g.z[1], 0.0001520143f);
+  g.a[0] = __builtin_fabsf(g.h[0]);                         g.a[1] = __builtin_fabsf(g.h[1]);
+  g.q[0] = __builtin_fmaf(g.a[0], SL_GELU_C5, SL_GELU_C4);  g.q[1] = __builtin_fmaf(g.a[1], SL_GELU_C5, SL_GELU_C4);
 }
 __device__ __forceinline__ void gelu_q2(GeluPair& g) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    g.q[k] = __builtin_fmaf(g.q[k], g.z[k], 0.0092705272f);
-    g.q[k] = __builtin_fmaf(g.q[k], g.z[k], 0.0422820123f);
-    g.q[k] = __builtin_fmaf(g.q[k], g.z[k], 0.0705230784f);
-    g.q[k] = __builtin_fmaf(g.q[k], g.z[k], 1.0f);
+    g.q[k] = __builtin_fmaf(g.q[k], g.a[k], SL_GELU_C3);
+    g.q[k] = __builtin_fmaf(g.q[k], g.a[k], SL_GELU_C2);
+    g.q[k] = __builtin_fmaf(g.q[k], g.a[k], SL_GELU_C1);
   }
 }
 __device__ __forceinline__ void gelu_q3(GeluPair& g) {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) { float q = g.q[k]; q = q * q; q = q * q; q = q * q; q = q * q; g.q[k] = q; }
+  for (int k = 0; k < 2; ++k) g.q[k] = __builtin_amdgcn_exp2f(g.q[k] * g.a[k]);
 }
 __device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi);
 __device__ __forceinline__ unsigned int gelu_q4(const GeluPair& g) {
   float v[2];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const float ha = __builtin_fabsf(g.h[k]);
-    const float r = __builtin_amdgcn_rcpf(g.q[k]);
-    v[k] = __builtin_fmaf(-ha, r, g.h[k] + ha);
-  }
+  for (int k = 0; k < 2; ++k) v[k] = __builtin_fmaf(-g.a[k], g.q[k], g.h[k] + g.a[k]);
   return cvt_pk_bf16(v[0], v[1]);
 }
 
@@ -365,7 +357,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
       // packed form: the GELU of an element PAIR (gelu_fast2, the arithmetic of ffn_fused_kernel) in two halves behind two MFMAs --
       // 15 packed instructions + 2 v_rcp per pair instead of 2 x 17 scalar ones (the phase probe of the scalar form: both waves of a
       // SIMD sit in phase A 74 % of the time and their 2 x 21 vector instructions per MFMA, not the matrix cores, pace it)
-      f32x2 ph, pha, pq, pz;
+      f32x2 ph, pha, pq;
 #pragma unroll
       for (int sp = 0; sp < 8; ++sp) {
         if constexpr (MORE)
@@ -378,11 +370,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
           const f32x2 xv = f32x2{hcur[2 * sp] + b2v.x, hcur[2 * sp + 1] + b2v.y};
           ph = xv * 0.5f;
           pha = __builtin_elementwise_abs(ph);
-          pz = pha * 1.41421356237309504880f;
-          pq = pz * 0.0000430638f + 0.0002765672f;
-          pq = pq * pz + 0.0001520143f;
-          pq = pq * pz + 0.0092705272f;
-          pq = pq * pz + 0.0422820123f;
+          pq = pha * SL_GELU_C5 + SL_GELU_C4;
+          pq = pq * pha + SL_GELU_C3;
+          pq = pq * pha + SL_GELU_C2;
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MORE)
@@ -391,12 +381,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MORE) { if (2 * sp + 1 + FF_PF < 16) wfa[(2 * sp + 1) % FF_PF] = w1[(2 * sp + 1 + FF_PF) * 64 + lane]; }
         {
-          pq = pq * pz + 0.0705230784f;
-          pq = pq * pz + 1.0f;
-          pq = pq * pq; pq = pq * pq; pq = pq * pq; pq = pq * pq;
+          pq = pq * pha + SL_GELU_C1;
+          pq = pq * pha;
           f32x2 r;
-          r.x = __builtin_amdgcn_rcpf(pq.x);
-          r.y = __builtin_amdgcn_rcpf(pq.y);
+          r.x = __builtin_amdgcn_exp2f(pq.x);
+          r.y = __builtin_amdgcn_exp2f(pq.y);
           const f32x2 gv2 = (ph + pha) - pha * r;
           hb[sp] = pack_bf16x2(gv2.x, gv2.y);
           if ((sp & 1) && sp < 7) bv = *reinterpret_cast<const float4*>(bt + 8 * ((sp + 1) >> 1));

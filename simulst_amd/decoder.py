@@ -461,15 +461,22 @@ class MMADecoder:
             a.Kpool = st.Kpool[l].data_ptr() if st.Kpool is not None else None
         return arr
 
-    def decode_steps(self, st: DecoderState, last_tokens: torch.Tensor, n_steps: int, mask_eos: bool):
+    def decode_steps(self, st: DecoderState, last_tokens: torch.Tensor, n_steps: int, mask_eos: bool, rows: Optional[int] = None):
         """n_steps WRITE steps entirely on the device (simulst_mma_decode). last_tokens [B] int64 is
-        updated in place; returns tokens [n_steps, B]."""
+        updated in place; returns tokens [n_steps, B].  rows (lockstep states only): the steps run for the FIRST `rows` rows of the
+        state alone -- every per-row buffer of the state is batch-major, so a prefix of the rows is the same state with a smaller
+        B; the rows behind it keep what they hold (greedy_offline_ragged retires finished rows this way)."""
         ops = self.ops
         B, dev = st.B, self.device
         assert st.n_prev_host + n_steps < st.cap, "decoder state capacity exceeded"
         d = self._decoder_desc(st, st.n_prev_host if st.lockstep else -1)
         ws = st.ws
-        okey = f"out{n_steps}"
+        if rows is not None and rows < B:
+            assert st.lockstep and 0 < rows
+            d.B = B = rows
+            okey = f"out{n_steps}x{rows}"
+        else:
+            okey = f"out{n_steps}"
         if okey not in ws:                     # persistent: a cached hipGraph replays into the same buffer
             ws[okey] = torch.empty(n_steps, B, device=dev, dtype=torch.int64)
         out = ws[okey]
@@ -558,3 +565,51 @@ class MMADecoder:
                                          mask_eos=mask_eos or s == 0, out=out[s])
                 self.commit(st)
         return out.t().contiguous(), st
+
+    def greedy_offline_ragged(self, enc_btd: torch.Tensor, enc_len: torch.Tensor, steps_per_row, mask_eos: bool = False,
+                              s_cap: Optional[int] = None, cap: Optional[int] = None, chunk: int = 8):
+        """greedy_offline for a ragged launch sequence whose rows want DIFFERENT numbers of steps, steps_per_row non-increasing
+        (the rows of a length-sorted shard: int(0.1 T + 10) tokens each, exp/infer_st.yaml:3-5).  The reference's generator
+        finalises a hypothesis at its cap and shrinks the batch (eval/generate.py:187-209 -> SequenceGenerator); here the rows that
+        have reached their cap form a SUFFIX of the batch, so retiring them is running the next `chunk` steps over a shorter prefix
+        of the same state (decode_steps(rows=...)): no gather, no copy.  Row counts are rounded up to whole 16-row tiles and stay
+        in the kernel class the full batch runs in (>= 129 rows: the layer chains), so every kept token is the one greedy_offline
+        picks (tests/test_offline_eval.py).  Returns tokens [B, steps_per_row[0]] (padding_idx behind a row's own cap), state."""
+        cfg = self.cfg
+        B, S, D = enc_btd.shape
+        steps = [int(x) for x in steps_per_row]
+        assert len(steps) == B and all(steps[i] >= steps[i + 1] for i in range(B - 1)), "rows must come longest first"
+        U = steps[0]
+        key = (B, max(cap or 0, U + 2), max(s_cap or 0, S, 1))
+        if not hasattr(self, "_offline_states"):
+            self._offline_states = {}
+        st = self._offline_states.get(key)
+        if st is None:
+            st = self._offline_states[key] = self.new_state(B, cap=key[1], S_cap=key[2])
+            st.tok_buf = torch.empty(B, device=self.device, dtype=torch.int64)
+        else:
+            for hs in st.head_step:
+                hs.zero_()
+            st.n_prev.zero_()
+            st.n_prev_host, st.enc_rows = 0, 0
+        st.online = False
+        self.append_encoder_out(st, enc_btd, enc_len)
+        toks = st.tok_buf.fill_(cfg.eos)
+        out = torch.full((B, U), cfg.padding_idx, device=self.device, dtype=torch.int64)
+        floor_rows = min(B, 144) if B >= 129 else B          # simulst_create: dec_chain_min_rows = 129
+        import bisect
+        neg = [-x for x in steps]                            # ascending: rows with steps > s = bisect_left(neg, -s)
+        s = 0
+        while s < U:
+            live = bisect.bisect_left(neg, -s)
+            rows = min(B, max(floor_rows, (live + 15) // 16 * 16))
+            e = min(U, s + chunk)
+            if U - e < chunk // 2:                           # no tiny last call
+                e = U
+            o = self.decode_steps(st, toks, e - s, mask_eos, rows=rows)
+            out[:rows, s:e] = o.t()
+            s = e
+        # a row's tokens behind its own cap were computed while it rode in a tile: not part of its hypothesis
+        idx = torch.arange(U, device=self.device).unsqueeze(0) >= torch.tensor(steps, device=self.device).unsqueeze(1)
+        out.masked_fill_(idx, cfg.padding_idx)
+        return out, st

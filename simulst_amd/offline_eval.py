@@ -6,6 +6,7 @@ int(max_len_a * T + max_len_b) = int(0.1 * T + 10) tokens per utterance (exp/inf
 sorted by length, neighbours in length form ragged launch sequences (per-utterance semantics),
 the sequences are dealt to a few HIP streams, and hypotheses are cut at the first EOS or the per-utterance cap.
 """
+import os
 from typing import List, Sequence
 
 import torch
@@ -106,11 +107,19 @@ def make_batch(idx: Sequence[int], lengths: Sequence[int], device, dtype, fbank_
     return fb.to(device=device, dtype=dtype), L.to(device), L, max_steps(Tmax), Tpad
 
 
-def decode_batch(model, batch):
+def decode_batch(model, batch, retire=True):
+    """One ragged launch sequence (rows longest first).  retire: rows leave the step loop at their OWN cap int(0.1 T + 10)
+    (decoder.greedy_offline_ragged; the reference's generator shrinks its batch the same way, eval/generate.py:187-209); False: every
+    row rides to the cap of the longest member (rounds 2-5).  The hypotheses after trim_hypotheses are the same either way."""
     fb, Ld, L, steps, Tpad = batch
     enc = model.encoder.forward(fb, Ld)
-    toks, _ = model.decoder.greedy_offline(enc["encoder_out_btd"], enc["encoder_lengths"], steps, False,
-                                           s_cap=Tpad // 4 + 1, cap=(steps + 2 + 31) // 32 * 32)
+    kw = dict(s_cap=Tpad // 4 + 1, cap=(steps + 2 + 31) // 32 * 32)
+    if retire and not os.environ.get("SIMULST_NO_RETIRE"):             # (the switch: A/B measurements of tools/eval_sharded.py)
+        per_row = [max_steps(int(t)) for t in L.tolist()]
+        if all(per_row[i] >= per_row[i + 1] for i in range(len(per_row) - 1)) and per_row[-1] < per_row[0]:
+            toks, _ = model.decoder.greedy_offline_ragged(enc["encoder_out_btd"], enc["encoder_lengths"], per_row, False, **kw)
+            return toks
+    toks, _ = model.decoder.greedy_offline(enc["encoder_out_btd"], enc["encoder_lengths"], steps, False, **kw)
     return toks.clone()
 
 

@@ -325,6 +325,35 @@ def test_config5_full_rank_shard_of_the_40k_set():
     assert seen == set(mine) and n_tok > 400000
 
 
+def test_retired_rows_leave_every_hypothesis_unchanged():
+    """Round 6: decode_batch(retire=True) runs each chunk of steps over the prefix of rows that have not reached
+    their own cap int(0.1 T + 10) -- the reference's generator finalises a hypothesis at its cap and shrinks the batch
+    (eval/generate.py:187-209) -- against retire=False, where every row rides to the cap of the longest member: every kept token of
+    every hypothesis identical, on a ragged 330-row sequence (bf16, layer chains) and on a 100-row one (below the chains' 129 rows:
+    the prefix keeps the full batch's kernel class), and the tokens behind a row's cap are the padding symbol."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.offline_eval import decode_batch, make_batch, max_steps, trim_hypotheses
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=3)
+    model = SimulSTModel(cfg, init_model(cfg, seed=999), dtype=torch.bfloat16)
+    for n, lo, hi in ((330, 120, 1500), (100, 200, 900), (140, 300, 310)):
+        lengths = sorted(torch.randint(lo, hi, (n,), generator=torch.Generator().manual_seed(n)).tolist(), reverse=True)
+        batch = make_batch(list(range(n)), lengths, "cuda", torch.bfloat16)
+        with torch.no_grad():
+            a = decode_batch(model, batch, retire=True).cpu()
+            b = decode_batch(model, batch, retire=False).cpu()
+        torch.cuda.synchronize()
+        na, nb = trim_hypotheses(a, batch[2], cfg.eos), trim_hypotheses(b, batch[2], cfg.eos)
+        assert torch.equal(na, nb)
+        diff = 0
+        for r in range(n):
+            k = int(na[r])
+            diff += int(a[r, :k].tolist() != b[r, :k].tolist())
+            assert (a[r, max_steps(lengths[r]):] == cfg.padding_idx).all()
+        assert diff == 0, (n, diff)
+
+
 def test_config5_one_ranks_shard(cfg_w):
     from oracle import agent as oag
     from oracle.configs import from_model_config
