@@ -75,7 +75,7 @@ int simulst_create(simulst_handle** out, void* hip_stream);
 int simulst_destroy(simulst_handle* h);
 int simulst_set_stream(simulst_handle* h, void* hip_stream);
 const char* simulst_last_error(simulst_handle* h);
-int simulst_version(void);            /* 105 (round 5: simulst_get_option); a binding built for another value must not use the library */
+int simulst_version(void);            /* 106 (round 6: simulst_emformer_ffn_prenorm; 105, round 5: simulst_get_option and simulst_stream_ctl grew p_probe / step_probe / step_force / probe_P); a binding built for another value must not use the library */
 /* HIP streams with a compute-unit mask (hipExtStreamCreateWithCUMask) or a priority, for hosts whose framework cannot create them.
  * cu_mask: mask_words 32-bit words; on MI355X bit i is compute unit (i / 8) of XCD (i % 8) (tools/microbench_cumask.hip), every XCD
  * must keep at least one unit; NULL / 0: no mask.  priority: 0 default, > 0 greatest, < 0 least (ignored with a mask).  Used by
@@ -275,6 +275,19 @@ int simulst_emformer_pack_rows(simulst_handle* h, const void* x, void* X, int32_
 int simulst_emformer_ffn(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
                          const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
                          int64_t rows, int32_t D, int32_t F, int32_t dtype);
+
+/* simulst_emformer_ffn over the rows of B utterances, x / out [B][n_rc + T][D], with the NEXT layer's pre-attention LayerNorm
+ * (_EmformerLayer.layer_norm_input, torchaudio_models/emformer.py:431-452: feed-forward -> residual -> next layer's pre-LN) and its
+ * segment summaries (:163-167; AvgPool1d(ceil_mode) of the normalised utterance rows, per utterance as simulst_emformer_prenorm) in
+ * the same launch: besides out, the rc | utterance rows of z_next [B][n_mem + n_rc + T + n_sum][D] get LayerNorm(out rows; next_gamma,
+ * next_beta) and its summary rows the segment means -- what simulst_emformer_prenorm(out, ...) would write; the memory rows of z_next
+ * are not touched.  lengths [B] int32 (encoder frames) or NULL.  bf16, D == 256, F <= 2048 and a multiple of 64, seg_len == 16,
+ * n_rc a multiple of 32 (a 32-row wave never straddles the right-context block or a segment); n_sum == 0 or ceil(T / 16). */
+int simulst_emformer_ffn_prenorm(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
+                                 const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                                 const float* next_gamma, const float* next_beta, const int32_t* lengths, void* z_next,
+                                 int32_t B, int32_t T, int32_t D, int32_t F, int32_t n_mem, int32_t n_rc, int32_t n_sum,
+                                 int32_t seg_len, int32_t dtype);
 
 /* ---- Emformer layer pieces ------------------------------------------------------
  * Per-utterance row blocks of a layer buffer Z [B][n_mem + n_rc + T + n_sum][D]:

@@ -33,7 +33,8 @@
 #include "gemm_args.h"
 
 int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
-                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed, int uniform);
+                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed, int uniform,
+                       const sl_ffn_z* zout = nullptr);
 
 namespace {
 
@@ -286,6 +287,33 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
   else FFN(0, 8);
 #undef FFN
   return sl_launch_status(h, "simulst_emformer_ffn");
+}
+
+// simulst_emformer_ffn over the rows of B utterances ([B][n_rc + T][256]) with the NEXT Emformer layer's pre-attention LayerNorm and
+// segment summaries in the launch's epilogue (ffn_pipe.hip ZOUT): replaces simulst_emformer_ffn + simulst_emformer_prenorm of the
+// next layer.  Same shape limits as the pipelined feed-forward (bf16, D == 256, F <= 2048) plus 16-frame segments and whole 32-row
+// waves of right-context rows.
+extern "C" int simulst_emformer_ffn_prenorm(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
+                                            const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                                            const float* next_gamma, const float* next_beta, const int32_t* lengths, void* z_next,
+                                            int32_t B, int32_t T, int32_t D, int32_t F, int32_t n_mem, int32_t n_rc, int32_t n_sum,
+                                            int32_t seg_len, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, ln_gamma); SL_CHECK_NULL(h, ln_beta); SL_CHECK_NULL(h, w1_packed);
+  SL_CHECK_NULL(h, b1); SL_CHECK_NULL(h, w2_packed); SL_CHECK_NULL(h, b2); SL_CHECK_NULL(h, out);
+  SL_CHECK_NULL(h, next_gamma); SL_CHECK_NULL(h, next_beta); SL_CHECK_NULL(h, z_next);
+  SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_emformer_ffn_prenorm: bf16 only");
+  SL_REQUIRE(h, D == FF_D && F >= 64 && F % 64 == 0 && F <= 2048, SIMULST_E_SHAPE, "simulst_emformer_ffn_prenorm: D == 256, F % 64 == 0, F <= 2048");
+  SL_REQUIRE(h, B >= 0 && T > 0 && n_mem >= 0 && n_rc >= 0 && n_rc % 32 == 0 && seg_len == 16, SIMULST_E_SHAPE,
+             "simulst_emformer_ffn_prenorm: 16-frame segments, right-context rows a multiple of 32");
+  SL_REQUIRE(h, n_sum == 0 || n_sum == (T + 15) / 16, SIMULST_E_SHAPE, "simulst_emformer_ffn_prenorm: n_sum must be 0 or ceil(T / 16)");
+  SL_REQUIRE(h, x != out, SIMULST_E_ARG, "simulst_emformer_ffn_prenorm: in place (the residual rows are re-read at the end)");
+  if (B == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_LINEAR);
+  sl_ffn_z z;
+  z.Z = (bf16*)z_next; z.g = next_gamma; z.b = next_beta; z.lengths = lengths;
+  z.rows_x = n_rc + T; z.T = T; z.n_mem = n_mem; z.n_rc = n_rc; z.n_sum = n_sum; z.tiles = (z.rows_x + 127) / 128;
+  return sl_launch_ffn_pipe(h, x, ln_gamma, ln_beta, w1_packed, b1, w2_packed, b2, out, (long)B * z.rows_x, F, 4, 0, 1, &z);
 }
 
 #ifdef SL_DEBUG_HOOKS

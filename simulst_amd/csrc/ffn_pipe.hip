@@ -152,10 +152,18 @@ __device__ __forceinline__ void stage_piece(const bf16* __restrict__ wp, int til
 // SPREAD (round 6, uniform schedule only): the 2 * PIECES LDS-DMA pieces of an iteration are issued ONE PER MFMA GAP behind the first
 // fc1 MFMAs instead of as a burst behind the barrier, where all waves of both resident workgroups issue theirs at the same moment
 // (MI355X_MICROARCH.md: a piece costs its wave 100-185 cycles inside a phase already carrying 8 pieces, 25-60 in a later gap).
-template <int WAVES, bool PK, bool UNI, bool SPREAD = false>
+// ZOUT (round 6): the launch also does the NEXT layer's pre-attention LayerNorm (_EmformerLayer.layer_norm_input,
+// torchaudio_models/emformer.py:431-452: feed-forward -> residual -> next layer's pre-LN) and its segment summaries (:163-167, the
+// AvgPool1d of the normalised utterance rows), i.e. what simulst_emformer_prenorm did in a launch of its own: the epilogue holds every
+// output row whole (32 lanes x 8 columns), so the row's statistics are one 32-lane reduction, the normalised row goes to its place in
+// the next layer's Z buffer and a wave's 32 rows are exactly two 16-row segments.  For that the workgroups tile every utterance on
+// its own (rows_x = n_rc + T rows, n_rc a multiple of 32): a wave never straddles two utterances or two segments.
+
+template <int WAVES, bool PK, bool UNI, bool SPREAD = false, bool ZOUT = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kernel(
     const bf16* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const bf16* __restrict__ W1p,
-    const float* __restrict__ b1, const bf16* __restrict__ W2p, const float* __restrict__ b2, bf16* __restrict__ out, long M, int F) {
+    const float* __restrict__ b1, const bf16* __restrict__ W2p, const float* __restrict__ b2, bf16* __restrict__ out, long M, int F,
+    sl_ffn_z z) {
   using G = FPG<WAVES>;
   constexpr int NS = G::NS, AH = G::AHEAD;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -167,7 +175,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
   float* b1s = b2s + FF_D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const long row0 = (long)blockIdx.x * (32 * WAVES) + wave * 32;
+  // rows [row0, row0 + 32) of the flattened activations, valid below row_end: the whole matrix, or (ZOUT) this utterance's rows
+  int zb = 0, zlocal0 = 0;
+  long row0, row_end;
+  if constexpr (ZOUT) {
+    zb = (int)blockIdx.x / z.tiles;
+    zlocal0 = ((int)blockIdx.x - zb * z.tiles) * (32 * WAVES) + wave * 32;
+    row0 = (long)zb * z.rows_x + zlocal0;
+    row_end = (long)(zb + 1) * z.rows_x;
+  } else {
+    row0 = (long)blockIdx.x * (32 * WAVES) + wave * 32;
+    row_end = M;
+  }
   const int nt = F / 32;
   const unsigned voff = (unsigned)tid * 16u;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
   uint4 xa[16];
   {
     const long r = row0 + lr;
-    const bool ok = r < M;
+    const bool ok = r < row_end;
     const bf16* xr = X + (ok ? r : 0) * FF_D + lh * 8;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -442,20 +461,131 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (!ZOUT) {
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int rl = it * 2 + lh;
-    const long r = row0 + rl;
-    if (r >= M) continue;
-    const uint4 yv = *reinterpret_cast<const uint4*>(st + rl * RS + lr * 16);
-    const uint4 xv = ld16(X + r * FF_D + lr * 8);
-    const unsigned int yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
-    unsigned int ou[4];
+    for (int it = 0; it < 16; ++it) {
+      const int rl = it * 2 + lh;
+      const long r = row0 + rl;
+      if (r >= row_end) continue;
+      const uint4 yv = *reinterpret_cast<const uint4*>(st + rl * RS + lr * 16);
+      const uint4 xv = ld16(X + r * FF_D + lr * 8);
+      const unsigned int yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
+      unsigned int ou[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      ou[q] = pack_bf16x2(__uint_as_float(yu[q] << 16) + __uint_as_float(xu[q] << 16),
-                          __uint_as_float(yu[q] & 0xffff0000u) + __uint_as_float(xu[q] & 0xffff0000u));
-    st_stream16(out + r * FF_D + lr * 8, make_uint4(ou[0], ou[1], ou[2], ou[3]));
+      for (int q = 0; q < 4; ++q)
+        ou[q] = pack_bf16x2(__uint_as_float(yu[q] << 16) + __uint_as_float(xu[q] << 16),
+                            __uint_as_float(yu[q] & 0xffff0000u) + __uint_as_float(xu[q] & 0xffff0000u));
+      st_stream16(out + r * FF_D + lr * 8, make_uint4(ou[0], ou[1], ou[2], ou[3]));
+    }
+  } else {
+    // ---- the same rows, plus the next layer's LayerNorm of each and the segment summaries.  No lane leaves the loop: the reductions
+    //      need the whole wave (a row past the utterance's end is computed on zeros and stored nowhere)
+    float g8[8], b8[8];
+    {
+      const float4 ga = *reinterpret_cast<const float4*>(z.g + lr * 8), gb = *reinterpret_cast<const float4*>(z.g + lr * 8 + 4);
+      const float4 ba = *reinterpret_cast<const float4*>(z.b + lr * 8), bb = *reinterpret_cast<const float4*>(z.b + lr * 8 + 4);
+      g8[0] = ga.x; g8[1] = ga.y; g8[2] = ga.z; g8[3] = ga.w; g8[4] = gb.x; g8[5] = gb.y; g8[6] = gb.z; g8[7] = gb.w;
+      b8[0] = ba.x; b8[1] = ba.y; b8[2] = ba.z; b8[3] = ba.w; b8[4] = bb.x; b8[5] = bb.y; b8[6] = bb.z; b8[7] = bb.w;
+    }
+    const long zrows = (long)z.n_mem + z.n_rc + z.T + z.n_sum;
+    bf16* Zb = z.Z + ((long)zb * zrows + z.n_mem) * FF_D;          // the utterance's rc | utt | sum rows
+    const int len = z.lengths ? z.lengths[zb] : z.T;
+    const bool utt_wave = zlocal0 >= z.n_rc;                       // wave-uniform: its 32 rows are utterance rows = two 16-row segments
+    const int t0w = zlocal0 - z.n_rc;
+    // Four passes over the wave's 16 row pairs instead of one loop: a row's chain (load -> sum -> 5-step reduction -> centre -> second
+    // reduction -> rsq -> scale -> store) is ~500 cycles of latency with two waves per SIMD to hide it; batched, the 16 reductions of a
+    // pass are independent instructions behind one another (one loop: +62 us per launch at 1 280 utterances, batched: +54).
+    // Arithmetic: emformer_prenorm_kernel's (fp32 statistics, the mean first, then the centred second moment) with two liberties that
+    // make it cheap -- the row sums run over 32 lanes x 8 columns on the DPP data path instead of 64 lanes x 4 columns through
+    // ds_bpermute, and 1 / sqrt is v_rsq_f32 (1 ulp).  Repeating the prenorm kernel's order and its exact 1 / sqrtf was built and
+    // measured: +102 us per launch instead of +54, i.e. the whole gain of the fusion; so the normalised rows can
+    // differ from the separate launch's in the last bf16 bit of ~0.1 % of the elements (tests/test_hip_kernels.py bounds it).
+    float o[16][8], red[16];
+    auto half_sum32 = [&](float v) {           // sum over the 32 lanes of a wave half: DPP inside 16-lane rows, one ds_bpermute across
+      v += lane_xor<1>(v); v += lane_xor<2>(v); v += lane_xor<4>(v); v += lane_xor<8>(v);
+      v += __shfl_xor(v, 16, 64);
+      return v;
+    };
+    // pass 1: the output rows (as the plain epilogue) and the rows' partial sums
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int rl = it * 2 + lh;
+      const long r = row0 + rl;
+      const bool rok = r < row_end;
+      const uint4 yv = *reinterpret_cast<const uint4*>(st + rl * RS + lr * 16);
+      uint4 xv = make_uint4(0, 0, 0, 0);
+      if (rok) xv = ld16(X + r * FF_D + lr * 8);
+      const unsigned int yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
+      unsigned int ou[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        ou[q] = pack_bf16x2(__uint_as_float(yu[q] << 16) + __uint_as_float(xu[q] << 16),
+                            __uint_as_float(yu[q] & 0xffff0000u) + __uint_as_float(xu[q] & 0xffff0000u));
+      if (rok) st_stream16(out + r * FF_D + lr * 8, make_uint4(ou[0], ou[1], ou[2], ou[3]));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o[it][2 * q] = __uint_as_float(ou[q] << 16); o[it][2 * q + 1] = __uint_as_float(ou[q] & 0xffff0000u); }
+      red[it] = ((o[it][0] + o[it][1]) + (o[it][2] + o[it][3])) + ((o[it][4] + o[it][5]) + (o[it][6] + o[it][7]));
+    }
+    // pass 2: the mean, then the centred second moment
+#pragma unroll
+    for (int it = 0; it < 16; ++it) red[it] = half_sum32(red[it]) * (1.0f / FF_D);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      float qv = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { o[it][j] -= red[it]; qv = __builtin_fmaf(o[it][j], o[it][j], qv); }
+      red[it] = qv;
+    }
+    // pass 3: 1 / sqrt(variance + eps)
+#pragma unroll
+    for (int it = 0; it < 16; ++it) red[it] = __builtin_amdgcn_rsqf(half_sum32(red[it]) * (1.0f / FF_D) + 1e-5f);
+    const float (&ra)[16] = red;
+    // pass 4: the normalised rows into the next layer's Z buffer; the segment summaries = means of the normalised utterance rows
+    //         (fp32, before rounding), the ragged last window over its real frames: AvgPool1d(ceil_mode) per utterance.  Order of
+    //         the sums as in emformer_prenorm_kernel: wave w of its workgroup adds rows w, w + 4, w + 8, w + 12 of the segment, then
+    //         ((P0 + P1) + P2) + P3 -- this half owns the rows of its parity: P_lh in acc[0] (even it), P_(lh + 2) in acc[1] (odd it)
+    float acc[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int rl = it * 2 + lh;
+      const bool rok = row0 + rl < row_end;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[it][j] = __builtin_fmaf(o[it][j] * ra[it], g8[j], b8[j]);
+      if (rok) {
+        unsigned int zu[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zu[q] = pack_bf16x2(o[it][2 * q], o[it][2 * q + 1]);
+        *reinterpret_cast<uint4*>(Zb + (long)(zlocal0 + rl) * FF_D + lr * 8) = make_uint4(zu[0], zu[1], zu[2], zu[3]);
+      }
+      if (utt_wave && z.n_sum > 0) {
+        const int seg = (t0w >> 4) + (it >> 3), t0 = seg * 16;
+        const int t1 = min(t0 + 16, z.T);
+        const int cnt = min(t1, max(len, t0 + 1)) - t0;
+        if ((rl & 15) < cnt && rok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[it & 1][j] += o[it][j];
+        }
+        if ((it & 7) == 7) {
+          float sm[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float pe = __shfl_xor(acc[0][j], 32, 64), po = __shfl_xor(acc[1][j], 32, 64);      // the other half's P1 / P3
+            sm[j] = ((acc[0][j] + pe) + acc[1][j]) + po;
+          }
+          if (lh == 0 && t0 < z.T && seg < z.n_sum) {
+            const float cntf = (float)cnt;
+            unsigned int su[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) su[q] = pack_bf16x2(sm[2 * q] / cntf, sm[2 * q + 1] / cntf);
+            *reinterpret_cast<uint4*>(Zb + (long)(z.n_rc + z.T + seg) * FF_D + lr * 8) = make_uint4(su[0], su[1], su[2], su[3]);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+        }
+      }
+    }
   }
 }
 
@@ -676,7 +806,8 @@ __global__ __launch_bounds__(256, 1) void ffn_wide_kernel(
 }  // namespace
 
 int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
-                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed, int uniform) {
+                       const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed, int uniform,
+                       const sl_ffn_z* zout) {
   // the packed-GELU instantiations (measured slower: 826 vs 887 TFLOP/s at 1280 utterances) exist in DEBUG_HOOKS builds only
 #ifndef SL_DEBUG_HOOKS
   packed = 0;
@@ -688,6 +819,7 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
 #endif
   if (!h->ffn_pipe_lds_attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
 #ifdef SL_EXPERIMENTS
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
@@ -703,9 +835,16 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
     if (e != hipSuccess) { h->err = "simulst_emformer_ffn: cannot raise the dynamic LDS limit (pipelined form)"; return (int)e; }
     h->ffn_pipe_lds_attr_set = true;
   }
+  if (zout) {      // the shipped form with the next layer's LayerNorm + summaries in its epilogue; workgroups tile each utterance
+    const long nb = rows / zout->rows_x;
+    hipLaunchKernelGGL((ffn_pipe_kernel<4, false, true, true, true>), dim3((unsigned)(nb * zout->tiles)), dim3(256), FPG<4>::LDS, h->stream,
+                       (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F, *zout);
+    return sl_launch_status(h, "simulst_emformer_ffn_prenorm");
+  }
+  const sl_ffn_z noz = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
 #define FPL(W, P, U, ...)                                                                                                           \
   hipLaunchKernelGGL((ffn_pipe_kernel<W, P, U, ##__VA_ARGS__>), dim3((unsigned)((rows + 32 * W - 1) / (32 * W))), dim3(64 * W), FPG<W>::LDS, h->stream, \
-                     (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F)
+                     (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F, noz)
 #ifdef SL_DEBUG_HOOKS
   if (packed) { if (waves == 8) FPL(8, true, false); else FPL(4, true, false); } else
 #endif

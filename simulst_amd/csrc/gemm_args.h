@@ -111,3 +111,14 @@ int sl_launch_vocab_argmax(simulst_handle* h, const void* x, const void* W, cons
 bool sl_wave_tile_wanted(int dtype, const LinArgs& p);
 int sl_launch_wave_tile(simulst_handle* h, int dtype, int epilogue, const void* A, const void* W, const float* bias,
                         const void* R, void* C, const LinArgs& p);
+
+// simulst_emformer_ffn_prenorm (ffn_pipe.hip ZOUT): where the fused feed-forward launch writes the NEXT layer's normalised rows and
+// segment summaries
+struct sl_ffn_z {
+  bf16* Z;                         // next layer's [B][n_mem + n_rc + T + n_sum][256]
+  const float* g;                  // its LayerNorm affine
+  const float* b;
+  const int* lengths;              // [B] encoder frames per utterance or null (all T)
+  int rows_x, T, n_mem, n_rc, n_sum, tiles;      // rows_x = n_rc + T; tiles: workgroups per utterance
+};
+

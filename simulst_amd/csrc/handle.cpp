@@ -7,7 +7,8 @@
 // 104: round 4 -- kernel classes 11-15 (one per layer-chain kernel), simulst_set_option replaces the two path-selection hooks,
 // simulst_decoder_attn_proj_chain, the simulst_debug_* entry points only in DEBUG_HOOKS builds.
 // 105: round 5 -- simulst_get_option (what a handle actually runs with, for the roofline models of bench.py).
-extern "C" int simulst_version(void) { return 105; }
+// 106: round 6 -- simulst_emformer_ffn_prenorm (the next layer's LayerNorm + summaries in the feed-forward launch); no structure changed.
+extern "C" int simulst_version(void) { return 106; }
 
 extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (!out) return SIMULST_E_NULL;

@@ -21,6 +21,7 @@ Ragged batches keep per-utterance semantics (= the reference at B == 1, which is
 the reference computes for the valid frames of a padded batch).
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -192,6 +193,8 @@ class S2TEmformerEncoder:
     fuse_ffn_layernorm = True      # bf16 row-panel path: LayerNorm as fc1's prologue instead of its own launch
     fuse_ffn = True                # bf16, D == 256: LayerNorm + fc1 + GELU + fc2 + residual in ONE launch, hidden on chip
     fuse_ffn_min_rows = 4096       # below this the two-launch path fills the chip better (256 rows per workgroup)
+    # ... and the NEXT layer's pre-attention LayerNorm + summaries in that launch's epilogue (round 6; SIMULST_FUSE_PRENORM=0: A/B runs)
+    fuse_prenorm = os.environ.get("SIMULST_FUSE_PRENORM", "1") != "0"
 
     def _packed(self, l, name):
         """Fragment-major copy of an encoder projection weight (bf16 only, made once): lets simulst_linear take the
@@ -244,10 +247,18 @@ class S2TEmformerEncoder:
         if n_mem > 0:
             Za[:, :n_mem] = mems0
         states = []
+        # round 6: from layer 1 on the pre-attention LayerNorm and the summaries are written by the previous layer's feed-forward launch
+        # (simulst_emformer_ffn_prenorm): its epilogue holds every output row whole.  16-frame segments, whole 32-row waves of
+        # right-context rows, the fused feed-forward's own domain
+        ffn_fused = self.fuse_ffn and B * rows_x >= self.fuse_ffn_min_rows and all("w1_ffn" in L for L in W.layers)
+        fuse_prenorm = self.fuse_prenorm and ffn_fused and S == 16 and n_rc % 32 == 0 and cfg.ffn_dim <= 2048
+        prenorm_done = False
         for l, L in enumerate(W.layers):
             Z, Zn = (Za, Zb) if l % 2 == 0 else (Zb, Za)
-            ops.emformer_prenorm(X, L["ln_in_g"], L["ln_in_b"], lengths_i32, Z, T=T, n_mem=n_mem, n_rc=n_rc,
-                                 n_sum=n_sum, seg_len=S)
+            if not prenorm_done:
+                ops.emformer_prenorm(X, L["ln_in_g"], L["ln_in_b"], lengths_i32, Z, T=T, n_mem=n_mem, n_rc=n_rc,
+                                     n_sum=n_sum, seg_len=S)
+            prenorm_done = False
             tall = B * rows_x >= 4096              # the row-panel kernel's domain (simulst_linear dispatch)
             wq, fq = self._packed(l, "wqkv") if tall else (L["wqkv"], False)
             ops.linear(Z.view(B * rows_z, D), wq, L["bqkv"], out=QKV.view(B * rows_z, 3 * D), w_fragment_major=fq)
@@ -261,8 +272,15 @@ class S2TEmformerEncoder:
             # fc1 + GELU on the row panel too since its GELU went to the packed fp32 pipe (1568 vs 1795 us at 605 k rows);
             # there the pre-FFN LayerNorm is the kernel's prologue (once per 128-row panel, on the stationary fragments)
             if self.fuse_ffn and "w1_ffn" in L and B * rows_x >= self.fuse_ffn_min_rows:
-                ops.emformer_ffn(X1.view(B * rows_x, D), L["ln_ff_g"], L["ln_ff_b"], L["w1_ffn"], L["b1"], L["w2_ffn"],
-                                 L["b2"], X.view(B * rows_x, D))
+                if fuse_prenorm and l + 1 < len(W.layers):
+                    Ln = W.layers[l + 1]               # Zn: its memory rows were written by this layer's out-proj above
+                    ops.emformer_ffn_prenorm(X1, L["ln_ff_g"], L["ln_ff_b"], L["w1_ffn"], L["b1"], L["w2_ffn"], L["b2"], X,
+                                             Ln["ln_in_g"], Ln["ln_in_b"], lengths_i32, Zn, T=T, n_mem=n_mem, n_rc=n_rc,
+                                             n_sum=n_sum, seg_len=S)
+                    prenorm_done = True
+                else:
+                    ops.emformer_ffn(X1.view(B * rows_x, D), L["ln_ff_g"], L["ln_ff_b"], L["w1_ffn"], L["b1"], L["w2_ffn"],
+                                     L["b2"], X.view(B * rows_x, D))
                 states.append(None)
                 continue
             w1, f1 = self._packed(l, "w1") if tall else (L["w1"], False)

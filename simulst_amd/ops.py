@@ -129,6 +129,16 @@ class Ops:
                                                    _p(b2), _p(out), rows, D, F, dt(x)), "simulst_emformer_ffn")
         return out
 
+    def emformer_ffn_prenorm(self, x, ln_g, ln_b, w1p, b1, w2p, b2, out, next_g, next_b, lengths, Z, *, T, n_mem, n_rc, n_sum, seg_len):
+        """emformer_ffn over x / out [B, n_rc + T, D] + the next layer's emformer_prenorm(out, next_g, next_b, lengths, Z) in the same
+        launch (simulst_emformer_ffn_prenorm)."""
+        _chk_contig(x, out, w1p, w2p, Z)
+        B, _, D = x.shape
+        self.h.check(self.lib.simulst_emformer_ffn_prenorm(self.h.ptr, _p(x), _p(ln_g), _p(ln_b), _p(w1p), _p(b1), _p(w2p), _p(b2),
+                                                           _p(out), _p(next_g), _p(next_b), _p(lengths), _p(Z), B, T, D, b1.numel(),
+                                                           n_mem, n_rc, n_sum, seg_len, dt(x)), "simulst_emformer_ffn_prenorm")
+        return out
+
     def emformer_prenorm(self, X, gamma, beta, lengths, Z, *, T, n_mem, n_rc, n_sum, seg_len):
         B, _, D = X.shape
         self.h.check(self.lib.simulst_emformer_prenorm(self.h.ptr, _p(X), _p(gamma), _p(beta), _p(lengths), _p(Z),

@@ -1042,6 +1042,79 @@ def test_emformer_ffn_pipelined_equals_the_block_form(ops, rows, F):
             torch.testing.assert_close(outs[43].float().cpu(), _ffn_reference(x, gam, bet, W1, b1, W2, b2), atol=3e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("B,T,use_len", [(3, 250, True), (5, 64, False), (2, 37, True), (40, 250, True)])
+def test_emformer_ffn_with_the_next_layers_prenorm_in_its_epilogue(ops, B, T, use_len):
+    """simulst_emformer_ffn_prenorm (round 6) against simulst_emformer_ffn followed by simulst_emformer_prenorm on its output: the
+    feed-forward rows bit for bit; the next layer's normalised rows and segment summaries to the last bf16 bit except where the
+    different order of the fp32 row sums / v_rsq_f32 moves a rounding (counted: <= 0.2 % of the elements, each by one bf16 step);
+    memory rows of the Z buffer untouched; ragged lengths
+    (summaries of the last real window over its real frames), a T that is no multiple of 16 or of 32."""
+    from simulst_amd.encoder import ffn_pack_w1, ffn_pack_w2
+    D, F, R, S = 256, 512, 8, 16
+    N = -(-T // S)
+    n_rc, n_mem, n_sum = ((N * R + 31) // 32) * 32, N - 1, N          # right-context rows padded to whole waves for this test
+    rows_x, rows_z = n_rc + T, n_mem + n_rc + T + n_sum
+    g_ = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, rows_x, D, generator=g_).to(torch.bfloat16).cuda()
+    W1 = (torch.randn(F, D, generator=g_) * D ** -0.5).to(torch.bfloat16).cuda()
+    W2 = (torch.randn(D, F, generator=g_) * F ** -0.5).to(torch.bfloat16).cuda()
+    b1, b2 = (torch.randn(F, generator=g_) * 0.1).cuda(), (torch.randn(D, generator=g_) * 0.1).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g_)).cuda(), (0.1 * torch.randn(D, generator=g_)).cuda()
+    g2, be2 = (1 + 0.1 * torch.randn(D, generator=g_)).cuda(), (0.1 * torch.randn(D, generator=g_)).cuda()
+    lengths = None
+    if use_len:
+        lengths = torch.randint(1, T + 1, (B,), generator=g_).to(torch.int32).cuda()
+        lengths[0] = T
+    w1p, w2p = ffn_pack_w1(W1), ffn_pack_w2(W2)
+    kw = dict(T=T, n_mem=n_mem, n_rc=n_rc, n_sum=n_sum, seg_len=S)
+    ref_out = torch.empty_like(x)
+    ops.emformer_ffn(x.view(B * rows_x, D), gam, bet, w1p, b1, w2p, b2, ref_out.view(B * rows_x, D))
+    Zr = torch.full((B, rows_z, D), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.emformer_prenorm(ref_out, g2, be2, lengths, Zr, **kw)
+    out = torch.full_like(x, float("nan"))
+    Z = torch.full((B, rows_z, D), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.emformer_ffn_prenorm(x, gam, bet, w1p, b1, w2p, b2, out, g2, be2, lengths, Z, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)
+    assert torch.equal(Z[:, :n_mem], Zr[:, :n_mem]) and bool((Z[:, :n_mem] == 7.0).all())
+    a, b = Z[:, n_mem:].float(), Zr[:, n_mem:].float()
+    assert torch.isfinite(a).all()
+    differing = int((a != b).sum())
+    assert differing <= 2e-3 * a.numel(), (differing, a.numel())
+    torch.testing.assert_close(a, b, atol=3.2e-2, rtol=8e-3)          # one bf16 step where a rounding moved
+
+
+def test_encoder_with_the_prenorm_in_the_feed_forward_launch_equals_the_separate_launch(ops):
+    """The full-size bf16 encoder, ragged batch: layers 1 .. 11 take their pre-attention LayerNorm and summaries from the previous
+    layer's feed-forward launch (fuse_prenorm) against the separate simulst_emformer_prenorm launches; and the layer
+    workspace filled with NaN before the pass: every row a launch reads has been written before it, whatever the cached buffers held."""
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.encoder import S2TEmformerEncoder
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=4)
+    enc = S2TEmformerEncoder(cfg, init_model(cfg, seed=999), dtype=torch.bfloat16, ops=ops)
+    fb = torch.randn(24, 1000, 80, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16).cuda()
+    L = torch.full((24,), 1000, device="cuda")
+    L[3], L[7], L[11] = 640, 311, 17
+    enc.fuse_ffn, enc.fuse_ffn_min_rows = True, 0
+    enc.fuse_prenorm = True
+    a = enc.forward(fb, L)["encoder_out_btd"].float().clone()
+    for ws in enc._layer_ws.values():                       # the cached workspace of this shape
+        for k in ("Za", "Zb", "QKV", "X1", "Y"):
+            ws[k].fill_(float("nan"))
+    a2 = enc.forward(fb, L)["encoder_out_btd"].float().clone()
+    assert torch.isfinite(a2).all() and torch.equal(a, a2)
+    enc.fuse_prenorm = False
+    for ws in enc._layer_ws.values():
+        for k in ("Za", "Zb", "QKV", "X1", "Y"):
+            ws[k].fill_(float("nan"))
+    b = enc.forward(fb, L)["encoder_out_btd"].float().clone()
+    assert torch.isfinite(b).all()
+    valid = (torch.arange(a.size(1), device="cuda").unsqueeze(0) < enc.out_lengths(L, 2).unsqueeze(1)).unsqueeze(-1)
+    torch.testing.assert_close(a * valid, b * valid, atol=6e-2, rtol=5e-2)
+    assert float(((a - b) * valid).abs().mean()) < 2e-3
+
+
 def test_encoder_with_fused_ffn_equals_two_launch_path(ops):
     """The full-size bf16 encoder with the fused feed-forward block against the same encoder with it switched off."""
     from simulst_amd.config import mma_model_s
