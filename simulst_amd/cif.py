@@ -6,6 +6,7 @@ submodule) is the HIP kernel ``simulst_cif_integrate``: wavefront prefix-sum of 
 floor(csum / beta), segmented weighted sum in one pass over the source.
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -31,12 +32,21 @@ class CIFLayer:
         cw = w[prefix + ".alpha_proj.0.weight"]                 # ConvTBC [k, C_in, C_out]
         self.k = cw.shape[0]
         # GEMM over overlapping channel-last rows: W[o][tau*C + c] = cw[tau][c][o]
-        self.conv_w = cw.permute(2, 0, 1).reshape(cw.shape[2], -1).contiguous().to(device=device, dtype=dtype)
+        # Round 6: the weight head runs in fp32 whatever the model's dtype -- fp32 copies of its two weight
+        # matrices, the encoder rows promoted, the conv output kept in fp32.  The weights alpha are SUMMED over the source (the
+        # integrate-and-fire scan), so an error that does not change sign from frame to frame accumulates linearly: the bf16 copies
+        # of the head's weights alone put +0.042 on the accumulated weight of a 250-frame source, the same sign for every utterance
+        # (tools/cif_alpha_budget.py, profiles/r06_cif_alpha_budget.json: 38 % of the path's mean signed error).  The head is
+        # 0.1 GFLOP per utterance; the encoder (13.5 GFLOP) stays in the model's dtype.
+        self.head_dtype = torch.float32 if self.head_fp32 else dtype
+        self.conv_w = cw.permute(2, 0, 1).reshape(cw.shape[2], -1).contiguous().to(device=device, dtype=self.head_dtype)
         self.conv_b = w[prefix + ".alpha_proj.0.bias"].float().to(device)
         self.ln_g = w[prefix + ".alpha_proj.1.weight"].float().to(device)
         self.ln_b = w[prefix + ".alpha_proj.1.bias"].float().to(device)
-        self.out_w = w[prefix + ".alpha_proj.4.weight"].reshape(-1).contiguous().to(device=device, dtype=dtype)
+        self.out_w = w[prefix + ".alpha_proj.4.weight"].reshape(-1).contiguous().to(device=device, dtype=self.head_dtype)
         self.out_b = float(w[prefix + ".alpha_proj.4.bias"][0])
+
+    head_fp32 = os.environ.get("SIMULST_CIF_HEAD_FP32", "1") != "0"       # (0: the head in the model's dtype, rounds 1-5; A/B runs)
 
     def _alpha(self, x_btd: torch.Tensor, hist: Optional[torch.Tensor]):
         """sigmoid(alpha_proj(x)). x [B,T,D]; hist [B,k-1,D] = frames before x (None: zero left pad)."""
@@ -44,13 +54,13 @@ class CIFLayer:
         B, T, D = x_btd.shape
         k = self.k
         if hist is not None:
-            xc = torch.cat([hist, x_btd], dim=1).contiguous()
+            xc = torch.cat([hist, x_btd], dim=1).to(self.head_dtype).contiguous()
             lead = 0
         else:
-            xc = x_btd.contiguous()
+            xc = x_btd.to(self.head_dtype).contiguous()
             lead = (k - 1) * D
         Tc = xc.size(1)
-        h = torch.empty(B, T, D, device=x_btd.device, dtype=x_btd.dtype)
+        h = torch.empty(B, T, D, device=x_btd.device, dtype=self.head_dtype)
         ops.linear_raw(xc, self.conv_w, self.conv_b, h, M_batches=B, rows_per_batch=T, N=D, K=k * D, a_bs=Tc * D,
                        a_rs=D, a_lead=lead, c_bs=T * D, c_rs=D, epilogue=EPI_BIAS)
         return ops.cif_alpha_head(h, self.ln_g, self.ln_b, self.out_w, self.out_b)

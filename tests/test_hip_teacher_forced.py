@@ -23,8 +23,13 @@ pytestmark = pytest.mark.gpu
 
 # measured on MI355X, 16 utterances x 1000 frames x 9 copies = 144 rows (profiles/r05_teacher_forced_audit.json):
 # p 0.0258, logits 0.054 (MMA-hard); accumulated weight 0.221, logits 0.52 (CIF)   [after round 5's encoder kernels; before: 0.0220 / 0.056 / 0.237 / 0.53]
+# Round 6 (profiles/r06_teacher_forced_audit.json): p 0.0273, logits 0.056 (MMA-hard); accumulated weight 0.187 (mean signed +0.032), logits 0.44 (CIF)
+# -- the CIF weight head runs in fp32 now (simulst_amd/cif.py; tools/cif_alpha_budget.py, profiles/r06_cif_alpha_budget.json: the head's
+# bf16 weight copies alone had put +0.042, same sign for every utterance, on a 250-frame source).  What is left is upstream of the head:
+# +0.024 from the encoder's weight matrices being bf16 at all (the oracle's fp32 arithmetic over rounded matrices shows it), the rest the
+# encoder's activation roundings -- unbiased noise that the convex side of the sigmoid (mean alpha 0.3) turns into a positive mean.
 P_BOUND, L_BOUND_MMA = 0.035, 0.09
-W_BOUND, L_BOUND_CIF = 0.35, 0.8
+W_BOUND, L_BOUND_CIF = 0.25, 0.7
 
 
 @pytest.fixture(scope="module")
@@ -69,6 +74,7 @@ def test_cif_bf16_accumulated_weights_and_fired_counts_along_the_oracle_trajecto
     r = tfa.audit_cif(cfg, w, utts, copies=9, dtype=torch.bfloat16)
     assert r["layer_chains"] and r["updates"] == 16 * r["chunks"]
     assert r["accumulated_weight_abs_err"]["max"] <= W_BOUND, r["accumulated_weight_abs_err"]
+    assert abs(r["accumulated_weight_mean_signed_err"]) <= 0.045, r["accumulated_weight_mean_signed_err"]       # measured +0.032 (round 5: +0.051)
     f = r["fired_counts"]
     assert f["not_explained_by_the_weight_error"] == 0, f["worst"]
     assert f["oracle_fire_margin_at_those"]["max"] is None or f["oracle_fire_margin_at_those"]["max"] <= r["accumulated_weight_abs_err"]["max"]
