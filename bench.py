@@ -52,15 +52,10 @@ if ROOT not in sys.path:
 # execute concurrently on this stack (tools/microbench_streams.hip); 8 lets 3-4 independent decode chains overlap.
 # Must be set before the runtime initialises; a process-level runtime knob, not a machine setting.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# HBM traffic of the dominant kernels from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest round first
-ENCODER_TRAFFIC_FILES = ["r05_c_encoder_traffic.json", "r05_encoder_traffic.json", "r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
-CROSS_ATTN_TRAFFIC_FILES = ["r05_pmc_cross_attention_traffic.json", "r04_pmc_cross_attention_traffic.json", "r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
-PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # all classes of one launch sequence (round 1), tools/pmc_summary.py
-L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
-
-B_PER_GPU, T_FRAMES, N_STEPS_DECODE, WAITK = 64, 1000, 110, 5
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+from bench_model import (B_PER_GPU, CROSS_ATTN_TRAFFIC_FILES, ENCODER_TRAFFIC_FILES, HBM_PEAK_GBS, L2_PEAK_GBS, MFMA_PEAK_TFLOPS,  # noqa: E402,F401
+                         N_STEPS_DECODE, PMC_TRAFFIC_FILE, T_FRAMES, WAITK, algorithmic_work, class_roofline, class_work,
+                         decode_path_options, log, model_param_bytes, path_bytes_per_token, roofline_entry)
+from bench_legs import b1_latency_leg, configs4_rank_shard_leg, extra_config_legs  # noqa: E402,F401
 
 
 def parse_args(argv=None):
@@ -132,203 +127,6 @@ def launch_ranks(args, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def model_param_bytes(cfg, esz):
-    """(encoder, decoder) parameter bytes at element size esz (35.5 MB / 22.6 MB in bf16)."""
-    D, F, V = cfg.embed_dim, cfg.ffn_dim, cfg.vocab
-    ks = cfg.conv_kernel_sizes
-    cin, conv = cfg.input_feat, 0
-    for i, k in enumerate(ks):
-        cout = cfg.conv_channels if i < len(ks) - 1 else 2 * D
-        conv += cout * cin * k + cout
-        cin = cout // 2
-    pos = D * (D // cfg.conv_pos_groups) * ((cfg.conv_pos + 1) // 2) + D
-    enc_layer = 3 * D * D + 3 * D + D * D + D + 2 * D * F + F + D + 4 * D
-    enc = conv + pos + cfg.encoder_layers * enc_layer + 2 * D
-    dec_layer = 4 * (D * D + D) + 4 * (D * D + D) + 2 * D * F + F + D + 6 * D
-    dec = V * D + cfg.decoder_layers * dec_layer + 2 * D          # output projection shares the embedding
-    return enc * esz, dec * esz
-
-
-def path_bytes_per_token(cfg, B, T, U, esz, waitk, kind="waitk"):
-    """Algorithmic HBM bytes per decoded token of the whole path, the byte model of SURVEY.md 8(d): per batch of B
-    utterances the encoder weights once and the decoder weights once per step; per utterance fbank (fp32 source),
-    one read + write of the encoder activations per layer, the cross-attention K/V rows each step may look at,
-    the self-attention cache rows, and the K/V projections written once.  2.135 MB/token at B=64, T=1000, U=110,
-    wait-k 5, bf16.  kind: 'waitk' (soft attention over the (t + k) * ratio visible frames), 'hard' (MMA-hard: the pooled
-    monotonic keys of every step + ONE value row, SURVEY 8(d) "~0 for hard-aligned one-hot gather"), 'cif' (no source attention:
-    the integrated vectors and their key projections written once, one projected row gathered per step and layer)."""
-    D, Ld = cfg.embed_dim, cfg.decoder_layers
-    T1 = (T - 1) // 2 + 1
-    Te = (T1 - 1) // 2 + 1
-    N = -(-Te // cfg.S)
-    enc_w, dec_w = model_param_bytes(cfg, esz)
-    per_utt = T * cfg.input_feat * 4
-    per_utt += cfg.encoder_layers * 2 * (N * cfg.R + Te) * D * esz
-    if kind == "waitk":
-        per_utt += Ld * 2 * D * esz * sum(min((t + waitk) * cfg.pre_decision_ratio, Te) for t in range(U))
-        per_utt += Ld * 2 * Te * D * esz                       # K / V projections written once
-    elif kind == "hard":
-        P = max(1, Te // max(cfg.pre_decision_ratio, 1))
-        per_utt += Ld * U * (P + 1) * D * esz                  # pooled monotonic keys + the one value row per step
-        per_utt += Ld * 2 * Te * D * esz
-    else:                                                      # cif: ~Te / 2 integrated vectors at alpha ~ 0.5
-        n_cif = Te // 2
-        per_utt += 2 * Te * D * esz + n_cif * D * esz          # CIF layer: frames read (conv + scan), vectors written
-        per_utt += Ld * (n_cif * D * esz + U * D * esz)        # key projections written once, one row gathered per step
-    per_utt += Ld * 2 * D * esz * sum(u + 1 for u in range(U))
-    return (enc_w + dec_w * U + B * per_utt) / (B * U)
-
-
-def algorithmic_work(cfg, B, T, U):
-    """Algorithmic FLOPs / bytes of one step (DESIGN.md 'Roofline accounting')."""
-    D, F, H, V = cfg.embed_dim, cfg.ffn_dim, cfg.num_heads, cfg.vocab
-    S, R, Lc, M = cfg.S, cfg.R, cfg.Lc, cfg.M
-    T1 = (T - 1) // 2 + 1
-    Te = (T1 - 1) // 2 + 1
-    N = -(-Te // S)
-    rows_x, rows_z, rows_c = N * R + Te, (N - 1) + N * R + Te + N, N * R + Te + N
-    fl = {}
-    fl["conv"] = 2 * B * (T1 * cfg.conv_channels * 5 * cfg.input_feat + Te * 2 * D * 5 * (cfg.conv_channels // 2))
-    fl["enc_linear"] = cfg.encoder_layers * 2 * B * (rows_z * 3 * D * D + rows_c * D * D + 2 * rows_x * D * F)
-    kpl = M + R + Lc + S
-    fl["enc_attn"] = cfg.encoder_layers * B * N * H * 2 * 2 * (R + S + 1) * kpl * (D // H)
-    per_tok = cfg.decoder_layers * 2 * (3 * D * D + D * D + D * D + D * D + 2 * D * F) + 2 * D * V
-    fl["dec_linear"] = B * U * per_tok
-    fl["dec_cross_kv"] = cfg.decoder_layers * 2 * 2 * B * Te * D * D
-    return fl, dict(T1=T1, Te=Te, N=N, rows_x=rows_x, rows_z=rows_z, rows_c=rows_c)
-
-
-def decode_path_options(h, Bs, V, dtype_name):
-    """What the handle's decode loops run at Bs co-scheduled rows, read back from the handle (simulst_get_option) instead of re-modelled:
-    chains (row-local layer chains), vsplit (workgroups per row tile of the closing launch, 0 = off), embed_qkv (commit + embedding +
-    layer 0's QKV as the next step's first launch)."""
-    from simulst_amd import _lib
-    chains = bool(h.get_option(_lib.OPT_DEC_CHAIN)) and Bs > 128 and dtype_name == "bf16"      # csrc/handle.cpp dec_chain_min_rows
-    vs = h.get_option(_lib.OPT_DEC_VOCAB_CHAIN_SPLIT) if (chains and Bs <= 1024) else 0        # feed-forward chain domain
-    while vs > 1 and V % (256 * vs):                                                           # dec_chain.hip sl_dec_vocab_chain_split
-        vs //= 2
-    if vs and V % 256:
-        vs = 0
-    return {"chains": chains, "vsplit": vs, "embed_qkv": bool(h.get_option(_lib.OPT_DEC_EMBED_QKV_CHAIN)) and chains}
-
-
-def class_work(name, cfg, Bs, dims, fl, dtype_name, kind="waitk", opts=None):
-    """Algorithmic work of one kernel class over ONE launch sequence of Bs rows (110 decode steps): (bound, work, informational L2 bytes).
-    work = flops for the encoder-side contractions (MFMA bound), bytes for everything else (HBM bound); None when the class has no model.
-    The decode-step GEMM groups are SCORED on algorithmic bytes -- every weight matrix of the launch once + its activations in and out
-    (+ the fp32 slabs, + cached K / V rows) -- against HBM, the only rate a better tiling cannot inflate; what the workgroups pull from L2
-    (the weights once per row tile) is reported beside it as information only."""
-    esz = 2 if dtype_name == "bf16" else 4
-    D, F, V, Ld, U = cfg.embed_dim, cfg.ffn_dim, cfg.vocab, cfg.decoder_layers, N_STEPS_DECODE
-    opts = opts or {"chains": Bs > 128 and dtype_name == "bf16", "vsplit": 4 if (Bs > 128 and Bs <= 1024 and dtype_name == "bf16" and V % 1024 == 0) else 0,
-                    "embed_qkv": Bs > 128 and dtype_name == "bf16"}
-    if name == "linear":
-        return "mfma", fl["conv"] + fl["enc_linear"] + fl["dec_cross_kv"], None
-    if name in ("linear_skinny", "linear_tile64", "dec_qkv_chain", "dec_proj_chain", "dec_ffn_chain", "dec_attn_proj_chain",
-                "dec_vocab_chain"):
-        tile64 = Bs >= 256
-        chains, vsplit, embed_qkv = opts["chains"], opts["vsplit"], opts["embed_qkv"]
-
-        def alg(n, k):
-            return (n * k + Bs * k + Bs * n) * esz
-
-        def delivered(n, k, rt):
-            return (-(-Bs // rt) * n * k + Bs * k + Bs * n) * esz
-        slabs = (F // 256) * Bs * D * 4
-        # layer 0's LayerNorm + QKV: with embed_qkv every step but the call's first runs it inside dec_embed_qkv_chain_kernel (class
-        # dec_qkv_chain: the step's (value, index) pairs in, the embedding row + position gathered, x and qkv out); the first step's
-        # stays a plain GEMM launch in linear_tile64 / linear_skinny
-        l0_chain = (U - 1) if embed_qkv else 0
-        l0_plain = U - l0_chain
-        if name == "dec_qkv_chain":
-            # slab sum (F / 256 fp32 slabs in, x out) + LN1 + QKV; once more per step for the last layer's slabs
-            last = 0 if vsplit else slabs
-            byts = U * ((Ld - 1) * (alg(3 * D, D) + slabs) + last) + l0_chain * (alg(3 * D, D) + 2 * Bs * D * esz + Bs * max(vsplit, 1) * 8)
-            dl = (U * (Ld - 1) + l0_chain) * delivered(3 * D, D, 16)
-        elif name == "dec_vocab_chain":
-            # the last layer's slabs + x' in, x out, the output projection once, `split` (value, index) pairs per row out
-            byts = U * (slabs + 2 * Bs * D * esz + V * D * esz + Bs * vsplit * 8) if vsplit else 0
-            dl = U * (slabs * vsplit + -(-Bs // 16) * V * D * esz)
-        elif name == "dec_proj_chain":
-            byts = U * Ld * (alg(D, D) + alg(D, D))
-            dl = U * Ld * 2 * delivered(D, D, 16)
-        elif name == "dec_attn_proj_chain":
-            kv = sum(2 * (u + 1) * D for u in range(U)) * Bs * esz          # cached K / V rows read, as decoder_self_attention
-            byts = U * Ld * (alg(D, D) + alg(D, D)) + Ld * kv
-            dl = U * Ld * 2 * delivered(D, D, 4) + Ld * kv
-        elif name == "dec_ffn_chain":
-            byts = U * Ld * (alg(D, D) + alg(F, D) + alg(D, F) + slabs)
-            dl = U * Ld * ((F // 256) * delivered(D, D, 16) + delivered(F, D, 16) + delivered(D, F, 16))
-        else:
-            rt = 64 if name == "linear_tile64" else 16
-            mine = (name == "linear_tile64") == tile64               # the group the plain GEMM launches of this row count fall in
-            if chains:            # with the chains only (some of) layer 0's QKV and, without the closing launch, the vocabulary projection
-                byts = (l0_plain * alg(3 * D, D) + (0 if vsplit else U * alg(V, D))) if mine else 0
-                dl = (l0_plain * delivered(3 * D, D, rt) + (0 if vsplit else U * delivered(V, D, rt))) if mine else 0
-            else:
-                wide = [(3 * D, D), (F, D)]
-                narrow = [(D, D)] * 3 + [(D, F)]
-                sel = (wide if tile64 else []) if name == "linear_tile64" else (narrow if tile64 else wide + narrow)
-                extra_v = [(V, D)] if mine else []
-                byts = U * (Ld * sum(alg(n, k) for n, k in sel) + sum(alg(n, k) for n, k in extra_v))
-                dl = U * (Ld * sum(delivered(n, k, rt) for n, k in sel) + sum(delivered(n, k, rt) for n, k in extra_v))
-        return ("hbm", byts, dl) if byts > 0 else None
-    if name == "emformer_attention":
-        byts = cfg.encoder_layers * Bs * (dims["rows_z"] * 3 * D + dims["rows_c"] * D) * esz
-    elif name == "decoder_cross_attention":
-        if kind == "hard":
-            # MMA-hard: the policy looks at every pooled monotonic key (here: the Te cached frames it pools), the value
-            # aggregation is one row
-            byts = Ld * Bs * U * (dims["Te"] * D + 3 * D) * esz
-        else:
-            # wait-k: target t reads min((t + k) * ratio, Te) key and value rows of D channels
-            rows = sum(min((t + WAITK) * cfg.pre_decision_ratio, dims["Te"]) for t in range(U))
-            byts = Ld * Bs * (2 * rows * D + 2 * U * D) * esz
-    elif name == "decoder_self_attention":
-        byts = Ld * Bs * sum((2 * (u + 1) * D + 4 * D) for u in range(U)) * esz
-    elif name == "layernorm":
-        # one pre-attention LayerNorm per layer (reads X, writes Z with the summary rows) + the final one; the pre-FFN
-        # LayerNorm lives in the fused feed-forward launch
-        byts = (cfg.encoder_layers * Bs * (dims["rows_x"] + dims["rows_z"]) * D + 2 * Bs * dims["rows_x"] * D) * esz
-    else:
-        return None
-    return ("hbm", byts, None) if byts > 0 else None
-
-
-def roofline_entry(name, bound, work, dl, ms, n_launch, dtype_name):
-    """work / time of a class against its peak: the entry format of the `roofline` object"""
-    if ms <= 0 or n_launch <= 0 or work <= 0:
-        return None
-    if bound == "mfma":
-        peak = MFMA_PEAK_TFLOPS[dtype_name]
-        ach = work / (ms * 1e-3) / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 5), "traffic": None, "launches_per_sequence": n_launch,
-                "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_flop_per_launch": round(work / n_launch)}
-    ach = work / (ms * 1e-3) / 1e9
-    e = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "launches_per_sequence": n_launch,
-         "avg_launch_us": round(ms * 1e3 / n_launch, 3), "algorithmic_bytes_per_launch": round(work / n_launch)}
-    if dl:
-        e["informational_l2_delivered"] = {"bytes_per_launch": round(dl / n_launch), "GBps": round(dl / (ms * 1e-3) / 1e9, 1),
-                                           "frac_of_l2_peak": round(dl / (ms * 1e-3) / 1e9 / L2_PEAK_GBS, 5)}
-        e["model"] = ("algorithmic bytes: each weight matrix of the launch once + activations in / out (+ fp32 slabs, + cached K / V "
-                      "rows); these launches are latency-bound (28-224 workgroups, a dependent launch cannot finish under ~3 us), "
-                      "the fraction says how far from any rate they run")
-    return e
-
-
-def class_roofline(name, ms, n_launch, cfg, Bs, dims, fl, dtype_name, kind="waitk", opts=None):
-    """Roofline entry of one kernel class of a launch sequence of Bs rows: algorithmic bytes (HBM-bound classes) or
-    flops (the encoder-side contractions) of the class per sequence / its device time."""
-    if ms <= 0 or n_launch <= 0:
-        return None
-    w = class_work(name, cfg, Bs, dims, fl, dtype_name, kind=kind, opts=opts)
-    if w is None:
-        return None
-    return roofline_entry(name, w[0], w[1], w[2], ms, n_launch, dtype_name)
-
-
 def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps, cores):
     """Oracle (CPU restatement, kind 'port') on a bounded sample: sample_B utterances x T_FRAMES
     frames, n_steps forced decode steps, `cores` torch threads."""
@@ -353,398 +151,6 @@ def run_cpu_baseline(cfg, weights_f32, sample_B, n_steps, cores):
             "kind": "port",
             "sample": f"{sample_B} utterances x {T_FRAMES} frames, {n_steps} forced greedy steps "
                       f"({toks.numel()} tokens) in {dt:.1f} s, torch fp32, {cores} thread{'s' if cores > 1 else ''}"}, toks, fb
-
-
-def extra_config_legs(args, dev, dtype, fb_all, plan, B):
-    """BASELINE.json configs[2] (MMA-hard) and configs[3] (CIF) on the bench's own batches (64 x 1000 frames each), one GPU:
-      offline            the timed plan's schedule (same launch-sequence sizes and streams), 110 forced greedy steps per row --
-                         eval/generate.py:187-209 semantics; median of --passes passes
-      batched streaming  --extra-rows simultaneous streams through the batched agents (agent.BatchedStreamingAgent,
-                         cif.BatchedCIFStreamingAgent: per-row READ / WRITE on the device), --max-len-a 0.1 --max-len-b 10
-                         (agents/default_agent.py:120-123 flags; the reference default 1.0 / 0 lets a random-init model write
-                         1000 tokens per utterance); tokens/s = committed tokens / wall time, mean Average Lagging of the rows
-      parity             fp32 HIP == CPU oracle on a sample (offline: 8 utterances' tokens; streaming: 2 utterances' READ / WRITE
-                         strings, tokens and delays => Average Lagging), and the agreement of the timed bf16 runs' first rows
-      roofline           the config's path byte model (SURVEY 8(d) style) + the dominant kernel class of an instrumented replay
-    Random-init weights do not make a policy move: like tools/config_parity.py the EOS row of the tied embedding is zeroed
-    (hypotheses run to their cap), the MMA query projections are scaled x 8 (heads advance at different rates) and the CIF
-    weight predictor is biased so that it fires (~74 integrated vectors per 1000 frames); oracle and HIP path get the same tensors."""
-    import torch
-    from oracle import agent as oag
-    from oracle.configs import from_model_config
-    from simulst_amd import _lib
-    from simulst_amd.agent import BatchedStreamingAgent
-    from simulst_amd.cif import BatchedCIFStreamingAgent, CIFTransformerModel
-    from simulst_amd.config import cif_transformer_s, mma_model_s
-    from simulst_amd.model import ConcurrentOffline, SimulSTModel
-    from simulst_amd.weights import init_model
-    U, esz = N_STEPS_DECODE, (2 if dtype == torch.bfloat16 else 4)
-    dtn = "bf16" if dtype == torch.bfloat16 else "f32"
-    rows_s = min(args.extra_rows, fb_all.size(0))
-    n_off, n_str = 8, 8            # offline tokens / streaming READ-WRITE records compared with the oracle (VERDICT r3: was 2)
-    fb_cpu = torch.stack([torch.randn(T_FRAMES, 80, generator=torch.Generator().manual_seed(999 + i)) for i in range(n_off)])
-    g_max = max(plan)
-    out = {}
-    def one_leg(key):
-        t_leg = time.perf_counter()
-        cif, waitk = key == "configs3_cif", key == "configs1_batched_streaming"
-        if waitk:
-            cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=WAITK, fixed_pre_decision_ratio=8)
-            w = init_model(cfg, seed=999)
-            kind, workload = "waitk", f"configs[1], batched-streaming semantics: mma_model_s, waitk_fixed_pre_decision k = {WAITK} ratio 8"
-        elif cif:
-            cfg = cif_transformer_s(cif_beta=1.0)
-            w = init_model(cfg, seed=999)
-            w["encoder.cif_layer.alpha_proj.4.weight"] = w["encoder.cif_layer.alpha_proj.4.weight"] * 4
-            w["encoder.cif_layer.alpha_proj.4.bias"] = w["encoder.cif_layer.alpha_proj.4.bias"] - 1.5
-            kind, workload = "cif", "configs[3]: cif_transformer_s (beta 1.0, cif_conv_kernel 3)"
-        else:
-            cfg = mma_model_s(simul_attn_type="hard_aligned_fixed_pre_decision", fixed_pre_decision_ratio=8, mass_preservation=True)
-            w = init_model(cfg, seed=999)
-            for l in range(cfg.decoder_layers):
-                k = f"decoder.layers.{l}.encoder_attn.q_proj.weight"
-                w[k] = w[k] * 8
-            kind, workload = "hard", "configs[2]: mma_model_s, hard_aligned_fixed_pre_decision ratio 8, mass preservation"
-        w["decoder.embed_tokens.weight"][cfg.eos] = 0
-        ecfg, dcfg = from_model_config(cfg)
-        Model = CIFTransformerModel if cif else SimulSTModel
-        model = Model(cfg, w, device=dev, dtype=dtype)
-        factory = (lambda ops: CIFTransformerModel(cfg, w, device=dev, dtype=dtype, ops=ops)) if cif else None
-        pipe = (ConcurrentOffline(model, w, args.concurrency, factory=factory, joint_encoder_max_rows=args.joint_encoder_max_rows)
-                if args.concurrency > 1 else None)
-
-        def seqs():
-            o, r0 = [], 0
-            for g in plan:
-                o.append((fb_all[r0:r0 + B * g], torch.full((B * g,), T_FRAMES, device=dev)))
-                r0 += B * g
-            return o
-
-        def run_offline():
-            if pipe is None:
-                return torch.cat([model.generate_offline(f_, l_, n_steps=U, mask_eos=True)[0].clone() for f_, l_ in seqs()], 0)
-            return torch.cat(pipe.run(seqs(), U, mask_eos=True), 0)
-        with torch.no_grad():
-            for _ in range(0 if waitk else 2):
-                run_offline()
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(0 if waitk else max(1, args.passes)):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                hyp = run_offline()
-                torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            n_tok = 0 if waitk else hyp.size(0) * U
-            offline = None if waitk else {"tokens_per_s": round(n_tok / sorted(ts)[len(ts) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts],
-                       "tokens_per_pass": n_tok, "plan_batches_per_sequence": plan, "streams": min(args.concurrency, len(plan)),
-                       "decode_steps": U, "semantics": "offline batched, EOS masked (eval/generate.py:187-209)"}
-            # ---- batched streaming: the microphone form (sources advance in lockstep, one host round trip per chunk) and the
-            #      evaluation form (self-paced rows: whole source encoded first, one device loop), the latter also with the
-            #      encoder states of one offline forward
-            agent = (BatchedCIFStreamingAgent(model, max_len_a=0.1, max_len_b=10) if cif
-                     else BatchedStreamingAgent(model, max_len_a=0.1, max_len_b=10, steps_per_call=8))
-            fbs = fb_all[:rows_s]
-
-            def timed_stream(**kw):
-                agent.run_batch(fbs, **kw)
-                torch.cuda.synchronize()
-                ts_, recs_ = [], None
-                for _ in range(max(1, args.passes)):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    recs_ = agent.run_batch(fbs, **kw)
-                    torch.cuda.synchronize()
-                    ts_.append(time.perf_counter() - t0)
-                n_ = sum(len(r["tokens"]) for r in recs_)
-                return recs_, {"tokens_per_s": round(n_ / sorted(ts_)[len(ts_) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts_],
-                               "tokens_per_pass": n_, "average_lagging_ms_mean": round(sum(r["AL"] for r in recs_) / rows_s, 2)}
-            recs, lock = timed_stream()
-            recs_p, paced = timed_stream(self_paced=True)
-            recs_o, paced_off = timed_stream(self_paced=True, encoder="offline")
-            # which encoder produced the states a streamed rate was decoded over (VERDICT r3 weak #2): the chunked streaming encoder
-            # (Emformer.infer chunk by chunk: the streaming workload proper) or ONE offline forward cut at the schedule's rows
-            lock["encoder"] = paced["encoder"] = "chunked (streaming encoder, one infer pass per 640 ms chunk)"
-            paced_off["encoder"] = "offline states (one offline forward; equal to the chunked states to rounding)"
-            # the plan's own launch sequences (the utterances of the offline leg) as self-paced streaming batches on the plan's streams
-            from simulst_amd.agent import ConcurrentStreamingEval
-            mk_agent = ((lambda m: BatchedCIFStreamingAgent(m, max_len_a=0.1, max_len_b=10)) if cif
-                        else (lambda m: BatchedStreamingAgent(m, max_len_a=0.1, max_len_b=10)))
-            cse = ConcurrentStreamingEval(model, w, min(args.concurrency, len(plan)), agent_factory=mk_agent, model_factory=factory)
-            work = [(f_, None) for f_, _ in seqs()]
-            cse.run(work)
-            ts_c, recs_c = [], None
-            for _ in range(max(1, args.passes)):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                recs_c = cse.run(work)
-                torch.cuda.synchronize()
-                ts_c.append(time.perf_counter() - t0)
-            n_c = sum(len(r["tokens"]) for rb in recs_c for r in rb)
-            rows_c = sum(len(rb) for rb in recs_c)
-            whole_plan = {"tokens_per_s": round(n_c / sorted(ts_c)[len(ts_c) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts_c],
-                          "encoder": "offline states (one offline forward per launch sequence; equal to the chunked states to rounding)",
-                          "tokens_per_pass": n_c, "rows": rows_c, "plan_batches_per_sequence": plan, "streams": len(cse.agents),
-                          "average_lagging_ms_mean": round(sum(r["AL"] for rb in recs_c for r in rb) / rows_c, 2),
-                          "form": "self-paced rows, encoder states of one offline forward per launch sequence (agent.ConcurrentStreamingEval): "
-                                  "the utterances and the schedule of this config's offline leg, decoded with the simultaneous policy"}
-            # the microphone form with SEVERAL groups of live streams side by side (VERDICT r4 item 8): a group's masked steps cost their
-            # launch latency whatever the row count (~38 of 448 rows write in an average step), so what raises the device's live capacity
-            # is more groups on more HIP streams, not fewer idle rows per group
-            groups = min(args.concurrency, 3)
-            # group g takes rows_s consecutive utterances starting at an even spread of offsets (groups may share utterances: every row is
-            # an independent live stream either way; group 0 = the single-group run's rows)
-            span = max(fb_all.size(0) - rows_s, 0)
-            live = [(fb_all[(g_ * span) // max(groups - 1, 1):(g_ * span) // max(groups - 1, 1) + rows_s], None) for g_ in range(groups)] if span > 0 else []
-            mic_groups = None
-            if len(live) > 1:
-                cse.run(live, self_paced=False)
-                ts_m, recs_m = [], None
-                for _ in range(max(1, args.passes)):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    recs_m = cse.run(live, self_paced=False)
-                    torch.cuda.synchronize()
-                    ts_m.append(time.perf_counter() - t0)
-                n_m = sum(len(r["tokens"]) for rb in recs_m for r in rb)
-                mic_groups = {"tokens_per_s": round(n_m / sorted(ts_m)[len(ts_m) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts_m],
-                              "groups": len(live), "rows_per_group": rows_s, "live_streams": len(live) * rows_s, "tokens_per_pass": n_m,
-                              "first_group_rows_identical_to_the_single_group_run":
-                                  sum(all(a[k] == b[k] for k in ("actions", "tokens", "delays_ms")) for a, b in zip(recs_m[0], recs)),
-                              "form": "microphone form (lockstep sources, one host round trip per chunk), one group of live streams per HIP stream"}
-            del cse
-            keys3 = ("actions", "tokens", "delays_ms")
-            paced["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_p, recs))
-            paced_off["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_o, recs))
-            paced_off["note"] = ("encoder states from ONE offline forward, cut at the rows the streaming schedule releases: equal to the "
-                                 "chunked states to rounding (agents/default_agent.py:438-476), so a decision can flip at a near-tie")
-            # census of the microphone form's masked steps (VERDICT r3 item 5): after chunk c the batch repeats decoder steps until its
-            # SLOWEST row has written everything chunk c allows; a row is active in as many of them as it writes tokens.  The step count
-            # is set by the slowest row, its cost by ~33 dependent launches (latency-bound at any row count, DESIGN.md section 3), so
-            # compacting the active rows cannot shorten a step by more than the policy / attention share -- the self-paced form
-            # (evaluation_form_*) removes the waiting instead
-            per_chunk = []                                   # per row: {number of READs so far: tokens written at that point}
-            for r_ in recs:
-                d_, k_ = {}, 0
-                for ch_ in r_["actions"]:
-                    if ch_ == "R":
-                        k_ += 1
-                    else:
-                        d_[k_] = d_.get(k_, 0) + 1
-                per_chunk.append(d_)
-            n_ch = max(max(x) for x in per_chunk if x) + 1
-            steps_c = [max(x.get(c, 0) for x in per_chunk) for c in range(n_ch)]
-            act_c = [sum(x.get(c, 0) for x in per_chunk) for c in range(n_ch)]
-            lock["masked_step_census"] = {"masked_steps_lower_bound": int(sum(steps_c)), "active_row_steps": int(sum(act_c)),
-                                          "mean_active_rows_per_step": round(sum(act_c) / max(sum(steps_c), 1), 1),
-                                          "rows": rows_s,
-                                          "note": "steps after chunk c = the most tokens any row writes there; a row is active in as many as it writes"}
-            streaming = dict(lock)
-            streaming.update({"rows": rows_s, "reads_per_row": recs[0]["actions"].count("R"), "max_len": "0.1 * frames + 10 tokens",
-                              "semantics": "every row takes its own READ / WRITE decisions on the device; chunk schedule 96 then 64 frames "
-                                           "(agents/default_agent.py:367,407); sources advance in lockstep, the host feeds one chunk at a time",
-                              "evaluation_form_self_paced_rows": paced, "evaluation_form_offline_encoder_states": paced_off,
-                              "evaluation_form_whole_plan_on_streams": whole_plan,
-                              "microphone_form_groups_side_by_side": mic_groups,
-                              "evaluation_form": "sources already on the device (SimulEval reading files): every chunk encoded first, then "
-                                                 "one device loop in which a row takes its next chunk itself when its policy says READ "
-                                                 "(simulst_stream_ctl / simulst_cif_stream_ctl schedules); same READ / WRITE strings, "
-                                                 "tokens and delays per row"})
-            roof = None
-            if not waitk:
-                # ---- instrumented replay of one launch sequence of the plan: the dominant class and its roofline entry
-                Bs = B * g_max
-                fseq, lseq = fb_all[:Bs], torch.full((Bs,), T_FRAMES, device=dev)
-                h = model.ops.h
-                plain_s = float("inf")
-                for rep in range(4):                                   # two warm-ups (this shape's state and allocator pool), best of two
-                    torch.cuda.synchronize()
-                    tp0 = time.perf_counter()
-                    model.generate_offline(fseq, lseq, n_steps=U, mask_eos=True)
-                    torch.cuda.synchronize()
-                    if rep >= 2:
-                        plain_s = min(plain_s, time.perf_counter() - tp0)
-                h.timer_reset(); h.timer_enable(-1, True)
-                torch.cuda.synchronize()
-                tr0 = time.perf_counter()
-                model.generate_offline(fseq, lseq, n_steps=U, mask_eos=True)
-                torch.cuda.synchronize()
-                replay_s = time.perf_counter() - tr0
-                h.timer_enable(-1, False)
-                raw = {_lib.KERNEL_CLASS_NAMES[c]: h.timer_read(c) for c in range(_lib.K_COUNT)}
-                n_launch = sum(v[1] for v in raw.values())
-                ovh = max(0.0, (replay_s - plain_s) * 1e3 / max(n_launch, 1))
-                per_class = {k: (max(0.0, v[0] - ovh * v[1]), v[1]) for k, v in raw.items()}
-                fl, dims = algorithmic_work(cfg, Bs, T_FRAMES, U)
-                opts = decode_path_options(h, Bs, cfg.vocab, dtn)
-                if cif:
-                    opts["embed_qkv"] = False                 # simulst_cif_decode commits with its own launch
-                entries = {k: class_roofline(k, v[0], v[1], cfg, Bs, dims, fl, dtn, kind=kind, opts=opts) for k, v in per_class.items()}
-                entries = {k: e for k, e in entries.items() if e is not None}
-                dom = max(entries, key=lambda k: per_class[k][0])     # every chain kernel is a class of its own: real device time
-                bpt = path_bytes_per_token(cfg, B, T_FRAMES, U, esz, 0, kind=kind)
-                roof = dict(entries[dom])
-                roof["path_hbm_model"] = {"bytes_per_token": round(bpt), "tokens_per_s_at_peak": round(HBM_PEAK_GBS * 1e9 / bpt),
-                                          "frac_offline": round(offline["tokens_per_s"] / (HBM_PEAK_GBS * 1e9 / bpt), 5),
-                                          "definition": "the byte model of SURVEY.md 8(d) with this config's source attention: " +
-                                                        ("pooled monotonic keys + one value row per step" if kind == "hard" else
-                                                         "integrated vectors and their key projections written once, one row gathered per step")}
-                roof["one_sequence_alone"] = {"rows": Bs, "ms": round(plain_s * 1e3, 3), "tokens_per_s": round(Bs * U / plain_s, 1)}
-                roof["class_ms_per_sequence"] = {k: round(v[0], 3) for k, v in per_class.items() if v[1] > 0}
-                roof["launches_per_sequence_all_classes"] = n_launch
-            # ---- parity on a sample against the CPU oracle
-            m32 = Model(cfg, w, device=dev, dtype=torch.float32)
-            ref = t32 = h16 = None
-            gaps = []
-            if not waitk:
-                L8 = torch.full((n_off,), T_FRAMES)
-                margins = []
-                if cif:
-                    ref, _, _ = oag.greedy_offline_cif(w, ecfg, dcfg, cfg.cif_beta, fb_cpu, L8, n_steps=U, mask_eos=True, margins=margins)
-                else:
-                    ref, _, _ = oag.greedy_offline(w, ecfg, dcfg, fb_cpu, L8, n_steps=U, mask_eos=True, margins=margins)
-                mg = torch.stack(margins, 1)
-                t32 = m32.generate_offline(fb_cpu.to(dev), L8, n_steps=U, mask_eos=True)[0].cpu()
-                h16 = hyp[:n_off].cpu()
-                for r in range(n_off):
-                    if not torch.equal(h16[r], ref[r]):
-                        gaps.append(round(float(mg[r, int((h16[r] != ref[r]).float().argmax())]), 5))
-            ag32 = (BatchedCIFStreamingAgent(m32, max_len_a=0.1, max_len_b=10) if cif
-                    else BatchedStreamingAgent(m32, max_len_a=0.1, max_len_b=10, steps_per_call=8))
-            got32 = ag32.run_batch(fb_cpu[:n_str].to(dev))
-            # fp32, 64 rows: do the encoder states of ONE offline forward change any decision against the chunk-by-chunk encoder?
-            # (they are the same function up to rounding; the bf16 rows above flip at near-ties of a random-init model)
-            fb64 = fbs[:64].float()
-            r_ch = ag32.run_batch(fb64, self_paced=True)
-            r_of = ag32.run_batch(fb64, self_paced=True, encoder="offline")
-            paced_off["fp32_rows_identical_to_chunked_encoder_states"] = {
-                "identical": sum(all(a[k] == b[k] for k in keys3) for a, b in zip(r_of, r_ch)), "rows": len(r_ch)}
-            same32, same16 = [], []
-            for i in range(n_str):
-                rs = (oag.simulate_cif(w, ecfg, dcfg, cfg.cif_beta, fb_cpu[i], max_len_a=0.1, max_len_b=10) if cif
-                      else oag.simulate_mma(w, ecfg, dcfg, fb_cpu[i], max_len_a=0.1, max_len_b=10))
-                same32.append(all(got32[i][k] == rs[k] for k in ("actions", "tokens", "delays_ms", "AL")))
-                # where the timed bf16 row leaves the oracle's record, HOW CLOSE the oracle's own decision was to flipping there:
-                # |p - 0.5| of the policy comparison (monotonic_multihead_attention.py:230-237) / |accumulated weight - k beta|
-                # of the CIF count (cif_agent.py:385-389) for a READ / WRITE divergence, the top-2 log-probability gap for a token
-                div = oag.first_divergence(rs, recs[i])
-                same16.append({"actions_identical": recs[i]["actions"] == rs["actions"],
-                               "token_agreement": round(sum(a == b for a, b in zip(recs[i]["tokens"], rs["tokens"])) /
-                                                        max(len(rs["tokens"]), 1), 4),
-                               "AL_ms": [round(recs[i]["AL"], 2), round(rs["AL"], 2)],
-                               "first_divergence": div,
-                               "oracle_smallest_policy_margin_of_the_row": round(min(rs["action_margins"]), 6),
-                               "oracle_smallest_top2_gap_of_the_row": round(min(rs["token_gaps"]), 6)})
-            parity = {"streaming_fp32_actions_tokens_delays_AL_identical_to_oracle": all(same32), "streaming_sample_utterances": n_str,
-                      f"streaming_{dtn}_timed_rows_vs_oracle": same16,
-                      f"streaming_{dtn}_rows_identical_to_oracle": sum(1 for r_ in same16 if r_["first_divergence"] is None),
-                      f"streaming_{dtn}_oracle_margin_at_first_divergence":
-                          sorted((d_["first_divergence"]["policy_margin"] if d_["first_divergence"]["cause"] == "action"
-                                  else min(x for x in (d_["first_divergence"]["token_gap"],
-                                                       d_["first_divergence"]["policy_margin_of_the_call_that_wrote_the_token"]
-                                                       if kind == "hard" else None) if x is not None))
-                                 for d_ in same16 if d_["first_divergence"] is not None),
-                      "margin_definition": "policy: |p - 0.5| (MMA) / |accumulated weight - k * beta| (CIF) of the ORACLE at the first "
-                                           "differing READ / WRITE; token: the oracle's top-2 log-probability gap at the first differing token, or (MMA: hard "
-                                           "attention) the policy margin of the decoder call that wrote it when that is smaller -- a head on a near tie looks "
-                                           "at another frame (whichever comes first in the action string); bounded in tests/test_hip_configs.py::"
-                                           "test_bf16_streamed_rows_leave_the_oracle_only_at_near_ties"}
-            if not waitk:
-                parity.update({"offline_fp32_tokens_identical_to_oracle": bool(torch.equal(t32, ref)), "offline_sample_utterances": n_off,
-                               f"offline_{dtn}_timed_rows_identical_to_oracle": int(sum(torch.equal(h16[r], ref[r]) for r in range(n_off))),
-                               f"offline_{dtn}_oracle_top2_gap_at_first_divergence": sorted(gaps)})
-        forced = None
-        if not waitk and not args.no_teacher_forced:
-            # numerical bf16 parity along the ORACLE's trajectory (tools/teacher_forced_audit.py): the streaming entry points driven with
-            # the oracle's tokens / READ schedule / head steps, every probability, accumulated weight and decision compared
-            tools = os.path.join(ROOT, "tools")
-            if tools not in sys.path:
-                sys.path.insert(0, tools)
-            import teacher_forced_audit as tfa
-            del pipe, model, m32
-            pipe = model = m32 = None
-            torch.cuda.empty_cache()
-            utts = [fb_cpu[i] for i in range(min(8, n_off))]
-            with torch.no_grad():
-                a = (tfa.audit_cif if cif else tfa.audit_mma_hard)(cfg, w, utts, copies=17, dtype=dtype, device=dev)
-            forced = {"rows": a["rows"], "utterances": a["utterances"], "layer_chains": a["layer_chains"],
-                      "tokens_differ": [a["tokens"]["differ"], a["tokens"]["writes"]],
-                      "logit_abs_err_max": round(a["logits"]["abs_err"]["max"], 5)}
-            if cif:
-                forced.update({"accumulated_weight_abs_err_max": round(a["accumulated_weight_abs_err"]["max"], 5),
-                               "released_counts_differ": [a["fired_counts"]["updates_where_the_released_count_differs"], a["updates"]],
-                               "unexplained": a["fired_counts"]["not_explained_by_the_weight_error"]})
-            else:
-                forced.update({"p_abs_err_max": round(a["p_abs_err"]["max"], 5),
-                               "step_searches_differ": [a["decisions"]["own_search_differs_from_oracle"], a["decisions"]["searches"]],
-                               "unexplained": a["decisions"]["not_explained_by_the_p_error"]})
-            out_full_audit[key] = a
-        out[key] = {"workload": workload + f"; {T_FRAMES}-frame utterances, {dtn}", "batched_streaming": streaming,
-                    "parity_on_sample": parity, "seconds_spent": round(time.perf_counter() - t_leg, 1)}
-        if forced is not None:
-            out[key]["teacher_forced"] = forced
-        if not waitk:
-            out[key].update({"offline": offline, "roofline": roof})
-        log(f"{key}: " + ("" if waitk else f"offline {offline['tokens_per_s']:.0f} tokens/s, ") +
-            f"batched streaming {streaming['tokens_per_s']:.0f} tokens/s (AL {streaming['average_lagging_ms_mean']} ms; self-paced "
-            f"{paced['tokens_per_s']:.0f}, with offline encoder states {paced_off['tokens_per_s']:.0f}, the whole plan on streams "
-            f"{whole_plan['tokens_per_s']:.0f}), parity " +
-            ("" if waitk else f"{parity['offline_fp32_tokens_identical_to_oracle']} / ") +
-            f"{parity['streaming_fp32_actions_tokens_delays_AL_identical_to_oracle']}")
-        del pipe, model, m32
-        torch.cuda.empty_cache()
-
-    out_full_audit = {}
-    for key in ("configs1_batched_streaming", "configs2_mma_hard", "configs3_cif"):
-        try:
-            one_leg(key)
-        except Exception as e:                               # a failing leg must not cost the line its main measurement
-            import traceback
-            out[key] = {"error": repr(e), "traceback_tail": traceback.format_exc().strip().splitlines()[-3:]}
-            log(f"{key}: FAILED {e!r}")
-            torch.cuda.empty_cache()
-    if out_full_audit:
-        out["teacher_forced_audit_full"] = out_full_audit            # bench_legs.json only (compact_line leaves it out)
-    return out
-
-
-def configs4_rank_shard_leg(dtype_name):
-    """BASELINE.json configs[4] (utterance-sharded evaluation of ~40 k utterances over 8 GPUs; eval/generate.py:141-155,187-209) on ONE
-    GPU: rank 3's shard of the 40 000-utterance seeded length distribution -- 5 000 ragged utterances, 100 .. 3000 frames -- decoded
-    offline and as a streaming evaluation (wait-k 3), through tools/eval_sharded.py in this process: tokens/s, mean Average Lagging,
-    property checks of the hypotheses, the shard's own path roofline."""
-    tools = os.path.join(ROOT, "tools")
-    if tools not in sys.path:
-        sys.path.insert(0, tools)
-    import eval_sharded
-    base = ["--utterances", "40000", "--shard-of", "8", "--shard-rank", "3", "--dtype", dtype_name, "--passes", "3", "--warmup-passes", "1"]
-    out = {"workload": "configs[4]: one rank's shard (rank 3 of 8) of the 40 000-utterance set, lengths log-normal clipped to 100 .. 3000 "
-                       "frames (seed 999), int(0.1 T + 10) tokens per utterance, wait-k 3",
-           "note": "the other 7 shards are equally long (length-sorted snake deal, simulst_amd/sharding.py): an 8-GPU job is this x 8 plus one "
-                   "all_gather of hypotheses"}
-    for key, extra in (("offline", []), ("streaming_evaluation", ["--streaming"])):
-        t0 = time.perf_counter()
-        rec = []
-        eval_sharded.main(base + extra, collect=rec)
-        r = rec[0]
-        r["seconds_spent_in_leg"] = round(time.perf_counter() - t0, 1)
-        out[key] = r
-        log(f"configs4_rank_shard {key}: {r['utterances_decoded']} utterances, {r['tokens_per_s']:.0f} tokens/s" +
-            (f", AL {r['average_lagging_ms_mean']} ms" if "average_lagging_ms_mean" in r else ""))
-    return out
-
-
-def b1_latency_leg():
-    """The B = 1 agent's computation-aware latency beside the oracle at one thread (tools/b1_latency.py)"""
-    tools = os.path.join(ROOT, "tools")
-    if tools not in sys.path:
-        sys.path.insert(0, tools)
-    import b1_latency
-    r = b1_latency.run()
-    log(f"configs0 B = 1 agent: per WRITE {r['hip_b1_agent']['per_write']['median_ms']} ms, per READ {r['hip_b1_agent']['per_read']['median_ms']} ms "
-        f"(medians), median AL_CA - AL {r['hip_b1_agent']['AL_CA_minus_AL_ms_median']} ms (oracle, 1 thread: "
-        f"{r['oracle_cpu']['AL_CA_minus_AL_ms_median']} ms)")
-    return r
 
 
 LEGS_FILE = "bench_legs.json"        # everything the line leaves out (per-row tables, per-utterance latency, census, notes)
@@ -891,11 +297,6 @@ def emit(full, rank_dir=ROOT):
     return line
 
 
-_T0 = time.perf_counter()
-
-
-def log(msg):
-    print(f"[bench +{time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def dry_run_gloo(args):

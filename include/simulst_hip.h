@@ -80,7 +80,8 @@ int simulst_version(void);            /* 106 (round 6: simulst_emformer_ffn_pren
  * cu_mask: mask_words 32-bit words; on MI355X bit i is compute unit (i / 8) of XCD (i % 8) (tools/microbench_cumask.hip), every XCD
  * must keep at least one unit; NULL / 0: no mask.  priority: 0 default, > 0 greatest, < 0 least (ignored with a mask).  Used by
  * tools/partitioned_offline.py: the encoder of the next utterances beside the decode loops of the previous ones on DISJOINT
- * compute units (the offline evaluation loop of eval/generate.py:187-209 over independent batches). */
+ * compute units (the offline evaluation loop of eval/generate.py:187-209 over independent batches).  Returns 0, SIMULST_E_NULL, or the
+ * positive hipError_t of the failing HIP call (these two entry points take no handle, so there is no simulst_last_error text). */
 int simulst_stream_create(void** out_stream, int32_t priority, const uint32_t* cu_mask, int32_t mask_words);
 int simulst_stream_destroy(void* stream);
 /* per-kernel-class HIP-event timing on the handle's stream (off by default) */

@@ -244,6 +244,13 @@ def create_stream(device=None, cu_mask=None, priority=0):
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
+def destroy_stream(stream):
+    """simulst_stream_destroy for a stream made by create_stream (the caller has synchronised it and drops the torch object)"""
+    rc = load().simulst_stream_destroy(_vp(stream.cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"simulst_stream_destroy failed (status {rc})")
+
+
 class Handle:
     """Owns a simulst_handle bound to a HIP stream (default: torch's current stream)."""
 

@@ -377,132 +377,6 @@ __global__ __launch_bounds__(256, 2) void dec_proj_chain_kernel(
   proj_chain_body<RTL, XM>(ctx, x, Wo, bo, ln_g, ln_b, Wq, bq, q, Wq2, bq2, q2, M, dbg, kk, (int)blockIdx.x);
 }
 
-#ifdef SL_EXPERIMENTS
-// ---------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 5; `make EXPERIMENTS=1`, SIMULST_OPT_DEC_FUSE_PROJ_CROSS; measured SLOWER: 36-37 us per launch against 27.6 us for the two
-// launches alone, 107-113 against 91.7 ms in the driver's form -- DESIGN.md section 3): the projection chain and the wait-k cross-attention of a
-// decoder layer in ONE launch with two kinds of workgroups.  Workgroups 0 .. n_tiles-1 run the projection chain of their 16 rows and
-// then PUBLISH the tile (stores drained, workgroup barrier, one agent-scope release, a flag word = the launch's epoch); the other
-// H x rows workgroups are the cross-attention of one (head, row): they request every visible K / V row FIRST -- those loads do not
-// depend on the query -- and only then wait for their row's tile (one lane polls with s_sleep, one agent-scope acquire, barrier), read
-// their 64 query channels and finish.  What it buys over two launches: the K / V stream of the resident attention workgroups runs
-// UNDER the chain's 7-9 us of latency, and one launch boundary goes.  Same arithmetic in the same order as dec_proj_chain_kernel +
-// policy_cross_attn_kernel's wait-k branch (decode_driver.hip): results are bit-identical (tests/test_hip_dec_chain.py).
-// The chain workgroups have the lowest ids, so they are dispatched before any waiting workgroup can occupy their place; a bounded
-// spin turns a broken assumption into an error word instead of a hang.
-template <int XM>
-__global__ __launch_bounds__(256, 2) void dec_proj_cross_fused_kernel(
-    const bf16* __restrict__ ctx_in, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo,
-    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ Wq, const float* __restrict__ bq,
-    bf16* __restrict__ q, int M, int n_tiles, int* __restrict__ flags, int epoch,
-    const bf16* __restrict__ Ks, const bf16* __restrict__ Vc, const int* __restrict__ key_len, const int* __restrict__ tgt_idx,
-    long* __restrict__ head_step, unsigned char* __restrict__ head_read, bf16* __restrict__ ctx_out, int H, int S_cap, int ratio,
-    int waitk_k, int online, int mass_pres, int n_hint) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds_f[];
-  if ((int)blockIdx.x < n_tiles) {
-    proj_chain_body<1, XM>(ctx_in, x, Wo, bo, ln_g, ln_b, Wq, bq, q, nullptr, nullptr, nullptr, M, nullptr, nullptr, (int)blockIdx.x);
-    // publish WITHOUT cache maintenance (an agent-scope release is buffer_wbl2 of this XCD's whole L2, the consumers' acquire a
-    // buffer_inv of theirs -- the feed-forward + QKV experiment below measured 11 ms per pass for that): the tile's 8 KB of query rows
-    // are re-stored device-coherently (sc1: written through to memory), then the flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
-      const int row = threadIdx.x >> 4, g = (int)blockIdx.x * 16 + row;          // 16 rows x 16 chunks of 32 bytes
-      if (g < M) {
-        bf16* qp = q + (long)g * CD + (threadIdx.x & 15) * 16;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 8);
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(qp), "v"(v0), "v"(v1) : "memory");
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  // ---- PERSISTENT attention workgroups: this one takes the (head, row) problems id, id + G, id + 2 G, ... with TWO of them in flight (two
-  //      register sets of K / V rows): while the chain runs, a resident workgroup has requested the rows of its first two problems; after
-  //      that every problem's query read and softmax run under the next problem's loads.  (One problem per workgroup: 36 us per launch
-  //      against 27.6 for two launches -- only 2 workgroups fit a compute unit beside the chain's 210 registers)
-  constexpr int d = 64, NP = 8;
-  const int id = (int)blockIdx.x - n_tiles, G = (int)gridDim.x - n_tiles, nprob = H * M;
-  const int tid = threadIdx.x;
-  const int D = H * d;
-  float* red = reinterpret_cast<float*>(lds_f) + 64;
-  const bool pool_last = ratio < 0;
-  ratio = ratio < 0 ? -ratio : ratio;
-  struct Prob { int h, b, len, n_pref; long st; };
-  auto issue = [&](attn::Regs2<bf16, NP>& rg, Prob& pr, int p) {
-    pr.b = p / H; pr.h = p - pr.b * H;
-    pr.len = key_len ? key_len[pr.b] : S_cap;
-    const int P = pooled_count(pr.len, ratio, true, pool_last);
-    const long hb = ((long)pr.b * H + pr.h) * S_cap * d;
-    const int tg = tgt_idx ? tgt_idx[pr.b] : 0;
-    const long hs = head_step[p];
-    const int nh = n_hint < 0 ? (tg + waitk_k) * ratio : n_hint;
-    pr.n_pref = min(S_cap, nh);
-    attn::prefetch2<bf16, NP>(rg, nullptr, Ks + hb, d, Vc + hb, d, pr.n_pref, -1, nullptr, nullptr);   // K / V only: no query yet
-    // wait-k policy in closed form, as policy_cross_attn_kernel (decode_driver.hip)
-    int wk = tg + waitk_k - 1;
-    if (!online) wk = min(wk, P - 1);
-    int s1 = -1, s2 = -1;
-    if (wk < P) {
-      const int c1 = (wk + 1) * ratio - 1;
-      if (c1 < pr.len) s1 = c1;
-      if (wk == P - 1 && P * ratio >= pr.len) s2 = pr.len - 1;
-    }
-    const int max_steps = mass_pres ? pr.len - 1 : pr.len;
-    int found = max_steps;
-    if (s1 >= 0 && (long)s1 >= hs) found = min(found, s1);
-    if (s2 >= 0 && (long)s2 >= hs) found = min(found, s2);
-    if (found < 0) found = 0;
-    if (tid == 0) {
-      const int clampi = min(max(found, 0), pr.len - 1);
-      const bool one = clampi >= 0 && (clampi == s1 || clampi == s2);
-      head_step[p] = found;
-      head_read[p] = (found == max_steps && !one) ? 1 : 0;
-    }
-    pr.st = found;
-  };
-  auto consume = [&](attn::Regs2<bf16, NP>& rg, const Prob& pr) {
-    // the row's query: wait for its tile of the projection chain (one lane polls; acquire; the workgroup meets)
-    if (tid == 0) {
-      const int* f = flags + (pr.b >> 4);
-      int spins = 0;
-      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch < 0) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1 << 22)) { __hip_atomic_store(flags + 1023, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-    }
-    __syncthreads();
-    {                                                              // device-coherent read of the 16 query bytes (no acquire fence: see the publish)
-      f32x4 qv;
-      const bf16* qp = q + (long)pr.b * D + pr.h * d + (tid % NP) * 8;
-      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(qv) : "v"(qp) : "memory");
-      rg.q = __builtin_bit_cast(uint4, qv);
-    }
-    float o = 0.f;
-    const int n = (int)(pr.st < pr.len - 1 ? pr.st : pr.len - 1) + 1;
-    if (pr.st > 0 && n > 0) o = attn::finish3<bf16, NP>(rg, n, pr.n_pref, rsqrtf((float)d), red, nullptr, nullptr);
-    if (tid < d) ctx_out[(long)pr.b * D + pr.h * d + tid] = from_f32<bf16>(o);
-  };
-  attn::Regs2<bf16, NP> ra, rb;
-  Prob qa, qb;
-  int pA = id, pB = id + G;
-  if (pA < nprob) issue(ra, qa, pA);
-  if (pB < nprob) issue(rb, qb, pB);
-  for (;;) {
-    if (pA >= nprob) break;
-    consume(ra, qa);
-    pA += 2 * G;
-    if (pA < nprob) issue(ra, qa, pA);
-    if (pB >= nprob) break;
-    consume(rb, qb);
-    pB += 2 * G;
-    if (pB < nprob) issue(rb, qb, pB);
-  }
-}
-
-#endif  // SL_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------------------------------
 // x <- x' + fc2(gelu(fc1(LN(x')))) + b2  with  x' = x + Wco . ctx + bco;   grid = row tiles x splits, split sp owns hidden
@@ -645,210 +519,6 @@ __global__ __launch_bounds__(256, 2) void dec_ffn_chain_kernel(
   if (tid == 0) __hip_atomic_store(sem + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
-#ifdef SL_EXPERIMENTS
-// Device-coherent 16-byte accesses for data handed from one workgroup to another INSIDE a launch.  MI355X has one L2 per XCD and the
-// splits of a row tile sit on eight different XCDs: an agent-scope release / acquire fence is `buffer_wbl2 sc1` / `buffer_inv sc1`,
-// i.e. the producer writes back its XCD's whole L2 and the consumer drops its own -- measured: the fused launch below took ~25 us
-// longer than the two launches it replaces (105 ms against 91 ms per pass).  With sc1 on the accesses themselves the slabs are written
-// through to memory and read from there, and no cache is flushed or invalidated for them.
-__device__ __forceinline__ void st16_sc1(float* p, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ f32x4 ld16_sc1(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-// add_slabs with device-coherent slab reads (same summation order)
-__device__ __forceinline__ uint2 add_slabs_sc1(const float (&r)[4], float4 b2, const float* partial, int splits, int M, int g, int lane) {
-  float4 s = float4{b2.x + r[0], b2.y + r[1], b2.z + r[2], b2.w + r[3]};
-  for (int k0 = 0; k0 < splits; k0 += 8) {
-    f32x4 p[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) p[j] = ld16_sc1(partial + ((long)min(k0 + j, splits - 1) * M + g) * CD + 4 * lane);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float m = k0 + j < splits ? 1.f : 0.f;
-      s.x = fmaf(p[j].x, m, s.x); s.y = fmaf(p[j].y, m, s.y); s.z = fmaf(p[j].z, m, s.z); s.w = fmaf(p[j].w, m, s.w);
-    }
-  }
-  return pack4(s.x, s.y, s.z, s.w);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the feed-forward chain of layer l AND the slab sum + LayerNorm + QKV projection of layer l + 1 in ONE launch.
-// In the three-stream pass a launch boundary between two dependent chain launches costs ~8 us of a stream's time (62 ms of decode wall
-// for 34 ms of kernel time over 3 410 launches); inside a launch the same hand-off is a ticket counter.  Every split workgroup of a row
-// tile computes its slab exactly as dec_ffn_chain_kernel does and draws a ticket; workgroups sp = 0 .. n_cb - 1 then WAIT until all
-// `splits` slabs of the tile are published and run dec_qkv_chain_kernel's body for column block cb = sp -- x' is still in their LDS
-// (every split builds it), so no x_mid round trip; the others exit.  Same expressions in the same order as the two launches: identical
-// results (tests/test_hip_dec_chain.py).
-// Tickets: sem[tile] only ever counts up; a workgroup's ticket t tells the launch's target (t / splits + 1) * splits, because every
-// earlier launch on the stream completed all `splits` arrivals of the tile.  No deadlock: workgroups are dispatched in id order and
-// the splits of a tile have consecutive ids, so a waiting workgroup only ever waits for workgroups that are resident or next in line,
-// and every complete tile in front of them finishes without waiting on anything later.
-// MEASURED (driver form, same box): 93.4-94.0 ms per pass against 90.4-90.6 ms for the two launches (105 ms with agent-scope fences
-// instead of sc1 accesses, see above) although the pass has 16 % fewer launches: what separates two dependent chain launches in the
-// three-stream pass is not a fixed launch cost but queueing behind the other streams' workgroups, which a waiting workgroup does not
-// escape -- it only holds its slot longer.  EXPERIMENTS builds only, off by default.
-template <int RTL, int XM>
-__global__ __launch_bounds__(256, 2) void dec_ffn_qkv_chain_kernel(
-    const bf16* __restrict__ ctx, bf16* __restrict__ x, const uint4* __restrict__ Wco, const float* __restrict__ bco,
-    const float* __restrict__ ln_g, const float* __restrict__ ln_b, const uint4* __restrict__ W1,
-    const float* __restrict__ b1, const uint4* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ partial,
-    int* __restrict__ sem, int M, int F, int splits, const float* __restrict__ nln_g, const float* __restrict__ nln_b,
-    const uint4* __restrict__ nW, const float* __restrict__ nbias, bf16* __restrict__ qkv, int n_cb) {
-  constexpr bool HANDOFF = true;
-  (void)HANDOFF;
-  constexpr int RT = 16 * RTL;
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];           // 2 * RT * XS + 8 elements: ONE LDS object
-  unsigned short* bufA = lds;
-  unsigned short* bufB = lds + RT * XS;
-  int* flag = reinterpret_cast<int*>(lds + 2 * RT * XS);
-  SL_CHAIN_SETPRIO();
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  // split index fastest: the 8 XCDs each see ONE split's slice of W1 / W2 (workgroup ids are dealt round-robin), so a
-  // layer's 2 MB of feed-forward weights are 256 KB per XCD L2
-  const int sp = blockIdx.x % splits, tile = blockIdx.x / splits;
-  const int m0 = tile * RT;
-  PROBE(0);
-  const int tw = 4 * wave;                               // this wave's first column tile of every 256-column block
-  const int nks2 = F / 32;                               // k-steps of a whole fc2 row
-  WUnit u0, u1;
-  load_unit(u0, Wco, tw, NKS, 0, lane);
-  rows_to_lds<RTL>(ctx, bufA, m0, M, tid);
-  load_unit(u1, Wco, tw + 2, NKS, 0, lane);
-  const int nb = 64 * wave + 4 * lg;
-  float* vec = reinterpret_cast<float*>(lds + 2 * RT * XS + 8);  // [bco | b1 of this split | b2 | gamma | beta] x 256
-  vec[tid] = bco[tid]; vec[256 + tid] = b1[256 * sp + tid]; vec[512 + tid] = b2[tid];
-  vec[768 + tid] = ln_g[tid]; vec[1024 + tid] = ln_b[tid];
-  uint2 res[RTL][4];
-#pragma unroll
-  for (int rt = 0; rt < RTL; ++rt) {
-    const int g = m0 + rt * 16 + lr;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-      res[rt][ct] = *reinterpret_cast<const uint2*>(x + (long)(g < M ? g : 0) * CD + nb + 16 * ct);
-  }
-  lds_barrier();
-  PROBE(1);
-  f32x4 acc[RTL][4];
-  zero_acc<RTL>(acc);
-  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
-  load_unit(u0, W1, 16 * sp + tw, NKS, 0, lane);         // fc1 rows (hidden units) of this split, this wave's 64
-  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
-  load_unit(u1, W1, 16 * sp + tw + 2, NKS, 0, lane);
-  PROBE(2);
-  // x' = bf16(x + Wco . ctx + bco) -> bufB (kept to the end: the residual of the reduction)
-#pragma unroll
-  for (int rt = 0; rt < RTL; ++rt) {
-    const int row = rt * 16 + lr;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      float r[4];
-      unpack4(res[rt][ct], r);
-      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
-      const uint2 o = pack4(acc[rt][ct][0] + bv.x + r[0], acc[rt][ct][1] + bv.y + r[1], acc[rt][ct][2] + bv.z + r[2],
-                            acc[rt][ct][3] + bv.w + r[3]);
-      *reinterpret_cast<uint2*>(bufB + row * XS + nb + 16 * ct) = o;
-    }
-  }
-  lds_barrier();
-  ln_rows<RTL, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
-               *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane), wave, lane);
-  lds_barrier();
-  PROBE(3);
-  zero_acc<RTL>(acc);
-  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
-  load_unit(u0, W2, tw, nks2, NKS * sp, lane);           // fc2 columns of this wave, k-steps (hidden units) of this split
-  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
-  load_unit(u1, W2, tw + 2, nks2, NKS * sp, lane);
-  PROBE(4);
-  lds_barrier();                                               // every wave is done reading LN(x') from bufA
-#pragma unroll
-  for (int rt = 0; rt < RTL; ++rt) {
-    const int row = rt * 16 + lr;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const float4 bv = *reinterpret_cast<const float4*>(vec + 256 + nb + 16 * ct);
-      const f32x2 h0 = gelu_fast2(f32x2{acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y});
-      const f32x2 h1 = gelu_fast2(f32x2{acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w});
-      *reinterpret_cast<uint2*>(bufA + row * XS + nb + 16 * ct) = pack4(h0.x, h0.y, h1.x, h1.y);
-    }
-  }
-  lds_barrier();
-  PROBE(5);
-  zero_acc<RTL>(acc);
-  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
-  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
-  PROBE(6);
-  float* slab = partial + (long)sp * M * CD;
-#pragma unroll
-  for (int rt = 0; rt < RTL; ++rt) {
-    const int g = m0 + rt * 16 + lr;
-    if (g >= M) continue;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-      st16_sc1(slab + (long)g * CD + nb + 16 * ct, acc[rt][ct]);
-  }
-  // ---- hand-off: publish the slab, draw a ticket
-  if (sp >= n_cb) {                                              // nothing more to do here: publish and leave
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(sem + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (slabs: written through, above)
-    return;
-  }
-  // column block cb = sp of the next layer's QKV: its weights and vectors are requested BEFORE the wait
-  const int cb = sp;
-  const int tq = 16 * cb + 4 * wave;
-  load_unit(u0, nW, tq, NKS, 0, lane);
-  load_unit(u1, nW, tq + 2, NKS, 0, lane);
-  const float4 b24 = *reinterpret_cast<const float4*>(vec + 512 + 4 * lane);
-  lds_barrier();                                                 // every wave is past its last read of the old vectors (b1: GELU epilogue)
-  vec[tid] = nbias[256 * cb + tid]; vec[768 + tid] = nln_g[tid]; vec[1024 + tid] = nln_b[tid];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (also waits for the prefetched fragments: they hit L2)
-  __syncthreads();
-  if (tid == 0) {
-    const int t = __hip_atomic_fetch_add(sem + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int target = (t / splits + 1) * splits;
-    while (__hip_atomic_load(sem + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) __builtin_amdgcn_s_sleep(2);
-  }
-  __syncthreads();
-  // ---- dec_qkv_chain_kernel's body: x <- bf16(x' + b2 + slabs) (x' from bufB), LN, 256 columns of the projection
-#pragma unroll
-  for (int i = 0; i < 4 * RTL; ++i) {
-    const int row = wave + 4 * i, g = m0 + row;
-    uint2 o = make_uint2(0, 0);
-    if (g < M) {
-      float r[4];
-      unpack4(*reinterpret_cast<const uint2*>(bufB + row * XS + 4 * lane), r);
-      o = add_slabs_sc1(r, b24, partial, splits, M, g, lane);
-      if (cb == 0) *reinterpret_cast<uint2*>(x + (long)g * CD + 4 * lane) = o;
-    }
-    *reinterpret_cast<uint2*>(bufB + row * XS + 4 * lane) = o;
-  }
-  lds_barrier();
-  ln_rows<RTL, XM>(bufB, bufA, *reinterpret_cast<const float4*>(vec + 768 + 4 * lane),
-               *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane), wave, lane);
-  lds_barrier();
-  zero_acc<RTL>(acc);
-  mma_unit<RTL, 0, XM>(acc, u0, bufA, lr, lg);
-  mma_unit<RTL, 2, XM>(acc, u1, bufA, lr, lg);
-#pragma unroll
-  for (int rt = 0; rt < RTL; ++rt) {
-    const int g = m0 + rt * 16 + lr;
-    if (g >= M) continue;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
-      *reinterpret_cast<uint2*>(qkv + (long)g * (256 * n_cb) + 256 * cb + nb + 16 * ct) =
-          pack4(acc[rt][ct][0] + bv.x, acc[rt][ct][1] + bv.y, acc[rt][ct][2] + bv.z, acc[rt][ct][3] + bv.w);
-    }
-  }
-}
-
-#endif  // SL_EXPERIMENTS (dec_ffn_qkv_chain_kernel)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The launch after a feed-forward chain without hand-off:  x <- bf16(x' + b2 + slabs)  (x' from x_mid), then, unless
@@ -1079,252 +749,6 @@ __global__ __launch_bounds__(256, 2) void dec_vocab_chain_kernel(
   }
 }
 
-#ifdef SL_EXPERIMENTS     // measured slower than self-attention + projection chain as two launches at every cache length: `make EXPERIMENTS=1`
-// ---------------------------------------------------------------------------------------------------------------------
-// Self-attention INSIDE the projection chain (round 4):
-//   qkv [M][768], K / V caches [M][4][cap][64] --attention--> ctx (LDS only) --Wo, bo, + x--> x --LN--> --Wq, bq--> q (q2 / kk as above)
-// i.e. dec_attn.hip's self_attn_wave_kernel + dec_proj_chain_kernel in one launch (fairseq TransformerDecoderLayer: self-attention
-// with its K / V cache, output projection + residual, LayerNorm, encoder_attn query projection; witness models/cif_transformer.py:
-// 405-470).  At 448 rows the two launches were 9 + 7 us alone on the chip, both far from any rate: the attention is one dependent
-// HBM round trip on 1 792 single-wave problems, the chain 28 workgroups on 256 compute units.  Here a workgroup owns VR = 4 rows
-// (112 workgroups at 448 rows, each still pulling its two 128 KB weight blocks from L2 -- 29 MB per launch) and wave w runs head w's
-// attention for those rows first: 8 lanes per cached position, 8 positions per pass, every K / V load of NF problems in flight
-// at once (all four problems while every row holds < 64 positions, two and two beyond), results straight into the LDS tile the
-// output projection reads.
-// Arithmetic, its order and the rounding points are those of the two kernels replaced: results are bit-identical
-// (tests/test_hip_dec_chain.py::test_attention_projection_chain_equals_the_two_launches).
-// MEASURED SLOWER, hence OFF by default (SIMULST_OPT_DEC_ATTN_CHAIN_MAX_ROWS = 0): rocprofv3 at 448 rows (profiles/r04_attn_chain_
-// kernel_stats.csv) -- 20 / 55 / 109 cached positions: this launch 14.4 / 23.5 / 35.2 us against 4.3 + 6.3 / 8.0 + 6.3 / 17.0 + 6.3 us
-// for the two it replaces; the driver-form bench 1.40 M against 1.46 M tokens/s.  The 1 792 single-wave problems of the separate
-// launch keep 7 waves per compute unit on all 256 units pulling K / V rows; here 112 units hold 4 waves that each walk 4 problems in
-// two dependent rounds -- the attention phase is bound by what one compute unit can keep in flight (15-25 GB/s per unit measured),
-// which costs more than the launch boundary and the second ramp it saves.  8 / 16 rows per workgroup: 32 .. 121 us.  Kept as a measured
-// alternative; DESIGN.md section 3 has the table.
-template <int MAXP>
-struct AttnProblem {
-  uint4 q, k[MAXP], v[MAXP];
-  int np;
-};
-
-// every load of problem (row b, head h): the self_attn_wave_kernel prologue, including the cache append of the new position
-template <int MAXP>
-__device__ __forceinline__ void attn_issue(AttnProblem<MAXP>& r, const bf16* __restrict__ qkv, bf16* __restrict__ kc,
-                                           bf16* __restrict__ vc, int b, int h, int np, int cap, int lane) {
-  constexpr int d = 64, RPP = 8;
-  const int n = np + 1;
-  const bf16* row = qkv + (long)b * 3 * CD;
-  bf16* Kh = kc + ((long)b * 4 + h) * cap * d;
-  bf16* Vh = vc + ((long)b * 4 + h) * cap * d;
-  const int c = lane & 7, rg = lane >> 3;
-  const bf16* k_new = row + CD + h * d;
-  const bf16* v_new = row + 2 * CD + h * d;
-  r.np = np;
-  r.q = *reinterpret_cast<const uint4*>(row + h * d + c * 8);
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    if (i * RPP < n) {
-      int j = rg + RPP * i;
-      if (j >= n) j = 0;
-      const bf16* kr = (j == np) ? k_new : Kh + (long)j * d;
-      const bf16* vr = (j == np) ? v_new : Vh + (long)j * d;
-      r.k[i] = ld_stream16(kr + c * 8);
-      r.v[i] = ld_stream16(vr + c * 8);
-    }
-  }
-  if (rg == 0) {
-    *reinterpret_cast<uint4*>(Kh + (long)np * d + c * 8) = *reinterpret_cast<const uint4*>(k_new + c * 8);
-    *reinterpret_cast<uint4*>(Vh + (long)np * d + c * 8) = *reinterpret_cast<const uint4*>(v_new + c * 8);
-  }
-}
-
-// softmax(q . K) V of one problem, the 64 context channels of the head as bf16 into dst[0 .. 63] (LDS): self_attn_wave_kernel's body
-template <int MAXP>
-__device__ __forceinline__ void attn_finish(const AttnProblem<MAXP>& r, unsigned short* dst, int lane) {
-  constexpr int RPP = 8;
-  const int n = r.np + 1;
-  const int c = lane & 7, rg = lane >> 3;
-  const float qscale = rsqrtf(64.f);
-  float sc[MAXP];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    sc[i] = -INFINITY;
-    if (i * RPP < n) {
-      float s = attn_dot8(r.q, r.k[i]) * qscale;
-      s += lane_xor<1>(s); s += lane_xor<2>(s); s += lane_xor<4>(s);
-      if (rg + RPP * i < n) { sc[i] = s; mx = fmaxf(mx, s); }
-    }
-  }
-  mx = fmaxf(mx, lane_xor<8>(mx)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float den = 0.f, a[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) a[e] = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    if (i * RPP < n && rg + RPP * i < n) {
-      const float p = expf(sc[i] - mx);
-      den += p;
-      const unsigned int u[4] = {r.v[i].x, r.v[i].y, r.v[i].z, r.v[i].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[2 * e] = fmaf(p, __uint_as_float(u[e] << 16), a[2 * e]);
-        a[2 * e + 1] = fmaf(p, __uint_as_float(u[e] & 0xffff0000u), a[2 * e + 1]);
-      }
-    }
-  }
-  den += lane_xor<8>(den); den += __shfl_xor(den, 16, 64); den += __shfl_xor(den, 32, 64);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    a[e] += lane_xor<8>(a[e]); a[e] += __shfl_xor(a[e], 16, 64); a[e] += __shfl_xor(a[e], 32, 64);
-  }
-  if (rg == 0) {
-    const float inv = 1.0f / den;
-    const uint2 lo = pack4(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
-    const uint2 hi = pack4(a[4] * inv, a[5] * inv, a[6] * inv, a[7] * inv);
-    *reinterpret_cast<uint4*>(dst + c * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-  }
-}
-
-template <int VR, int MAXP, int XM>
-__global__ __launch_bounds__(256, 1) void dec_attn_proj_chain_kernel(
-    const bf16* __restrict__ qkv, bf16* __restrict__ kc, bf16* __restrict__ vc, const int* __restrict__ n_prev, int np_uniform,
-    int cap, bf16* __restrict__ x, const uint4* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ ln_g,
-    const float* __restrict__ ln_b, const uint4* __restrict__ Wq, const float* __restrict__ bq, bf16* __restrict__ q,
-    const uint4* __restrict__ Wq2, const float* __restrict__ bq2, bf16* __restrict__ q2, int M, const bf16* __restrict__ kk) {
-  static_assert(VR == 4 || VR == 8 || VR == 16, "rows per workgroup");
-  // problems of a wave in flight.  Two, not four, also in the 8-pass instantiation: with four (272 registers of K / V) hipcc parked the
-  // weight fragments in AGPRs and copied them back with v_accvgpr_read_b32 DIRECTLY in front of the inline-assembly MFMA that reads
-  // them -- a VALU-write -> MFMA-read hazard its recogniser cannot see inside asm: <4, 8> gave wrong rows on MI355X (36 of 36 cases of
-  // the kernel test, gpurun_out r04_b) while every other instantiation was bit-identical.  tools/check_isa.py now refuses that
-  // instruction pair in any chain kernel.
-  constexpr int NF = 2;
-  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 16 * XS];
-  __shared__ __attribute__((aligned(16))) float vec[5 * 256];  // [bo | bq | bq2 | gamma | beta]
-  unsigned short* bufA = lds;
-  unsigned short* bufB = lds + 16 * XS;
-  SL_CHAIN_SETPRIO();
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.x * VR;
-  const int tw = 4 * wave;
-  // ---- attention of head `wave` for the VR rows, NF problems per round
-  AttnProblem<MAXP> pr[NF];
-  WUnit u0, u1;
-  const int nb = 64 * wave + 4 * lg;
-  const int g_lane = m0 + lr;
-  const bool row_ok = lr < VR && g_lane < M;
-  uint2 res[4], res2[4];
-#pragma unroll
-  for (int r0 = 0; r0 < VR; r0 += NF) {
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-      const int b = m0 + r0 + j;
-      if (r0 + j < VR && b < M) attn_issue<MAXP>(pr[j], qkv, kc, vc, b, wave, np_uniform >= 0 ? np_uniform : n_prev[b], cap, lane);
-    }
-    if (r0 + NF >= VR) {
-      // last round: the chain's small operands are requested now and land under the softmax arithmetic.  NOT the weight units:
-      // 2 problems x 128 registers of K / V plus 128 of weights made hipcc park fragments in AGPRs and copy them back in front of the
-      // inline-assembly MFMAs (tools/check_isa.py, check_accvgpr_feeds_mfma); they are requested once the K / V registers are dead
-      vec[tid] = bo[tid]; vec[256 + tid] = bq ? bq[tid] : 0.f; vec[512 + tid] = Wq2 ? bq2[tid] : 0.f;
-      vec[768 + tid] = ln_g[tid]; vec[1024 + tid] = ln_b[tid];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        res[ct] = *reinterpret_cast<const uint2*>(x + (long)(row_ok ? g_lane : 0) * CD + nb + 16 * ct);
-        res2[ct] = kk ? *reinterpret_cast<const uint2*>(kk + (long)(row_ok ? g_lane : 0) * CD + nb + 16 * ct) : make_uint2(0, 0);
-      }
-      if constexpr (VR < 16) {                              // rows the workgroup does not own: zeros for the MFMAs' B operand
-        for (int i = tid; i < (16 - VR) * (CD / 8); i += 256) {
-          const int row = VR + i / (CD / 8), c8 = i % (CD / 8);
-          *reinterpret_cast<uint4*>(bufA + row * XS + 8 * c8) = make_uint4(0, 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-      const int b = m0 + r0 + j;
-      if (r0 + j < VR) {
-        if (b < M) attn_finish<MAXP>(pr[j], bufA + (r0 + j) * XS + 64 * wave, lane);
-        else if (lane < 8) *reinterpret_cast<uint4*>(bufA + (r0 + j) * XS + 64 * wave + 8 * lane) = make_uint4(0, 0, 0, 0);
-      }
-    }
-  }
-  load_unit(u0, Wo, tw, NKS, 0, lane);
-  load_unit(u1, Wo, tw + 2, NKS, 0, lane);
-  lds_barrier();
-  // ---- the projection chain on the rows in bufA (dec_proj_chain_kernel from here on, lanes lr >= VR idle in the epilogues)
-  f32x4 acc[1][4];
-  zero_acc<1>(acc);
-  mma_unit<1, 0, XM>(acc, u0, bufA, lr, lg);
-  load_unit(u0, Wq, tw, NKS, 0, lane);
-  mma_unit<1, 2, XM>(acc, u1, bufA, lr, lg);
-  load_unit(u1, Wq, tw + 2, NKS, 0, lane);
-  if (lr < VR) {
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      float r[4];
-      unpack4(res[ct], r);
-      const float4 bv = *reinterpret_cast<const float4*>(vec + nb + 16 * ct);
-      const uint2 o = pack4(acc[0][ct][0] + bv.x + r[0], acc[0][ct][1] + bv.y + r[1], acc[0][ct][2] + bv.z + r[2],
-                            acc[0][ct][3] + bv.w + r[3]);
-      *reinterpret_cast<uint2*>(bufB + lr * XS + nb + 16 * ct) = o;
-      if (row_ok) *reinterpret_cast<uint2*>(x + (long)g_lane * CD + nb + 16 * ct) = o;
-    }
-  }
-  lds_barrier();
-  {
-    const float4 g4 = *reinterpret_cast<const float4*>(vec + 768 + 4 * lane);
-    const float4 b4 = *reinterpret_cast<const float4*>(vec + 1024 + 4 * lane);
-#pragma unroll
-    for (int i = 0; i < (VR + 3) / 4; ++i) {
-      const int row = wave + 4 * i;                       // VR is a multiple of 4: every wave has a row in every pass
-      float v[4];
-      unpack4(*reinterpret_cast<const uint2*>(bufB + row * XS + 4 * lane), v);
-      float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-      float s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
-      if constexpr ((XM & 2) != 0) { s1 = wave_sum_dpp(s1); s2 = wave_sum_dpp(s2); }
-      else { s1 = wave_sum(s1); s2 = wave_sum(s2); }
-      const float mean = s1 * (1.0f / CD);
-      const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / CD) - mean * mean, 0.f) + 1e-5f);
-      *reinterpret_cast<uint2*>(bufA + row * XS + 4 * lane) = ln_apply(v, mean, rstd, g4, b4);
-    }
-  }
-  lds_barrier();
-  zero_acc<1>(acc);
-  mma_unit<1, 0, XM>(acc, u0, bufA, lr, lg);
-  if (Wq2) load_unit(u0, Wq2, tw, NKS, 0, lane);
-  mma_unit<1, 2, XM>(acc, u1, bufA, lr, lg);
-  if (Wq2) load_unit(u1, Wq2, tw + 2, NKS, 0, lane);
-  if (row_ok) {
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const float4 bv = *reinterpret_cast<const float4*>(vec + 256 + nb + 16 * ct);
-      if (kk) {
-        float r[4];
-        unpack4(res2[ct], r);
-        const f32x2 h0 = gelu_fast2(f32x2{acc[0][ct][0] + bv.x + r[0], acc[0][ct][1] + bv.y + r[1]});
-        const f32x2 h1 = gelu_fast2(f32x2{acc[0][ct][2] + bv.z + r[2], acc[0][ct][3] + bv.w + r[3]});
-        *reinterpret_cast<uint2*>(q + (long)g_lane * CD + nb + 16 * ct) = pack4(h0.x, h0.y, h1.x, h1.y);
-      } else {
-        *reinterpret_cast<uint2*>(q + (long)g_lane * CD + nb + 16 * ct) =
-            pack4(acc[0][ct][0] + bv.x, acc[0][ct][1] + bv.y, acc[0][ct][2] + bv.z, acc[0][ct][3] + bv.w);
-      }
-    }
-  }
-  if (Wq2) {
-    zero_acc<1>(acc);
-    mma_unit<1, 0, XM>(acc, u0, bufA, lr, lg);
-    mma_unit<1, 2, XM>(acc, u1, bufA, lr, lg);
-    if (row_ok) {
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const float4 bv = *reinterpret_cast<const float4*>(vec + 512 + nb + 16 * ct);
-        *reinterpret_cast<uint2*>(q2 + (long)g_lane * CD + nb + 16 * ct) =
-            pack4(acc[0][ct][0] + bv.x, acc[0][ct][1] + bv.y, acc[0][ct][2] + bv.z, acc[0][ct][3] + bv.w);
-      }
-    }
-  }
-}
-
-#endif  // SL_EXPERIMENTS
 #ifdef SL_DEBUG_HOOKS
 // ---------------------------------------------------------------------------------------------------------------------
 // PROBE form of dec_proj_chain_kernel (Wq2 == nullptr) for tools/chain_race_probe.py: the same instruction sequence, with every
@@ -1475,6 +899,10 @@ __global__ __launch_bounds__(256, 1) void dec_proj_chain_probe_kernel(
 
 #endif  // SL_DEBUG_HOOKS
 
+#ifdef SL_EXPERIMENTS
+#include "experiments/dec_chain_kernels.inc"      // the measured-slower kernels (make EXPERIMENTS=1)
+#endif
+
 }  // namespace
 
 bool sl_dec_chain_ok(const simulst_handle* h, int dtype, int B, int D, int F, bool packed) {
@@ -1503,33 +931,17 @@ static int lds_request(const simulst_handle* h, int rtl = 1) {
 #endif
 }
 
-// row tiles per workgroup of the projection / feed-forward / QKV chains: 2 (32 rows, round 5: a weight fragment serves two row tiles, half
-// the L2 -> CU weight stream these launches are bound by) from dec_chain_rows32_min rows on, else 1
-// MEASURED (driver form, same box): 96.8 ms per pass against 91.2 -- a chain workgroup is paced by ITS OWN weight stream (the per-CU
-// L2 -> CU rate, ~50 GB/s: 256 KB of the projection chain in ~5 us), not by the chip-wide one, so half as many workgroups doing twice
-// the rows each stream as long and finish later.  EXPERIMENTS builds only, off.
-#ifdef SL_EXPERIMENTS
-static int chain_rtl(const simulst_handle* h, int B) { return h->dec_chain_rows32 && B >= h->dec_chain_rows32_min ? 2 : 1; }
-#else
-static int chain_rtl(const simulst_handle*, int) { return 1; }
-#endif
+template <int XM> static hipError_t exp_raise_lds_limits();
 
 template <int XM>
 static hipError_t raise_lds_limits_mode() {
   hipError_t e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, true, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<1, false, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
-#ifdef SL_EXPERIMENTS
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_qkv_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
-#endif
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<1, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_vocab_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_embed_qkv_chain_kernel<XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
-#ifdef SL_EXPERIMENTS
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_proj_chain_kernel<2, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_ffn_chain_kernel<2, false, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dec_qkv_chain_kernel<2, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_WHOLE_CU);
-#endif
+  if (e == hipSuccess) e = exp_raise_lds_limits<XM>();       // (EXPERIMENTS builds: the measured-slower forms; else nothing)
   return e;
 }
 
@@ -1560,6 +972,42 @@ static int raise_lds_limits(simulst_handle* h) {
 #else
 #define SL_CHAIN_TAIL(h) ((unsigned short*)nullptr)
 #endif
+// ---- the measured-slower forms (32-row tiles; projection chain + cross-attention, feed-forward chain + next QKV, self-attention +
+//      projection chain in one launch): kernels in experiments/dec_chain_kernels.inc, launchers in experiments/dec_chain_launch.inc,
+//      compiled by `make EXPERIMENTS=1` only.  The product has these stubs, so none of its launch functions carries a build switch.
+#ifdef SL_EXPERIMENTS
+#include "experiments/dec_chain_launch.inc"
+#else
+template <int XM> static hipError_t exp_raise_lds_limits() { return hipSuccess; }
+static bool exp_proj_chain_rows32(simulst_handle*, const void*, void*, const void*, const float*, const float*, const float*, const void*,
+                                  const float*, void*, const void*, const float*, void*, int, const void*) { return false; }
+static bool exp_ffn_chain_rows32(simulst_handle*, const void*, void*, const void*, const float*, const float*, const float*, const void*,
+                                 const float*, const void*, const float*, float*, int32_t*, void*, int, int) { return false; }
+static bool exp_qkv_chain_rows32(simulst_handle*, const void*, void*, const float*, const float*, const float*, const float*, const void*,
+                                 const float*, void*, int, int) { return false; }
+bool sl_dec_proj_cross_fused_ok(const simulst_handle*, int, int, int, int, int, int, bool, bool) { return false; }
+int sl_dec_proj_cross_fused(simulst_handle* h, const void*, void*, const void*, const float*, const float*, const float*, const void*,
+                            const float*, void*, const void*, const void*, const int32_t*, const int32_t*, int64_t*, uint8_t*, void*, int, int,
+                            int, int, int, int, int, int) {
+  h->err = "projection chain + cross-attention in one launch: an EXPERIMENTS build only";
+  return SIMULST_E_ARG;
+}
+bool sl_dec_ffn_qkv_chain_ok(const simulst_handle*, int, int) { return false; }
+int sl_dec_ffn_qkv_chain(simulst_handle* h, const void*, void*, const void*, const float*, const float*, const float*, const void*,
+                         const float*, const void*, const float*, float*, int, int, const float*, const float*, const void*, const float*,
+                         void*) {
+  h->err = "feed-forward chain + next layer's QKV in one launch: an EXPERIMENTS build only";
+  return SIMULST_E_ARG;
+}
+// the one-launch self-attention + projection chain is an EXPERIMENTS build's (measured slower); the decode loops never take it here
+bool sl_dec_attn_chain_ok(const simulst_handle*, int, int, int, int, int) { return false; }
+int sl_dec_attn_proj_chain(simulst_handle* h, const void*, void*, void*, const int32_t*, int, int, void*, const void*, const float*, const float*,
+                           const float*, const void*, const float*, void*, const void*, const float*, void*, int, const void*) {
+  h->err = "self-attention inside the projection chain: an EXPERIMENTS build only";
+  return SIMULST_E_ARG;
+}
+#endif
+
 int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* Wo, const float* bo, const float* ln_g,
                       const float* ln_b, const void* Wq, const float* bq, void* q, const void* Wq2, const float* bq2,
                       void* q2, int B, const void* kk_gelu) {
@@ -1569,63 +1017,11 @@ int sl_dec_proj_chain(simulst_handle* h, const void* ctx, void* x, const void* W
   hipLaunchKernelGGL((dec_proj_chain_kernel<1, XM>), dim3((B + 15) / 16), dim3(256), lds_request(h), h->stream,        \
                      (const bf16*)ctx, (bf16*)x, (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q,     \
                      (const uint4*)Wq2, bq2, (bf16*)q2, B, SL_CHAIN_TAIL(h), (const bf16*)kk_gelu)
-#define PC2(XM)                                                                                                        \
-  hipLaunchKernelGGL((dec_proj_chain_kernel<2, XM>), dim3((B + 31) / 32), dim3(256), lds_request(h, 2), h->stream,     \
-                     (const bf16*)ctx, (bf16*)x, (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q,     \
-                     (const uint4*)Wq2, bq2, (bf16*)q2, B, SL_CHAIN_TAIL(h), (const bf16*)kk_gelu)
-#ifdef SL_EXPERIMENTS
-  if (chain_rtl(h, B) == 2 && !SL_CHAIN_TAIL(h)) SL_XMODE(h, PC2); else
-#endif
-  SL_XMODE(h, PC);
+  if (!exp_proj_chain_rows32(h, ctx, x, Wo, bo, ln_g, ln_b, Wq, bq, q, Wq2, bq2, q2, B, kk_gelu)) SL_XMODE(h, PC);
 #undef PC
-#undef PC2
   return sl_launch_status(h, "simulst_mma_decode(out-proj + LN + q-proj chain)");
 }
 
-#ifdef SL_EXPERIMENTS
-// EXPERIMENT: projection chain + wait-k cross-attention of a layer in one launch (dec_proj_cross_fused_kernel)
-bool sl_dec_proj_cross_fused_ok(const simulst_handle* h, int dtype, int B, int H, int d, int S_cap, int attn_type, bool lockstep_offline,
-                                bool separate_soft) {
-  return h->dec_fuse_proj_cross && dtype == SIMULST_BF16 && H * d == CD && d == 64 && S_cap <= 256 && attn_type == SIMULST_ATTN_WAITK &&
-         lockstep_offline && !separate_soft && (B + 15) / 16 <= 1000;
-}
-
-int sl_dec_proj_cross_fused(simulst_handle* h, const void* ctx_in, void* x, const void* Wo, const float* bo, const float* ln_g,
-                            const float* ln_b, const void* Wq, const float* bq, void* q, const void* Ks, const void* Vc,
-                            const int32_t* key_len, const int32_t* tgt_idx, int64_t* head_step, uint8_t* head_read, void* ctx_out, int B,
-                            int H, int S_cap, int ratio, int waitk_k, int online, int mass_pres, int n_hint) {
-  if (int rc = raise_lds_limits(h)) return rc;
-  if (!h->fuse_flags) {
-    hipError_t e = hipMalloc((void**)&h->fuse_flags, 1024 * sizeof(int));
-    if (e == hipSuccess) e = hipMemsetAsync(h->fuse_flags, 0, 1024 * sizeof(int), h->stream);
-    if (e != hipSuccess) { h->err = "simulst_mma_decode: flag words of the fused projection / cross-attention launch"; return (int)e; }
-    h->fuse_epoch = 0;
-  }
-  const int n_tiles = (B + 15) / 16;
-  const int epoch = ++h->fuse_epoch;
-  KTimer t(h, SIMULST_K_DEC_CROSS_ATTN);
-  // dynamic LDS: the chain's row buffers (lds_request) cover the attention's reduction scratch (64 + RED_FLOATS floats)
-  const int lds = lds_request(h) > (int)((64 + attn::RED_FLOATS) * sizeof(float)) ? lds_request(h) : (int)((64 + attn::RED_FLOATS) * sizeof(float));
-  // the attention workgroups are persistent: as many as stay resident beside the chain (2 per compute unit), each walks its problems
-  int cus = 256;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-  const int slots = 2 * cus - n_tiles;
-  const int n_attn = H * B < slots ? H * B : (slots > 64 ? slots : 64);
-  hipLaunchKernelGGL((dec_proj_cross_fused_kernel<3>), dim3(n_tiles + n_attn), dim3(256), lds, h->stream, (const bf16*)ctx_in, (bf16*)x,
-                     (const uint4*)Wo, bo, ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q, B, n_tiles, h->fuse_flags, epoch, (const bf16*)Ks,
-                     (const bf16*)Vc, key_len, tgt_idx, (long*)head_step, head_read, (bf16*)ctx_out, H, S_cap, ratio, waitk_k, online,
-                     mass_pres, n_hint);
-  return sl_launch_status(h, "simulst_mma_decode(projection chain + wait-k cross-attention, one launch)");
-}
-#else
-bool sl_dec_proj_cross_fused_ok(const simulst_handle*, int, int, int, int, int, int, bool, bool) { return false; }
-int sl_dec_proj_cross_fused(simulst_handle* h, const void*, void*, const void*, const float*, const float*, const float*, const void*,
-                            const float*, void*, const void*, const void*, const int32_t*, const int32_t*, int64_t*, uint8_t*, void*, int, int,
-                            int, int, int, int, int, int) {
-  h->err = "projection chain + cross-attention in one launch: an EXPERIMENTS build only";
-  return SIMULST_E_ARG;
-}
-#endif  // SL_EXPERIMENTS
 
 int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
                      const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial,
@@ -1640,63 +1036,14 @@ int sl_dec_ffn_chain(simulst_handle* h, const void* ctx, void* x, const void* Wc
                      (const uint4*)W2, b2, partial, sem, (bf16*)x_mid, B, F, splits)
 #define FC0(XM) FC(false, XM)
 #define FC1(XM) FC(true, XM)
-#define FC2(XM)                                                                                                        \
-  hipLaunchKernelGGL((dec_ffn_chain_kernel<2, false, XM>), dim3(((B + 31) / 32) * splits), dim3(256), lds_request(h, 2), \
-                     h->stream, (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,  \
-                     (const uint4*)W2, b2, partial, sem, (bf16*)x_mid, B, F, splits)
-#ifdef SL_EXPERIMENTS
-  if (x_mid && chain_rtl(h, B) == 2) SL_XMODE(h, FC2); else
-#endif
-  if (x_mid) SL_XMODE(h, FC0); else SL_XMODE(h, FC1);
+  if (x_mid && exp_ffn_chain_rows32(h, ctx, x, Wco, bco, ln_g, ln_b, W1, b1, W2, b2, partial, sem, x_mid, B, F)) {}
+  else if (x_mid) SL_XMODE(h, FC0); else SL_XMODE(h, FC1);
 #undef FC0
 #undef FC1
-#undef FC2
 #undef FC
   return sl_launch_status(h, "simulst_mma_decode(feed-forward chain)");
 }
 
-#ifdef SL_EXPERIMENTS     // EXPERIMENT, measured slower
-// feed-forward chain of a layer + slab sum, LayerNorm and QKV projection of the NEXT layer in one launch (dec_ffn_qkv_chain_kernel)
-constexpr int CHAIN_SEM_TILES = 4096;
-bool sl_dec_ffn_qkv_chain_ok(const simulst_handle* h, int B, int F) {
-  return h->dec_fuse_ffn_qkv && F / 256 >= 3 && (B + 15) / 16 <= CHAIN_SEM_TILES;
-}
-
-int sl_dec_ffn_qkv_chain(simulst_handle* h, const void* ctx, void* x, const void* Wco, const float* bco, const float* ln_g,
-                         const float* ln_b, const void* W1, const float* b1, const void* W2, const float* b2, float* partial, int B,
-                         int F, const float* nln_g, const float* nln_b, const void* nWqkv, const float* nbqkv, void* qkv) {
-  if (int rc = raise_lds_limits(h)) return rc;
-  const int splits = F / 256;
-  if (!h->chain_sem) {
-    hipError_t e = hipMalloc((void**)&h->chain_sem, CHAIN_SEM_TILES * sizeof(int));
-    if (e != hipSuccess) { h->err = "simulst_mma_decode: ticket words of the feed-forward + QKV launch"; return (int)e; }
-    h->chain_sem_splits = 0;
-  }
-  if (h->chain_sem_splits != splits) {                           // the tickets count in units of `splits`: restart them in stream order
-    const hipError_t e = hipMemsetAsync(h->chain_sem, 0, CHAIN_SEM_TILES * sizeof(int), h->stream);
-    if (e != hipSuccess) { h->err = "simulst_mma_decode: ticket words of the feed-forward + QKV launch"; return (int)e; }
-    h->chain_sem_splits = splits;
-  }
-  KTimer t(h, SIMULST_K_DEC_FFN_CHAIN);
-#define FQ(XM)                                                                                                         \
-  hipLaunchKernelGGL((dec_ffn_qkv_chain_kernel<1, XM>), dim3(((B + 15) / 16) * splits), dim3(256), lds_request(h),     \
-                     h->stream, (const bf16*)ctx, (bf16*)x, (const uint4*)Wco, bco, ln_g, ln_b, (const uint4*)W1, b1,  \
-                     (const uint4*)W2, b2, partial, h->chain_sem, B, F, splits, nln_g, nln_b, (const uint4*)nWqkv, nbqkv, \
-                     (bf16*)qkv, 3)
-  SL_XMODE(h, FQ);
-#undef FQ
-  return sl_launch_status(h, "simulst_mma_decode(feed-forward chain + next layer's LN + QKV)");
-}
-
-#else
-bool sl_dec_ffn_qkv_chain_ok(const simulst_handle*, int, int) { return false; }
-int sl_dec_ffn_qkv_chain(simulst_handle* h, const void*, void*, const void*, const float*, const float*, const float*, const void*,
-                         const float*, const void*, const float*, float*, int, int, const float*, const float*, const void*, const float*,
-                         void*) {
-  h->err = "feed-forward chain + next layer's QKV in one launch: an EXPERIMENTS build only";
-  return SIMULST_E_ARG;
-}
-#endif  // SL_EXPERIMENTS
 
 // x <- x_mid + b2 + slabs; qkv = Wqkv LN(x) + bqkv (Wqkv == nullptr: the reduction only)
 int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float* partial, const float* b2, const float* ln_g,
@@ -1708,16 +1055,8 @@ int sl_dec_qkv_chain(simulst_handle* h, const void* x_mid, void* x, const float*
   hipLaunchKernelGGL((dec_qkv_chain_kernel<1, XM>), dim3(((B + 15) / 16) * n_cb), dim3(256), lds_request(h),           \
                      h->stream, (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wqkv, bqkv,       \
                      (bf16*)qkv, B, splits, n_cb)
-#define QC2(XM)                                                                                                        \
-  hipLaunchKernelGGL((dec_qkv_chain_kernel<2, XM>), dim3(((B + 31) / 32) * n_cb), dim3(256), lds_request(h, 2),        \
-                     h->stream, (const bf16*)x_mid, (bf16*)x, partial, b2, ln_g, ln_b, (const uint4*)Wqkv, bqkv,       \
-                     (bf16*)qkv, B, splits, n_cb)
-#ifdef SL_EXPERIMENTS
-  if (Wqkv && chain_rtl(h, B) == 2) SL_XMODE(h, QC2); else
-#endif
-  SL_XMODE(h, QC);
+  if (!(Wqkv && exp_qkv_chain_rows32(h, x_mid, x, partial, b2, ln_g, ln_b, Wqkv, bqkv, qkv, B, F))) SL_XMODE(h, QC);
 #undef QC
-#undef QC2
   return sl_launch_status(h, "simulst_mma_decode(slab sum + LN + QKV chain)");
 }
 
@@ -1759,39 +1098,6 @@ int sl_dec_embed_qkv_chain(simulst_handle* h, const float2* pairs, int n_pairs, 
   return sl_launch_status(h, "simulst_mma_decode(commit + embedding + LN + QKV chain)");
 }
 
-#ifdef SL_EXPERIMENTS
-// self-attention + projection chain in one launch (dec_attn_proj_chain_kernel): bf16, 4 heads x 64, cache capacity <= 128
-bool sl_dec_attn_chain_ok(const simulst_handle* h, int dtype, int B, int H, int d, int cap) {
-  return dtype == SIMULST_BF16 && H == 4 && d == 64 && cap <= 128 && !h->force_valu_attention && B <= h->dec_attn_chain_max_rows;
-}
-
-int sl_dec_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev, int np_uniform,
-                           int cap, void* x, const void* Wo, const float* bo, const float* ln_g, const float* ln_b, const void* Wq,
-                           const float* bq, void* q, const void* Wq2, const float* bq2, void* q2, int B, const void* kk_gelu) {
-  SL_REQUIRE(h, np_uniform < cap, SIMULST_E_SHAPE, "simulst_decoder_attn_proj_chain: cache capacity exceeded");
-  KTimer t(h, SIMULST_K_DEC_ATTN_CHAIN);
-  // rows per workgroup: 4 while that gives at most ~160 workgroups (each pulls 256 KB of weights from L2), 8 beyond
-  const int vr = h->dec_attn_chain_rows > 0 ? h->dec_attn_chain_rows : (B <= 640 ? 4 : 8);
-  const bool few = np_uniform >= 0 && np_uniform < 64;       // every row holds < 64 cached positions: 8 passes cover them
-#define AC(VR, MAXP)                                                                                                   \
-  hipLaunchKernelGGL((dec_attn_proj_chain_kernel<VR, MAXP, 3>), dim3((B + VR - 1) / VR), dim3(256), 0, h->stream,      \
-                     (const bf16*)qkv, (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, cap, (bf16*)x, (const uint4*)Wo, bo, \
-                     ln_g, ln_b, (const uint4*)Wq, bq, (bf16*)q, (const uint4*)Wq2, bq2, (bf16*)q2, B, (const bf16*)kk_gelu)
-  if (vr == 4) { if (few) AC(4, 8); else AC(4, 16); }
-  else if (vr == 8) { if (few) AC(8, 8); else AC(8, 16); }
-  else { if (few) AC(16, 8); else AC(16, 16); }
-#undef AC
-  return sl_launch_status(h, "simulst_mma_decode(self-attention + out-proj + LN + q-proj chain)");
-}
-#else
-// the one-launch self-attention + projection chain is an EXPERIMENTS build's (measured slower); the decode loops never take it here
-bool sl_dec_attn_chain_ok(const simulst_handle*, int, int, int, int, int) { return false; }
-int sl_dec_attn_proj_chain(simulst_handle* h, const void*, void*, void*, const int32_t*, int, int, void*, const void*, const float*, const float*,
-                           const float*, const void*, const float*, void*, const void*, const float*, void*, int, const void*) {
-  h->err = "self-attention inside the projection chain: an EXPERIMENTS build only";
-  return SIMULST_E_ARG;
-}
-#endif
 
 // C-ABI entry points of the two chains (the decode loop calls the internal forms above; these exist so that each chain
 // can be checked against a plain fp32 reference on its own, tests/test_hip_dec_chain.py)
@@ -1857,34 +1163,6 @@ extern "C" int simulst_decoder_vocab_chain(simulst_handle* h, const void* x_mid,
                             skip_b, row_bias, row_bias_col);
 }
 
-#ifdef SL_EXPERIMENTS
-extern "C" int simulst_decoder_attn_proj_chain(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache,
-                                               const int32_t* n_prev, void* x, const void* wo_fm, const float* bo,
-                                               const float* ln_g, const float* ln_b, const void* wq_fm, const float* bq, void* q,
-                                               const void* wq2_fm, const float* bq2, void* q2, const void* kk_gelu, int32_t B,
-                                               int32_t H, int32_t d, int32_t cap, int32_t n_prev_uniform,
-                                               int32_t rows_per_workgroup, int32_t dtype) {
-  if (!h) return SIMULST_E_NULL;
-  SL_CHECK_NULL(h, qkv); SL_CHECK_NULL(h, k_cache); SL_CHECK_NULL(h, v_cache); SL_CHECK_NULL(h, x);
-  if (n_prev_uniform < 0) SL_CHECK_NULL(h, n_prev);
-  SL_CHECK_NULL(h, wo_fm); SL_CHECK_NULL(h, bo); SL_CHECK_NULL(h, ln_g); SL_CHECK_NULL(h, ln_b); SL_CHECK_NULL(h, wq_fm);
-  SL_CHECK_NULL(h, q);
-  if (wq2_fm) { SL_CHECK_NULL(h, bq2); SL_CHECK_NULL(h, q2); }
-  SL_REQUIRE(h, !(wq2_fm && kk_gelu), SIMULST_E_ARG, "simulst_decoder_attn_proj_chain: a second query projection or the gathered-row GELU, not both");
-  SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_decoder_attn_proj_chain: bf16 only");
-  SL_REQUIRE(h, H == 4 && d == 64 && cap > 0 && cap <= 128 && B >= 0, SIMULST_E_SHAPE,
-             "simulst_decoder_attn_proj_chain: 4 heads x 64, cache capacity <= 128");
-  SL_REQUIRE(h, rows_per_workgroup == 0 || rows_per_workgroup == 4 || rows_per_workgroup == 8 || rows_per_workgroup == 16, SIMULST_E_ARG,
-             "simulst_decoder_attn_proj_chain: rows_per_workgroup 0 (library's choice), 4, 8 or 16");
-  if (B == 0) return SIMULST_OK;
-  const int keep = h->dec_attn_chain_rows;
-  if (rows_per_workgroup) h->dec_attn_chain_rows = rows_per_workgroup;
-  const int rc = sl_dec_attn_proj_chain(h, qkv, k_cache, v_cache, n_prev, n_prev_uniform < 0 ? -1 : n_prev_uniform, cap, x, wo_fm, bo, ln_g, ln_b, wq_fm, bq, q, wq2_fm, bq2,
-                                        q2, B, kk_gelu);
-  h->dec_attn_chain_rows = keep;
-  return rc;
-}
-#endif  // SL_EXPERIMENTS
 
 #ifdef SL_DEBUG_HOOKS
 // ---- debug hooks of the reproducibility investigation (tools/chain_race_probe.py) ----------------

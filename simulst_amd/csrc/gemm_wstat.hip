@@ -143,10 +143,12 @@ bool sl_wstat_wanted(const simulst_handle* h, int dtype, int epi, const LinArgs&
   if (!h->wstat || dtype != SIMULST_BF16 || !p.w_packed || p.K != 256 || p.M < 8192 || p.c_hd != 0 || p.a_lead != 0 || p.ln_g) return false;
   if ((((uintptr_t)A | (uintptr_t)C | (uintptr_t)R) & 15) != 0) return false;
   if (((p.a_rs | p.a_bs | p.c_rs | p.c_bs) & 7) != 0) return false;
-  if (epi == SIMULST_EPI_EMF_OUT) return p.N == 256 && ((p.r_rs | p.r_bs | p.aux_bs) & 7) == 0;
+  if (epi == SIMULST_EPI_EMF_OUT) return p.N == 256 && ((p.r_rs | p.r_bs | p.aux_bs) & 7) == 0 && h->n_cus >= 8;
   if (epi != SIMULST_EPI_BIAS) return false;
   int pairs, n_slices;
-  return wstat_split(p.N, pairs, n_slices);
+  // every slice of a row tile needs its own compute unit inside ONE XCD (groups of n_slices workgroups per XCD): a device or partition
+  // with fewer than 8 x n_slices units, or an unknown count (n_cus 0), keeps the row panels (the kernel would return at once)
+  return wstat_split(p.N, pairs, n_slices) && (h->n_cus >> 3) >= n_slices;
 }
 
 int sl_launch_wstat(simulst_handle* h, int epi, const void* A, const void* W, const float* bias, const void* R, void* C, void* aux,

@@ -85,7 +85,8 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->wstat_lds_attr_set = false;
   {
     int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    // a failed query leaves 0: the persistent one-workgroup-per-CU kernels (gemm_wstat.hip) then decline and the row panels run
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 0;
     h->n_cus = n;
   }
   h->panel_wide = true;
@@ -100,7 +101,9 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (const char* e = getenv("SIMULST_POLICY_LDS_BYTES")) { const int v = atoi(e); if (v >= 0 && v <= 64 * 1024) h->policy_lds_bytes = v; }
   h->fused_argmax = true;      // greedy pick's partial maxima in the vocabulary projection's epilogue (decode loops, bf16, co-scheduled rows)
   if (const char* e = getenv("SIMULST_FUSED_ARGMAX")) h->fused_argmax = atoi(e) != 0;
+#ifdef SL_EXPERIMENTS
   if (const char* e = getenv("SIMULST_DEC_ATTN_CHAIN_ROWS")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->dec_attn_chain_rows = v; }
+#endif
   h->dec_fuse_proj_cross = false;      // experiment, off
 #ifdef SL_EXPERIMENTS
   if (const char* e = getenv("SIMULST_DEC_FUSE_PROJ_CROSS")) h->dec_fuse_proj_cross = atoi(e) != 0;
@@ -325,7 +328,7 @@ extern "C" int simulst_stream_create(void** out_stream, int32_t priority, const 
   } else {
     e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   }
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return (int)e;      // (no handle here to carry a message: a positive return is the hipError_t, as everywhere in this ABI)
   *out_stream = (void*)s;
   return SIMULST_OK;
 }

@@ -200,7 +200,13 @@ def test_bf16_rows_with_room_at_every_decision_equal_the_oracle_records():
         d = e["first_divergence"]
         if d is not None:
             m = d["policy_margin"] if d["cause"] == "action" else d["token_gap"]
-            assert m is not None and m <= (r["policy_bound"] if d["cause"] == "action" else r["token_gap_bound"]), (e["row"], d)
+            ok = m is not None and m <= (r["policy_bound"] if d["cause"] == "action" else r["token_gap_bound"])
+            # ... or (round 6, row 31: top-2 gap 0.68) the token was written by a call whose own fire decision had no room (margin
+            # 0.033): the boundary between two integrated vectors moved, the decoder looked at another vector, and the logits move by far
+            # more than rounding -- the CIF counterpart of a monotonic head landing on another frame (test above)
+            moved = d["cause"] != "action" and d["policy_margin_of_the_call_that_wrote_the_token"] is not None and \
+                d["policy_margin_of_the_call_that_wrote_the_token"] <= r["policy_bound"]
+            assert ok or moved, (e["row"], d)
 
 
 @pytest.fixture()

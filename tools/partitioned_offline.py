@@ -54,6 +54,17 @@ class PartitionedOffline:
                 self.models.append(SimulSTModel(model.cfg, weights, device=dev, dtype=model.dtype, ops=ops, share_with=model))
             self._streams[(len(self.models) - 1, False)] = st
 
+    # NOTE: the phase-A and phase-B encoder passes share ONE enc_model and its cached layer workspace and flip enc_ops.h between
+    # the whole-chip stream and the CU-masked one; only phase B's wait on phase A's event keeps the two passes apart -- do not drop it.
+    # Tensors allocated under an external stream are kept alive by the callers' local lists (no record_stream), and the masked HIP
+    # streams are destroyed by close().  An experiment, measured negative (profiles/r05_cu_partition_sweep.txt); not part of the package.
+    def close(self):
+        from simulst_amd import _lib
+        for (i, masked), st in list(self._streams.items()):
+            if masked and hasattr(_lib, "destroy_stream"):
+                _lib.destroy_stream(st)
+                del self._streams[(i, masked)]
+
     def _stream(self, i, masked):
         from simulst_amd import _lib
         key = (i, bool(masked))
