@@ -42,7 +42,7 @@ def plan_shard(lengths: Sequence[int], world: int, rank: int, max_rows: int, str
 
 
 def plan_shard_by_work(lengths: Sequence[int], world: int, rank: int, max_rows: int, streams: int,
-                       step_floor_rows: float = None, min_rows: int = 64) -> List[List[int]]:
+                       step_floor_rows: float = None, min_rows: int = 64, retire: bool = False) -> List[List[int]]:
     """plan_shard with the cuts placed by cost instead of by count.  A launch sequence runs as many steps as its LONGEST member
     needs and every row rides along, so sequences of equal row count waste row-steps where the lengths fall off fast (the long
     tail: 24 % of the row-steps of a 5 000-utterance shard of the synthetic set at 834 rows per sequence).  Cost model of a
@@ -52,7 +52,12 @@ def plan_shard_by_work(lengths: Sequence[int], world: int, rank: int, max_rows: 
     from a queue, most expensive first (sequence_cost), not round-robin: the costs differ by up to 10 x.  The cuts of the
     length-sorted shard that minimise the total cost are found by dynamic programming over the sequence count (numpy, O(n^2) per
     count); counts are tried up to 8 x the streams and the cheapest plan wins.  Same contract as plan_shard: every utterance of the
-    rank exactly once, longest first, at most max_rows per sequence."""
+    rank exactly once, longest first, at most max_rows per sequence.
+    retire (round 6): the rows of a sequence leave its step loop at their OWN cap (decode_batch(retire=True)), so a sequence costs
+    U_longest * step_floor_rows + the sum of its rows' steps; the second term is the same for every plan, which leaves the latency
+    floors: the planner then packs as many rows per sequence as max_rows allows (fewer, longer-lived sequences) instead of cutting
+    where the lengths fall off -- as far as the encoder's padding allows: every row of a sequence is encoded at the longest member's
+    frame count, which the cost charges at 0.042 row-steps per frame."""
     import numpy as np
     if step_floor_rows is None:
         step_floor_rows = 400.0 / max(1, streams)
@@ -66,6 +71,10 @@ def plan_shard_by_work(lengths: Sequence[int], world: int, rank: int, max_rows: 
     k_max = max(k_min, min(n // max(1, min_rows), 8 * max(1, streams)))
     INF = float("inf")
     ar = np.arange(n + 1)
+    csum = np.concatenate([[0.0], np.cumsum(U)])
+    # encoder cost of a frame in row-steps: 23 ns per frame (30 ms per 1 280 x 1000 frames) against 0.56 us per row-step
+    enc_frame_cost = 0.042
+    Tp = np.array([(lengths[i] + 63) // 64 * 64 for i in mine], dtype=np.float64)
     # best[k][j] = cheapest way to cut the first j utterances into k sequences; cost of (i, j] = U[i] * (floor + j - i)
     best = np.full(n + 1, INF); best[0] = 0.0
     plans, arg_all = {}, []
@@ -73,7 +82,10 @@ def plan_shard_by_work(lengths: Sequence[int], world: int, rank: int, max_rows: 
         nxt, arg = np.full(n + 1, INF), np.zeros(n + 1, dtype=np.int64)
         for j in range(1, n + 1):
             lo = max(0, j - max_rows)
-            cand = best[lo:j] + U[lo:j] * (step_floor_rows + (j - ar[lo:j]))
+            if retire:           # + the encoder over (j - i) rows padded to the longest member's frames (round 6)
+                cand = best[lo:j] + U[lo:j] * step_floor_rows + (csum[j] - csum[lo:j]) + (j - ar[lo:j]) * Tp[lo:j] * enc_frame_cost
+            else:
+                cand = best[lo:j] + U[lo:j] * (step_floor_rows + (j - ar[lo:j]))
             a = int(np.argmin(cand))
             nxt[j], arg[j] = cand[a], lo + a
         arg_all.append(arg)
@@ -89,18 +101,22 @@ def plan_shard_by_work(lengths: Sequence[int], world: int, rank: int, max_rows: 
     return [mine[i:j] for i, j in reversed(cuts)]
 
 
-def sequence_cost(idx: Sequence[int], lengths: Sequence[int], streams: int = 3) -> float:
-    """the planner's cost of one launch sequence (steps of its longest member x (latency floor + rows))"""
+def sequence_cost(idx: Sequence[int], lengths: Sequence[int], streams: int = 3, retire: bool = False) -> float:
+    """the planner's cost of one launch sequence (steps of its longest member x (latency floor + rows); with retired rows: x the floor
+    + the rows' own steps)"""
+    if retire:
+        return max(max_steps(lengths[i]) for i in idx) * 400.0 / max(1, streams) + sum(max_steps(lengths[i]) for i in idx)
     return max(max_steps(lengths[i]) for i in idx) * (400.0 / max(1, streams) + len(idx))
 
 
 def make_batch(idx: Sequence[int], lengths: Sequence[int], device, dtype, fbank_of=synthetic_fbank):
     """Padded ragged batch of the utterances idx: (fbank [n, Tpad, 80] zero past each length, lengths on device,
-    lengths on host, decode steps of the longest, Tpad).  Tpad is rounded up to 256 frames so that a few shapes
-    serve the whole shard."""
+    lengths on host, decode steps of the longest, Tpad).  Tpad is rounded up to 64 frames = one Emformer segment of 16 encoder
+    frames (round 6; 256 before: every sequence of a shard has its own row count anyway, so coarser rounding only encoded padding --
+    1.30 x the shard's real frames against 1.21 x, tools/shard_decomposition.py)."""
     L = torch.tensor([lengths[i] for i in idx])
     Tmax = int(L.max())
-    Tpad = (Tmax + 255) // 256 * 256
+    Tpad = (Tmax + 63) // 64 * 64
     fb = torch.zeros(len(idx), Tpad, 80)
     for r, i in enumerate(idx):
         fb[r, :lengths[i]] = fbank_of(i, lengths[i])

@@ -60,6 +60,10 @@ def main(argv=None, collect=None):
     ap.add_argument("--plan", default="work", choices=["work", "rows"],
                     help="work: sequence cuts by cost (offline_eval.plan_shard_by_work) and a queue, most expensive first; rows: equal row "
                          "counts dealt round-robin (round 2)")
+    ap.add_argument("--plan-retire", dest="plan_retire", action="store_true",
+                    help="--plan work: cut the sequences by the cost of RETIRING rows (floor x steps of the longest + the rows' own steps + the "
+                         "encoder's padding).  Measured on the rank shard: 6 sequences of up to 1024 rows instead of 7, best pass 0.362 s "
+                         "against 0.365 s, but half of the passes 10-20 %% slower (profiles/r06_config5_shard_*): off by default")
     ap.add_argument("--warmup-passes", type=int, default=0,
                     help="whole untimed passes over the shard before the timed ones (allocator pools of every launch-sequence shape, like "
                          "bench.py's warm-up steps); the default warm-up is one sequence per stream")
@@ -116,9 +120,12 @@ def main(argv=None, collect=None):
     S = max(1, args.streams)
     # --shard-of N: this GPU decodes rank --shard-rank's shard of an N-rank job (nothing is gathered: the other shards do not exist)
     world_plan, rank_plan = (args.shard_of, args.shard_rank) if args.shard_of > 0 else (world, rank)
-    plan = (plan_shard_by_work if args.plan == "work" else plan_shard)(lengths, world_plan, rank_plan, args.batch, S)
-    if args.plan == "work":                             # the queue order: most expensive sequence first
-        plan.sort(key=lambda idx: -sequence_cost(idx, lengths, S))
+    retire = not args.streaming and not os.environ.get("SIMULST_NO_RETIRE")       # offline: rows leave at their own cap (round 6)
+    if args.plan == "work":
+        plan = plan_shard_by_work(lengths, world_plan, rank_plan, args.batch, S, retire=retire and args.plan_retire)
+        plan.sort(key=lambda idx: -sequence_cost(idx, lengths, S, retire=retire and args.plan_retire))   # the queue order: most expensive first
+    else:
+        plan = plan_shard(lengths, world_plan, rank_plan, args.batch, S)
     batches = [(idx,) + make_batch(idx, lengths, dev, dtype) for idx in plan]
     if args.streaming:
         # a streamed hypothesis ends when it holds MORE than max_len tokens (agents/default_agent.py:268-271): one more than the offline cap
