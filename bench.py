@@ -177,6 +177,9 @@ def _leg_summary(leg):
         mg = bs.get("microphone_form_groups_side_by_side") or {}
         if mg:
             o["streamed_groups_tokens_per_s"] = [mg.get("tokens_per_s"), mg.get("live_streams")]
+        mc = bs.get("microphone_form_one_compacted_group") or {}
+        if mc:
+            o["streamed_compacted_group_tokens_per_s"] = [mc.get("tokens_per_s"), mc.get("live_streams"), mc.get("slots_per_round")]
         o["AL_ms_mean"] = bs.get("average_lagging_ms_mean")
         o["rows"] = bs.get("rows")
     if par:

@@ -169,6 +169,33 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                                   sum(all(a[k] == b[k] for k in ("actions", "tokens", "delays_ms")) for a, b in zip(recs_m[0], recs)),
                               "form": "microphone form (lockstep sources, one host round trip per chunk), one group of live streams per HIP stream"}
             del cse
+            # ... and (round 6) ONE big group of live streams whose masked rounds run over the rows that take part:
+            # the device lists them at the start of every round (simulst_stream_ctl.row_map), so a round costs what ~an eighth of the
+            # group costs and one group holds thousands of streams.  Adaptive policies only: wait-k rows are all active in every round
+            mic_compact = None
+            if not cif and not waitk and fb_all.size(0) >= 1024:
+                n_live = min(fb_all.size(0), 8064)
+                slots = 512 if n_live <= 4096 else 1024
+                big = BatchedStreamingAgent(model, max_len_a=0.1, max_len_b=10, steps_per_call=8, compact_rows=slots)
+                fbl = fb_all[:n_live]
+                big.run_batch(fbl)
+                ts_b, recs_b = [], None
+                for _ in range(max(1, args.passes)):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    recs_b = big.run_batch(fbl)
+                    torch.cuda.synchronize()
+                    ts_b.append(time.perf_counter() - t0)
+                n_b = sum(len(r["tokens"]) for r in recs_b)
+                mic_compact = {"tokens_per_s": round(n_b / sorted(ts_b)[len(ts_b) // 2], 1), "passes_ms": [round(x * 1e3, 3) for x in ts_b],
+                               "live_streams": n_live, "slots_per_round": slots, "tokens_per_pass": n_b,
+                               "average_lagging_ms_mean": round(sum(r["AL"] for r in recs_b) / n_live, 2),
+                               "first_rows_identical_to_the_single_group_run":
+                                   [sum(all(a[k] == b[k] for k in ("actions", "tokens", "delays_ms")) for a, b in zip(recs_b, recs)), len(recs)],
+                               "form": "microphone form, ONE group, every masked round over `slots_per_round` slots filled on the device with "
+                                       "the rows taking part (active-row compaction)"}
+                del big, recs_b
+                torch.cuda.empty_cache()
             keys3 = ("actions", "tokens", "delays_ms")
             paced["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_p, recs))
             paced_off["rows_identical_to_the_lockstep_run"] = sum(all(a[k] == b[k] for k in keys3) for a, b in zip(recs_o, recs))
@@ -202,6 +229,7 @@ def extra_config_legs(args, dev, dtype, fb_all, plan, B):
                               "evaluation_form_self_paced_rows": paced, "evaluation_form_offline_encoder_states": paced_off,
                               "evaluation_form_whole_plan_on_streams": whole_plan,
                               "microphone_form_groups_side_by_side": mic_groups,
+                              "microphone_form_one_compacted_group": mic_compact,
                               "evaluation_form": "sources already on the device (SimulEval reading files): every chunk encoded first, then "
                                                  "one device loop in which a row takes its next chunk itself when its policy says READ "
                                                  "(simulst_stream_ctl / simulst_cif_stream_ctl schedules); same READ / WRITE strings, "

@@ -75,7 +75,7 @@ int simulst_create(simulst_handle** out, void* hip_stream);
 int simulst_destroy(simulst_handle* h);
 int simulst_set_stream(simulst_handle* h, void* hip_stream);
 const char* simulst_last_error(simulst_handle* h);
-int simulst_version(void);            /* 106 (round 6: simulst_emformer_ffn_prenorm; 105, round 5: simulst_get_option and simulst_stream_ctl grew p_probe / step_probe / step_force / probe_P); a binding built for another value must not use the library */
+int simulst_version(void);            /* 107 (round 6: simulst_stream_ctl grew row_map / compact_rows; 106: simulst_emformer_ffn_prenorm; 105, round 5: simulst_get_option and simulst_stream_ctl grew p_probe / step_probe / step_force / probe_P); a binding built for another value must not use the library */
 /* HIP streams with a compute-unit mask (hipExtStreamCreateWithCUMask) or a priority, for hosts whose framework cannot create them.
  * cu_mask: mask_words 32-bit words; on MI355X bit i is compute unit (i / 8) of XCD (i % 8) (tools/microbench_cumask.hip), every XCD
  * must keep at least one unit; NULL / 0: no mask.  priority: 0 default, > 0 greatest, < 0 least (ignored with a mask).  Used by
@@ -625,6 +625,16 @@ typedef struct {
    * (:196-257); a step_force [n_layers][B][H] entry >= 0 replaces the found step for head_step and the value aggregation, so a run can
    * be driven along another implementation's trajectory (teacher forcing) while its own decisions are recorded. */
   float* p_probe; int64_t* step_probe; const int64_t* step_force; int32_t probe_P;
+  /* Active-row compaction (round 6; compact_rows <= 0: off).  A batch of LIVE streams (the microphone form: the reference's agent
+   * runs the same loop for one stream, agents/default_agent.py:364-413, models/mma_model.py:191-210) has only a fraction of its rows
+   * taking part in a given round -- a row that asked for source is parked until the next chunk -- while the row-local GEMMs of a round
+   * cost by the rows they are launched over.  With compact_rows > 0 every round first lists the rows that take part (active[b] != 0)
+   * into row_map [compact_rows] int32 (device scratch), at most compact_rows of them in row order, the others wait for a later round
+   * with their masks untouched; every launch of the round then runs over compact_rows SLOTS: the step's activations (x, qkv, ctx, q,
+   * logits) are indexed by slot, everything a stream owns (K / V caches, enc_len, n_prev, head_step, tokens_io, hyp, the masks) by
+   * its own row.  A row's tokens, delays and READ / WRITE sequence do not depend on the slots it travelled in.  Needs
+   * 128 < compact_rows <= B, S_cap <= 256 and no audit hooks; the decoder descriptor's step buffers must hold max(B, compact_rows) rows. */
+  int32_t* row_map; int32_t compact_rows;
 } simulst_stream_ctl;
 
 int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder_desc* d, const simulst_dec_layer* layers,

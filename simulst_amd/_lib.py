@@ -90,7 +90,8 @@ class StreamCtl(C.Structure):
                [(n, C.c_int32) for n in ("cap", "cur_ms", "max_len_now", "n_chunks")] + \
                [(n, C.c_void_p) for n in ("sched_rows", "sched_ms", "sched_max_len", "chunk_idx", "enc_len", "tok_chunk", "row_chunks")] + \
                [(n, C.c_int32) for n in ("ff_waitk", "ff_ratio")] + \
-               [(n, C.c_void_p) for n in ("p_probe", "step_probe", "step_force")] + [("probe_P", C.c_int32)]
+               [(n, C.c_void_p) for n in ("p_probe", "step_probe", "step_force")] + [("probe_P", C.c_int32)] + \
+               [("row_map", C.c_void_p), ("compact_rows", C.c_int32)]
 
 
 # name -> argtypes (restype is int unless noted); mirrors include/simulst_hip.h one to one
@@ -178,7 +179,7 @@ DEBUG_SIGNATURES = {
  OPT_WEIGHT_STATIONARY, OPT_CONV_TILE256, OPT_DEC_FUSE_FFN_QKV, OPT_DEC_CHAIN_ROWS32) = range(15)
 
 _lib = None
-ABI_VERSION = 106          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
+ABI_VERSION = 107          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
 
 
 def load():

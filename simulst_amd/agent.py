@@ -182,9 +182,14 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
     (tests/test_hip_streaming.py::test_batched_streaming_*).
     """
 
-    def __init__(self, model, max_len_a: float = 1, max_len_b: int = 0, steps_per_call: int = 4):
+    def __init__(self, model, max_len_a: float = 1, max_len_b: int = 0, steps_per_call: int = 4, compact_rows: int = 0):
+        """compact_rows > 0 (microphone form; round 6): every masked round runs over that many SLOTS instead of over all B rows --
+        the rows that take part in the round are listed on the device first (simulst_stream_ctl.row_map), at most compact_rows of
+        them, the others wait a round.  A round of a big group of live streams then costs what its ACTIVE rows cost (a parked row
+        waits for its next chunk), so one group can hold thousands of streams; records are unchanged."""
         super().__init__(model, max_len_a, max_len_b, force_finish=False)
         self.steps_per_call = steps_per_call
+        self.compact_rows = compact_rows
 
     def run_batch(self, fbank: torch.Tensor, self_paced: bool = False, encoder: str = "chunked", lengths=None):
         """fbank [B, T, 80] (equal lengths).  Returns one record per row, same keys as run_utterance.
@@ -338,6 +343,11 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
         hyp = torch.zeros(B, cap, device=dev, dtype=torch.int64)
         delays = torch.zeros(B, cap, device=dev, dtype=torch.int32)
         tokens = torch.full((B,), cfg.eos, device=dev, dtype=torch.int64)
+        # active-row compaction: slots per round (the kernels want more than 128 -- the layer chains' row class -- and at most B)
+        n_slots = min(int(self.compact_rows), B) if self.compact_rows and B > 144 else 0
+        if n_slots and n_slots <= 128:
+            raise ValueError("compact_rows: more than 128 slots per round (or 0: off)")
+        row_map = torch.empty(n_slots, device=dev, dtype=torch.int32) if n_slots else None
         enc_state = {}
         src = FrameSource(fbank[0])
         actions = [[] for _ in range(B)]
@@ -364,7 +374,8 @@ class BatchedStreamingAgent(FairseqSimulSTAgent):
             active.copy_(1 - done)
             ctl = _lib.StreamCtl(active.data_ptr(), read_flag.data_ptr(), online.data_ptr(), done.data_ptr(),
                                  delays.data_ptr(), hyp.data_ptr(), cap, src.elapsed_ms(),
-                                 int(self.max_len(src.pos)), 0, None, None, None, None, None, None, None, 0, 0)
+                                 int(self.max_len(src.pos)), 0, None, None, None, None, None, None, None, 0, 0,
+                                 row_map=row_map.data_ptr() if row_map is not None else None, compact_rows=n_slots)
             while True:
                 dec.stream_steps(st, tokens, ctl, self.steps_per_call)
                 if not bool(active.any().item()):

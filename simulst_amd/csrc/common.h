@@ -294,7 +294,8 @@ __device__ __forceinline__ void store4(bf16* p, const float (&o)[4]) {
 // internal (not exported): self-attention with a host-known uniform n_prev (np_uniform >= 0) or the
 // device array (np_uniform < 0)
 int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev,
-                      int np_uniform, void* ctx, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t dtype);
+                      int np_uniform, void* ctx, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t dtype,
+                      const int32_t* row_map = nullptr);
 
 // fused decoder self-attention block (decode_fused.hip): LN + q/k/v rows of the head + cache append + attention +
 // the head's columns of the output projection as an fp32 partial [B][H][D]

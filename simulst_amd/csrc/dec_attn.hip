@@ -16,15 +16,19 @@ namespace {
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void self_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc,
                                                         T* __restrict__ vc, const int* __restrict__ n_prev,
-                                                        int np_uniform, T* __restrict__ ctx, int H, int d, int cap) {
+                                                        int np_uniform, T* __restrict__ ctx, int H, int d, int cap,
+                                                        const int* __restrict__ row_map) {
   extern __shared__ float sm[];
   float* q_s = sm;                 // [64]
   float* red = sm + 64;            // [1024 + 8]
   float* sc = red + attn::RED_FLOATS;   // [max(cap, 256)]
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  // row_map (active-row compaction, decode_driver.hip): the step's qkv / ctx rows live at slot blockIdx.y, the caches at stream row b
+  const int h = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x;
+  const int b = row_map ? row_map[slot] : slot;
+  if (b < 0) return;
   const int D = H * d;
   const int np = np_uniform >= 0 ? np_uniform : n_prev[b];
-  const T* row = qkv + (long)b * 3 * D;
+  const T* row = qkv + (long)slot * 3 * D;
   T* Kh = kc + ((long)b * H + h) * cap * d;
   T* Vh = vc + ((long)b * H + h) * cap * d;
   const int n = np + 1;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const T* __restrict__ qk
     __syncthreads();
     o = attn::looped<T>(q_s, Kh, d, Vh, d, n, d, np, row + D + h * d, row + 2 * D + h * d, sc, red, nullptr);
   }
-  if (tid < d) ctx[(long)b * D + h * d + tid] = from_f32<T>(o);
+  if (tid < d) ctx[(long)slot * D + h * d + tid] = from_f32<T>(o);
 }
 
 // Wave-per-(head, utterance) variant for bf16, head_dim 64 and <= 128 cached positions: everything -- scores, max,
@@ -67,12 +71,14 @@ template <int MAXP>      // passes of 8 rows: 8 covers 64 cached positions (host
 __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kc,
                                                              bf16* __restrict__ vc, const int* __restrict__ n_prev,
                                                              int np_uniform, bf16* __restrict__ ctx, int BH, int H,
-                                                             int cap) {
+                                                             int cap, const int* __restrict__ row_map) {
   constexpr int d = 64, NPL = 8, RPP = 8;                  // lanes per row, rows per pass
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= BH) return;
-  const int b = pair / H, h = pair - b * H;
+  const int slot = pair / H, h = pair - slot * H;          // qkv / ctx rows at `slot`, the caches at stream row b (row_map: see above)
+  const int b = row_map ? row_map[slot] : slot;
+  if (b < 0) return;
   const int D = H * d;
   const int np = np_uniform >= 0 ? np_uniform : n_prev[b];
 #ifdef SL_ABLATE_SELF       // timing ablation (results invalid): one cached row instead of np + 1 -- what the launch costs without its bytes
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restr
 #else
   const int n = np + 1;
 #endif
-  const bf16* row = qkv + (long)b * 3 * D;
+  const bf16* row = qkv + (long)slot * 3 * D;
   bf16* Kh = kc + ((long)b * H + h) * cap * d;
   bf16* Vh = vc + ((long)b * H + h) * cap * d;
   const int c = lane & (NPL - 1), rg = lane >> 3;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void self_attn_wave_kernel(const bf16* __restr
   if (rg == 0) {
     const float inv = 1.0f / den;
     float o[4];
-    bf16* dst = ctx + (long)b * D + h * d + c * 8;
+    bf16* dst = ctx + (long)slot * D + h * d + c * 8;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -216,7 +222,7 @@ extern "C" int simulst_decoder_self_attention(simulst_handle* h, const void* qkv
 }
 
 int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v_cache, const int32_t* n_prev,
-                      int np_uniform, void* ctx, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t dtype) {
+                      int np_uniform, void* ctx, int32_t B, int32_t H, int32_t d, int32_t cap, int32_t dtype, const int32_t* row_map) {
   if (!h) return SIMULST_E_NULL;
   SL_CHECK_NULL(h, qkv); SL_CHECK_NULL(h, k_cache); SL_CHECK_NULL(h, v_cache); SL_CHECK_NULL(h, ctx);
   SL_REQUIRE(h, np_uniform < cap, SIMULST_E_SHAPE, "simulst_decoder_self_attention: cache capacity exceeded");
@@ -232,16 +238,16 @@ int sl_self_attention(simulst_handle* h, const void* qkv, void* k_cache, void* v
     // barrier-free wave-per-(head, utterance) kernel: every cached position fits 16 passes of 8 rows
     if (np_uniform >= 0 && np_uniform < 64)      // every row holds < 64 positions: half the registers, twice the waves
       hipLaunchKernelGGL(self_attn_wave_kernel<8>, dim3((B * H + 3) / 4), dim3(256), 0, h->stream, (const bf16*)qkv,
-                         (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, B * H, H, cap);
+                         (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, B * H, H, cap, row_map);
     else
       hipLaunchKernelGGL(self_attn_wave_kernel<16>, dim3((B * H + 3) / 4), dim3(256), 0, h->stream, (const bf16*)qkv,
-                         (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, B * H, H, cap);
+                         (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, B * H, H, cap, row_map);
     return sl_launch_status(h, "simulst_decoder_self_attention(wave)");
   }
 #define SA_F32(NP) hipLaunchKernelGGL((self_attn_kernel<float, NP>), grid, dim3(256), lds, h->stream, (const float*)qkv, \
-                                     (float*)k_cache, (float*)v_cache, n_prev, np_uniform, (float*)ctx, H, d, cap)
+                                     (float*)k_cache, (float*)v_cache, n_prev, np_uniform, (float*)ctx, H, d, cap, row_map)
 #define SA_BF16(NP) hipLaunchKernelGGL((self_attn_kernel<bf16, NP>), grid, dim3(256), lds, h->stream, (const bf16*)qkv, \
-                                      (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, H, d, cap)
+                                      (bf16*)k_cache, (bf16*)v_cache, n_prev, np_uniform, (bf16*)ctx, H, d, cap, row_map)
   if (dtype == SIMULST_F32) { SL_DISPATCH_NP(attn::lanes_per_row<float>(d), SA_F32) }
   else { SL_DISPATCH_NP(attn::lanes_per_row<bf16>(d), SA_BF16) }
 #undef SA_F32

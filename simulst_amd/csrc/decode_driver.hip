@@ -42,6 +42,11 @@ struct StreamCtl {
   long* step_probe;          // [n_layers][B][H] out: the step this kernel's own search found
   const long* step_force;    // [n_layers][B][H] in: a value >= 0 replaces the found step (head_step, value aggregation)
   int probe_P;
+  // active-row compaction (round 6; null: off): slot i of a round's launches works for stream row_map[i] (-1: empty slot).  The
+  // step's ACTIVATIONS (x, qkv, ctx, q, logits / pairs) are indexed by slot, every piece of per-stream STATE (caches, enc_len, n_prev,
+  // head_step, tokens, the masks of this structure) by the stream's own row
+  const int* row_map;
+  int compact_rows;          // slots per round
 };
 
 // head-split projections around the policy kernel (all null: separate GEMM launches do the projections)
@@ -81,11 +86,14 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void 
     // computed once when its last frame arrives instead of from the window's frames at every step (nullptr: from the frames)
     const float* __restrict__ Kpool, int P_cap) {
   constexpr int W = VL<T>::W;
+  const int slot = blockIdx.y;              // row of the step's activations (q, ctx); the stream's state lives at row b
+  int brow = slot;
+  if (ctl.row_map) { brow = ctl.row_map[slot]; if (brow < 0) return; }
   if (ctl.active) {   // row parked / finished, or an EARLIER layer asked for source (heads of one layer all run)
-    const unsigned char rf = ctl.read_flag[blockIdx.y];
-    if (!ctl.active[blockIdx.y] || (rf && rf != ctl.layer)) return;
+    const unsigned char rf = ctl.read_flag[brow];
+    if (!ctl.active[brow] || (rf && rf != ctl.layer)) return;
   }
-  if (ctl.online) online = ctl.online[blockIdx.y];
+  if (ctl.online) online = ctl.online[brow];
   extern __shared__ float sm[];
   float* q_s = sm;                 // [64]
   float* red = sm + 64;            // [1024 + 8]
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void 
   float* qsoft_s = xn + H * d;     // [64] scaled soft-energy query (fused projection only)
   __shared__ int s_found;
   __shared__ __attribute__((aligned(16))) T xn_t[1024];   // normalised row in the operand dtype (MFMA projection)
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int h = blockIdx.x, b = brow, tid = threadIdx.x, lane = tid & 63;
   const int D = H * d;
   const int len = key_len ? key_len[b] : S_cap;
   const int r = b * H + h;
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void 
   const bool fusedq = FQ && xres != nullptr;
   const int n_pref = min(S_cap, n_hint);
   if constexpr (NP > 0) {
-    if (fast) attn::prefetch2<T, NP>(rg2, fusedq ? nullptr : qs + (long)b * D + h * d, Kh, d, Vh, d, n_pref, -1, nullptr, nullptr);
+    if (fast) attn::prefetch2<T, NP>(rg2, fusedq ? nullptr : qs + (long)slot * D + h * d, Kh, d, Vh, d, n_pref, -1, nullptr, nullptr);
   }
   if constexpr (FQ) if (fusedq) {
     // LayerNorm of the residual row (fp32 stats, rounded to the activation dtype like the unfused path), then
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void 
   } else {
   {
     if (!fusedq) {
-      if (tid < d) q_s[tid] = to_f32(qm[(long)b * D + h * d + tid]) * rsqrtf((float)d);
+      if (tid < d) q_s[tid] = to_f32(qm[(long)slot * D + h * d + tid]) * rsqrtf((float)d);
       __syncthreads();
     }
     for (int j = tid; j < P; j += 256) {
@@ -324,14 +332,14 @@ __global__ __launch_bounds__(256, NP >= 16 ? 2 : (FQ ? 3 : SL_POLICY_WGS)) void 
       } else {
         __syncthreads();
         if (!fusedq) {
-          if (tid < d) q_s[tid] = to_f32(qs[(long)b * D + h * d + tid]) * rsqrtf((float)d);
+          if (tid < d) q_s[tid] = to_f32(qs[(long)slot * D + h * d + tid]) * rsqrtf((float)d);
           __syncthreads();
         }
         o = attn::looped<T>(fusedq ? qfused : q_s, Kh, d, Vh, d, n, d, -1, nullptr, nullptr, sc, red, nullptr);
       }
     }
   }
-  if (tid < d) ctx[(long)b * D + h * d + tid] = from_f32<T>(o);
+  if (tid < d) ctx[(long)slot * D + h * d + tid] = from_f32<T>(o);
 }
 
 // ---- long sources (S_cap > 256), wait-k: the keys in blocks of 256, one workgroup per (head, row, block) ----------------------
@@ -442,8 +450,10 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
   __shared__ float sv[4];
   __shared__ int si[4];
   __shared__ int s_tok;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* row = logits + (long)b * V;
+  const int slot = blockIdx.x, tid = threadIdx.x;      // the step's logits / pairs / next embedding live at row `slot`, the stream at row b
+  int b = slot;
+  if (ctl.row_map) { b = ctl.row_map[slot]; if (b < 0) return; }
+  const float* row = logits + (long)slot * V;
   const int np = n_prev[b];
   // streaming commit follows agent.predict (agents/default_agent.py:415-424): plain argmax, nothing masked
   const bool streaming = ctl.active != nullptr;
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
     // the vocabulary projection left one (largest value, its lowest index) pair per 64-column tile, pad / masked eos already
     // excluded there (gemm_mid.hip, LinArgs::amax): fold the tiles with the same rule
     for (int t = tid; t < n_tiles; t += 256) {
-      const float2 pr = partial[(long)b * n_tiles + t];
+      const float2 pr = partial[(long)slot * n_tiles + t];
       const int c = __float_as_int(pr.y);
       if (pr.x > best || (pr.x == best && c < bi)) { best = pr.x; bi = c; }
     }
@@ -545,6 +555,7 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
     sv[0] = __int_as_float(np + 1);
     }
   }
+  if (ctl.row_map) return;                               // compacted rounds embed after the NEXT round's compaction (its slots differ)
   __syncthreads();
   const long tok = s_tok;
   const long pr = pad_idx + 1 + __float_as_int(sv[0]);   // position row of the NEXT input token
@@ -552,15 +563,50 @@ __global__ __launch_bounds__(256) void argmax_embed_kernel(const float* __restri
     x[(long)b * D + c] = from_f32<T>(scale * to_f32(E[tok * D + c]) + pos[pr * D + c]);
 }
 
+// Active-row compaction (round 6): slots [0, cap_rows) <- the first cap_rows rows that take part in the coming round (active; a
+// finished row has active = 0), in row order; the other slots -1.  One workgroup; rows beyond cap_rows keep their masks and are listed
+// in a later round.
+__global__ __launch_bounds__(1024) void stream_compact_kernel(const unsigned char* __restrict__ active, int B, int* __restrict__ row_map,
+                                                              int cap_rows) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int b = b0 + tid;
+    const bool a = b < B && active[b] != 0;
+    const unsigned long long m = __ballot(a);
+    const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (a && off + in_wave < cap_rows) row_map[off + in_wave] = b;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base += t; }
+    __syncthreads();
+  }
+  for (int i = base + tid; i < cap_rows; i += 1024) row_map[i] = -1;
+}
+
 template <typename T>
 __global__ void embed_first_kernel(const long* __restrict__ tokens, const T* __restrict__ E,
                                    const float* __restrict__ pos, const int* __restrict__ n_prev, T* __restrict__ x,
-                                   int D, int pad_idx, float scale) {
-  const int b = blockIdx.x;
+                                   int D, int pad_idx, float scale, const int* __restrict__ row_map = nullptr) {
+  const int slot = blockIdx.x;
+  int b = slot;
+  if (row_map) {
+    b = row_map[slot];
+    if (b < 0) {                             // empty slot: a finite row for the row-local chains that run over it
+      for (int c = threadIdx.x; c < D; c += blockDim.x) x[(long)slot * D + c] = from_f32<T>(0.f);
+      return;
+    }
+  }
   const long tok = tokens[b];
   const long pr = pad_idx + 1 + n_prev[b];
   for (int c = threadIdx.x; c < D; c += blockDim.x)
-    x[(long)b * D + c] = from_f32<T>(scale * to_f32(E[tok * D + c]) + pos[pr * D + c]);
+    x[(long)slot * D + c] = from_f32<T>(scale * to_f32(E[tok * D + c]) + pos[pr * D + c]);
 }
 
 int lin(simulst_handle* h, int dtype, int B, int N, int K, const void* A, const void* W, const float* bias,
@@ -788,8 +834,19 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   SL_REQUIRE(h, dd->dtype == SIMULST_F32 || dd->dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_mma_decode: dtype");
   SL_REQUIRE(h, dd->B > 0 && dd->D > 0 && dd->H > 0 && dd->D % dd->H == 0 && dd->n_layers > 0 && n_steps >= 0,
              SIMULST_E_SHAPE, "simulst_mma_decode: shape");
-  const int B = dd->B, D = dd->D, H = dd->H, F = dd->F, V = dd->V, d = D / H, dt = dd->dtype;
+  // active-row compaction (simulst_stream_ctl.row_map): every launch of a round runs over `B` SLOTS, the streams are dd->B rows
+  const bool compact = ctlp && ctl.row_map != nullptr;
+  const int B_streams = dd->B;
+  const int B = compact ? ctl.compact_rows : dd->B, D = dd->D, H = dd->H, F = dd->F, V = dd->V, d = D / H, dt = dd->dtype;
   int rc;
+  if (compact) {
+    SL_REQUIRE(h, ctl.compact_rows > h->fuse_q_max_rows && ctl.compact_rows <= B_streams, SIMULST_E_ARG,
+               "simulst_mma_stream_steps: compact_rows must exceed the fused-query row limit (128) and not the number of streams");
+    SL_REQUIRE(h, !(dd->attn_type == SIMULST_ATTN_WAITK && dd->S_cap > KB_KEYS), SIMULST_E_ARG,
+               "simulst_mma_stream_steps: active-row compaction covers sources of up to 256 encoder rows");
+    SL_REQUIRE(h, !ctl.p_probe && !ctl.step_probe && !ctl.step_force, SIMULST_E_ARG, "simulst_mma_stream_steps: the audit hooks index by stream");
+    do_embed = false;                            // every round embeds after its own compaction
+  }
   if (do_embed) {
     KTimer t(h, SIMULST_K_MISC);
     if (dt == SIMULST_F32)
@@ -832,6 +889,17 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
   bool qkv_done = false;                         // this layer's QKV came out of the previous layer's feed-forward launch
   int pending_pairs = 0;                         // pairs of the previous step's projection that no launch has committed yet
   for (int s = 0; s < n_steps; ++s) {
+    if (compact) {                               // this round's slots, then their input embeddings
+      KTimer t(h, SIMULST_K_MISC);
+      hipLaunchKernelGGL(stream_compact_kernel, dim3(1), dim3(1024), 0, h->stream, ctl.active, B_streams, (int*)ctl.row_map, B);
+      if (dt == SIMULST_F32)
+        hipLaunchKernelGGL(embed_first_kernel<float>, dim3(B), dim3(256), 0, h->stream, (const long*)tokens_io,
+                           (const float*)dd->E, dd->pos_table, dd->n_prev, (float*)dd->x, D, dd->pad_idx, dd->embed_scale, ctl.row_map);
+      else
+        hipLaunchKernelGGL(embed_first_kernel<bf16>, dim3(B), dim3(256), 0, h->stream, (const long*)tokens_io,
+                           (const bf16*)dd->E, dd->pos_table, dd->n_prev, (bf16*)dd->x, D, dd->pad_idx, dd->embed_scale, ctl.row_map);
+      if ((rc = sl_launch_status(h, "simulst_mma_stream_steps(compaction + embedding)")) != 0) return rc;
+    }
     for (int l = 0; l < dd->n_layers; ++l) {
       const simulst_dec_layer& L = layers[l];
       const void* xin = dd->x;                   // residual row entering the cross-attention block
@@ -861,7 +929,7 @@ static int run_decode(simulst_handle* h, const simulst_decoder_desc* dd, const s
         }
         if (!attn_chain)
           if ((rc = sl_self_attention(h, dd->qkv, L.k_cache, L.v_cache, dd->n_prev, np_uniform < 0 ? -1 : np_uniform + s,
-                                      dd->ctx, B, H, d, dd->cap, dt))) return rc;
+                                      dd->ctx, B, H, d, dd->cap, dt, compact ? ctl.row_map : nullptr))) return rc;
         if (!chain)
           if ((rc = lin(h, dt, B, D, D, dd->ctx, L.wo, L.bo, dd->x, dd->x, SIMULST_EPI_BIAS_RES, nullptr, nullptr, pk))) return rc;
       }
@@ -985,6 +1053,8 @@ extern "C" int simulst_mma_stream_steps(simulst_handle* h, const simulst_decoder
   ctl.row_chunks = c->row_chunks;
   ctl.ff_waitk = c->sched_rows ? c->ff_waitk : 0; ctl.ff_ratio = c->ff_ratio;
   ctl.p_probe = c->p_probe; ctl.step_probe = (long*)c->step_probe; ctl.step_force = (const long*)c->step_force; ctl.probe_P = c->probe_P;
+  ctl.row_map = c->compact_rows > 0 ? c->row_map : nullptr; ctl.compact_rows = c->compact_rows;
+  SL_REQUIRE(h, c->compact_rows <= 0 || c->row_map, SIMULST_E_NULL, "simulst_mma_stream_steps: compact_rows needs the row_map scratch");
   SL_REQUIRE(h, !c->p_probe || c->probe_P > 0, SIMULST_E_SHAPE, "simulst_mma_stream_steps: p_probe needs probe_P");
   if (c->sched_rows) {
     SL_REQUIRE(h, c->ff_waitk == 0 || (dd && dd->attn_type == SIMULST_ATTN_WAITK && c->ff_waitk == dd->waitk_k && c->ff_ratio == dd->ratio),

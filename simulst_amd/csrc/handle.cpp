@@ -8,7 +8,8 @@
 // simulst_decoder_attn_proj_chain, the simulst_debug_* entry points only in DEBUG_HOOKS builds.
 // 105: round 5 -- simulst_get_option (what a handle actually runs with, for the roofline models of bench.py).
 // 106: round 6 -- simulst_emformer_ffn_prenorm (the next layer's LayerNorm + summaries in the feed-forward launch); no structure changed.
-extern "C" int simulst_version(void) { return 106; }
+// 107: round 6 -- simulst_stream_ctl grew row_map / compact_rows (active-row compaction of simulst_mma_stream_steps).
+extern "C" int simulst_version(void) { return 107; }
 
 extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (!out) return SIMULST_E_NULL;

@@ -110,6 +110,44 @@ def test_agent_actions_tokens_al_identical_to_oracle(ops, attn, kw):
 @pytest.mark.parametrize("attn,kw", [("waitk_fixed_pre_decision", dict(waitk_lagging=3)),
                                      ("hard_aligned_fixed_pre_decision", {}),
                                      ("infinite_lookback_fixed_pre_decision", {})])
+def test_live_streams_with_active_row_compaction_keep_their_records(ops, attn, kw, dtype):
+    """Round 6 (simulst_stream_ctl.row_map): 200 live streams in the microphone form, every masked round over 144 SLOTS that the
+    device fills with the rows taking part (the first round of a chunk has more candidates than slots, so rows also wait a round):
+    every row's READ / WRITE string, tokens, delays and Average Lagging equal the uncompacted batch's, and in fp32 the B = 1 agent's
+    on a sample of rows (the extension of test_batched_streaming_rows_equal_single_streams the verdict asked for)."""
+    from simulst_amd.agent import BatchedStreamingAgent, FairseqSimulSTAgent
+    from simulst_amd.config import mma_model_s
+    from simulst_amd.model import SimulSTModel
+    from simulst_amd.weights import init_model
+    cfg = mma_model_s(encoder_layers=2, decoder_layers=2, simul_attn_type=attn, max_target_positions=40, **kw)
+    w = init_model(cfg, seed=4242)
+    if "waitk" not in attn:
+        for l in range(2):
+            w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] = w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] * 8
+    w["decoder.embed_tokens.weight"][cfg.eos] *= 1.5
+    model = SimulSTModel(cfg, w, dtype=dtype, ops=ops)
+    B, T = 200, 560
+    fb = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(78))
+    plain = BatchedStreamingAgent(model, steps_per_call=4).run_batch(fb)
+    for slots, spc in ((144, 4), (160, 1)):
+        got = BatchedStreamingAgent(model, steps_per_call=spc, compact_rows=slots).run_batch(fb)
+        for b in range(B):
+            for k in ("actions", "tokens", "delays_ms", "AL"):
+                assert got[b][k] == plain[b][k], (attn, b, k, slots)
+    if "waitk" not in attn:
+        assert len({r["actions"] for r in plain}) > 1, "test needs rows that diverge"
+    if dtype == torch.float32:
+        single = FairseqSimulSTAgent(model)
+        for b in (0, 57, 143, 144, 199):
+            ref = single.run_utterance(fb[b].cuda())
+            for k in ("actions", "tokens", "delays_ms", "AL"):
+                assert got[b][k] == ref[k], (attn, b, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("attn,kw", [("waitk_fixed_pre_decision", dict(waitk_lagging=3)),
+                                     ("hard_aligned_fixed_pre_decision", {}),
+                                     ("infinite_lookback_fixed_pre_decision", {})])
 def test_batched_streaming_rows_equal_single_streams(ops, attn, kw, dtype):
     """B streams through one batch with per-row READ/WRITE divergence (simulst_mma_stream_steps): every row's
     actions / tokens / delays are IDENTICAL to the B=1 agent on that utterance; the fp32 rows are also checked

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--steps-per-call", type=int, default=8)
     ap.add_argument("--encoder", default="chunked", choices=["chunked", "offline"])
     ap.add_argument("--self-paced", action="store_true", help="evaluation form: rows take their chunks themselves")
+    ap.add_argument("--compact-rows", type=int, default=0,
+                    help="microphone form: slots per masked round (active-row compaction, simulst_stream_ctl.row_map); 0: every round over all rows")
     args = ap.parse_args()
     from simulst_amd.agent import BatchedStreamingAgent
     from simulst_amd.cif import BatchedCIFStreamingAgent, CIFTransformerModel
@@ -37,14 +39,14 @@ def main():
         cfg = mma_model_s(simul_attn_type="waitk_fixed_pre_decision", waitk_lagging=5, fixed_pre_decision_ratio=8)
         w = init_model(cfg, seed=999)
         w["decoder.embed_tokens.weight"][cfg.eos] = 0
-        agent = BatchedStreamingAgent(SimulSTModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10, steps_per_call=args.steps_per_call)
+        agent = BatchedStreamingAgent(SimulSTModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10, steps_per_call=args.steps_per_call, compact_rows=args.compact_rows)
     else:
         cfg = mma_model_s(simul_attn_type="hard_aligned_fixed_pre_decision", fixed_pre_decision_ratio=8, mass_preservation=True)
         w = init_model(cfg, seed=999)
         for l in range(cfg.decoder_layers):
             w[f"decoder.layers.{l}.encoder_attn.q_proj.weight"] *= 8
         w["decoder.embed_tokens.weight"][cfg.eos] = 0
-        agent = BatchedStreamingAgent(SimulSTModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10, steps_per_call=args.steps_per_call)
+        agent = BatchedStreamingAgent(SimulSTModel(cfg, w, dtype=torch.bfloat16), max_len_a=0.1, max_len_b=10, steps_per_call=args.steps_per_call, compact_rows=args.compact_rows)
     fb = torch.randn(args.rows, 1000, 80, device="cuda", generator=torch.Generator(device="cuda").manual_seed(999)).to(torch.bfloat16)
     kw = dict(self_paced=True, encoder=args.encoder) if args.self_paced else {}
     agent.run_batch(fb, **kw)
@@ -55,7 +57,8 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         n = sum(len(r["tokens"]) for r in recs)
-        print(f"{args.rows} rows: {dt * 1e3:.1f} ms, {n} tokens, {n / dt:.0f} tokens/s", flush=True)
+        print(f"config {args.config}, {args.rows} rows, compact_rows {args.compact_rows}: {dt * 1e3:.1f} ms, {n} tokens, {n / dt:.0f} tokens/s, "
+              f"mean AL {sum(r['AL'] for r in recs) / len(recs):.1f} ms", flush=True)
 
 
 if __name__ == "__main__":
