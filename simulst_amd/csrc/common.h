@@ -65,8 +65,9 @@ struct simulst_handle {
   bool dec_fuse_ffn_qkv;       // decode loops: feed-forward chain of layer l + LN / QKV of layer l + 1 in one launch (dec_chain.hip, round 5)
   int* chain_sem;              // its ticket words (one per row tile), device memory, lazily allocated
   int chain_sem_splits;
-  bool tile256;                // bf16 GLU contractions (the subsampler) on 256 x 256 tiles, one 8-wave workgroup per CU (gemm_tile256.hip)
-  bool tile256_lds_attr_set;
+  int tile256;                 // bf16 GLU contractions (the subsampler) on 256 x 256 tiles, one 8-wave workgroup per CU (gemm_tile256.hip):
+                               //   0 off (128 x 128 tiles), 1 register-staged 128-deep k-tiles (round 5), 2 LDS-DMA ring of 64-deep k-tiles (round 6)
+  bool tile256_lds_attr_set, tile256_ring_attr_set;
   bool wstat;                  // tall K = 256 projections of the encoder on the weight-stationary kernel (gemm_wstat.hip)
   bool wstat_lds_attr_set;
   int n_cus;                   // compute units of the device (persistent one-workgroup-per-CU launches)

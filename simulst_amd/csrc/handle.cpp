@@ -78,9 +78,10 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
 #endif
   h->chain_sem = nullptr;
   h->chain_sem_splits = 0;
-  h->tile256 = true;
-  if (const char* e = getenv("SIMULST_CONV_TILE256")) h->tile256 = atoi(e) != 0;
+  h->tile256 = 2;
+  if (const char* e = getenv("SIMULST_CONV_TILE256")) { const int v = atoi(e); if (v >= 0 && v <= 2) h->tile256 = v; }
   h->tile256_lds_attr_set = false;
+  h->tile256_ring_attr_set = false;
   h->wstat = true;
   if (const char* e = getenv("SIMULST_WEIGHT_STATIONARY")) h->wstat = atoi(e) != 0;
   h->wstat_lds_attr_set = false;
@@ -237,7 +238,9 @@ extern "C" int simulst_set_option(simulst_handle* h, int32_t option, int32_t val
     case SIMULST_OPT_FUSED_ARGMAX: h->fused_argmax = value != 0; return SIMULST_OK;
     case SIMULST_OPT_DEC_EMBED_QKV_CHAIN: h->dec_embed_qkv_chain = value != 0; return SIMULST_OK;
     case SIMULST_OPT_WEIGHT_STATIONARY: h->wstat = value != 0; return SIMULST_OK;
-    case SIMULST_OPT_CONV_TILE256: h->tile256 = value != 0; return SIMULST_OK;
+    case SIMULST_OPT_CONV_TILE256:
+      SL_REQUIRE(h, value >= 0 && value <= 2, SIMULST_E_ARG, "simulst_set_option(CONV_TILE256): 0 (128 x 128 tiles), 1 (256 x 256, register stage), 2 (256 x 256, LDS-DMA ring)");
+      h->tile256 = value; return SIMULST_OK;
     case SIMULST_OPT_DEC_CHAIN_ROWS32:
 #ifdef SL_EXPERIMENTS
       h->dec_chain_rows32 = value != 0; return SIMULST_OK;

@@ -64,8 +64,8 @@ def test_shipped_library_has_no_debug_hooks():
         assert lib.simulst_set_option(h, opt, val) == -4, (opt, val)
     v = ctypes.c_int32(-1)
     assert lib.simulst_get_option(h, _lib.OPT_DEC_VOCAB_CHAIN_SPLIT, ctypes.byref(v)) == 0 and v.value == 4
-    for opt in (_lib.OPT_WEIGHT_STATIONARY, _lib.OPT_CONV_TILE256):              # round 5's encoder kernels: on by default
-        assert lib.simulst_get_option(h, opt, ctypes.byref(v)) == 0 and v.value == 1
+    assert lib.simulst_get_option(h, _lib.OPT_WEIGHT_STATIONARY, ctypes.byref(v)) == 0 and v.value == 1     # round 5's encoder kernels: on by default
+    assert lib.simulst_get_option(h, _lib.OPT_CONV_TILE256, ctypes.byref(v)) == 0 and v.value in (1, 2)     # (2: round 6's LDS-DMA ring)
     assert lib.simulst_get_option(h, _lib.OPT_DEC_FUSE_FFN_QKV, ctypes.byref(v)) == 0 and v.value == 0
     assert lib.simulst_get_option(h, 99, ctypes.byref(v)) == -4
     assert lib.simulst_set_option(h, 99, 1) == -4

@@ -115,37 +115,32 @@ def test_subsampler_bf16_glu_tiles_vs_fp32(ops):
 
 
 def test_subsampler_big_tiles_equal_the_128_tiles(ops):
-    """The subsampler's two convolutions on 256 x 256 tiles (round 5, csrc/gemm_tile256.hip: 8 waves, two LDS stages, half the operand
-    stream of the 128 x 128 kernel) against the 128 x 128 tile kernel (SIMULST_OPT_CONV_TILE256 = 0): same MFMA shape, k order and GLU
-    arithmetic -- IDENTICAL outputs.  40 x 999 frames: 20 000 and 10 000 output rows, ragged last tiles, K = 400 with a partial last
-    k-tile and K = 2 560, utterance starts (zero lead frames) inside tiles."""
+    """The subsampler's two convolutions on 256 x 256 tiles (csrc/gemm_tile256.hip; SIMULST_OPT_CONV_TILE256 = 1: round 5's register
+    stage with 128-deep k-tiles, 2: round 6's LDS-DMA ring of 64-deep k-tiles -- swizzled source chunks, a page of zeros for the lead
+    frames / the k tail / rows past M) against the 128 x 128 tile kernel (0): same MFMA shape, k order and GLU arithmetic -- IDENTICAL
+    outputs.  40 x 999 frames: 20 000 and 10 000 output rows, ragged last tiles, K = 400 with a partial last k-tile and K = 2 560,
+    utterance starts (zero lead frames) inside tiles; then without the zero lead (the streaming form's addressing)."""
     from simulst_amd.config import mma_model_s
     from simulst_amd.encoder import S2TEmformerEncoder
     from simulst_amd.weights import init_model
     cfg = mma_model_s()
     enc = S2TEmformerEncoder(cfg, init_model(cfg, seed=6), dtype=torch.bfloat16, ops=ops)
     x = torch.randn(40, 999, 80, generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).cuda()
-    assert ops.h.get_option(_lib.OPT_CONV_TILE256) == 1
-    outs = []
-    for on in (1, 0):
-        ops.h.set_option(_lib.OPT_CONV_TILE256, on)
-        try:
-            outs.append(enc._subsample(x, lead=True).clone())
-        finally:
-            ops.h.set_option(_lib.OPT_CONV_TILE256, 1)
-    torch.cuda.synchronize()
-    assert outs[0].shape == (40, 250, cfg.embed_dim)
-    assert torch.equal(outs[0], outs[1]), int((outs[0] != outs[1]).sum())
-    assert float(outs[0].float().abs().mean()) > 0.1
-    # no zero lead (the streaming form's addressing: k - 1 context frames in front) at the same row counts
-    outs = []
-    for on in (1, 0):
-        ops.h.set_option(_lib.OPT_CONV_TILE256, on)
-        try:
-            outs.append(enc._subsample(x, lead=False).clone())
-        finally:
-            ops.h.set_option(_lib.OPT_CONV_TILE256, 1)
-    assert torch.equal(outs[0], outs[1]) and outs[0].shape[1] == 247
+    default = ops.h.get_option(_lib.OPT_CONV_TILE256)
+    assert default in (1, 2)
+    for lead, rows in ((True, 250), (False, 247)):
+        outs = {}
+        for on in (2, 1, 0):
+            ops.h.set_option(_lib.OPT_CONV_TILE256, on)
+            try:
+                outs[on] = enc._subsample(x, lead=lead).clone()
+            finally:
+                ops.h.set_option(_lib.OPT_CONV_TILE256, default)
+        torch.cuda.synchronize()
+        assert outs[0].shape == (40, rows, cfg.embed_dim)
+        for on in (1, 2):
+            assert torch.equal(outs[on], outs[0]), (on, lead, int((outs[on] != outs[0]).sum()))
+        assert float(outs[0].float().abs().mean()) > 0.1
 
 
 # ------------------------------------------------------------------ row ops
