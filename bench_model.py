@@ -10,8 +10,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # HBM traffic of the dominant kernels from committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest round first
-ENCODER_TRAFFIC_FILES = ["r05_c_encoder_traffic.json", "r05_encoder_traffic.json", "r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
-CROSS_ATTN_TRAFFIC_FILES = ["r05_pmc_cross_attention_traffic.json", "r04_pmc_cross_attention_traffic.json", "r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
+ENCODER_TRAFFIC_FILES = ["r06_encoder_traffic.json", "r05_c_encoder_traffic.json", "r05_encoder_traffic.json", "r03_encoder_traffic.json", "r02_encoder_traffic.json"]   # tools/encoder_traffic.py
+CROSS_ATTN_TRAFFIC_FILES = ["r06_pmc_cross_attention_traffic.json", "r05_pmc_cross_attention_traffic.json", "r04_pmc_cross_attention_traffic.json", "r03_pmc_cross_attention_traffic.json", "r02_e_pmc_cross_attention_traffic.json"]
 PMC_TRAFFIC_FILE = "r01_n_pmc_traffic.json"   # all classes of one launch sequence (round 1), tools/pmc_summary.py
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md "L2 (per XCD)": 34.5 TB/s aggregate
 
