@@ -75,7 +75,7 @@ int simulst_create(simulst_handle** out, void* hip_stream);
 int simulst_destroy(simulst_handle* h);
 int simulst_set_stream(simulst_handle* h, void* hip_stream);
 const char* simulst_last_error(simulst_handle* h);
-int simulst_version(void);            /* 107 (round 6: simulst_stream_ctl grew row_map / compact_rows; 106: simulst_emformer_ffn_prenorm; 105, round 5: simulst_get_option and simulst_stream_ctl grew p_probe / step_probe / step_force / probe_P); a binding built for another value must not use the library */
+int simulst_version(void);            /* 108 (round 6: simulst_emformer_ffn_prenorm_qkv + simulst_emformer_qkv_mem_sum; 107: simulst_stream_ctl grew row_map / compact_rows; 106: simulst_emformer_ffn_prenorm; 105, round 5: simulst_get_option and simulst_stream_ctl grew p_probe / step_probe / step_force / probe_P); a binding built for another value must not use the library */
 /* HIP streams with a compute-unit mask (hipExtStreamCreateWithCUMask) or a priority, for hosts whose framework cannot create them.
  * cu_mask: mask_words 32-bit words; on MI355X bit i is compute unit (i / 8) of XCD (i % 8) (tools/microbench_cumask.hip), every XCD
  * must keep at least one unit; NULL / 0: no mask.  priority: 0 default, > 0 greatest, < 0 least (ignored with a mask).  Used by
@@ -289,6 +289,28 @@ int simulst_emformer_ffn_prenorm(simulst_handle* h, const void* x, const float* 
                                  const float* next_gamma, const float* next_beta, const int32_t* lengths, void* z_next,
                                  int32_t B, int32_t T, int32_t D, int32_t F, int32_t n_mem, int32_t n_rc, int32_t n_sum,
                                  int32_t seg_len, int32_t dtype);
+
+/* ... and the next layer's fused Q | K | V projection (torchaudio_models/emformer.py:109-131: emb_to_query over rc | utterance | summary,
+ * emb_to_key_value over memory | rc | utterance; here one [768][256] matrix over every row, as the layer loop's simulst_linear) of the
+ * rc | utterance rows in the same launch: the normalised rows go from the epilogue's registers straight into the product and never
+ * reach HBM.  Rows [n_mem, n_mem + n_rc + T) of every utterance of qkv_next [B * (n_mem + n_rc + T + n_sum) + 16][768] are written
+ * exactly as simulst_linear(z_next, wqkv, bqkv) would write them (same instruction, k order, bias add and rounding: bit for bit); the
+ * 16 spare rows behind the buffer take the stores of a workgroup's rows past its utterance's end.  z_next gets its summary rows
+ * only (its rc | utterance rows are NOT written); the Q | K | V rows of its memory and summary rows: simulst_emformer_qkv_mem_sum.
+ * wqkv_fm: simulst_pack_fragment_major of the [768][256] weight; bqkv [768] fp32.  Shape limits as simulst_emformer_ffn_prenorm. */
+int simulst_emformer_ffn_prenorm_qkv(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
+                                     const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                                     const float* next_gamma, const float* next_beta, const int32_t* lengths, void* z_next,
+                                     const void* wqkv_fm, const float* bqkv, void* qkv_next,
+                                     int32_t B, int32_t T, int32_t D, int32_t F, int32_t n_mem, int32_t n_rc, int32_t n_sum,
+                                     int32_t seg_len, int32_t dtype);
+
+/* The rest of that layer's Q | K | V buffer: the memory rows [0, n_mem) and the summary rows [n_mem + n_rc + T, + n_sum) of every
+ * utterance of z [B][n_mem + n_rc + T + n_sum][256] (memory rows: the previous layer's out-projection; summary rows:
+ * simulst_emformer_ffn_prenorm_qkv) through the same product -- the rows simulst_linear(z, wqkv, bqkv) would write, bit for bit --
+ * into the same rows of qkv [B * rows_z + 16][768] (the 16 spare rows as above).  One launch, one wave per 32 such rows. */
+int simulst_emformer_qkv_mem_sum(simulst_handle* h, const void* z, const void* wqkv_fm, const float* bqkv, void* qkv,
+                                 int32_t B, int32_t T, int32_t D, int32_t n_mem, int32_t n_rc, int32_t n_sum, int32_t dtype);
 
 /* ---- Emformer layer pieces ------------------------------------------------------
  * Per-utterance row blocks of a layer buffer Z [B][n_mem + n_rc + T + n_sum][D]:

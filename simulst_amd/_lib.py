@@ -121,6 +121,9 @@ SIGNATURES = {
     "simulst_emformer_ffn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32],
     "simulst_emformer_ffn_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                      _i32, _i32, _i32],
+    "simulst_emformer_ffn_prenorm_qkv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                         _i32, _i32, _i32, _i32, _i32],
+    "simulst_emformer_qkv_mem_sum": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_emformer_prenorm": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "simulst_layernorm": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i32],
     "simulst_segment_mean": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _i32],
@@ -179,7 +182,7 @@ DEBUG_SIGNATURES = {
  OPT_WEIGHT_STATIONARY, OPT_CONV_TILE256, OPT_DEC_FUSE_FFN_QKV, OPT_DEC_CHAIN_ROWS32) = range(15)
 
 _lib = None
-ABI_VERSION = 107          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
+ABI_VERSION = 108          # simulst_version(): bumped whenever a descriptor structure changes (csrc/handle.cpp)
 
 
 def load():

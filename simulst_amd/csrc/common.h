@@ -41,6 +41,7 @@ struct simulst_handle {
   uint64_t graph_key;
   bool ffn_lds_attr_set;       // simulst_emformer_ffn did the same for the fused feed-forward kernel
   bool ffn_pipe_lds_attr_set;  // ... and for its software-pipelined form (ffn_pipe.hip)
+  bool qkv_rows_lds_attr_set;  // ... and for qkv_rows_kernel (ffn_pipe.hip)
   bool ea_general_only;        // SIMULST_EA_GENERAL=1: expected alignment through the chunked log-space kernel for every S (A/B measurements)
   int ffn_variant;             // simulst_debug_ffn_variant (DEBUG_HOOKS builds: timing ablations of the fused feed-forward launch)
   int ffn_waves;               // SIMULST_OPT_FFN_WAVES: 0 the library's choice, 4 / 8 force that geometry of the fused feed-forward

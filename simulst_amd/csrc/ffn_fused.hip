@@ -32,6 +32,8 @@
 // contraction, again for the residual: L2/MALL-hot) + rows * D * 2 written; weights 2 * D * F * 2 B from L2 per workgroup.
 #include "gemm_args.h"
 
+int sl_launch_qkv_rows(simulst_handle* h, const void* z, const void* wqkv_fm, const float* bqkv, void* qkv, int n_utt, int rows_z, int n_mem,
+                       int sum0, int n_sum);
 int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, const float* ln_b, const void* w1p, const float* b1,
                        const void* w2p, const float* b2, void* out, long rows, int F, int waves, int packed, int uniform,
                        const sl_ffn_z* zout = nullptr);
@@ -293,12 +295,13 @@ extern "C" int simulst_emformer_ffn(simulst_handle* h, const void* x, const floa
 // segment summaries in the launch's epilogue (ffn_pipe.hip ZOUT): replaces simulst_emformer_ffn + simulst_emformer_prenorm of the
 // next layer.  Same shape limits as the pipelined feed-forward (bf16, D == 256, F <= 2048) plus 16-frame segments and whole 32-row
 // waves of right-context rows.
-extern "C" int simulst_emformer_ffn_prenorm(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
-                                            const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
-                                            const float* next_gamma, const float* next_beta, const int32_t* lengths, void* z_next,
-                                            int32_t B, int32_t T, int32_t D, int32_t F, int32_t n_mem, int32_t n_rc, int32_t n_sum,
-                                            int32_t seg_len, int32_t dtype) {
-  if (!h) return SIMULST_E_NULL;
+static int ffn_prenorm_launch(simulst_handle* h, const char* who, const void* x, const float* ln_gamma, const float* ln_beta,
+                              const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                              const float* next_gamma, const float* next_beta, const int32_t* lengths, void* z_next,
+                              const void* wqkv_fm, const float* bqkv, void* qkv_next,
+                              int32_t B, int32_t T, int32_t D, int32_t F, int32_t n_mem, int32_t n_rc, int32_t n_sum,
+                              int32_t seg_len, int32_t dtype) {
+  (void)who;
   SL_CHECK_NULL(h, x); SL_CHECK_NULL(h, ln_gamma); SL_CHECK_NULL(h, ln_beta); SL_CHECK_NULL(h, w1_packed);
   SL_CHECK_NULL(h, b1); SL_CHECK_NULL(h, w2_packed); SL_CHECK_NULL(h, b2); SL_CHECK_NULL(h, out);
   SL_CHECK_NULL(h, next_gamma); SL_CHECK_NULL(h, next_beta); SL_CHECK_NULL(h, z_next);
@@ -313,7 +316,49 @@ extern "C" int simulst_emformer_ffn_prenorm(simulst_handle* h, const void* x, co
   sl_ffn_z z;
   z.Z = (bf16*)z_next; z.g = next_gamma; z.b = next_beta; z.lengths = lengths;
   z.rows_x = n_rc + T; z.T = T; z.n_mem = n_mem; z.n_rc = n_rc; z.n_sum = n_sum; z.tiles = (z.rows_x + 127) / 128;
+  z.Wqkv = (const bf16*)wqkv_fm; z.bqkv = bqkv; z.QKV = (bf16*)qkv_next;
   return sl_launch_ffn_pipe(h, x, ln_gamma, ln_beta, w1_packed, b1, w2_packed, b2, out, (long)B * z.rows_x, F, 4, 0, 1, &z);
+}
+
+extern "C" int simulst_emformer_ffn_prenorm(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
+                                            const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                                            const float* next_gamma, const float* next_beta, const int32_t* lengths, void* z_next,
+                                            int32_t B, int32_t T, int32_t D, int32_t F, int32_t n_mem, int32_t n_rc, int32_t n_sum,
+                                            int32_t seg_len, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  return ffn_prenorm_launch(h, "simulst_emformer_ffn_prenorm", x, ln_gamma, ln_beta, w1_packed, b1, w2_packed, b2, out, next_gamma,
+                            next_beta, lengths, z_next, nullptr, nullptr, nullptr, B, T, D, F, n_mem, n_rc, n_sum, seg_len, dtype);
+}
+
+// ... and the next layer's fused Q | K | V projection of the rc | utterance rows as well (ffn_pipe.hip QOUT): the normalised rows go
+// straight from the epilogue's registers into the product, and rows [n_mem, n_mem + n_rc + T) of every utterance of qkv_next
+// ([B * (n_mem + n_rc + T + n_sum) + 16][768]: 16 spare rows behind the buffer take the stores of a workgroup's rows past its
+// utterance's end) are written as simulst_linear over z_next would write them, bit for bit.  z_next gets its summary rows only; its
+// memory and summary rows' Q | K | V stay with simulst_linear_raw.  wqkv_fm: simulst_pack_fragment_major of the [768][256] weight.
+extern "C" int simulst_emformer_ffn_prenorm_qkv(simulst_handle* h, const void* x, const float* ln_gamma, const float* ln_beta,
+                                                const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, void* out,
+                                                const float* next_gamma, const float* next_beta, const int32_t* lengths, void* z_next,
+                                                const void* wqkv_fm, const float* bqkv, void* qkv_next,
+                                                int32_t B, int32_t T, int32_t D, int32_t F, int32_t n_mem, int32_t n_rc, int32_t n_sum,
+                                                int32_t seg_len, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, wqkv_fm); SL_CHECK_NULL(h, bqkv); SL_CHECK_NULL(h, qkv_next);
+  return ffn_prenorm_launch(h, "simulst_emformer_ffn_prenorm_qkv", x, ln_gamma, ln_beta, w1_packed, b1, w2_packed, b2, out, next_gamma,
+                            next_beta, lengths, z_next, wqkv_fm, bqkv, qkv_next, B, T, D, F, n_mem, n_rc, n_sum, seg_len, dtype);
+}
+
+// The rest of that layer's Q | K | V buffer: the memory rows [0, n_mem) and the summary rows [n_mem + n_rc + T, + n_sum) of every
+// utterance of z [B][n_mem + n_rc + T + n_sum][256] through the same product (ffn_pipe.hip qkv_rows_kernel; the rows simulst_linear
+// would write, bit for bit), into the same rows of qkv [B * rows_z + 16][768].
+extern "C" int simulst_emformer_qkv_mem_sum(simulst_handle* h, const void* z, const void* wqkv_fm, const float* bqkv, void* qkv,
+                                            int32_t B, int32_t T, int32_t D, int32_t n_mem, int32_t n_rc, int32_t n_sum, int32_t dtype) {
+  if (!h) return SIMULST_E_NULL;
+  SL_CHECK_NULL(h, z); SL_CHECK_NULL(h, wqkv_fm); SL_CHECK_NULL(h, bqkv); SL_CHECK_NULL(h, qkv);
+  SL_REQUIRE(h, dtype == SIMULST_BF16, SIMULST_E_DTYPE, "simulst_emformer_qkv_mem_sum: bf16 only");
+  SL_REQUIRE(h, D == FF_D && B >= 0 && T > 0 && n_mem >= 0 && n_rc >= 0 && n_sum >= 0, SIMULST_E_SHAPE, "simulst_emformer_qkv_mem_sum: D == 256");
+  if (B == 0 || n_mem + n_sum == 0) return SIMULST_OK;
+  KTimer t(h, SIMULST_K_LINEAR);
+  return sl_launch_qkv_rows(h, z, wqkv_fm, bqkv, qkv, B, n_mem + n_rc + T + n_sum, n_mem, n_mem + n_rc + T, n_sum);
 }
 
 #ifdef SL_DEBUG_HOOKS

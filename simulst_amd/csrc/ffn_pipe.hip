@@ -152,6 +152,108 @@ __device__ __forceinline__ void stage_piece(const bf16* __restrict__ wp, int til
 // SPREAD (round 6, uniform schedule only): the 2 * PIECES LDS-DMA pieces of an iteration are issued ONE PER MFMA GAP behind the first
 // fc1 MFMAs instead of as a burst behind the barrier, where all waves of both resident workgroups issue theirs at the same moment
 // (MI355X_MICROARCH.md: a piece costs its wave 100-185 cycles inside a phase already carrying 8 pieces, 25-60 in a later gap).
+// The fused Q | K | V projection of 32 rows per wave (QOUT below and qkv_rows_kernel): simulst_linear's weight-stationary kernel
+// (gemm_wstat.hip) operation for operation -- v_mfma_f32_16x16x32_bf16, weights as the A operand, k-steps 0 .. 7, its permuted column
+// tiles (a lane's two accumulators = 8 consecutive columns of its row), fp32 bias add, one rounding -- so the rows are that launch's
+// bit for bit; only where the weights come from differs: there a 96 KB slice sits in LDS for the whole launch, here the 24 column
+// pairs (16 KB each) stream through four 16 KB slots at the start of the workgroup's LDS, by LDS-DMA with a per-lane gather from the
+// fragment-major matrix, three pairs ahead.  256 threads; fq[rt][s]: the wave's B operand (row 16 rt + lane % 16, columns
+// 32 s + 8 (lane / 16) .. + 7); qrow[rt]: where that row's 8 (lane / 16) .. + 7 columns of pair 0 go -- every lane stores in every
+// iteration (the counted waits rely on it).  Whatever the workgroup kept in lds[0, 64 KB) and bias_lds[0, 768) is overwritten.
+__device__ __forceinline__ void qkv_pair_ring(char* lds, float* bias_lds, const bf16* Wqkv, const float* bqkv, const uint4 (&fq)[2][8],
+                                              bf16* const (&qrow)[2], int tid, int wave_u) {
+  const int lane = tid & 63, l16 = lane & 15, lg = lane >> 4;
+  for (int k = tid; k < 768; k += 256) bias_lds[k] = bqkv[k];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                              // every wave holds its fragments: the slots are free
+  // this wave's 4 of a pair's 16 one-KiB pieces: piece f = 4 wave + i = (tile h = f >> 3 of the pair, k-step s = f & 7); lane (m = lane
+  // & 15, kg = lane >> 4) of it is the wstat fill's entry for permuted row m: column 32 pp + 8 (m >> 2) + 4 h + (m & 3), k-group kg
+  const unsigned lane_el = (unsigned)(((l16 >> 3) * 8) * 512 + (lg * 16 + 8 * ((l16 >> 2) & 1) + (l16 & 3)) * 8);
+  const char* wq = reinterpret_cast<const char*>(Wqkv);
+  const unsigned ring0 = lds_addr(lds);
+  auto stage_pair = [&](int pp) {
+    const unsigned slot = ring0 + (unsigned)(pp & 3) * FP_W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = 4 * wave_u + i, h = f >> 3, s8 = f & 7;
+      const unsigned el = lane_el + (unsigned)(32 * h) + (unsigned)((2 * pp) * 8 + s8) * 512u;
+      glds16(wq + 2ul * el, slot + (unsigned)f * 1024u);
+    }
+  };
+  stage_pair(0); stage_pair(1); stage_pair(2);
+  for (int pp = 0; pp < 24; ++pp) {
+    // pair pp's pieces have landed = all but the operations issued after them are done: per iteration 4 pieces + 2 stores
+    if (pp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (pp == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (pp == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (pp <= 21) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (pp == 22) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __syncthreads();                                            // ... everybody's have, and everybody is past pair pp - 1 (slot (pp + 3) & 3)
+    if (pp + 3 < 24) stage_pair(pp + 3);
+    const uint4* wls = reinterpret_cast<const uint4*>(lds + (pp & 3) * FP_W) + lane;
+    f32x4 qa[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) qa[rt][0] = qa[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const uint4 w0 = wls[s8 * 64], w1 = wls[(8 + s8) * 64];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        qa[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&w0), *reinterpret_cast<const bf16x8_t*>(&fq[rt][s8]), qa[rt][0], 0, 0, 0);
+        qa[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&w1), *reinterpret_cast<const bf16x8_t*>(&fq[rt][s8]), qa[rt][1], 0, 0, 0);
+      }
+    }
+    const float4 bq0 = *reinterpret_cast<const float4*>(bias_lds + 32 * pp + 8 * lg), bq1 = *reinterpret_cast<const float4*>(bias_lds + 32 * pp + 8 * lg + 4);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const float yq[8] = {qa[rt][0][0] + bq0.x, qa[rt][0][1] + bq0.y, qa[rt][0][2] + bq0.z, qa[rt][0][3] + bq0.w,
+                           qa[rt][1][0] + bq1.x, qa[rt][1][1] + bq1.y, qa[rt][1][2] + bq1.z, qa[rt][1][3] + bq1.w};
+      unsigned int ou[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf16 lo = __float2bfloat16(yq[2 * q]), hi = __float2bfloat16(yq[2 * q + 1]);
+        ou[q] = (unsigned int)(*reinterpret_cast<const unsigned short*>(&lo)) | ((unsigned int)(*reinterpret_cast<const unsigned short*>(&hi)) << 16);
+      }
+      {   // ONE 16-byte store: hipcc splits the C++ store into two 8-byte ones (each half leaves as soon as its accumulator is done)
+          // and the counted waits above would be off by two per iteration.  The `s_nop 1` belongs to the instruction: a store of more
+          // than 64 bits reads its data registers for a while after issue and gfx940+ wants TWO wait states before a VALU writes
+          // them; the hazard recogniser does not see into the statement, and hipcc did put the next row tile's `v_add_f32` into the
+          // first data register one instruction behind the store -- with the memory pipe loaded by another stream's kernels the
+          // first two columns of rows 12 .. 15 of a tile then carried that fp32 sum (tests/test_hip_properties.py multi-stream test,
+          // tools/check_isa.py rule 4)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 ov = {ou[0], ou[1], ou[2], ou[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(qrow[rt] + 32 * pp), "v"(ov) : "memory");
+      }
+    }
+  }
+}
+
+// The Q | K | V rows of the memory and summary rows of the layer buffer (simulst_emformer_qkv_mem_sum): what
+// simulst_emformer_ffn_prenorm_qkv leaves to do.  One wave per 32 of an utterance's n_mem + n_sum such rows, gathered straight from Z.
+__global__ __launch_bounds__(256, 2) void qkv_rows_kernel(const bf16* __restrict__ Z, const bf16* __restrict__ Wqkv, const float* __restrict__ bqkv,
+                                                          bf16* __restrict__ QKV, int n_utt, int rows_z, int n_mem, int sum0, int n_sum, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* bias_lds = reinterpret_cast<float*>(lds + 4 * FP_W);
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, lg = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = (int)blockIdx.x * 4 + wave_u;                  // (a wave past the last utterance works on zeros: the ring needs all four)
+  const int u = wg / tiles, v0 = (wg - u * tiles) * 32;
+  uint4 fq[2][8];
+  bf16* qrow[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int v = v0 + 16 * rt + l16;
+    const bool ok = u < n_utt && v < n_mem + n_sum;
+    const long row = (long)u * rows_z + (v < n_mem ? v : sum0 + v - n_mem);
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) fq[rt][s8] = ok ? ld16(Z + row * FF_D + 32 * s8 + 8 * lg) : make_uint4(0, 0, 0, 0);
+    qrow[rt] = QKV + (ok ? row : (long)n_utt * rows_z + l16) * 768 + 8 * lg;
+  }
+  qkv_pair_ring(lds, bias_lds, Wqkv, bqkv, fq, qrow, tid, wave_u);
+}
+
 // ZOUT (round 6): the launch also does the NEXT layer's pre-attention LayerNorm (_EmformerLayer.layer_norm_input,
 // torchaudio_models/emformer.py:431-452: feed-forward -> residual -> next layer's pre-LN) and its segment summaries (:163-167, the
 // AvgPool1d of the normalised utterance rows), i.e. what simulst_emformer_prenorm did in a launch of its own: the epilogue holds every
@@ -159,7 +261,7 @@ __device__ __forceinline__ void stage_piece(const bf16* __restrict__ wp, int til
 // the next layer's Z buffer and a wave's 32 rows are exactly two 16-row segments.  For that the workgroups tile every utterance on
 // its own (rows_x = n_rc + T rows, n_rc a multiple of 32): a wave never straddles two utterances or two segments.
 
-template <int WAVES, bool PK, bool UNI, bool SPREAD = false, bool ZOUT = false>
+template <int WAVES, bool PK, bool UNI, bool SPREAD = false, bool ZOUT = false, bool QOUT = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kernel(
     const bf16* __restrict__ X, const float* __restrict__ ln_g, const float* __restrict__ ln_b, const bf16* __restrict__ W1p,
     const float* __restrict__ b1, const bf16* __restrict__ W2p, const float* __restrict__ b2, bf16* __restrict__ out, long M, int F,
@@ -553,11 +655,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
       const bool rok = row0 + rl < row_end;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[it][j] = __builtin_fmaf(o[it][j] * ra[it], g8[j], b8[j]);
-      if (rok) {
+      {
         unsigned int zu[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) zu[q] = pack_bf16x2(o[it][2 * q], o[it][2 * q + 1]);
-        *reinterpret_cast<uint4*>(Zb + (long)(zlocal0 + rl) * FF_D + lr * 8) = make_uint4(zu[0], zu[1], zu[2], zu[3]);
+        if constexpr (QOUT)       // the row stays on chip as the B operand of the QKV product below (wave-private staging, chunk lr at lr ^ (row & 15))
+          *reinterpret_cast<uint4*>(st + rl * RS + ((lr ^ (rl & 15)) << 4)) = make_uint4(zu[0], zu[1], zu[2], zu[3]);
+        else if (rok)
+          *reinterpret_cast<uint4*>(Zb + (long)(zlocal0 + rl) * FF_D + lr * 8) = make_uint4(zu[0], zu[1], zu[2], zu[3]);
       }
       if (utt_wave && z.n_sum > 0) {
         const int seg = (t0w >> 4) + (it >> 3), t0 = seg * 16;
@@ -585,6 +690,33 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 2) void ffn_pipe_kerne
           for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
         }
       }
+    }
+    // ---- QOUT (round 6): the NEXT layer's fused Q | K | V projection of these 32 rows, in this launch (qkv_pair_ring above: the rows
+    //      simulst_linear would write, bit for bit; the 24 column pairs stream through the four 16 KB slots the wave staging areas
+    //      occupy).  The normalised rows never go to HBM: the next layer's Z buffer keeps only its memory and summary rows, whose
+    //      Q | K | V rows are simulst_emformer_qkv_mem_sum's (qkv_rows_kernel).
+    if constexpr (QOUT) {
+      static_assert(WAVES == 4, "the pair ring is the four 16 KB staging areas");
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int l16 = lane & 15, lg = lane >> 4;
+      uint4 fq[2][8];                                               // B operand: row tile rt, k-step s: row 16 rt + l16, columns 32 s + 8 lg .. + 7
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+          fq[rt][s8] = *reinterpret_cast<const uint4*>(st + (16 * rt + l16) * RS + ((((4 * s8 + lg) ^ l16)) << 4));
+      // rows of this lane's two row tiles in the QKV buffer; a row past the utterance's end goes to one of the 16 spare rows behind
+      // the buffer, so that every iteration issues exactly two stores (the ring's counted waits rely on it)
+      const long n_utt = (long)gridDim.x / z.tiles;
+      bf16* qrow[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int local = zlocal0 + 16 * rt + l16;
+        const long qr = local < z.rows_x ? (long)zb * zrows + z.n_mem + local : n_utt * zrows + l16;
+        qrow[rt] = z.QKV + qr * 768 + 8 * lg;
+      }
+      qkv_pair_ring(lds, b1s, z.Wqkv, z.bqkv, fq, qrow, tid, wave_u);      // (b1s: the fc1 bias is no longer needed)
     }
   }
 }
@@ -820,6 +952,7 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
   if (!h->ffn_pipe_lds_attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
 #ifdef SL_EXPERIMENTS
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ffn_pipe_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FPG<4>::LDS);
@@ -837,11 +970,15 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
   }
   if (zout) {      // the shipped form with the next layer's LayerNorm + summaries in its epilogue; workgroups tile each utterance
     const long nb = rows / zout->rows_x;
-    hipLaunchKernelGGL((ffn_pipe_kernel<4, false, true, true, true>), dim3((unsigned)(nb * zout->tiles)), dim3(256), FPG<4>::LDS, h->stream,
-                       (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F, *zout);
+    if (zout->QKV)
+      hipLaunchKernelGGL((ffn_pipe_kernel<4, false, true, true, true, true>), dim3((unsigned)(nb * zout->tiles)), dim3(256), FPG<4>::LDS, h->stream,
+                         (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F, *zout);
+    else
+      hipLaunchKernelGGL((ffn_pipe_kernel<4, false, true, true, true>), dim3((unsigned)(nb * zout->tiles)), dim3(256), FPG<4>::LDS, h->stream,
+                         (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F, *zout);
     return sl_launch_status(h, "simulst_emformer_ffn_prenorm");
   }
-  const sl_ffn_z noz = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+  const sl_ffn_z noz = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
 #define FPL(W, P, U, ...)                                                                                                           \
   hipLaunchKernelGGL((ffn_pipe_kernel<W, P, U, ##__VA_ARGS__>), dim3((unsigned)((rows + 32 * W - 1) / (32 * W))), dim3(64 * W), FPG<W>::LDS, h->stream, \
                      (const bf16*)x, ln_g, ln_b, (const bf16*)w1p, b1, (const bf16*)w2p, b2, (bf16*)out, rows, F, noz)
@@ -884,4 +1021,19 @@ int sl_launch_ffn_pipe(simulst_handle* h, const void* x, const float* ln_g, cons
   }
 #endif
   return sl_launch_status(h, "simulst_emformer_ffn(pipelined)");
+}
+
+int sl_launch_qkv_rows(simulst_handle* h, const void* z, const void* wqkv_fm, const float* bqkv, void* qkv, int n_utt, int rows_z, int n_mem,
+                       int sum0, int n_sum) {
+  const int tiles = (n_mem + n_sum + 31) / 32;
+  const size_t lds = (size_t)4 * FP_W + 768 * sizeof(float);
+  if (!h->qkv_rows_lds_attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)qkv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { h->err = "simulst_emformer_qkv_mem_sum: cannot raise the dynamic LDS limit"; return (int)e; }
+    h->qkv_rows_lds_attr_set = true;
+  }
+  const long waves = (long)n_utt * tiles;
+  hipLaunchKernelGGL(qkv_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, h->stream, (const bf16*)z, (const bf16*)wqkv_fm, bqkv,
+                     (bf16*)qkv, n_utt, rows_z, n_mem, sum0, n_sum, tiles);
+  return sl_launch_status(h, "simulst_emformer_qkv_mem_sum");
 }

@@ -120,5 +120,10 @@ struct sl_ffn_z {
   const float* b;
   const int* lengths;              // [B] encoder frames per utterance or null (all T)
   int rows_x, T, n_mem, n_rc, n_sum, tiles;      // rows_x = n_rc + T; tiles: workgroups per utterance
+  // QOUT (non-null QKV): the next layer's fused Q | K | V projection of the rc | utterance rows in the same launch -- Wqkv [768][256]
+  // in fragment-major order (simulst_pack_fragment_major), bqkv [768], QKV [B * rows_z + 16][768] (16 spare rows behind the buffer)
+  const bf16* Wqkv;
+  const float* bqkv;
+  bf16* QKV;
 };
 

@@ -9,7 +9,8 @@
 // 105: round 5 -- simulst_get_option (what a handle actually runs with, for the roofline models of bench.py).
 // 106: round 6 -- simulst_emformer_ffn_prenorm (the next layer's LayerNorm + summaries in the feed-forward launch); no structure changed.
 // 107: round 6 -- simulst_stream_ctl grew row_map / compact_rows (active-row compaction of simulst_mma_stream_steps).
-extern "C" int simulst_version(void) { return 107; }
+// 108: round 6 -- simulst_emformer_ffn_prenorm_qkv (... and the next layer's Q | K | V projection of the rc | utterance rows); no structure changed.
+extern "C" int simulst_version(void) { return 108; }
 
 extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   if (!out) return SIMULST_E_NULL;
@@ -117,6 +118,7 @@ extern "C" int simulst_create(simulst_handle** out, void* hip_stream) {
   h->conv_pos_lds_attr_set = false;
   h->ffn_lds_attr_set = false;
   h->ffn_pipe_lds_attr_set = false;
+  h->qkv_rows_lds_attr_set = false;
   h->ffn_variant = 0;
   h->ffn_waves = 0;
   h->ea_general_only = false;

@@ -195,6 +195,8 @@ class S2TEmformerEncoder:
     fuse_ffn_min_rows = 4096       # below this the two-launch path fills the chip better (256 rows per workgroup)
     # ... and the NEXT layer's pre-attention LayerNorm + summaries in that launch's epilogue (round 6; SIMULST_FUSE_PRENORM=0: A/B runs)
     fuse_prenorm = os.environ.get("SIMULST_FUSE_PRENORM", "1") != "0"
+    # ... and the next layer's Q | K | V projection of the rc | utterance rows (SIMULST_FUSE_QKV=0: A/B runs)
+    fuse_qkv = os.environ.get("SIMULST_FUSE_QKV", "1") != "0"
 
     def _packed(self, l, name):
         """Fragment-major copy of an encoder projection weight (bf16 only, made once): lets simulst_linear take the
@@ -234,11 +236,13 @@ class S2TEmformerEncoder:
             if len(self._layer_ws) >= 4:
                 self._layer_ws.clear()
             e = dict(device=X.device, dtype=X.dtype)
+            # QKV: 16 spare rows behind the buffer (simulst_emformer_ffn_prenorm_qkv parks the stores of tile rows past an utterance's end there)
             ws = self._layer_ws[key] = dict(Za=torch.empty(B, rows_z, D, **e), Zb=torch.empty(B, rows_z, D, **e),
-                                            QKV=torch.empty(B, rows_z, 3 * D, **e), CTX=torch.empty(B, rows_c, D, **e),
+                                            QKVf=torch.empty(B * rows_z + 16, 3 * D, **e), CTX=torch.empty(B, rows_c, D, **e),
                                             X1=torch.empty_like(X), Y=torch.empty_like(X),
                                             Hf=torch.empty(B * rows_x, cfg.ffn_dim, **e))
-        Za, Zb, QKV, CTX, X1, Y, Hf = (ws[k] for k in ("Za", "Zb", "QKV", "CTX", "X1", "Y", "Hf"))
+        Za, Zb, QKVf, CTX, X1, Y, Hf = (ws[k] for k in ("Za", "Zb", "QKVf", "CTX", "X1", "Y", "Hf"))
+        QKV = QKVf[:B * rows_z].view(B, rows_z, 3 * D)
         # CTX: segments past an utterance's length are skipped by the attention launch and must read as zeros.  Za / Zb need no clearing:
         # every row a layer's QKV launch reads has been written before it -- memory rows by the copy below / the previous layer's
         # out-proj (all n_mem of them, every utterance), rc | utterance | summary rows by simulst_emformer_prenorm (all rows, padded
@@ -252,16 +256,23 @@ class S2TEmformerEncoder:
         # right-context rows, the fused feed-forward's own domain
         ffn_fused = self.fuse_ffn and B * rows_x >= self.fuse_ffn_min_rows and all("w1_ffn" in L for L in W.layers)
         fuse_prenorm = self.fuse_prenorm and ffn_fused and S == 16 and n_rc % 32 == 0 and cfg.ffn_dim <= 2048
-        prenorm_done = False
+        tall = B * rows_x >= 4096              # the row-panel kernel's domain (simulst_linear dispatch)
+        # ... and so is that layer's Q | K | V projection of the rc | utterance rows (simulst_emformer_ffn_prenorm_qkv): the normalised
+        # rows never leave the chip; memory and summary rows (n_mem + n_sum of rows_z per utterance): simulst_emformer_qkv_mem_sum
+        fuse_qkv = fuse_prenorm and self.fuse_qkv and tall and self.use_panel_gemm and all("wqkv_fm" in L for L in W.layers)
+        prenorm_done = qkv_done = False
         for l, L in enumerate(W.layers):
             Z, Zn = (Za, Zb) if l % 2 == 0 else (Zb, Za)
             if not prenorm_done:
                 ops.emformer_prenorm(X, L["ln_in_g"], L["ln_in_b"], lengths_i32, Z, T=T, n_mem=n_mem, n_rc=n_rc,
                                      n_sum=n_sum, seg_len=S)
             prenorm_done = False
-            tall = B * rows_x >= 4096              # the row-panel kernel's domain (simulst_linear dispatch)
             wq, fq = self._packed(l, "wqkv") if tall else (L["wqkv"], False)
-            ops.linear(Z.view(B * rows_z, D), wq, L["bqkv"], out=QKV.view(B * rows_z, 3 * D), w_fragment_major=fq)
+            if qkv_done:
+                ops.emformer_qkv_mem_sum(Z, wq, L["bqkv"], QKVf, T=T, n_mem=n_mem, n_rc=n_rc, n_sum=n_sum)
+            else:
+                ops.linear(Z.view(B * rows_z, D), wq, L["bqkv"], out=QKV.view(B * rows_z, 3 * D), w_fragment_major=fq)
+            qkv_done = False
             ops.emformer_attention(QKV, lengths_i32, CTX, B=B, T=T, D=D, H=cfg.num_heads, S=S, R=R, Lc=cfg.Lc,
                                    M=cfg.M, n_mem=n_mem, n_seg=N, use_summary=use_mem)
             wo, fo = self._packed(l, "wo") if tall else (L["wo"], False)
@@ -274,9 +285,15 @@ class S2TEmformerEncoder:
             if self.fuse_ffn and "w1_ffn" in L and B * rows_x >= self.fuse_ffn_min_rows:
                 if fuse_prenorm and l + 1 < len(W.layers):
                     Ln = W.layers[l + 1]               # Zn: its memory rows were written by this layer's out-proj above
-                    ops.emformer_ffn_prenorm(X1, L["ln_ff_g"], L["ln_ff_b"], L["w1_ffn"], L["b1"], L["w2_ffn"], L["b2"], X,
-                                             Ln["ln_in_g"], Ln["ln_in_b"], lengths_i32, Zn, T=T, n_mem=n_mem, n_rc=n_rc,
-                                             n_sum=n_sum, seg_len=S)
+                    if fuse_qkv:                       # (QKV: this layer's attention, its only reader, is behind us on the stream)
+                        ops.emformer_ffn_prenorm_qkv(X1, L["ln_ff_g"], L["ln_ff_b"], L["w1_ffn"], L["b1"], L["w2_ffn"], L["b2"], X,
+                                                     Ln["ln_in_g"], Ln["ln_in_b"], lengths_i32, Zn, Ln["wqkv_fm"], Ln["bqkv"], QKVf,
+                                                     T=T, n_mem=n_mem, n_rc=n_rc, n_sum=n_sum, seg_len=S)
+                        qkv_done = True
+                    else:
+                        ops.emformer_ffn_prenorm(X1, L["ln_ff_g"], L["ln_ff_b"], L["w1_ffn"], L["b1"], L["w2_ffn"], L["b2"], X,
+                                                 Ln["ln_in_g"], Ln["ln_in_b"], lengths_i32, Zn, T=T, n_mem=n_mem, n_rc=n_rc,
+                                                 n_sum=n_sum, seg_len=S)
                     prenorm_done = True
                 else:
                     ops.emformer_ffn(X1.view(B * rows_x, D), L["ln_ff_g"], L["ln_ff_b"], L["w1_ffn"], L["b1"], L["w2_ffn"],

@@ -139,6 +139,32 @@ class Ops:
                                                            n_mem, n_rc, n_sum, seg_len, dt(x)), "simulst_emformer_ffn_prenorm")
         return out
 
+    def emformer_ffn_prenorm_qkv(self, x, ln_g, ln_b, w1p, b1, w2p, b2, out, next_g, next_b, lengths, Z, wqkv_fm, bqkv, QKV, *, T, n_mem,
+                                 n_rc, n_sum, seg_len):
+        """emformer_ffn_prenorm + the next layer's Q | K | V rows of the rc | utterance rows (simulst_emformer_ffn_prenorm_qkv).  QKV: the
+        flat [B * rows_z + 16, 768] buffer (16 spare rows); Z gets its summary rows only."""
+        _chk_contig(x, out, w1p, w2p, Z, wqkv_fm, QKV)
+        B, _, D = x.shape
+        rows_z = n_mem + n_rc + T + n_sum
+        if QKV.numel() < (B * rows_z + 16) * 3 * D:
+            raise ValueError("emformer_ffn_prenorm_qkv: QKV needs 16 spare rows behind its B * rows_z")
+        self.h.check(self.lib.simulst_emformer_ffn_prenorm_qkv(self.h.ptr, _p(x), _p(ln_g), _p(ln_b), _p(w1p), _p(b1), _p(w2p), _p(b2),
+                                                               _p(out), _p(next_g), _p(next_b), _p(lengths), _p(Z), _p(wqkv_fm), _p(bqkv),
+                                                               _p(QKV), B, T, D, b1.numel(), n_mem, n_rc, n_sum, seg_len, dt(x)),
+                     "simulst_emformer_ffn_prenorm_qkv")
+        return out
+
+    def emformer_qkv_mem_sum(self, Z, wqkv_fm, bqkv, QKV, *, T, n_mem, n_rc, n_sum):
+        """Q | K | V rows of the memory and summary rows of Z [B, rows_z, D] into the same rows of the flat QKV buffer
+        (simulst_emformer_qkv_mem_sum): what emformer_ffn_prenorm_qkv leaves."""
+        _chk_contig(Z, wqkv_fm, QKV)
+        B, rows_z, D = Z.shape
+        if QKV.numel() < (B * rows_z + 16) * 3 * D:
+            raise ValueError("emformer_qkv_mem_sum: QKV needs 16 spare rows behind its B * rows_z")
+        self.h.check(self.lib.simulst_emformer_qkv_mem_sum(self.h.ptr, _p(Z), _p(wqkv_fm), _p(bqkv), _p(QKV), B, T, D, n_mem, n_rc, n_sum,
+                                                           dt(Z)), "simulst_emformer_qkv_mem_sum")
+        return QKV
+
     def emformer_prenorm(self, X, gamma, beta, lengths, Z, *, T, n_mem, n_rc, n_sum, seg_len):
         B, _, D = X.shape
         self.h.check(self.lib.simulst_emformer_prenorm(self.h.ptr, _p(X), _p(gamma), _p(beta), _p(lengths), _p(Z),

@@ -1079,6 +1079,66 @@ def test_emformer_ffn_with_the_next_layers_prenorm_in_its_epilogue(ops, B, T, us
     torch.testing.assert_close(a, b, atol=3.2e-2, rtol=8e-3)          # one bf16 step where a rounding moved
 
 
+@pytest.mark.parametrize("B,T,use_len", [(40, 250, True), (3, 250, False), (5, 37, True), (33, 100, True)])
+def test_emformer_ffn_with_the_next_layers_qkv_projection_in_its_launch(ops, B, T, use_len):
+    """simulst_emformer_ffn_prenorm_qkv + simulst_emformer_qkv_mem_sum (round 6) against simulst_emformer_ffn_prenorm followed by
+    simulst_linear over the whole Z buffer: feed-forward rows, summary rows and every Q | K | V row BIT FOR BIT wherever simulst_linear
+    takes its weight-stationary or row-panel kernel (>= 4096 rows; the product repeats that kernel's instruction, k order, bias add and
+    rounding), else within a bf16 step; Z's memory and rc | utterance rows are not touched, nor the spare rows' neighbours; a wave
+    tile that straddles an utterance's end (T + n_rc no multiple of 32 / 128), utterance counts that leave waves of the mem | summary
+    launch without an utterance."""
+    from simulst_amd.encoder import ffn_pack_w1, ffn_pack_w2
+    D, F, R, S = 256, 512, 8, 16
+    N = -(-T // S)
+    n_rc, n_mem, n_sum = ((N * R + 31) // 32) * 32, N - 1, N
+    rows_x, rows_z = n_rc + T, n_mem + n_rc + T + n_sum
+    g_ = torch.Generator().manual_seed(B * 1000 + T + 1)
+    x = torch.randn(B, rows_x, D, generator=g_).to(torch.bfloat16).cuda()
+    W1 = (torch.randn(F, D, generator=g_) * D ** -0.5).to(torch.bfloat16).cuda()
+    W2 = (torch.randn(D, F, generator=g_) * F ** -0.5).to(torch.bfloat16).cuda()
+    Wq = (torch.randn(3 * D, D, generator=g_) * D ** -0.5).to(torch.bfloat16).cuda()
+    bq = (torch.randn(3 * D, generator=g_) * 0.1).cuda()
+    b1, b2 = (torch.randn(F, generator=g_) * 0.1).cuda(), (torch.randn(D, generator=g_) * 0.1).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g_)).cuda(), (0.1 * torch.randn(D, generator=g_)).cuda()
+    g2, be2 = (1 + 0.1 * torch.randn(D, generator=g_)).cuda(), (0.1 * torch.randn(D, generator=g_)).cuda()
+    lengths = None
+    if use_len:
+        lengths = torch.randint(1, T + 1, (B,), generator=g_).to(torch.int32).cuda()
+        lengths[0] = T
+    w1p, w2p, wq_fm = ffn_pack_w1(W1), ffn_pack_w2(W2), ops.pack_fragment_major(Wq)
+    kw = dict(T=T, n_mem=n_mem, n_rc=n_rc, n_sum=n_sum, seg_len=S)
+    mem = torch.randn(B, n_mem, D, generator=g_).to(torch.bfloat16).cuda()
+    # reference: the prenorm launch, then simulst_linear over all of Z
+    ref_out = torch.empty_like(x)
+    Zr = torch.zeros(B, rows_z, D, device="cuda", dtype=torch.bfloat16)
+    Zr[:, :n_mem] = mem
+    ops.emformer_ffn_prenorm(x, gam, bet, w1p, b1, w2p, b2, ref_out, g2, be2, lengths, Zr, **kw)
+    Qr = torch.empty(B * rows_z, 3 * D, device="cuda", dtype=torch.bfloat16)
+    ops.linear(Zr.view(B * rows_z, D), wq_fm, bq, out=Qr, w_fragment_major=True)
+    # fused
+    out = torch.full_like(x, float("nan"))
+    Z = torch.full((B, rows_z, D), 7.0, device="cuda", dtype=torch.bfloat16)
+    Z[:, :n_mem] = mem
+    Qf = torch.full((B * rows_z + 16 + 4, 3 * D), 5.0, device="cuda", dtype=torch.bfloat16)
+    ops.emformer_ffn_prenorm_qkv(x, gam, bet, w1p, b1, w2p, b2, out, g2, be2, lengths, Z, wq_fm, bq, Qf, **kw)
+    torch.cuda.synchronize()
+    Q = Qf[:B * rows_z].view(B, rows_z, 3 * D)
+    assert bool((Q[:, :n_mem] == 5.0).all()) and bool((Q[:, n_mem + rows_x:] == 5.0).all())       # not this launch's rows
+    ops.emformer_qkv_mem_sum(Z, wq_fm, bq, Qf, **{k: v for k, v in kw.items() if k != "seg_len"})
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)
+    assert torch.equal(Z[:, n_mem + rows_x:], Zr[:, n_mem + rows_x:])                               # the summaries
+    assert bool((Z[:, n_mem:n_mem + rows_x] == 7.0).all()) and torch.equal(Z[:, :n_mem], mem)
+    assert bool((Qf[B * rows_z + 16:] == 5.0).all())                                               # behind the spare rows
+    assert torch.isfinite(Q.float()).all()
+    Qr = Qr.view(B, rows_z, 3 * D)
+    if B * rows_z >= 4096:
+        assert torch.equal(Q, Qr), (int((Q != Qr).sum()), float((Q.float() - Qr.float()).abs().max()))
+    else:
+        torch.testing.assert_close(Q.float(), Qr.float(), atol=3.2e-2, rtol=8e-3)
+        assert int((Q != Qr).sum()) <= 1e-3 * Q.numel()
+
+
 def test_encoder_with_the_prenorm_in_the_feed_forward_launch_equals_the_separate_launch(ops):
     """The full-size bf16 encoder, ragged batch: layers 1 .. 11 take their pre-attention LayerNorm and summaries from the previous
     layer's feed-forward launch (fuse_prenorm) against the separate simulst_emformer_prenorm launches; and the layer
@@ -1092,16 +1152,24 @@ def test_encoder_with_the_prenorm_in_the_feed_forward_launch_equals_the_separate
     L = torch.full((24,), 1000, device="cuda")
     L[3], L[7], L[11] = 640, 311, 17
     enc.fuse_ffn, enc.fuse_ffn_min_rows = True, 0
-    enc.fuse_prenorm = True
+    enc.fuse_prenorm = enc.fuse_qkv = True
     a = enc.forward(fb, L)["encoder_out_btd"].float().clone()
     for ws in enc._layer_ws.values():                       # the cached workspace of this shape
-        for k in ("Za", "Zb", "QKV", "X1", "Y"):
+        for k in ("Za", "Zb", "QKVf", "X1", "Y"):
             ws[k].fill_(float("nan"))
     a2 = enc.forward(fb, L)["encoder_out_btd"].float().clone()
     assert torch.isfinite(a2).all() and torch.equal(a, a2)
+    # ... and the next layer's Q | K | V projection in that launch too (fuse_qkv) against the separate simulst_linear: the same
+    # rows bit for bit (8 280 rows: simulst_linear takes the weight-stationary kernel whose arithmetic the fused product repeats)
+    enc.fuse_qkv = False
+    for ws in enc._layer_ws.values():
+        for k in ("Za", "Zb", "QKVf", "X1", "Y"):
+            ws[k].fill_(float("nan"))
+    a3 = enc.forward(fb, L)["encoder_out_btd"].float().clone()
+    assert torch.equal(a, a3), float((a - a3).abs().max())
     enc.fuse_prenorm = False
     for ws in enc._layer_ws.values():
-        for k in ("Za", "Zb", "QKV", "X1", "Y"):
+        for k in ("Za", "Zb", "QKVf", "X1", "Y"):
             ws[k].fill_(float("nan"))
     b = enc.forward(fb, L)["encoder_out_btd"].float().clone()
     assert torch.isfinite(b).all()

@@ -34,3 +34,11 @@ def test_guard_recognises_the_failing_form():
             "s_nop 15", "s_nop 7"]
     assert check_isa.check_chain_accumulators(body)
     assert not check_isa.check_chain_accumulators([body[0], body[1], body[2], body[4], body[5], body[3]])
+    # rule 4 (round 6): the sequence hipcc put behind the asm store of the fused Q | K | V projection -- the next row tile's first
+    # sum into the store's first data register one instruction later -- and the repaired one (the statement ends in `s_nop 1`)
+    st = "global_store_dwordx4 v[68:69], v[84:87], off"
+    assert check_isa.check_wide_store_data([st, "v_add_f32_e32 v66, v76, v128", "v_add_f32_e32 v84, v77, v129", "v_add_f32_e32 v85, v78, v130"])
+    assert not check_isa.check_wide_store_data([st, "s_nop 1", "v_add_f32_e32 v66, v76, v128", "v_add_f32_e32 v84, v77, v129"])
+    assert not check_isa.check_wide_store_data([st, "v_add_f32_e32 v66, v76, v128", "v_mov_b32_e32 v67, 0", "v_add_f32_e32 v84, v77, v129"])
+    assert not check_isa.check_wide_store_data(["global_store_dwordx2 v[68:69], v[84:85], off", "v_add_f32_e32 v84, v77, v129"])
+    assert check_isa.check_wide_store_data(["buffer_store_dwordx4 v[4:7], v0, s[0:3], 0 offen", "v_mov_b32_e32 v5, 0"])

@@ -14,6 +14,12 @@
 3. In the same kernels no v_accvgpr_read_b32 may feed the A / B operand of an MFMA one or two instructions later (round 4, see
    check_accvgpr_feeds_mfma).
 
+4. No VALU instruction writes a data register of a vector-memory store of more than 64 bits within the two wait states behind the
+   store (gfx940+: the store still reads them).  hipcc's hazard recogniser guarantees it for the stores it emits and cannot for a
+   store inside an `asm` statement (round 6: the fused Q | K | V projection's `global_store_dwordx4`, csrc/ffn_pipe.hip
+   qkv_pair_ring -- with another stream's kernels loading the memory pipe, the first data register carried the next tile's fp32 sum;
+   the statement now ends in `s_nop 1`).
+
     python tools/check_isa.py [path/to/libsimulst_hip.so]        # exit status 1 on a violation
 """
 import glob
@@ -108,6 +114,36 @@ def check_accvgpr_feeds_mfma(body):
     return out
 
 
+WIDE_STORE = re.compile(r"^(global|flat|scratch)_store_dwordx[34]\s+(\S+),\s*(\S+?),|^buffer_store_dwordx[34]\s+(\S+?),")
+
+
+def check_wide_store_data(body):
+    """rule 4 -> list of (store, offending instruction)"""
+    bad = []
+    for n, ins in enumerate(body):
+        m = WIDE_STORE.match(ins)
+        if not m:
+            continue
+        tok = m.group(4) if m.group(4) else (m.group(2) if m.group(1) == "scratch" else m.group(3))
+        data = regs(tok)
+        if not data:
+            continue
+        waited = 0
+        for nxt in body[n + 1: n + 4]:
+            if waited >= 2:
+                break
+            mn = re.match(r"s_nop\s+(\d+)", nxt)
+            if mn:
+                waited += int(mn.group(1)) + 1
+                continue
+            if nxt.startswith("v_") and not nxt.startswith("v_mfma") and not nxt.startswith("v_cmp"):
+                ops = nxt.split(None, 1)[1].split(",") if " " in nxt else []
+                if ops and regs(ops[0].strip()) & data:
+                    bad.append((ins, nxt))
+            waited += 1
+    return bad
+
+
 def main():
     so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "simulst_amd", "libsimulst_hip.so")
     kernels = disassemble(so)
@@ -121,6 +157,14 @@ def main():
     for name, n, ex in bad:
         print(f"  SWIZZLED packed fp32 in {name}: {n}, e.g. '{ex}'")
         rc = 1
+    n_wide = n_hit = 0
+    for name, body in sorted(kernels.items()):
+        n_wide += sum(1 for i in body if WIDE_STORE.match(i))
+        for st, ins in check_wide_store_data(body):
+            print(f"  {name[:70]}: `{ins}` writes a data register of `{st}` within two wait states")
+            n_hit += 1
+    print(f"  {n_wide} vector-memory stores of more than 64 bits, {n_hit} with a VALU write into their data registers within two wait states")
+    rc = rc or (1 if n_hit else 0)
     chains = {k: b for k, b in kernels.items() if re.search(r"dec_(proj|ffn|ffn_qkv|qkv|attn_proj|vocab|embed_qkv)_chain_kernel", k)}
     if not chains:
         print("the layer-chain kernels are missing from the library", file=sys.stderr)
