@@ -152,24 +152,30 @@ __device__ __forceinline__ void stage_piece(const bf16* __restrict__ wp, int til
 // SPREAD (round 6, uniform schedule only): the 2 * PIECES LDS-DMA pieces of an iteration are issued ONE PER MFMA GAP behind the first
 // fc1 MFMAs instead of as a burst behind the barrier, where all waves of both resident workgroups issue theirs at the same moment
 // (MI355X_MICROARCH.md: a piece costs its wave 100-185 cycles inside a phase already carrying 8 pieces, 25-60 in a later gap).
-// The fused Q | K | V projection of 32 rows per wave (QOUT below and qkv_rows_kernel): simulst_linear's weight-stationary kernel
+// A K = 256 projection of 32 rows per wave with the weights streamed through LDS (the next layer's fused Q | K | V projection, QOUT and
+// qkv_rows_kernel; measured and not kept, DESIGN.md section 3: the attention output projection in front of the feed-forward): simulst_linear's weight-stationary kernel
 // (gemm_wstat.hip) operation for operation -- v_mfma_f32_16x16x32_bf16, weights as the A operand, k-steps 0 .. 7, its permuted column
-// tiles (a lane's two accumulators = 8 consecutive columns of its row), fp32 bias add, one rounding -- so the rows are that launch's
-// bit for bit; only where the weights come from differs: there a 96 KB slice sits in LDS for the whole launch, here the 24 column
-// pairs (16 KB each) stream through four 16 KB slots at the start of the workgroup's LDS, by LDS-DMA with a per-lane gather from the
-// fragment-major matrix, three pairs ahead.  256 threads; fq[rt][s]: the wave's B operand (row 16 rt + lane % 16, columns
-// 32 s + 8 (lane / 16) .. + 7); qrow[rt]: where that row's 8 (lane / 16) .. + 7 columns of pair 0 go -- every lane stores in every
-// iteration (the counted waits rely on it).  Whatever the workgroup kept in lds[0, 64 KB) and bias_lds[0, 768) is overwritten.
-__device__ __forceinline__ void qkv_pair_ring(char* lds, float* bias_lds, const bf16* Wqkv, const float* bqkv, const uint4 (&fq)[2][8],
-                                              bf16* const (&qrow)[2], int tid, int wave_u) {
+// tiles (a lane's two accumulators = 8 consecutive columns of its row), and in the callers' epilogues its fp32 bias add (+ residual)
+// and one rounding -- so the rows are that launch's bit for bit; only where the weights come from differs: there a 96 / 128 KB slice
+// sits in LDS for the whole launch, here the NP column pairs (16 KB each) stream through four 16 KB slots at the start of the
+// workgroup's LDS, by LDS-DMA with a per-lane gather from the fragment-major matrix, three pairs ahead.  256 threads; fq[rt][s]: the
+// wave's B operand (row 16 rt + lane % 16, columns 32 s + 8 (lane / 16) .. + 7).  epi(pp, qa): qa[rt][h][e] = row 16 rt + lane % 16,
+// column 32 pp + 8 (lane / 16) + 4 h + e, before the bias; it must issue EXACTLY TWO vector-memory instructions (its two row-tile
+// stores, from every lane: rows that must not be stored go to spare rows) and leave none of its own in flight that the compiler
+// tracks -- the counted waits below rely on both.  UNROLL: pp is a compile-time constant in epi (register arrays indexed by it).
+// Whatever the workgroup kept in lds[0, 64 KB) is overwritten; the caller's LDS writes before the call are visible in epi.
+// Measured and not kept (round 6): a pair's 16 ds_read_b128 one iteration ahead of its MFMAs (second register set) -- the launch
+// stayed at 1 286 us (1 280 utterances): the Q | K | V phase costs its share of the launch's MFMA work at the launch's overall rate
+// (+ 18.75 % flops, + 20 % time), beside the other resident workgroup's main loop; its own read -> multiply chain is not what paces it.
+template <int NP, bool UNROLL, typename Epi>
+__device__ __forceinline__ void pair_ring(char* lds, const bf16* Wfm, const uint4 (&fq)[2][8], int tid, int wave_u, Epi&& epi) {
   const int lane = tid & 63, l16 = lane & 15, lg = lane >> 4;
-  for (int k = tid; k < 768; k += 256) bias_lds[k] = bqkv[k];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();                                              // every wave holds its fragments: the slots are free
   // this wave's 4 of a pair's 16 one-KiB pieces: piece f = 4 wave + i = (tile h = f >> 3 of the pair, k-step s = f & 7); lane (m = lane
   // & 15, kg = lane >> 4) of it is the wstat fill's entry for permuted row m: column 32 pp + 8 (m >> 2) + 4 h + (m & 3), k-group kg
   const unsigned lane_el = (unsigned)(((l16 >> 3) * 8) * 512 + (lg * 16 + 8 * ((l16 >> 2) & 1) + (l16 & 3)) * 8);
-  const char* wq = reinterpret_cast<const char*>(Wqkv);
+  const char* wq = reinterpret_cast<const char*>(Wfm);
   const unsigned ring0 = lds_addr(lds);
   auto stage_pair = [&](int pp) {
     const unsigned slot = ring0 + (unsigned)(pp & 3) * FP_W;
@@ -180,17 +186,17 @@ __device__ __forceinline__ void qkv_pair_ring(char* lds, float* bias_lds, const 
       glds16(wq + 2ul * el, slot + (unsigned)f * 1024u);
     }
   };
-  stage_pair(0); stage_pair(1); stage_pair(2);
-  for (int pp = 0; pp < 24; ++pp) {
-    // pair pp's pieces have landed = all but the operations issued after them are done: per iteration 4 pieces + 2 stores
-    if (pp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (pp == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (pp == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (pp <= 21) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else if (pp == 22) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  auto iteration = [&](int pp) {
+    // pair pp's pieces have landed = all but the operations issued after them are done: the pieces of the (up to two) pairs
+    // requested after it, 4 each, and the stores of the (up to three) iterations since its request, 2 each
+    const int younger = 4 * ((pp + 2 < NP - 1 ? pp + 2 : NP - 1) - pp) + 2 * (pp < 3 ? pp : 3);
+    if (younger == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (younger == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (younger == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // (the last pair: three iterations' stores)
     __syncthreads();                                            // ... everybody's have, and everybody is past pair pp - 1 (slot (pp + 3) & 3)
-    if (pp + 3 < 24) stage_pair(pp + 3);
+    if (pp + 3 < NP) stage_pair(pp + 3);
     const uint4* wls = reinterpret_cast<const uint4*>(lds + (pp & 3) * FP_W) + lane;
     f32x4 qa[2][2];
 #pragma unroll
@@ -204,30 +210,54 @@ __device__ __forceinline__ void qkv_pair_ring(char* lds, float* bias_lds, const 
         qa[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&w1), *reinterpret_cast<const bf16x8_t*>(&fq[rt][s8]), qa[rt][1], 0, 0, 0);
       }
     }
+    epi(pp, qa);
+  };
+  static_assert(NP >= 4, "three pairs are requested ahead");
+  stage_pair(0); stage_pair(1); stage_pair(2);
+  if constexpr (UNROLL) {
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) iteration(pp);
+  } else {
+#pragma unroll 1
+    for (int pp = 0; pp < NP; ++pp) iteration(pp);
+  }
+}
+
+// 8 fp32 values of a row -> bf16, ONE 16-byte store.  hipcc splits the C++ store into two 8-byte ones (each half leaves as soon as
+// its accumulator is done) and pair_ring's counted waits would be off by two per iteration.  The `s_nop 1` belongs to the instruction:
+// a store of more than 64 bits reads its data registers for a while after issue and gfx940+ wants TWO wait states before a VALU
+// writes them; the hazard recogniser does not see into the statement, and hipcc did put the next row tile's `v_add_f32` into the
+// first data register one instruction behind the store -- with the memory pipe loaded by another stream's kernels the first two
+// columns of rows 12 .. 15 of a tile then carried that fp32 sum (tests/test_hip_properties.py multi-stream test, tools/check_isa.py
+// rule 4, tools/qkv_store_hazard_probe.py).  Returns the packed row piece.
+__device__ __forceinline__ uint4 ring_store8(bf16* dst, const float (&y)[8]) {
+  unsigned int ou[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bf16 lo = __float2bfloat16(y[2 * q]), hi = __float2bfloat16(y[2 * q + 1]);
+    ou[q] = (unsigned int)(*reinterpret_cast<const unsigned short*>(&lo)) | ((unsigned int)(*reinterpret_cast<const unsigned short*>(&hi)) << 16);
+  }
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 ov = {ou[0], ou[1], ou[2], ou[3]};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(dst), "v"(ov) : "memory");
+  return make_uint4(ou[0], ou[1], ou[2], ou[3]);
+}
+
+// The fused Q | K | V projection of the wave's 32 rows: bias_lds[0, 768) <- bqkv, then the 24-pair ring; qrow[rt]: where row
+// 16 rt + lane % 16's columns 8 (lane / 16) .. + 7 of pair 0 go.
+__device__ __forceinline__ void qkv_pair_ring(char* lds, float* bias_lds, const bf16* Wqkv, const float* bqkv, const uint4 (&fq)[2][8],
+                                              bf16* const (&qrow)[2], int tid, int wave_u) {
+  const int lg = (tid & 63) >> 4;
+  for (int k = tid; k < 768; k += 256) bias_lds[k] = bqkv[k];
+  pair_ring<24, false>(lds, Wqkv, fq, tid, wave_u, [&](int pp, const f32x4 (&qa)[2][2]) {
     const float4 bq0 = *reinterpret_cast<const float4*>(bias_lds + 32 * pp + 8 * lg), bq1 = *reinterpret_cast<const float4*>(bias_lds + 32 * pp + 8 * lg + 4);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const float yq[8] = {qa[rt][0][0] + bq0.x, qa[rt][0][1] + bq0.y, qa[rt][0][2] + bq0.z, qa[rt][0][3] + bq0.w,
                            qa[rt][1][0] + bq1.x, qa[rt][1][1] + bq1.y, qa[rt][1][2] + bq1.z, qa[rt][1][3] + bq1.w};
-      unsigned int ou[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bf16 lo = __float2bfloat16(yq[2 * q]), hi = __float2bfloat16(yq[2 * q + 1]);
-        ou[q] = (unsigned int)(*reinterpret_cast<const unsigned short*>(&lo)) | ((unsigned int)(*reinterpret_cast<const unsigned short*>(&hi)) << 16);
-      }
-      {   // ONE 16-byte store: hipcc splits the C++ store into two 8-byte ones (each half leaves as soon as its accumulator is done)
-          // and the counted waits above would be off by two per iteration.  The `s_nop 1` belongs to the instruction: a store of more
-          // than 64 bits reads its data registers for a while after issue and gfx940+ wants TWO wait states before a VALU writes
-          // them; the hazard recogniser does not see into the statement, and hipcc did put the next row tile's `v_add_f32` into the
-          // first data register one instruction behind the store -- with the memory pipe loaded by another stream's kernels the
-          // first two columns of rows 12 .. 15 of a tile then carried that fp32 sum (tests/test_hip_properties.py multi-stream test,
-          // tools/check_isa.py rule 4)
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 ov = {ou[0], ou[1], ou[2], ou[3]};
-        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(qrow[rt] + 32 * pp), "v"(ov) : "memory");
-      }
+      (void)ring_store8(qrow[rt] + 32 * pp, yq);
     }
-  }
+  });
 }
 
 // The Q | K | V rows of the memory and summary rows of the layer buffer (simulst_emformer_qkv_mem_sum): what
