@@ -262,6 +262,8 @@ __device__ __forceinline__ void qkv_pair_ring(char* lds, float* bias_lds, const 
 
 // The Q | K | V rows of the memory and summary rows of the layer buffer (simulst_emformer_qkv_mem_sum): what
 // simulst_emformer_ffn_prenorm_qkv leaves to do.  One wave per 32 of an utterance's n_mem + n_sum such rows, gathered straight from Z.
+// (Measured and not kept: eight waves per workgroup, i.e. half the weight stream per row -- 45-47 us against 40-42 at 1 280 utterances;
+// the launch is 24 barrier-to-barrier round trips long, not a stream.)
 __global__ __launch_bounds__(256, 2) void qkv_rows_kernel(const bf16* __restrict__ Z, const bf16* __restrict__ Wqkv, const float* __restrict__ bqkv,
                                                           bf16* __restrict__ QKV, int n_utt, int rows_z, int n_mem, int sum0, int n_sum, int tiles) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
