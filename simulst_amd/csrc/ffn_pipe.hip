@@ -167,6 +167,8 @@ __device__ __forceinline__ void stage_piece(const bf16* __restrict__ wp, int til
 // Measured and not kept (round 6): a pair's 16 ds_read_b128 one iteration ahead of its MFMAs (second register set) -- the launch
 // stayed at 1 286 us (1 280 utterances): the Q | K | V phase costs its share of the launch's MFMA work at the launch's overall rate
 // (+ 18.75 % flops, + 20 % time), beside the other resident workgroup's main loop; its own read -> multiply chain is not what paces it.
+// Nor is the per-lane gather: a copy of the weight in the ring's own order (every piece 1 KiB contiguous) ran the launch at 1 389-1 395 us
+// against 1 385-1 398 and qkv_rows_kernel at 42 against 42 on one box, same results.
 template <int NP, bool UNROLL, typename Epi>
 __device__ __forceinline__ void pair_ring(char* lds, const bf16* Wfm, const uint4 (&fq)[2][8], int tid, int wave_u, Epi&& epi) {
   const int lane = tid & 63, l16 = lane & 15, lg = lane >> 4;
